@@ -1,0 +1,175 @@
+/*
+ * tsii_hip.h -- C ABI of libtsii_hip.so, the MI355X (gfx950) kernels behind the
+ * partial-convolution inpainting hot path of yu45020/Text_Segmentation_Image_Inpainting.
+ *
+ * The reference has no FFI/plugin seam (pure Python nn.Modules calling aten ops), so this
+ * ABI is the seam a replacement .so provides underneath the reference's nn.Module surface;
+ * each entry point names the reference lines whose aten ops it replaces (paths relative to
+ * the reference repo root).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *  - fp32 everywhere.  Activations are NHWC-contiguous ([N,H,W,C]; a 1x1 conv sees them as
+ *    a row-major [M=N*H*W, C] matrix).  Mask "planes" are [N,H,W] fp32 holding exactly 0/1
+ *    (or small integer counts); a channel-constant mask [N,C,H,W] is represented by its plane.
+ *  - The caller owns every buffer (outputs, workspaces); nothing is allocated, freed or
+ *    retained by the library.  All calls are asynchronous on `stream` (a hipStream_t).
+ *  - Return value: 0 = enqueued; negative = invalid argument / unsupported shape / HIP
+ *    launch error, message via tsii_last_error() (thread-local).  Never throws.
+ *  - "row scale" (r0, split, r1): element (row m, channel k) of the operand is multiplied by
+ *    r0[m] if k < split else r1[m]; r0 == NULL disables it; r1 == NULL means 1.0 for k >= split.
+ *    This is how x*mask (partial_convolution.py:51,123) is fused for masks made of one or
+ *    two channel-constant planes (decoder concat of up-sampled + skip masks,
+ *    image_inpainting.py:83-84).
+ */
+#ifndef TSII_HIP_H
+#define TSII_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSII_ABI_VERSION 1
+
+/* activation kinds for the BN/activation kernels */
+#define TSII_ACT_NONE 0
+#define TSII_ACT_RELU 1
+#define TSII_ACT_LEAKY 2 /* slope argument */
+#define TSII_ACT_RELU6 3
+
+int tsii_version(void);
+const char* tsii_last_error(void);
+
+/* ---- K1: mask bookkeeping (partial_convolution.py:57-66,74-77,129-135) --------------- */
+
+/* plane[n,h,w] = sum_c mask[n,c,h,w]; mask given with element strides (any layout).
+ * With c == 1 this extracts channel 0 (the `mask[:, :1]` of :59 / :104). */
+int tsii_mask_channel_sum(const float* mask, int n, int h, int w, int c,
+                          int64_t sn, int64_t sh, int64_t sw, int64_t sc,
+                          float* plane, void* stream);
+
+/* S = a0*p0 + a1*p1 (p1 may be NULL); cnt = box_{kh x kw, stride, pad, dilation}(S) with zero
+ * padding (padding counts as hole); hole = (cnt == 0).
+ *   fill_holes != 0 (PartialConv :60-66,74-75): denom = hole ? 1 : cnt*post_scale,
+ *                                               new_mask = hole ? 0 : 1, inv = hole ? 0 : 1/denom
+ *   fill_holes == 0 (PartialConvNoHoles :130-135): denom = cnt*post_scale, new_mask = 1, inv = 1/denom
+ * post_scale = Cin for same_holes (:61), 1 otherwise.  All values are small integers: bit-exact.
+ * Any of denom / new_mask / inv may be NULL. */
+int tsii_mask_update(const float* p0, float a0, const float* p1, float a1,
+                     int n, int h, int w,
+                     int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                     int ho, int wo, float post_scale, int fill_holes,
+                     float* denom, float* new_mask, float* inv, void* stream);
+
+/* nearest x2 up-sampling of a plane (DoubleUpSample on the mask, partial_convolution.py:231) */
+int tsii_plane_upsample2x(const float* in, int n, int h, int w, float* out, void* stream);
+
+/* out = x * mask, both NHWC with identical shape (general per-channel masks, :51) */
+int tsii_mul_mask(const float* x, const float* mask, int64_t numel, float* out, void* stream);
+/* dx = dy * mask */
+/* (same entry point: multiplication is its own adjoint) */
+
+/* ---- K3: point-wise (1x1) convolution as fp32-MFMA GEMM ------------------------------
+ * PartialConv1x1 (:101-105), PartialConvNoHoles k=1 (:121-137), PartialConv k=1.
+ *   y[m,n] = keep[m] ? (sum_k x[m,k]*rs(m,k)*w[n,k]) / denom[m] + bias[n] : 0
+ * denom/keep/bias/r0 may be NULL (plain conv). */
+int tsii_pw_fwd(const float* x, int64_t m, int k, const float* w, int n, const float* bias,
+                const float* r0, int split, const float* r1,
+                const float* denom, const float* keep, float* y, void* stream);
+/* dx[m,k] = rs(m,k) * sum_n dy[m,n]*inv[m]*w[n,k];  wt_ws: k*n floats of scratch */
+int tsii_pw_bwd_dx(const float* dy, int64_t m, int n, const float* w, int k, const float* inv,
+                   const float* r0, int split, const float* r1, float* dx, float* wt_ws, void* stream);
+/* dw[n,k] = sum_m dy[m,n]*inv[m] * x[m,k]*rs(m,k);  dbias[n] = sum_m dy[m,n]*keep[m] (dbias may be
+ * NULL; keep NULL = all rows: the bias is added after the division, so its gradient is not scaled) */
+size_t tsii_pw_bwd_dw_ws_bytes(int64_t m, int n, int k);
+int tsii_pw_bwd_dw(const float* dy, const float* x, int64_t m, int n, int k, const float* inv, const float* keep,
+                   const float* r0, int split, const float* r1, float* dw, float* dbias,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* ---- K2: depth-wise partial convolution (PartialConv groups=C, MobileNetV2.py:174-176) --
+ *   y[n,ho,wo,c] = keep ? (sum_taps w[c,t]*x[n,hi,wi,c]*rmask[n,hi,wi]) / denom[n,ho,wo] + b[c] : 0
+ * w is the reference layout [C,1,kh,kw]; ws: c*kh*kw floats of scratch. */
+int tsii_dw_fwd(const float* x, const float* rmask, const float* w, const float* bias,
+                const float* denom, const float* keep,
+                int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                int ho, int wo, float* y, float* ws, void* stream);
+int tsii_dw_bwd_dx(const float* dy, const float* inv, const float* w, const float* rmask,
+                   int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                   int ho, int wo, float* dx, float* ws, void* stream);
+size_t tsii_dw_bwd_dw_ws_bytes(int n, int ho, int wo, int c, int kh, int kw);
+int tsii_dw_bwd_dw(const float* dy, const float* inv, const float* keep, const float* x, const float* rmask,
+                   int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                   int ho, int wo, float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- K4: dense k x k partial convolution, groups == 1 (PartialConv.forward :49-80) ------
+ * x*mask is either the two-plane row scale (r0/split/r1 at input resolution) or a full
+ * per-channel mask `mfull` (same NHWC shape as x; ImageFill stem, image_inpainting.py:23).
+ * w is the reference layout [Cout,Cin,kh,kw]. */
+size_t tsii_dense_ws_bytes(int cin, int cout, int kh, int kw);
+int tsii_dense_fwd(const float* x, const float* mfull, const float* r0, int split, const float* r1,
+                   const float* w, const float* bias, const float* denom, const float* keep,
+                   int n, int h, int wd, int cin, int cout,
+                   int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo,
+                   float* y, void* ws, size_t ws_bytes, void* stream);
+int tsii_dense_bwd_dx(const float* dy, const float* inv, const float* w,
+                      const float* mfull, const float* r0, int split, const float* r1,
+                      int n, int h, int wd, int cin, int cout,
+                      int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo,
+                      float* dx, void* ws, size_t ws_bytes, void* stream);
+size_t tsii_dense_bwd_dw_ws_bytes(int n, int ho, int wo, int cin, int cout, int kh, int kw);
+int tsii_dense_bwd_dw(const float* dy, const float* inv, const float* keep, const float* x,
+                      const float* mfull, const float* r0, int split, const float* r1,
+                      int n, int h, int wd, int cin, int cout,
+                      int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo,
+                      float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- K6: BatchNorm2d (+activation, +residual)  (partial_convolution.py:193-197,
+ *          residual add MobileNetV2.py:186-187, image_inpainting.py:216) ------------------
+ * y is [M,C].  Training: batch mean / biased variance (and running-stat update with
+ * momentum, unbiased variance, like nn.BatchNorm2d); eval: pass the running stats to apply. */
+size_t tsii_bn_ws_bytes(int64_t m, int c);
+int tsii_bn_stats(const float* y, int64_t m, int c, float* mean, float* var,
+                  float* running_mean, float* running_var, float momentum,
+                  void* ws, size_t ws_bytes, void* stream);
+/* out = act(gamma*(y-mean)/sqrt(var+eps)+beta) (+ residual) */
+int tsii_bn_act_fwd(const float* y, int64_t m, int c, const float* mean, const float* var,
+                    const float* gamma, const float* beta, float eps, int act, float slope,
+                    const float* residual, float* out, void* stream);
+/* training != 0: full batch-stat backward; else eval backward.  dgamma/dbeta always written. */
+int tsii_bn_act_bwd(const float* dout, const float* y, int64_t m, int c,
+                    const float* mean, const float* var, const float* gamma, const float* beta,
+                    float eps, int act, float slope, int training,
+                    float* dy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+/* activation only (PartialActivation :204-211): out = act(x); dx = dout*act'(x) */
+int tsii_act_fwd(const float* x, int64_t numel, int act, float slope, float* out, void* stream);
+int tsii_act_bwd(const float* dout, const float* x, int64_t numel, int act, float slope, float* dx, void* stream);
+
+/* ---- K7: nearest x2 up-sampling + channel concat (DoubleUpSample + torch.cat,
+ *          partial_convolution.py:229-231, image_inpainting.py:82-85) --------------------
+ * out[n,y,x,0:c1] = low[n,y/2,x/2,:], out[n,y,x,c1:] = skip[n,y,x,:];  low is [n,h,w,c1].
+ * c2 == 0 (skip NULL) is the plain DoubleUpSample of x. */
+int tsii_upcat_fwd(const float* low, const float* skip, int n, int h, int w, int c1, int c2,
+                   float* out, void* stream);
+int tsii_upcat_bwd(const float* dout, int n, int h, int w, int c1, int c2,
+                   float* dlow, float* dskip, void* stream);
+
+/* ---- K11 (first piece): mean-L1 loss (nn.L1Loss, loss.py:190; bench loss of SURVEY 8d) - */
+size_t tsii_l1_ws_bytes(int64_t numel);
+int tsii_l1_mean_fwd(const float* a, const float* b, int64_t numel, float* loss,
+                     void* ws, size_t ws_bytes, void* stream);
+/* da = sign(a-b) * (*gscale) / numel;  gscale is a device pointer to the upstream scalar grad */
+int tsii_l1_mean_bwd(const float* a, const float* b, int64_t numel, const float* gscale,
+                     float* da, void* stream);
+
+/* ---- training-step helpers ---------------------------------------------------------- */
+/* fused SGD step (nesterov momentum + weight decay; the optimiser the reference trained with,
+ * checkpoints/ReadME.md:4): g += wd*p; buf = mom*buf + g; p -= lr*(g + mom*buf) */
+int tsii_sgd_nesterov(float* p, const float* g, float* buf, int64_t numel,
+                      float lr, float momentum, float weight_decay, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSII_HIP_H */

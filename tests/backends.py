@@ -1,0 +1,47 @@
+"""Two ways to run the SAME parity checks:
+
+* ``gpu``  -- the product: libtsii_hip.so on an MI355X (tests marked ``@pytest.mark.gpu``).
+* ``emu``  -- TEST-ONLY: the unmodified kernel sources compiled against tests/emu (host SIMT
+  emulation) so index math / tiling / MFMA fragment layouts are checked in the CPU container.
+  It is wired in by monkeypatching the loader from the test process; the product package has
+  no knowledge of it and no CPU path of its own.
+"""
+import contextlib
+import ctypes
+
+import pytest
+import torch
+
+from text_segmentation_image_inpainting_amd import _lib
+
+
+@contextlib.contextmanager
+def emu_backend():
+    from tests.emu import build_emu
+    if not build_emu.available():
+        pytest.skip("host clang++ for the emulator build is not available")
+    cdll = _lib.bind(ctypes.CDLL(build_emu.build()))
+    saved = (_lib._LIB, _lib.stream, _lib.check_device)
+    _lib._LIB, _lib.stream, _lib.check_device = cdll, (lambda: None), (lambda t: None)
+    try:
+        yield torch.device("cpu")
+    finally:
+        _lib._LIB, _lib.stream, _lib.check_device = saved
+
+
+@contextlib.contextmanager
+def gpu_backend():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a ROCm GPU")
+    _lib.lib()  # fails loudly if libtsii_hip.so is missing
+    yield torch.device("cuda:0")
+    torch.cuda.synchronize()
+
+
+BACKENDS = {"emu": emu_backend, "gpu": gpu_backend}
+
+
+def both_backends(fn):
+    """Decorator: generate test_<name>[emu] (CPU suite) and test_<name>[gpu] (-m gpu)."""
+    return pytest.mark.parametrize(
+        "backend", [pytest.param("emu"), pytest.param("gpu", marks=pytest.mark.gpu)])(fn)

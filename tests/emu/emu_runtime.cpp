@@ -1,0 +1,175 @@
+// TEST-ONLY fiber scheduler behind tests/emu/hip/hip_runtime.h (see the header).
+#include <hip/hip_runtime.h>
+#include <ucontext.h>
+
+#include <cstdlib>
+#include <vector>
+
+namespace hipemu {
+
+dim3 tIdx, bIdx, bDim, gDim;
+
+enum { RUN = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    int state = DONE;
+};
+
+static constexpr size_t kStack = 256 * 1024;
+static std::vector<Fiber> fibers;
+static ucontext_t sched_ctx;
+static int cur = -1;
+static const std::function<void()>* body = nullptr;
+static unsigned xbuf[16][64][2];
+
+static void entry() {
+    (*body)();
+    fibers[cur].state = DONE;
+    swapcontext(&fibers[cur].ctx, &sched_ctx);
+}
+
+static void yield_to_sched(int st) {
+    fibers[cur].state = st;
+    swapcontext(&fibers[cur].ctx, &sched_ctx);
+}
+
+void syncthreads() { yield_to_sched(WAIT_BLOCK); }
+static void wavesync() { yield_to_sched(WAIT_WAVE); }
+
+int lane_id() { return cur & 63; }
+
+unsigned exchange32(unsigned v, int mode, int arg, int width) {
+    const int lane = cur & 63, wave = cur >> 6;
+    xbuf[wave][lane][0] = v;
+    wavesync();
+    int src = lane;
+    const int base = lane - (lane % width);
+    const int rel = lane % width;
+    if (mode == 0) { if (rel + arg < width) src = lane + arg; }
+    else if (mode == 1) { if (rel - arg >= 0) src = lane - arg; }
+    else if (mode == 2) { int r2 = rel ^ arg; if (r2 < width) src = base + r2; }
+    else { src = base + (((arg % width) + width) % width); }
+    unsigned r = xbuf[wave][src][0];
+    wavesync();
+    return r;
+}
+
+f32x16_emu mfma_32x32x2(float a, float b, f32x16_emu c) {
+    const int lane = cur & 63, wave = cur >> 6;
+    std::memcpy(&xbuf[wave][lane][0], &a, 4);
+    std::memcpy(&xbuf[wave][lane][1], &b, 4);
+    wavesync();
+    const int hi = lane >> 5, col = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            float av, bv;
+            std::memcpy(&av, &xbuf[wave][row + 32 * k][0], 4);
+            std::memcpy(&bv, &xbuf[wave][col + 32 * k][1], 4);
+            acc = fmaf(av, bv, acc);
+        }
+        c[r] = acc;
+    }
+    wavesync();
+    return c;
+}
+
+f32x4_emu mfma_16x16x4(float a, float b, f32x4_emu c) {
+    const int lane = cur & 63, wave = cur >> 6;
+    std::memcpy(&xbuf[wave][lane][0], &a, 4);
+    std::memcpy(&xbuf[wave][lane][1], &b, 4);
+    wavesync();
+    const int col = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int row = (lane >> 4) * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            float av, bv;
+            std::memcpy(&av, &xbuf[wave][row + 16 * k][0], 4);
+            std::memcpy(&bv, &xbuf[wave][col + 16 * k][1], 4);
+            acc = fmaf(av, bv, acc);
+        }
+        c[r] = acc;
+    }
+    wavesync();
+    return c;
+}
+
+static void run_block(int nthreads) {
+    for (int t = 0; t < nthreads; ++t) {
+        Fiber& f = fibers[t];
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = kStack;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())entry, 0);
+        f.state = RUN;
+    }
+    int live = nthreads;
+    const int nwaves = (nthreads + 63) / 64;
+    while (live > 0) {
+        bool progressed = false;
+        for (int t = 0; t < nthreads; ++t) {
+            Fiber& f = fibers[t];
+            if (f.state != RUN) continue;
+            cur = t;
+            tIdx.x = t % bDim.x;
+            tIdx.y = (t / bDim.x) % bDim.y;
+            tIdx.z = t / (bDim.x * bDim.y);
+            swapcontext(&sched_ctx, &f.ctx);
+            progressed = true;
+            if (f.state == DONE) --live;
+        }
+        bool released = false;
+        for (int w = 0; w < nwaves; ++w) {  // wave collectives
+            int waiting = 0, alive = 0;
+            for (int t = w * 64; t < std::min(nthreads, w * 64 + 64); ++t) {
+                if (fibers[t].state != DONE) ++alive;
+                if (fibers[t].state == WAIT_WAVE) ++waiting;
+            }
+            if (alive > 0 && waiting == alive) {
+                for (int t = w * 64; t < std::min(nthreads, w * 64 + 64); ++t)
+                    if (fibers[t].state == WAIT_WAVE) fibers[t].state = RUN;
+                released = true;
+            }
+        }
+        {
+            int waiting = 0;
+            for (int t = 0; t < nthreads; ++t) if (fibers[t].state == WAIT_BLOCK) ++waiting;
+            if (live > 0 && waiting == live) {
+                for (int t = 0; t < nthreads; ++t) if (fibers[t].state == WAIT_BLOCK) fibers[t].state = RUN;
+                released = true;
+            }
+        }
+        if (!progressed && !released && live > 0) {
+            std::fprintf(stderr, "hipemu: deadlock (divergent barrier / collective) in block (%u,%u,%u)\n",
+                         bIdx.x, bIdx.y, bIdx.z);
+            std::abort();
+        }
+    }
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& fn) {
+    const int nthreads = (int)(block.x * block.y * block.z);
+    if (nthreads > 1024) { std::fprintf(stderr, "hipemu: block too large\n"); std::abort(); }
+    if ((int)fibers.size() < nthreads) {
+        size_t old = fibers.size();
+        fibers.resize(nthreads);
+        for (size_t i = old; i < fibers.size(); ++i) fibers[i].stack = (char*)std::malloc(kStack);
+    }
+    body = &fn;
+    bDim = block;
+    gDim = grid;
+    for (unsigned z = 0; z < grid.z; ++z)
+        for (unsigned y = 0; y < grid.y; ++y)
+            for (unsigned x = 0; x < grid.x; ++x) {
+                bIdx = dim3(x, y, z);
+                run_block(nthreads);
+            }
+    body = nullptr;
+}
+
+}  // namespace hipemu

@@ -1,0 +1,106 @@
+// TEST-ONLY host emulation of the small HIP subset the kernels in
+// text_segmentation_image_inpainting_amd/csrc use.  It shadows <hip/hip_runtime.h>
+// when tests/emu/build_emu.py compiles the UNMODIFIED product sources with the host
+// clang++, so kernel index math, LDS tiling, wave shuffles and the MFMA fragment
+// layout can be checked against the oracle in the CPU-only container.  It is never
+// built into, loaded by, or reachable from the product library (which has no CPU
+// path at all); only tests/ load the resulting tests/emu/_build/libtsii_emu.so.
+//
+// Model: one OS thread; every HIP thread of a block is a ucontext fiber; blocks run
+// one after another.  __syncthreads() and the wave collectives (__shfl_*, MFMA) are
+// cooperative yield points.  Wavefront = 64 lanes, MFMA 32x32x2 f32 fragment layout
+// as documented for gfx950 (A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
+// D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31]).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+#define TSII_HIP_EMU 1
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+struct uint4 { unsigned x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+
+typedef float f32x16_emu __attribute__((ext_vector_type(16)));
+typedef float f32x4_emu __attribute__((ext_vector_type(4)));
+
+namespace hipemu {
+extern dim3 tIdx, bIdx, bDim, gDim;
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void syncthreads();
+unsigned exchange32(unsigned v, int src_lane_delta_mode, int arg, int width);
+f32x16_emu mfma_32x32x2(float a, float b, f32x16_emu c);
+f32x4_emu mfma_16x16x4(float a, float b, f32x4_emu c);
+int lane_id();
+}  // namespace hipemu
+
+#define threadIdx (hipemu::tIdx)
+#define blockIdx (hipemu::bIdx)
+#define blockDim (hipemu::bDim)
+#define gridDim (hipemu::gDim)
+#define warpSize 64
+
+static inline void __syncthreads() { hipemu::syncthreads(); }
+
+template <class T> static inline T __emu_x(T v, int mode, int arg, int width) {
+    static_assert(sizeof(T) == 4, "32-bit shuffles only");
+    unsigned u; std::memcpy(&u, &v, 4);
+    u = hipemu::exchange32(u, mode, arg, width);
+    T r; std::memcpy(&r, &u, 4);
+    return r;
+}
+template <class T> static inline T __shfl_down(T v, unsigned delta, int width = 64) { return __emu_x(v, 0, (int)delta, width); }
+template <class T> static inline T __shfl_up(T v, unsigned delta, int width = 64) { return __emu_x(v, 1, (int)delta, width); }
+template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) { return __emu_x(v, 2, mask, width); }
+template <class T> static inline T __shfl(T v, int src, int width = 64) { return __emu_x(v, 3, src, width); }
+
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+
+static inline f32x16_emu __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16_emu c, int, int, int) {
+    return hipemu::mfma_32x32x2(a, b, c);
+}
+static inline f32x4_emu __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4_emu c, int, int, int) {
+    return hipemu::mfma_16x16x4(a, b, c);
+}
+
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+
+// ---- runtime API subset -----------------------------------------------------
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipPeekAtLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return 0; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { std::memmove(d, s, n); return 0; }
+#define hipMemcpyDeviceToDevice 3
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })

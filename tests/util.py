@@ -9,8 +9,9 @@ def to_np(a):
     return np.asarray(a, dtype=np.float64)
 
 
-def rel_err(a, b):
-    """max|a-b| / max|b| over finite entries of b; NaN pattern must agree exactly."""
+def rel_err(a, b, floor=1e-30):
+    """max|a-b| / max(max|b|, floor) over finite entries of b; NaN pattern must agree exactly.
+    ``floor`` keeps analytically-zero quantities (both sides rounding noise) from failing."""
     a, b = to_np(a), to_np(b)
     assert a.shape == b.shape, (a.shape, b.shape)
     fa, fb = np.isfinite(a), np.isfinite(b)
@@ -18,10 +19,10 @@ def rel_err(a, b):
     if not fb.any():
         return 0.0
     scale = np.abs(b[fb]).max()
-    return float(np.abs(a[fb] - b[fb]).max() / max(scale, 1e-30))
+    return float(np.abs(a[fb] - b[fb]).max() / max(scale, floor))
 
 
-def assert_close(a, b, tol=1e-3, what=""):
-    e = rel_err(a, b)
+def assert_close(a, b, tol=1e-3, what="", floor=1e-30):
+    e = rel_err(a, b, floor)
     assert e <= tol, f"{what}: max-normalised rel err {e:.3e} > {tol:.1e}"
     return e

@@ -1,0 +1,98 @@
+"""ctypes binding of libtsii_hip.so (C ABI: include/tsii_hip.h).
+
+There is no CPU implementation behind this module: if the HIP library is missing or a tensor
+is not on a ROCm device, the call fails loudly.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtsii_hip.so")
+
+_p, _i, _l, _f, _z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+_GEOM = [_i] * 8  # kh kw sh sw ph pw dh dw
+
+# name -> (restype, argtypes); mirrors include/tsii_hip.h one to one
+SIGNATURES = {
+    "tsii_version": (_i, []),
+    "tsii_last_error": (ctypes.c_char_p, []),
+    "tsii_mask_channel_sum": (_i, [_p, _i, _i, _i, _i, _l, _l, _l, _l, _p, _p]),
+    "tsii_mask_update": (_i, [_p, _f, _p, _f, _i, _i, _i] + _GEOM + [_i, _i, _f, _i, _p, _p, _p, _p]),
+    "tsii_plane_upsample2x": (_i, [_p, _i, _i, _i, _p, _p]),
+    "tsii_mul_mask": (_i, [_p, _p, _l, _p, _p]),
+    "tsii_pw_fwd": (_i, [_p, _l, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p]),
+    "tsii_pw_bwd_dx": (_i, [_p, _l, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p]),
+    "tsii_pw_bwd_dw_ws_bytes": (_z, [_l, _i, _i]),
+    "tsii_pw_bwd_dw": (_i, [_p, _p, _l, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _z, _p]),
+    "tsii_dw_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _p]),
+    "tsii_dw_bwd_dx": (_i, [_p, _p, _p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _p]),
+    "tsii_dw_bwd_dw_ws_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
+    "tsii_dw_bwd_dw": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _p, _z, _p]),
+    "tsii_dense_ws_bytes": (_z, [_i, _i, _i, _i]),
+    "tsii_dense_fwd": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _z, _p]),
+    "tsii_dense_bwd_dx": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _z, _p]),
+    "tsii_dense_bwd_dw_ws_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
+    "tsii_dense_bwd_dw": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _p, _z, _p]),
+    "tsii_bn_ws_bytes": (_z, [_l, _i]),
+    "tsii_bn_stats": (_i, [_p, _l, _i, _p, _p, _p, _p, _f, _p, _z, _p]),
+    "tsii_bn_act_fwd": (_i, [_p, _l, _i, _p, _p, _p, _p, _f, _i, _f, _p, _p, _p]),
+    "tsii_bn_act_bwd": (_i, [_p, _p, _l, _i, _p, _p, _p, _p, _f, _i, _f, _i, _p, _p, _p, _p, _z, _p]),
+    "tsii_act_fwd": (_i, [_p, _l, _i, _f, _p, _p]),
+    "tsii_act_bwd": (_i, [_p, _p, _l, _i, _f, _p, _p]),
+    "tsii_upcat_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "tsii_upcat_bwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "tsii_l1_ws_bytes": (_z, [_l]),
+    "tsii_l1_mean_fwd": (_i, [_p, _p, _l, _p, _p, _z, _p]),
+    "tsii_l1_mean_bwd": (_i, [_p, _p, _l, _p, _p, _p]),
+    "tsii_sgd_nesterov": (_i, [_p, _p, _p, _l, _f, _f, _f, _p]),
+}
+
+_LIB = None
+
+
+def bind(cdll):
+    """Attach the header's signatures to a loaded library; fails if a symbol is missing."""
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(cdll, name)  # AttributeError -> missing export
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the MI355X HIP library has not been built "
+                "(python -m text_segmentation_image_inpainting_amd.build_ext). There is no CPU fallback.")
+        _LIB = bind(ctypes.CDLL(LIB_PATH))
+        if _LIB.tsii_version() != 1:
+            raise RuntimeError("libtsii_hip.so ABI version mismatch")
+    return _LIB
+
+
+def stream():
+    """hipStream_t of torch's current stream (the library enqueues on it, never syncs)."""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check_device(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("text_segmentation_image_inpainting_amd: tensors must live on a ROCm GPU "
+                           "(MI355X); this implementation has no CPU path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"text_segmentation_image_inpainting_amd: fp32 only, got {t.dtype}")
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def call(name, *args):
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {L.tsii_last_error().decode(errors='replace')}")

@@ -1,0 +1,90 @@
+"""Builds csrc/*.hip into libtsii_hip.so for gfx950 with hipcc (in-tree, no JIT cache).
+
+    python -m text_segmentation_image_inpainting_amd.build_ext [--force]
+
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container;
+the resulting .so travels to the GPU box with the repo snapshot.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libtsii_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm to build libtsii_hip.so)")
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest(paths):
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile_one(args):
+    hipcc, src, obj, stamp, dig = args
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return src, 0, "cached"
+    cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode == 0:
+        with open(stamp, "w") as f:
+            f.write(dig)
+    return src, r.returncode, r.stdout + r.stderr
+
+
+def build(force=False, verbose=True):
+    hipcc = _hipcc()
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "tsii_hip.h"))
+    jobs = []
+    for src in sources():
+        base = os.path.splitext(os.path.basename(src))[0]
+        obj = os.path.join(OBJ, base + ".o")
+        stamp = obj + ".sha"
+        dig = _digest([src] + sorted(headers))
+        if force and os.path.exists(stamp):
+            os.remove(stamp)
+        jobs.append((hipcc, src, obj, stamp, dig))
+    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+        results = list(ex.map(_compile_one, jobs))
+    failed = [(s, out) for s, rc, out in results if rc != 0]
+    for s, rc, out in results:
+        if verbose and out and out != "cached":
+            print(f"[build_ext] {os.path.basename(s)}:\n{out}", file=sys.stderr)
+    if failed:
+        raise RuntimeError("hipcc failed for: " + ", ".join(os.path.basename(s) for s, _ in failed))
+    objs = [j[2] for j in jobs]
+    relink = force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)
+    if relink:
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+    if verbose:
+        print(f"[build_ext] {LIB} ({'relinked' if relink else 'up to date'})")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

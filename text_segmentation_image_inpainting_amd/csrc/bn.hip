@@ -1,0 +1,273 @@
+// K6: BatchNorm2d (+ activation, + residual add) forward / backward on [M, C] NHWC activations
+// (nn.Sequential(BatchNorm2d, act) of models/partial_convolution.py:193-197; residual adds of
+// models/MobileNetV2.py:186-187 and models/image_inpainting.py:216).
+//
+// HBM-bound.  Statistics: task (partial row r, 4-channel group) strides over rows r, r+R, ... with
+// 16-byte loads; sums are taken about a per-channel pivot (row 0) so that E[d^2]-E[d]^2 does not
+// cancel, partial rows are combined in fp64.  Apply / backward-apply are single streaming passes.
+#include "tsii_common.h"
+
+namespace tsii {
+
+template <int W>
+__global__ void bn_stats_partial_kernel(const float* __restrict__ y, int64_t M, int C, int R,
+                                        float* __restrict__ part) {
+    const int CG = C / W;
+    const int64_t tasks = (int64_t)R * CG;
+    for (int64_t task = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; task < tasks; task += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(task % CG) * W;
+        const int r = (int)(task / CG);
+        const VecF<W> piv = vload<W>(y + c);
+        float s1[W], s2[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+        for (int64_t m = r; m < M; m += R) {
+            const VecF<W> v = vload<W>(y + m * C + c);
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const float d = v.v[i] - piv.v[i];
+                s1[i] += d;
+                s2[i] = fmaf(d, d, s2[i]);
+            }
+        }
+        float* p = part + (int64_t)r * 2 * C;
+#pragma unroll
+        for (int i = 0; i < W; ++i) { p[c + i] = s1[i]; p[C + c + i] = s2[i]; }
+    }
+}
+
+__global__ void bn_stats_final_kernel(const float* __restrict__ y, const float* __restrict__ part, int R, int64_t M, int C,
+                                      float* __restrict__ mean, float* __restrict__ var,
+                                      float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < R; ++r) {
+            s1 += (double)part[(int64_t)r * 2 * C + c];
+            s2 += (double)part[(int64_t)r * 2 * C + C + c];
+        }
+        const double e1 = s1 / (double)M;
+        double v = s2 / (double)M - e1 * e1;
+        if (v < 0.0) v = 0.0;
+        const double mu = (double)y[c] + e1;
+        mean[c] = (float)mu;
+        var[c] = (float)v;
+        if (running_mean != nullptr) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        if (running_var != nullptr) {
+            const double unb = M > 1 ? v * (double)M / (double)(M - 1) : v;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    }
+}
+
+template <int W>
+__global__ void bn_act_fwd_kernel(const float* __restrict__ y, int64_t M, int C, const float* __restrict__ mean,
+                                  const float* __restrict__ var, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, float eps, int act, float slope,
+                                  const float* __restrict__ residual, float* __restrict__ out) {
+    const int CG = C / W;
+    const int64_t total = M * CG;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % CG) * W;
+        const int64_t off = (idx / CG) * C + c;
+        VecF<W> v = vload<W>(y + off);
+        VecF<W> res;
+        if (residual != nullptr) res = vload<W>(residual + off);
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const float istd = 1.0f / sqrtf(var[c + i] + eps);
+            float z = (v.v[i] - mean[c + i]) * istd * gamma[c + i] + beta[c + i];
+            z = apply_act(z, act, slope);
+            if (residual != nullptr) z += res.v[i];
+            v.v[i] = z;
+        }
+        vstore<W>(out + off, v);
+    }
+}
+
+// backward pass 1: per-channel s1 = sum dz, s2 = sum dz * xhat, dz = dout * act'(z)
+template <int W>
+__global__ void bn_bwd_partial_kernel(const float* __restrict__ dout, const float* __restrict__ y, int64_t M, int C,
+                                      const float* __restrict__ mean, const float* __restrict__ var,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                      int act, float slope, int R, float* __restrict__ part) {
+    const int CG = C / W;
+    const int64_t tasks = (int64_t)R * CG;
+    for (int64_t task = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; task < tasks; task += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(task % CG) * W;
+        const int r = (int)(task / CG);
+        float mu[W], istd[W], ga[W], be[W], s1[W], s2[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            mu[i] = mean[c + i]; istd[i] = 1.0f / sqrtf(var[c + i] + eps);
+            ga[i] = gamma[c + i]; be[i] = beta[c + i]; s1[i] = 0.f; s2[i] = 0.f;
+        }
+        for (int64_t m = r; m < M; m += R) {
+            const VecF<W> yv = vload<W>(y + m * C + c);
+            const VecF<W> dv = vload<W>(dout + m * C + c);
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const float xh = (yv.v[i] - mu[i]) * istd[i];
+                const float z = xh * ga[i] + be[i];
+                const float dz = dv.v[i] * act_grad(z, act, slope);
+                s1[i] += dz;
+                s2[i] = fmaf(dz, xh, s2[i]);
+            }
+        }
+        float* p = part + (int64_t)r * 2 * C;
+#pragma unroll
+        for (int i = 0; i < W; ++i) { p[c + i] = s1[i]; p[C + c + i] = s2[i]; }
+    }
+}
+
+__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int R, int C, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < R; ++r) {
+            s1 += (double)part[(int64_t)r * 2 * C + c];
+            s2 += (double)part[(int64_t)r * 2 * C + C + c];
+        }
+        dbeta[c] = (float)s1;
+        dgamma[c] = (float)s2;
+    }
+}
+
+// backward pass 2: dy = gamma*istd*(dz - s1/M - xhat*s2/M)   (training)  |  gamma*istd*dz  (eval)
+template <int W>
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y, int64_t M, int C,
+                                    const float* __restrict__ mean, const float* __restrict__ var,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                    int act, float slope, int training, const float* __restrict__ dgamma,
+                                    const float* __restrict__ dbeta, float* __restrict__ dy) {
+    const int CG = C / W;
+    const int64_t total = M * CG;
+    const float invM = 1.0f / (float)M;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % CG) * W;
+        const int64_t off = (idx / CG) * C + c;
+        const VecF<W> yv = vload<W>(y + off);
+        VecF<W> dv = vload<W>(dout + off);
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const float istd = 1.0f / sqrtf(var[c + i] + eps);
+            const float xh = (yv.v[i] - mean[c + i]) * istd;
+            const float z = xh * gamma[c + i] + beta[c + i];
+            float dz = dv.v[i] * act_grad(z, act, slope);
+            if (training) dz = dz - dbeta[c + i] * invM - xh * dgamma[c + i] * invM;
+            dv.v[i] = dz * gamma[c + i] * istd;
+        }
+        vstore<W>(dy + off, dv);
+    }
+}
+
+template <int W>
+__global__ void act_fwd_kernel(const float* __restrict__ x, int64_t n4, int act, float slope, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        VecF<W> v = vload<W>(x + i * W);
+#pragma unroll
+        for (int e = 0; e < W; ++e) v.v[e] = apply_act(v.v[e], act, slope);
+        vstore<W>(out + i * W, v);
+    }
+}
+template <int W>
+__global__ void act_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x, int64_t n4, int act,
+                               float slope, float* __restrict__ dx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const VecF<W> xv = vload<W>(x + i * W);
+        VecF<W> dv = vload<W>(dout + i * W);
+#pragma unroll
+        for (int e = 0; e < W; ++e) dv.v[e] *= act_grad(xv.v[e], act, slope);
+        vstore<W>(dx + i * W, dv);
+    }
+}
+
+static inline int bn_rows(int64_t m, int c) { return partial_rows(m, (c % 4 == 0) ? c / 4 : c); }
+
+}  // namespace tsii
+
+using namespace tsii;
+
+extern "C" size_t tsii_bn_ws_bytes(int64_t m, int c) {
+    if (m <= 0 || c <= 0) return 0;
+    return (size_t)bn_rows(m, c) * 2 * c * sizeof(float);
+}
+
+extern "C" int tsii_bn_stats(const float* y, int64_t m, int c, float* mean, float* var, float* running_mean,
+                             float* running_var, float momentum, void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(y && mean && var && ws, "bn_stats: null pointer");
+    TSII_REQUIRE(m > 0 && c > 0, "bn_stats: bad shape");
+    TSII_REQUIRE(ws_bytes >= tsii_bn_ws_bytes(m, c), "bn_stats: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int R = bn_rows(m, c);
+    const bool vec = (c % 4 == 0) && aligned16(y);
+    const int64_t tasks = (int64_t)R * (vec ? c / 4 : c);
+    float* part = (float*)ws;
+    if (vec) hipLaunchKernelGGL((bn_stats_partial_kernel<4>), dim3(stream_grid(tasks, 256)), dim3(256), 0, st, y, m, c, R, part);
+    else hipLaunchKernelGGL((bn_stats_partial_kernel<1>), dim3(stream_grid(tasks, 256)), dim3(256), 0, st, y, m, c, R, part);
+    int rc = check_launch("bn_stats_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, y, part, R, m, c, mean, var,
+                       running_mean, running_var, momentum);
+    return check_launch("bn_stats_final");
+}
+
+extern "C" int tsii_bn_act_fwd(const float* y, int64_t m, int c, const float* mean, const float* var,
+                               const float* gamma, const float* beta, float eps, int act, float slope,
+                               const float* residual, float* out, void* stream) {
+    TSII_REQUIRE(y && mean && var && gamma && beta && out, "bn_act_fwd: null pointer");
+    TSII_REQUIRE(m > 0 && c > 0, "bn_act_fwd: bad shape");
+    TSII_REQUIRE(act >= 0 && act <= 3, "bn_act_fwd: unknown activation %d", act);
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(out) && (residual == nullptr || aligned16(residual));
+    const int64_t total = m * (vec ? c / 4 : c);
+    if (vec) hipLaunchKernelGGL((bn_act_fwd_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, st, y, m, c, mean, var, gamma, beta, eps, act, slope, residual, out);
+    else hipLaunchKernelGGL((bn_act_fwd_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, st, y, m, c, mean, var, gamma, beta, eps, act, slope, residual, out);
+    return check_launch("bn_act_fwd");
+}
+
+extern "C" int tsii_bn_act_bwd(const float* dout, const float* y, int64_t m, int c, const float* mean,
+                               const float* var, const float* gamma, const float* beta, float eps, int act,
+                               float slope, int training, float* dy, float* dgamma, float* dbeta, void* ws,
+                               size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(dout && y && mean && var && gamma && beta && dy && dgamma && dbeta && ws, "bn_act_bwd: null pointer");
+    TSII_REQUIRE(m > 0 && c > 0, "bn_act_bwd: bad shape");
+    TSII_REQUIRE(ws_bytes >= tsii_bn_ws_bytes(m, c), "bn_act_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int R = bn_rows(m, c);
+    const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(dout) && aligned16(dy);
+    const int64_t tasks = (int64_t)R * (vec ? c / 4 : c);
+    float* part = (float*)ws;
+    if (vec) hipLaunchKernelGGL((bn_bwd_partial_kernel<4>), dim3(stream_grid(tasks, 256)), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta, eps, act, slope, R, part);
+    else hipLaunchKernelGGL((bn_bwd_partial_kernel<1>), dim3(stream_grid(tasks, 256)), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta, eps, act, slope, R, part);
+    int rc = check_launch("bn_bwd_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, part, R, c, dgamma, dbeta);
+    rc = check_launch("bn_bwd_final");
+    if (rc) return rc;
+    const int64_t total = m * (vec ? c / 4 : c);
+    if (vec) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta, eps, act, slope, training, dgamma, dbeta, dy);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta, eps, act, slope, training, dgamma, dbeta, dy);
+    return check_launch("bn_bwd_apply");
+}
+
+extern "C" int tsii_act_fwd(const float* x, int64_t numel, int act, float slope, float* out, void* stream) {
+    TSII_REQUIRE(x && out && numel > 0, "act_fwd: bad arguments");
+    TSII_REQUIRE(act >= 0 && act <= 3, "act_fwd: unknown activation %d", act);
+    hipStream_t st = (hipStream_t)stream;
+    if (numel % 4 == 0 && aligned16(x) && aligned16(out))
+        hipLaunchKernelGGL((act_fwd_kernel<4>), dim3(stream_grid(numel / 4, 256)), dim3(256), 0, st, x, numel / 4, act, slope, out);
+    else
+        hipLaunchKernelGGL((act_fwd_kernel<1>), dim3(stream_grid(numel, 256)), dim3(256), 0, st, x, numel, act, slope, out);
+    return check_launch("act_fwd");
+}
+
+extern "C" int tsii_act_bwd(const float* dout, const float* x, int64_t numel, int act, float slope, float* dx,
+                            void* stream) {
+    TSII_REQUIRE(dout && x && dx && numel > 0, "act_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (numel % 4 == 0 && aligned16(x) && aligned16(dout) && aligned16(dx))
+        hipLaunchKernelGGL((act_bwd_kernel<4>), dim3(stream_grid(numel / 4, 256)), dim3(256), 0, st, dout, x, numel / 4, act, slope, dx);
+    else
+        hipLaunchKernelGGL((act_bwd_kernel<1>), dim3(stream_grid(numel, 256)), dim3(256), 0, st, dout, x, numel, act, slope, dx);
+    return check_launch("act_bwd");
+}

@@ -1,0 +1,95 @@
+// Error plumbing + two tiny shared kernels (partial-row reduction, 2-D transpose).
+#include "tsii_common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+namespace tsii {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: HIP error %d (%s)", what, (int)e, hipGetErrorString(e));
+        return -1000 - (int)e;
+    }
+    return 0;
+}
+
+// ---- out[j] = sum_r ws[r][j] -------------------------------------------------
+__global__ void reduce_rows_kernel(const float* __restrict__ ws, int rows, int64_t len, float* __restrict__ out) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < len; j += (int64_t)gridDim.x * blockDim.x) {
+        double acc = 0.0;
+        for (int r = 0; r < rows; ++r) acc += (double)ws[(int64_t)r * len + j];
+        out[j] = (float)acc;
+    }
+}
+
+int launch_reduce_rows(const float* ws, int rows, int64_t len, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(stream_grid(len, 256)), dim3(256), 0, stream, ws, rows, len, out);
+    return check_launch("reduce_rows");
+}
+
+// ---- 2-D transpose through a padded 32x32 LDS tile -----------------------------
+__global__ void transpose_kernel(const float* __restrict__ in, int rows, int cols, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < rows && c < cols) ? in[(int64_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        int c = c0 + j, r = r0 + tx;  // out is [cols, rows]
+        if (c < cols && r < rows) out[(int64_t)c * rows + r] = tile[tx][j];
+    }
+}
+
+int launch_transpose(const float* in, int rows_in, int cols_in, float* out, hipStream_t stream) {
+    dim3 grid(cdiv(cols_in, 32), cdiv(rows_in, 32));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, rows_in, cols_in, out);
+    return check_launch("transpose");
+}
+
+// ---- scaled column sums (bias gradients) -----------------------------------------
+__global__ void colsum_partial_kernel(const float* __restrict__ a, const float* __restrict__ rowmul, int64_t M, int N,
+                                      int64_t rows_per_block, float* __restrict__ part) {
+    const int64_t mbeg = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t mend = (mbeg + rows_per_block < M) ? mbeg + rows_per_block : M;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float s = 0.f;
+        for (int64_t m = mbeg; m < mend; ++m) {
+            float v = a[m * N + n];
+            if (rowmul != nullptr) v *= rowmul[m];
+            s += v;
+        }
+        part[(int64_t)blockIdx.x * N + n] = s;
+    }
+}
+
+static inline int64_t colsum_rpb(int64_t M) { int64_t r = cdiv64(M, 512); return r < 64 ? 64 : r; }
+size_t colsum_ws_floats(int64_t M, int N) { return (size_t)cdiv64(M, colsum_rpb(M)) * N; }
+
+int launch_colsum_scaled(const float* a, const float* rowmul, int64_t M, int N, float* out, float* ws,
+                         hipStream_t stream) {
+    const int64_t rpb = colsum_rpb(M);
+    const int rows = (int)cdiv64(M, rpb);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(rows), dim3(256), 0, stream, a, rowmul, M, N, rpb, ws);
+    int rc = check_launch("colsum_partial");
+    if (rc) return rc;
+    return launch_reduce_rows(ws, rows, N, out, stream);
+}
+
+}  // namespace tsii
+
+extern "C" int tsii_version(void) { return TSII_ABI_VERSION; }
+extern "C" const char* tsii_last_error(void) { return tsii::g_err; }

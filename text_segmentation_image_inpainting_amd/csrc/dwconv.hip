@@ -1,0 +1,263 @@
+// K2: depth-wise partial convolution (PartialConv with groups == C, same_holes;
+// models/partial_convolution.py:49-80 as built at models/MobileNetV2.py:174-176).
+//
+// HBM-bound streaming stencil on NHWC data: one thread owns 4 consecutive channels (16-byte
+// loads, a wavefront covers 256 channels = 1 KiB of one pixel per tap); the x*mask multiply
+// (:51), the division by cnt*Cin (:61,71 -- the depth-wise quirk of SURVEY.md F6) and the hole
+// zeroing (:72) are fused, so x is read once (taps re-hit L1/L2) and y is written once.
+// The valid count comes from K1 (mask.hip) as the `denom`/`keep`/`inv` planes.
+#include "tsii_common.h"
+
+namespace tsii {
+
+struct DwGeom {
+    int n, h, w, c, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo;
+};
+
+// weights arrive as [C][T] (reference layout [C,1,kh,kw]); kernels read wT[T][C]
+template <int W>
+__global__ void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ rmask,
+                              const float* __restrict__ wT, const float* __restrict__ bias,
+                              const float* __restrict__ denom, const float* __restrict__ keep,
+                              DwGeom g, float* __restrict__ y) {
+    const int CG = g.c / W;
+    const int64_t total = (int64_t)g.n * g.ho * g.wo * CG;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % CG) * W;
+        const int64_t pix = idx / CG;
+        const int ox = (int)(pix % g.wo);
+        const int oy = (int)((pix / g.wo) % g.ho);
+        const int64_t n = pix / ((int64_t)g.wo * g.ho);
+        VecF<W> acc;
+#pragma unroll
+        for (int i = 0; i < W; ++i) acc.v[i] = 0.f;
+        const bool kp = keep != nullptr ? (keep[pix] != 0.f) : true;
+        if (kp) {
+            for (int ky = 0; ky < g.kh; ++ky) {
+                const int iy = oy * g.sh - g.ph + ky * g.dh;
+                if (iy < 0 || iy >= g.h) continue;
+                for (int kx = 0; kx < g.kw; ++kx) {
+                    const int ix = ox * g.sw - g.pw + kx * g.dw;
+                    if (ix < 0 || ix >= g.w) continue;
+                    const int64_t ipix = (n * g.h + iy) * g.w + ix;
+                    const float m = rmask != nullptr ? rmask[ipix] : 1.f;
+                    const VecF<W> xv = vload<W>(x + ipix * g.c + c);
+                    const VecF<W> wv = vload<W>(wT + (int64_t)(ky * g.kw + kx) * g.c + c);
+#pragma unroll
+                    for (int i = 0; i < W; ++i) acc.v[i] = fmaf(xv.v[i] * m, wv.v[i], acc.v[i]);
+                }
+            }
+            const float dn = denom != nullptr ? denom[pix] : 1.f;
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                float v = acc.v[i];
+                if (denom != nullptr) v = v / dn;
+                if (bias != nullptr) v += bias[c + i];
+                acc.v[i] = v;
+            }
+        }
+        vstore<W>(y + pix * g.c + c, acc);
+    }
+}
+
+template <int W>
+__global__ void dw_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
+                                 const float* __restrict__ wT, const float* __restrict__ rmask,
+                                 DwGeom g, float* __restrict__ dx) {
+    const int CG = g.c / W;
+    const int64_t total = (int64_t)g.n * g.h * g.w * CG;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % CG) * W;
+        const int64_t pix = idx / CG;
+        const int ix = (int)(pix % g.w);
+        const int iy = (int)((pix / g.w) % g.h);
+        const int64_t n = pix / ((int64_t)g.w * g.h);
+        VecF<W> acc;
+#pragma unroll
+        for (int i = 0; i < W; ++i) acc.v[i] = 0.f;
+        const float m = rmask != nullptr ? rmask[pix] : 1.f;
+        if (m != 0.f) {
+            for (int ky = 0; ky < g.kh; ++ky) {
+                const int ty = iy + g.ph - ky * g.dh;
+                if (ty < 0 || (ty % g.sh) != 0) continue;
+                const int oy = ty / g.sh;
+                if (oy >= g.ho) continue;
+                for (int kx = 0; kx < g.kw; ++kx) {
+                    const int tx = ix + g.pw - kx * g.dw;
+                    if (tx < 0 || (tx % g.sw) != 0) continue;
+                    const int ox = tx / g.sw;
+                    if (ox >= g.wo) continue;
+                    const int64_t opix = (n * g.ho + oy) * g.wo + ox;
+                    const float s = inv != nullptr ? inv[opix] : 1.f;
+                    const VecF<W> gv = vload<W>(dy + opix * g.c + c);
+                    const VecF<W> wv = vload<W>(wT + (int64_t)(ky * g.kw + kx) * g.c + c);
+#pragma unroll
+                    for (int i = 0; i < W; ++i) acc.v[i] = fmaf(gv.v[i] * s, wv.v[i], acc.v[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < W; ++i) acc.v[i] *= m;
+        }
+        vstore<W>(dx + pix * g.c + c, acc);
+    }
+}
+
+// dW partials: task (row r, channel group) walks output pixels r, r+R, ... and keeps up to 9 taps
+// x W channels (+ bias) in registers; part[r][(T+1)][C]
+static constexpr int DW_TAPS = 9;
+template <int W>
+__global__ void dw_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
+                                 const float* __restrict__ keep, const float* __restrict__ x, const float* __restrict__ rmask,
+                                 DwGeom g, int R, float* __restrict__ part) {
+    const int CG = g.c / W;
+    const int T = g.kh * g.kw;
+    const int64_t npix = (int64_t)g.n * g.ho * g.wo;
+    const int64_t tasks = (int64_t)R * CG;
+    for (int64_t task = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; task < tasks; task += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(task % CG) * W;
+        const int r = (int)(task / CG);
+        float* prow = part + (int64_t)r * (T + 1) * g.c;
+        for (int t0 = 0; t0 < T; t0 += DW_TAPS) {
+            float acc[DW_TAPS][W];
+            float accb[W];
+#pragma unroll
+            for (int t = 0; t < DW_TAPS; ++t)
+#pragma unroll
+                for (int i = 0; i < W; ++i) acc[t][i] = 0.f;
+#pragma unroll
+            for (int i = 0; i < W; ++i) accb[i] = 0.f;
+            for (int64_t pix = r; pix < npix; pix += R) {
+                if (keep != nullptr && keep[pix] == 0.f) continue;  // hole: no gradient flows (partial_convolution.py:72)
+                const float s = inv != nullptr ? inv[pix] : 1.f;
+                const int ox = (int)(pix % g.wo);
+                const int oy = (int)((pix / g.wo) % g.ho);
+                const int64_t n = pix / ((int64_t)g.wo * g.ho);
+                VecF<W> gv = vload<W>(dy + pix * g.c + c);
+#pragma unroll
+                for (int i = 0; i < W; ++i) { accb[i] += gv.v[i]; gv.v[i] *= s; }  // bias is added after the division
+#pragma unroll
+                for (int t = 0; t < DW_TAPS; ++t) {
+                    const int tt = t0 + t;
+                    if (tt >= T) break;
+                    const int ky = tt / g.kw, kx = tt % g.kw;
+                    const int iy = oy * g.sh - g.ph + ky * g.dh;
+                    const int ix = ox * g.sw - g.pw + kx * g.dw;
+                    if (iy < 0 || iy >= g.h || ix < 0 || ix >= g.w) continue;
+                    const int64_t ipix = (n * g.h + iy) * g.w + ix;
+                    const float m = rmask != nullptr ? rmask[ipix] : 1.f;
+                    if (m == 0.f) continue;
+                    const VecF<W> xv = vload<W>(x + ipix * g.c + c);
+#pragma unroll
+                    for (int i = 0; i < W; ++i) acc[t][i] = fmaf(gv.v[i], xv.v[i] * m, acc[t][i]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < DW_TAPS; ++t) {
+                const int tt = t0 + t;
+                if (tt >= T) break;
+#pragma unroll
+                for (int i = 0; i < W; ++i) prow[(int64_t)tt * g.c + c + i] = acc[t][i];
+            }
+            if (t0 == 0) {
+#pragma unroll
+                for (int i = 0; i < W; ++i) prow[(int64_t)T * g.c + c + i] = accb[i];
+            }
+        }
+    }
+}
+
+// sum the R partial rows and scatter back to the reference layout dw[c][t], db[c]
+__global__ void dw_reduce_kernel(const float* __restrict__ part, int R, int T, int C,
+                                 float* __restrict__ dwgt, float* __restrict__ dbias) {
+    const int64_t len = (int64_t)(T + 1) * C;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < len; j += (int64_t)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int r = 0; r < R; ++r) s += (double)part[(int64_t)r * len + j];
+        const int t = (int)(j / C), c = (int)(j % C);
+        if (t < T) dwgt[(int64_t)c * T + t] = (float)s;
+        else if (dbias != nullptr) dbias[c] = (float)s;
+    }
+}
+
+static int check_geom(const DwGeom& g, const char* who) {
+    TSII_REQUIRE(g.n > 0 && g.h > 0 && g.w > 0 && g.c > 0 && g.kh > 0 && g.kw > 0 && g.sh > 0 && g.sw > 0 &&
+                 g.dh > 0 && g.dw > 0 && g.ph >= 0 && g.pw >= 0, "%s: bad geometry", who);
+    TSII_REQUIRE(g.ho == (g.h + 2 * g.ph - g.dh * (g.kh - 1) - 1) / g.sh + 1 &&
+                 g.wo == (g.w + 2 * g.pw - g.dw * (g.kw - 1) - 1) / g.sw + 1,
+                 "%s: output size %dx%d inconsistent with conv geometry", who, g.ho, g.wo);
+    return 0;
+}
+
+}  // namespace tsii
+
+using namespace tsii;
+
+#define DW_GEOM() DwGeom g = {n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo}
+
+extern "C" int tsii_dw_fwd(const float* x, const float* rmask, const float* w, const float* bias,
+                           const float* denom, const float* keep, int n, int h, int wd, int c, int kh, int kw,
+                           int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo, float* y, float* ws,
+                           void* stream) {
+    TSII_REQUIRE(x && w && y && ws, "dw_fwd: null pointer");
+    DW_GEOM();
+    if (check_geom(g, "dw_fwd")) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_transpose(w, c, kh * kw, ws, st);  // [C][T] -> [T][C]
+    if (rc) return rc;
+    const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(ws);
+    const int64_t total = (int64_t)n * ho * wo * (vec ? c / 4 : c);
+    if (vec) hipLaunchKernelGGL((dw_fwd_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, st, x, rmask, ws, bias, denom, keep, g, y);
+    else hipLaunchKernelGGL((dw_fwd_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, st, x, rmask, ws, bias, denom, keep, g, y);
+    return check_launch("dw_fwd");
+}
+
+extern "C" int tsii_dw_bwd_dx(const float* dy, const float* inv, const float* w, const float* rmask,
+                              int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw,
+                              int dh, int dw, int ho, int wo, float* dx, float* ws, void* stream) {
+    TSII_REQUIRE(dy && w && dx && ws, "dw_bwd_dx: null pointer");
+    DW_GEOM();
+    if (check_geom(g, "dw_bwd_dx")) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_transpose(w, c, kh * kw, ws, st);
+    if (rc) return rc;
+    const bool vec = (c % 4 == 0) && aligned16(dy) && aligned16(dx) && aligned16(ws);
+    const int64_t total = (int64_t)n * h * wd * (vec ? c / 4 : c);
+    if (vec) hipLaunchKernelGGL((dw_bwd_dx_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, st, dy, inv, ws, rmask, g, dx);
+    else hipLaunchKernelGGL((dw_bwd_dx_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, st, dy, inv, ws, rmask, g, dx);
+    return check_launch("dw_bwd_dx");
+}
+
+static int dw_rows(int n, int ho, int wo, int c) {
+    const bool vec = (c % 4 == 0);
+    return partial_rows((int64_t)n * ho * wo, vec ? c / 4 : c);
+}
+
+extern "C" size_t tsii_dw_bwd_dw_ws_bytes(int n, int ho, int wo, int c, int kh, int kw) {
+    if (n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || kh <= 0 || kw <= 0) return 0;
+    return (size_t)dw_rows(n, ho, wo, c) * (size_t)(kh * kw + 1) * c * sizeof(float);
+}
+
+extern "C" int tsii_dw_bwd_dw(const float* dy, const float* inv, const float* keep, const float* x, const float* rmask,
+                              int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw,
+                              int dh, int dw, int ho, int wo, float* dwgt, float* dbias, void* ws, size_t ws_bytes,
+                              void* stream) {
+    TSII_REQUIRE(dy && x && dwgt && ws, "dw_bwd_dw: null pointer");
+    DW_GEOM();
+    if (check_geom(g, "dw_bwd_dw")) return -1;
+    TSII_REQUIRE(ws_bytes >= tsii_dw_bwd_dw_ws_bytes(n, ho, wo, c, kh, kw), "dw_bwd_dw: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int R = dw_rows(n, ho, wo, c);
+    const bool vec = (c % 4 == 0) && aligned16(dy) && aligned16(x);
+    const int64_t tasks = (int64_t)R * (vec ? c / 4 : c);
+    float* part = (float*)ws;
+    if (vec) hipLaunchKernelGGL((dw_bwd_dw_kernel<4>), dim3(stream_grid(tasks, 256)), dim3(256), 0, st, dy, inv, keep, x, rmask, g, R, part);
+    else {
+        // partial_rows() was sized for the vector path; the scalar path has 4x the tasks per row, still correct
+        hipLaunchKernelGGL((dw_bwd_dw_kernel<1>), dim3(stream_grid(tasks, 256)), dim3(256), 0, st, dy, inv, keep, x, rmask, g, R, part);
+    }
+    int rc = check_launch("dw_bwd_dw");
+    if (rc) return rc;
+    const int T = kh * kw;
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(stream_grid((int64_t)(T + 1) * c, 256)), dim3(256), 0, st, part, R, T, c, dwgt, dbias);
+    return check_launch("dw_reduce");
+}

@@ -1,0 +1,419 @@
+// K3: point-wise (1x1) partial convolution as an fp32 GEMM on the gfx950 matrix cores.
+//
+// NHWC activations make a 1x1 conv a row-major GEMM  Y[M,N] = X[M,K] * W[N,K]^T  with
+// M = N_img*H*W (up to 2M rows at 512^2 bs 32) and K,N in 32..1024.  fp32 parity (1e-3) rules
+// out bf16 inputs, so the kernels use v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 157 TF/s
+// peak = the fp32 vector peak but with one VGPR per operand and the VALU left free).
+//
+//   gemm_nt : C[M,N] = sum_k A[m,k]*rs(m,k) * B[n,k]      forward, and dX with B = W^T
+//   gemm_tn : C[P,Q] = sum_m A[m,p]*sa[m]  * B[m,q]*rs(m,q)   dW, split over m (partials + reduce)
+//
+// Block = 256 threads = 4 waves; 128x128 (or 128x64 / 128x32) output tile, BK = 32; A/B tiles
+// are staged global -> registers -> LDS with the next tile's global loads issued before the
+// MFMA phase of the current one.  LDS rows are padded to 36 floats so the ds_read_b128 fragment
+// reads (16-lane groups, 144-byte row stride) are bank-conflict free.  The mask multiply
+// (x*m, partial_convolution.py:51/123), the division by the valid count and the hole zeroing
+// (:66-72) ride in the tile loader / epilogue, so no masked copy of x is ever materialised.
+#include "tsii_common.h"
+
+namespace tsii {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int GEMM_BK = 32;
+static constexpr int GEMM_LDS = GEMM_BK + 4;  // padded row stride (floats)
+
+struct Epilogue {
+    const float* denom;  // [M] divide
+    const float* keep;   // [M] 0 -> output 0
+    const float* bias;   // [N]
+    RowScale cs;         // output scale per (row, col)
+};
+
+// ---- tile loaders ----------------------------------------------------------------------
+// NT: tile of ROWS x 32 floats from a row-major matrix (K contiguous); 8 float4 per row.
+template <int ROWS, bool VEC>
+__device__ __forceinline__ void nt_load(const float* __restrict__ P, int64_t ld, int64_t row0, int64_t nrows,
+                                        int k0, int K, const RowScale& rs, float4 (&regs)[ROWS / 32]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int f = tid + 256 * i;
+        const int r = f >> 3, c4 = f & 7;
+        const int64_t row = row0 + r;
+        const int k = k0 + c4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < nrows) {
+            const float* p = P + row * ld + k;
+            if (VEC) {
+                if (k < K) v = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (k + 0 < K) v.x = p[0];
+                if (k + 1 < K) v.y = p[1];
+                if (k + 2 < K) v.z = p[2];
+                if (k + 3 < K) v.w = p[3];
+            }
+            if (rs.r0 != nullptr) {
+                const float s0 = rs.r0[row];
+                const float s1 = rs.r1 != nullptr ? rs.r1[row] : 1.f;
+                v.x *= (k + 0 < rs.split) ? s0 : s1;
+                v.y *= (k + 1 < rs.split) ? s0 : s1;
+                v.z *= (k + 2 < rs.split) ? s0 : s1;
+                v.w *= (k + 3 < rs.split) ? s0 : s1;
+            }
+        }
+        regs[i] = v;
+    }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void nt_store(float* __restrict__ S, const float4 (&regs)[ROWS / 32]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int f = tid + 256 * i;
+        const int r = f >> 3, c4 = f & 7;
+        *reinterpret_cast<float4*>(S + r * GEMM_LDS + c4 * 4) = regs[i];
+    }
+}
+
+// XCD-aware bijective block remap: consecutive logical tiles (which share an A row panel)
+// land on the same XCD / L2 instead of being dealt round-robin over the 8 XCDs.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
+    const unsigned xcd = bid & 7u, local = bid >> 3;
+    const unsigned q = nblocks >> 3, r = nblocks & 7u;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
+template <int WM, int WN, int TM, int TN, bool VEC>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda, RowScale as,
+                                                      const float* __restrict__ B, int64_t ldb,
+                                                      float* __restrict__ C, int64_t ldc,
+                                                      int64_t M, int N, int K, Epilogue ep, unsigned ntn) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    static_assert(WM * WN == 4, "4 waves per block");
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * GEMM_LDS];
+    float* As = smem;
+    float* Bs = smem + BM * GEMM_LDS;
+
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t m0 = (int64_t)(bid / ntn) * BM;
+    const int n0 = (int)(bid % ntn) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, hi = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    float4 ra[BM / 32], rb[BN / 32];
+    const RowScale none = {nullptr, nullptr, 0};
+    nt_load<BM, VEC>(A, lda, m0, M, 0, K, as, ra);
+    nt_load<BN, VEC>(B, ldb, n0, N, 0, K, none, rb);
+    nt_store<BM>(As, ra);
+    nt_store<BN>(Bs, rb);
+    __syncthreads();
+
+    const int nk = (K + GEMM_BK - 1) / GEMM_BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1 < nk);
+        if (more) {  // next tile's global loads fly during the MFMA phase
+            nt_load<BM, VEC>(A, lda, m0, M, (kt + 1) * GEMM_BK, K, as, ra);
+            nt_load<BN, VEC>(B, ldb, n0, N, (kt + 1) * GEMM_BK, K, none, rb);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float a[TM][4], b[TN][4];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const float4 v = *reinterpret_cast<const float4*>(As + ((wm * TM + t) * 32 + li) * GEMM_LDS + 8 * s + 4 * hi);
+                a[t][0] = v.x; a[t][1] = v.y; a[t][2] = v.z; a[t][3] = v.w;
+            }
+#pragma unroll
+            for (int u = 0; u < TN; ++u) {
+                const float4 v = *reinterpret_cast<const float4*>(Bs + ((wn * TN + u) * 32 + li) * GEMM_LDS + 8 * s + 4 * hi);
+                b[u][0] = v.x; b[u][1] = v.y; b[u][2] = v.z; b[u][3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int u = 0; u < TN; ++u)
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[u][j], acc[t][u], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            nt_store<BM>(As, ra);
+            nt_store<BN>(Bs, rb);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: D[row=(r&3)+8*(r>>2)+4*hi][col=lane&31]
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = m0 + (wm * TM + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (row >= M) continue;
+            const float dn = ep.denom != nullptr ? ep.denom[row] : 1.f;
+            const bool kp = ep.keep != nullptr ? (ep.keep[row] != 0.f) : true;
+            float c0 = 1.f, c1 = 1.f;
+            if (ep.cs.r0 != nullptr) { c0 = ep.cs.r0[row]; c1 = ep.cs.r1 != nullptr ? ep.cs.r1[row] : 1.f; }
+#pragma unroll
+            for (int u = 0; u < TN; ++u) {
+                const int col = n0 + (wn * TN + u) * 32 + li;
+                if (col >= N) continue;
+                float v = acc[t][u][r];
+                if (ep.denom != nullptr) v = v / dn;
+                if (ep.bias != nullptr) v += ep.bias[col];
+                if (!kp) v = 0.f;
+                if (ep.cs.r0 != nullptr) v *= (col < ep.cs.split) ? c0 : c1;
+                C[row * ldc + col] = v;
+            }
+        }
+    }
+}
+
+// ---- TN (dW): reduction over rows m, operands are [m][channel] --------------------------
+template <int COLS, bool VEC>
+__device__ __forceinline__ void tn_load(const float* __restrict__ P, int64_t ld, int64_t m0, int64_t mend,
+                                        int c0, int ncols, const float* __restrict__ rowmul, const RowScale& rs,
+                                        float4 (&regs)[COLS / 32]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < COLS / 32; ++i) {
+        const int f = tid + 256 * i;
+        const int r = f / (COLS / 4), c4 = f % (COLS / 4);
+        const int64_t row = m0 + r;
+        const int c = c0 + c4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < mend) {
+            const float* p = P + row * ld + c;
+            if (VEC) {
+                if (c < ncols) v = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (c + 0 < ncols) v.x = p[0];
+                if (c + 1 < ncols) v.y = p[1];
+                if (c + 2 < ncols) v.z = p[2];
+                if (c + 3 < ncols) v.w = p[3];
+            }
+            if (rowmul != nullptr) {
+                const float s = rowmul[row];
+                v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+            }
+            if (rs.r0 != nullptr) {
+                const float s0 = rs.r0[row];
+                const float s1 = rs.r1 != nullptr ? rs.r1[row] : 1.f;
+                v.x *= (c + 0 < rs.split) ? s0 : s1;
+                v.y *= (c + 1 < rs.split) ? s0 : s1;
+                v.z *= (c + 2 < rs.split) ? s0 : s1;
+                v.w *= (c + 3 < rs.split) ? s0 : s1;
+            }
+        }
+        regs[i] = v;
+    }
+}
+
+template <int COLS>
+__device__ __forceinline__ void tn_store(float* __restrict__ S, const float4 (&regs)[COLS / 32]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < COLS / 32; ++i) {
+        const int f = tid + 256 * i;
+        const int r = f / (COLS / 4), c4 = f % (COLS / 4);
+        *reinterpret_cast<float4*>(S + r * COLS + c4 * 4) = regs[i];
+    }
+}
+
+template <int WM, int WN, int TM, int TN, bool VEC>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ sa,
+                                                      const float* __restrict__ B, int64_t ldb, RowScale sb,
+                                                      float* __restrict__ Cws, int64_t M, int P, int Q, int64_t chunk) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    static_assert(WM * WN == 4, "4 waves per block");
+    __shared__ __attribute__((aligned(16))) float smem[GEMM_BK * (BM + BN)];
+    float* As = smem;
+    float* Bs = smem + GEMM_BK * BM;
+
+    const int q0 = blockIdx.x * BN, p0 = blockIdx.y * BM;
+    const int64_t mbeg = (int64_t)blockIdx.z * chunk;
+    const int64_t mend = (mbeg + chunk < M) ? mbeg + chunk : M;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, hi = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    float4 ra[BM / 32], rb[BN / 32];
+    const RowScale none = {nullptr, nullptr, 0};
+    tn_load<BM, VEC>(A, lda, mbeg, mend, p0, P, sa, none, ra);
+    tn_load<BN, VEC>(B, ldb, mbeg, mend, q0, Q, nullptr, sb, rb);
+    tn_store<BM>(As, ra);
+    tn_store<BN>(Bs, rb);
+    __syncthreads();
+
+    for (int64_t mt = mbeg; mt < mend; mt += GEMM_BK) {
+        const bool more = (mt + GEMM_BK < mend);
+        if (more) {
+            tn_load<BM, VEC>(A, lda, mt + GEMM_BK, mend, p0, P, sa, none, ra);
+            tn_load<BN, VEC>(B, ldb, mt + GEMM_BK, mend, q0, Q, nullptr, sb, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < GEMM_BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) a[t] = As[(2 * kk + hi) * BM + (wm * TM + t) * 32 + li];
+#pragma unroll
+            for (int u = 0; u < TN; ++u) b[u] = Bs[(2 * kk + hi) * BN + (wn * TN + u) * 32 + li];
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int u = 0; u < TN; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[u], acc[t][u], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            tn_store<BM>(As, ra);
+            tn_store<BN>(Bs, rb);
+            __syncthreads();
+        }
+    }
+
+    float* Cz = Cws + (int64_t)blockIdx.z * P * Q;
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = p0 + (wm * TM + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (p >= P) continue;
+#pragma unroll
+            for (int u = 0; u < TN; ++u) {
+                const int q = q0 + (wn * TN + u) * 32 + li;
+                if (q < Q) Cz[(int64_t)p * Q + q] = acc[t][u][r];
+            }
+        }
+}
+
+// ---- host-side dispatch ----------------------------------------------------------------
+template <int WM, int WN, int TM, int TN>
+static int launch_nt_cfg(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, float* C, int64_t ldc,
+                         int64_t M, int N, int K, Epilogue ep, bool vec, hipStream_t stream) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const unsigned ntn = (unsigned)cdiv(N, BN);
+    const int64_t nblocks = cdiv64(M, BM) * ntn;
+    TSII_REQUIRE(nblocks < (1ll << 31), "gemm_nt: grid too large");
+    if (vec)
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, true>), dim3((unsigned)nblocks), dim3(256), 0, stream,
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, false>), dim3((unsigned)nblocks), dim3(256), 0, stream,
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn);
+    return check_launch("gemm_nt");
+}
+
+static int launch_nt(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, float* C, int64_t ldc,
+                     int64_t M, int N, int K, Epilogue ep, hipStream_t stream) {
+    const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && aligned16(A) && aligned16(B);
+    if (N % 128 == 0 || N > 192) return launch_nt_cfg<2, 2, 2, 2>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, vec, stream);
+    if (N > 32) return launch_nt_cfg<2, 2, 2, 1>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, vec, stream);
+    return launch_nt_cfg<4, 1, 1, 1>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, vec, stream);
+}
+
+struct TnPlan {
+    bool big;
+    int bm, bn;
+    int splits;
+    int64_t chunk;
+};
+static TnPlan plan_tn(int64_t M, int P, int Q) {
+    TnPlan pl;
+    pl.big = (P >= 128 && Q >= 128);
+    pl.bm = pl.bn = pl.big ? 128 : 64;
+    const int tiles = cdiv(P, pl.bm) * cdiv(Q, pl.bn);
+    int64_t want = 1024 / tiles;
+    if (want < 1) want = 1;
+    int64_t chunk = cdiv64(M, want);
+    if (chunk < 256) chunk = 256;
+    chunk = cdiv64(chunk, GEMM_BK) * GEMM_BK;
+    pl.chunk = chunk;
+    pl.splits = (int)cdiv64(M, chunk);
+    return pl;
+}
+
+}  // namespace tsii
+
+using namespace tsii;
+
+extern "C" int tsii_pw_fwd(const float* x, int64_t m, int k, const float* w, int n, const float* bias,
+                           const float* r0, int split, const float* r1, const float* denom, const float* keep,
+                           float* y, void* stream) {
+    TSII_REQUIRE(x && w && y, "pw_fwd: null pointer");
+    TSII_REQUIRE(m > 0 && k > 0 && n > 0, "pw_fwd: bad shape m=%lld k=%d n=%d", (long long)m, k, n);
+    RowScale as = {r0, r1, split};
+    Epilogue ep = {denom, keep, bias, {nullptr, nullptr, 0}};
+    return launch_nt(x, k, as, w, k, y, n, m, n, k, ep, (hipStream_t)stream);
+}
+
+extern "C" int tsii_pw_bwd_dx(const float* dy, int64_t m, int n, const float* w, int k, const float* inv,
+                              const float* r0, int split, const float* r1, float* dx, float* wt_ws, void* stream) {
+    TSII_REQUIRE(dy && w && dx && wt_ws, "pw_bwd_dx: null pointer");
+    TSII_REQUIRE(m > 0 && k > 0 && n > 0, "pw_bwd_dx: bad shape");
+    // W [n,k] -> Wt [k,n] so both GEMM operands are contraction-contiguous
+    int rc = launch_transpose(w, n, k, wt_ws, (hipStream_t)stream);
+    if (rc) return rc;
+    RowScale as = {inv, nullptr, n};  // g = dy * inv[m]
+    Epilogue ep = {nullptr, nullptr, nullptr, {r0, r1, split}};
+    return launch_nt(dy, n, as, wt_ws, n, dx, k, m, k, n, ep, (hipStream_t)stream);
+}
+
+extern "C" size_t tsii_pw_bwd_dw_ws_bytes(int64_t m, int n, int k) {
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    TnPlan pl = plan_tn(m, n, k);
+    return ((size_t)pl.splits * n * k + colsum_ws_floats(m, n)) * sizeof(float);
+}
+
+extern "C" int tsii_pw_bwd_dw(const float* dy, const float* x, int64_t m, int n, int k, const float* inv,
+                              const float* keep, const float* r0, int split, const float* r1, float* dw, float* dbias,
+                              void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(dy && x && dw && ws, "pw_bwd_dw: null pointer");
+    TSII_REQUIRE(m > 0 && k > 0 && n > 0, "pw_bwd_dw: bad shape");
+    TSII_REQUIRE(ws_bytes >= tsii_pw_bwd_dw_ws_bytes(m, n, k), "pw_bwd_dw: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    TnPlan pl = plan_tn(m, n, k);
+    float* part = (float*)ws;
+    RowScale sb = {r0, r1, split};
+    const bool vec = (n % 4 == 0) && (k % 4 == 0) && aligned16(dy) && aligned16(x);
+    dim3 grid(cdiv(k, pl.bn), cdiv(n, pl.bm), pl.splits);
+    if (pl.big) {
+        if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk);
+        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, false>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk);
+    } else {
+        if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk);
+        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, false>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk);
+    }
+    int rc = check_launch("gemm_tn");
+    if (rc) return rc;
+    rc = launch_reduce_rows(part, pl.splits, (int64_t)n * k, dw, st);
+    if (rc) return rc;
+    if (dbias != nullptr) {
+        float* cpart = part + (size_t)pl.splits * n * k;
+        rc = launch_colsum_scaled(dy, keep, m, n, dbias, cpart, st);
+    }
+    return rc;
+}

@@ -1,0 +1,115 @@
+// Shared helpers for the gfx950 kernels of libtsii_hip.so (see include/tsii_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/tsii_hip.h"
+
+namespace tsii {
+
+// thread-local error string behind tsii_last_error()
+void set_error(const char* fmt, ...);
+// hipGetLastError() after a launch -> 0 / negative code with message
+int check_launch(const char* what);
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Streaming kernels use a capped grid + grid-stride loop: 256 CUs x 8 blocks.
+static inline unsigned stream_grid(int64_t work_items, int block) {
+    int64_t g = cdiv64(work_items, block);
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    if (act == TSII_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == TSII_ACT_LEAKY) return v > 0.f ? v : v * slope;
+    if (act == TSII_ACT_RELU6) return v < 0.f ? 0.f : (v > 6.f ? 6.f : v);
+    return v;
+}
+// derivative as a function of the pre-activation value (torch semantics: 0 at v <= 0,
+// ReLU6 passes gradient strictly inside (0,6))
+__device__ __forceinline__ float act_grad(float v, int act, float slope) {
+    if (act == TSII_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+    if (act == TSII_ACT_LEAKY) return v > 0.f ? 1.f : slope;
+    if (act == TSII_ACT_RELU6) return (v > 0.f && v < 6.f) ? 1.f : 0.f;
+    return 1.f;
+}
+
+// row scale (include/tsii_hip.h): r0 == nullptr -> 1
+struct RowScale {
+    const float* r0;
+    const float* r1;
+    int split;
+};
+__device__ __forceinline__ float row_scale_at(const RowScale& rs, int64_t row, int ch) {
+    if (rs.r0 == nullptr) return 1.f;
+    return ch < rs.split ? rs.r0[row] : (rs.r1 != nullptr ? rs.r1[row] : 1.f);
+}
+
+// generic helpers shared across translation units (reduce.hip)
+// out[j] = sum_r ws[r*len + j]  (double accumulation), r in [0,rows)
+int launch_reduce_rows(const float* ws, int rows, int64_t len, float* out, hipStream_t stream);
+// out[c*rows_in + r] = in[r*cols_in + c]  (2-D transpose of a [rows_in, cols_in] matrix)
+int launch_transpose(const float* in, int rows_in, int cols_in, float* out, hipStream_t stream);
+
+// out[n] = sum_m a[m*N+n] * rowmul[m] (rowmul may be null); ws: colsum_ws_floats(M,N) floats
+size_t colsum_ws_floats(int64_t M, int N);
+int launch_colsum_scaled(const float* a, const float* rowmul, int64_t M, int N, float* out, float* ws,
+                         hipStream_t stream);
+
+// number of partial rows for per-channel reductions over M rows with CG channel groups
+static inline int partial_rows(int64_t M, int CG) {
+    int64_t r = 131072 / (CG > 0 ? CG : 1);
+    if (r > 4096) r = 4096;
+    if (r > M) r = M;
+    if (r < 1) r = 1;
+    return (int)r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// W consecutive floats handled by one thread (W == 4: one 16-byte access)
+template <int W>
+struct VecF {
+    float v[W];
+};
+template <int W>
+__device__ __forceinline__ VecF<W> vload(const float* __restrict__ p) {
+    VecF<W> r;
+    if constexpr (W == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < W; ++i) r.v[i] = p[i];
+    }
+    return r;
+}
+template <int W>
+__device__ __forceinline__ void vstore(float* __restrict__ p, const VecF<W>& r) {
+    if constexpr (W == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < W; ++i) p[i] = r.v[i];
+    }
+}
+
+}  // namespace tsii
+
+#define TSII_REQUIRE(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            tsii::set_error(__VA_ARGS__);       \
+            return -1;                          \
+        }                                       \
+    } while (0)

@@ -1,0 +1,102 @@
+// K7: nearest x2 up-sampling + channel concat with the encoder skip
+// (DoubleUpSample, models/partial_convolution.py:229-231 + torch.cat, models/image_inpainting.py:82-85).
+// One streaming pass writes the concatenated NHWC tensor; the mask side of the same operation
+// never materialises (masks stay [N,H,W] planes, see mask.hip / tsii_plane_upsample2x).
+#include "tsii_common.h"
+
+namespace tsii {
+
+template <int W>
+__global__ void upcat_fwd_kernel(const float* __restrict__ low, const float* __restrict__ skip, int n, int h, int w,
+                                 int c1, int c2, float* __restrict__ out) {
+    const int C = c1 + c2, CG = C / W;
+    const int h2 = 2 * h, w2 = 2 * w;
+    const int64_t total = (int64_t)n * h2 * w2 * CG;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % CG) * W;
+        const int64_t pix = idx / CG;
+        const int x = (int)(pix % w2);
+        const int y = (int)((pix / w2) % h2);
+        const int64_t b = pix / ((int64_t)w2 * h2);
+        VecF<W> v;
+        if (c < c1) v = vload<W>(low + ((b * h + (y >> 1)) * w + (x >> 1)) * c1 + c);
+        else v = vload<W>(skip + pix * c2 + (c - c1));
+        vstore<W>(out + pix * C + c, v);
+    }
+}
+
+template <int W>
+__global__ void upcat_bwd_low_kernel(const float* __restrict__ dout, int n, int h, int w, int c1, int c2,
+                                     float* __restrict__ dlow) {
+    const int C = c1 + c2, CG = c1 / W;
+    const int w2 = 2 * w;
+    const int64_t total = (int64_t)n * h * w * CG;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % CG) * W;
+        const int64_t pix = idx / CG;
+        const int x = (int)(pix % w);
+        const int y = (int)((pix / w) % h);
+        const int64_t b = pix / ((int64_t)w * h);
+        const int64_t p00 = (b * 2 * h + 2 * y) * w2 + 2 * x;
+        const VecF<W> a0 = vload<W>(dout + p00 * C + c);
+        const VecF<W> a1 = vload<W>(dout + (p00 + 1) * C + c);
+        const VecF<W> a2 = vload<W>(dout + (p00 + w2) * C + c);
+        const VecF<W> a3 = vload<W>(dout + (p00 + w2 + 1) * C + c);
+        VecF<W> s;
+#pragma unroll
+        for (int i = 0; i < W; ++i) s.v[i] = (a0.v[i] + a1.v[i]) + (a2.v[i] + a3.v[i]);
+        vstore<W>(dlow + pix * c1 + c, s);
+    }
+}
+
+template <int W>
+__global__ void upcat_bwd_skip_kernel(const float* __restrict__ dout, int64_t npix, int c1, int c2,
+                                      float* __restrict__ dskip) {
+    const int C = c1 + c2, CG = c2 / W;
+    const int64_t total = npix * CG;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % CG) * W;
+        const int64_t pix = idx / CG;
+        vstore<W>(dskip + pix * c2 + c, vload<W>(dout + pix * C + c1 + c));
+    }
+}
+
+}  // namespace tsii
+
+using namespace tsii;
+
+extern "C" int tsii_upcat_fwd(const float* low, const float* skip, int n, int h, int w, int c1, int c2, float* out,
+                              void* stream) {
+    TSII_REQUIRE(low && out && (skip || c2 == 0), "upcat_fwd: null pointer");
+    TSII_REQUIRE(n > 0 && h > 0 && w > 0 && c1 > 0 && c2 >= 0, "upcat_fwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (c1 % 4 == 0) && (c2 % 4 == 0) && aligned16(low) && (c2 == 0 || aligned16(skip)) && aligned16(out);
+    const int64_t total = (int64_t)n * 4 * h * w * (vec ? (c1 + c2) / 4 : (c1 + c2));
+    if (vec) hipLaunchKernelGGL((upcat_fwd_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, st, low, skip, n, h, w, c1, c2, out);
+    else hipLaunchKernelGGL((upcat_fwd_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, st, low, skip, n, h, w, c1, c2, out);
+    return check_launch("upcat_fwd");
+}
+
+extern "C" int tsii_upcat_bwd(const float* dout, int n, int h, int w, int c1, int c2, float* dlow, float* dskip,
+                              void* stream) {
+    TSII_REQUIRE(dout, "upcat_bwd: null pointer");
+    TSII_REQUIRE(n > 0 && h > 0 && w > 0 && c1 > 0 && c2 >= 0, "upcat_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (c1 % 4 == 0) && (c2 % 4 == 0) && aligned16(dout) && (!dlow || aligned16(dlow)) && (!dskip || aligned16(dskip));
+    int rc = 0;
+    if (dlow != nullptr) {
+        const int64_t total = (int64_t)n * h * w * (vec ? c1 / 4 : c1);
+        if (vec) hipLaunchKernelGGL((upcat_bwd_low_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, st, dout, n, h, w, c1, c2, dlow);
+        else hipLaunchKernelGGL((upcat_bwd_low_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, st, dout, n, h, w, c1, c2, dlow);
+        rc = check_launch("upcat_bwd_low");
+        if (rc) return rc;
+    }
+    if (dskip != nullptr && c2 > 0) {
+        const int64_t npix = (int64_t)n * 4 * h * w;
+        const int64_t total = npix * (vec ? c2 / 4 : c2);
+        if (vec) hipLaunchKernelGGL((upcat_bwd_skip_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, st, dout, npix, c1, c2, dskip);
+        else hipLaunchKernelGGL((upcat_bwd_skip_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, st, dout, npix, c1, c2, dskip);
+        rc = check_launch("upcat_bwd_skip");
+    }
+    return rc;
+}

@@ -1,0 +1,422 @@
+"""autograd glue between the nn.Module mirror and the C ABI (include/tsii_hip.h).
+
+Every op works on NHWC-contiguous fp32 tensors ``[N, H, W, C]`` that live on the GPU and
+enqueues hand-written HIP kernels on torch's current stream.  PyTorch only provides the
+device memory, the stream and the autograd tape; there is no aten compute and no CPU path.
+Masks are carried as ``[N, H, W]`` planes (see ``masks.py``); they never require grad
+(models/partial_convolution.py:57 runs the mask path under ``no_grad``).
+"""
+from typing import NamedTuple, Optional
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr
+
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_RELU6 = 0, 1, 2, 3
+
+
+class Geom(NamedTuple):
+    kh: int
+    kw: int
+    sh: int
+    sw: int
+    ph: int
+    pw: int
+    dh: int
+    dw: int
+
+    def out_hw(self, h, w):
+        ho = (h + 2 * self.ph - self.dh * (self.kh - 1) - 1) // self.sh + 1
+        wo = (w + 2 * self.pw - self.dw * (self.kw - 1) - 1) // self.sw + 1
+        return ho, wo
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def make_geom(kernel_size, stride=1, padding=0, dilation=1) -> Geom:
+    (kh, kw), (sh, sw), (ph, pw), (dh, dw) = _pair(kernel_size), _pair(stride), _pair(padding), _pair(dilation)
+    return Geom(kh, kw, sh, sw, ph, pw, dh, dw)
+
+
+def _ws(nbytes: int, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty(max(4, (int(nbytes) + 3) // 4), dtype=torch.float32, device=like.device)
+
+
+def _c(t: Optional[torch.Tensor]):
+    return None if t is None else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------
+# K1 mask planes (no autograd)
+# ---------------------------------------------------------------------------------------
+def mask_channel_sum(mask_nchw: torch.Tensor, channels=None) -> torch.Tensor:
+    """plane[n,h,w] = sum over the first ``channels`` channels of an [N,C,H,W] mask (any strides)."""
+    _lib.check_device(mask_nchw)
+    n, c, h, w = mask_nchw.shape
+    c = c if channels is None else channels
+    plane = torch.empty((n, h, w), dtype=torch.float32, device=mask_nchw.device)
+    sn, sc, sh, sw = mask_nchw.stride()
+    call("tsii_mask_channel_sum", ptr(mask_nchw), n, h, w, c, sn, sh, sw, sc, ptr(plane), _lib.stream())
+    return plane
+
+
+def mask_update(p0, a0, p1, a1, g: Geom, post_scale: float, fill_holes: bool,
+                want_denom=True, want_mask=True, want_inv=True):
+    """K1: (denom, new_mask, inv) planes at the conv's output resolution."""
+    _lib.check_device(p0)
+    n, h, w = p0.shape
+    ho, wo = g.out_hw(h, w)
+    mk = lambda want: torch.empty((n, ho, wo), dtype=torch.float32, device=p0.device) if want else None
+    denom, new_mask, inv = mk(want_denom), mk(want_mask), mk(want_inv)
+    call("tsii_mask_update", ptr(p0), float(a0), ptr(p1), float(a1), n, h, w, *g, ho, wo,
+         float(post_scale), int(bool(fill_holes)), ptr(denom), ptr(new_mask), ptr(inv), _lib.stream())
+    return denom, new_mask, inv
+
+
+def plane_upsample2x(p: torch.Tensor) -> torch.Tensor:
+    _lib.check_device(p)
+    n, h, w = p.shape
+    out = torch.empty((n, 2 * h, 2 * w), dtype=torch.float32, device=p.device)
+    call("tsii_plane_upsample2x", ptr(p), n, h, w, ptr(out), _lib.stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# K3 point-wise partial convolution
+# ---------------------------------------------------------------------------------------
+class _Pointwise(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, r0, r1, denom, keep, inv, split):
+        _lib.check_device(x)
+        x, w = x.contiguous(), w.contiguous()
+        n, h, wd, k = x.shape
+        cout = w.shape[0]
+        assert w.shape[1] == k and w.shape[2] == 1 and w.shape[3] == 1, "point-wise weight must be [Cout,Cin,1,1]"
+        m = n * h * wd
+        y = torch.empty((n, h, wd, cout), dtype=torch.float32, device=x.device)
+        call("tsii_pw_fwd", ptr(x), m, k, ptr(w), cout, ptr(bias), ptr(r0), int(split), ptr(r1),
+             ptr(denom), ptr(keep), ptr(y), _lib.stream())
+        ctx.save_for_backward(x, w, r0, r1, inv, keep)
+        ctx.split, ctx.has_bias = int(split), bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, r0, r1, inv, keep = ctx.saved_tensors
+        gy = gy.contiguous()
+        n, h, wd, k = x.shape
+        cout = w.shape[0]
+        m = n * h * wd
+        dx = dw = db = None
+        st = _lib.stream()
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            wt = _ws(4 * k * cout, x)
+            call("tsii_pw_bwd_dx", ptr(gy), m, cout, ptr(w), k, ptr(inv), ptr(r0), ctx.split, ptr(r1),
+                 ptr(dx), ptr(wt), st)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(w)
+            db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            nbytes = _lib.lib().tsii_pw_bwd_dw_ws_bytes(m, cout, k)
+            ws = _ws(nbytes, x)
+            call("tsii_pw_bwd_dw", ptr(gy), ptr(x), m, cout, k, ptr(inv), ptr(keep), ptr(r0), ctx.split, ptr(r1),
+                 ptr(dw), ptr(db), ptr(ws), nbytes, st)
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def pconv_pointwise(x, w, bias=None, r0=None, split=0, r1=None, denom=None, keep=None, inv=None):
+    """y = keep ? (x*rs) @ w^T / denom + bias : 0   (include/tsii_hip.h, K3)."""
+    return _Pointwise.apply(x, w, bias, r0, r1, denom, keep, inv, split)
+
+
+# ---------------------------------------------------------------------------------------
+# K2 depth-wise partial convolution
+# ---------------------------------------------------------------------------------------
+class _Depthwise(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, rmask, denom, keep, inv, g):
+        _lib.check_device(x)
+        x, w = x.contiguous(), w.contiguous()
+        n, h, wd, c = x.shape
+        assert w.shape[0] == c and w.shape[1] == 1, "depth-wise weight must be [C,1,kh,kw]"
+        ho, wo = g.out_hw(h, wd)
+        y = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
+        ws = _ws(4 * c * g.kh * g.kw, x)
+        call("tsii_dw_fwd", ptr(x), ptr(rmask), ptr(w), ptr(bias), ptr(denom), ptr(keep), n, h, wd, c, *g,
+             ho, wo, ptr(y), ptr(ws), _lib.stream())
+        ctx.save_for_backward(x, w, rmask, inv, keep)
+        ctx.g, ctx.has_bias = g, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, rmask, inv, keep = ctx.saved_tensors
+        g = ctx.g
+        gy = gy.contiguous()
+        n, h, wd, c = x.shape
+        ho, wo = g.out_hw(h, wd)
+        st = _lib.stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            ws = _ws(4 * c * g.kh * g.kw, x)
+            call("tsii_dw_bwd_dx", ptr(gy), ptr(inv), ptr(w), ptr(rmask), n, h, wd, c, *g, ho, wo,
+                 ptr(dx), ptr(ws), st)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(w)
+            db = torch.empty(c, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            nbytes = _lib.lib().tsii_dw_bwd_dw_ws_bytes(n, ho, wo, c, g.kh, g.kw)
+            ws = _ws(nbytes, x)
+            call("tsii_dw_bwd_dw", ptr(gy), ptr(inv), ptr(keep), ptr(x), ptr(rmask), n, h, wd, c, *g, ho, wo,
+                 ptr(dw), ptr(db), ptr(ws), nbytes, st)
+        return dx, dw, db, None, None, None, None, None
+
+
+def pconv_depthwise(x, w, bias, rmask, denom, keep, inv, g: Geom):
+    return _Depthwise.apply(x, w, bias, rmask, denom, keep, inv, g)
+
+
+# ---------------------------------------------------------------------------------------
+# K4 dense partial convolution (general path)
+# ---------------------------------------------------------------------------------------
+class _Dense(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, mfull, r0, r1, denom, keep, inv, split, g):
+        _lib.check_device(x)
+        x, w = x.contiguous(), w.contiguous()
+        n, h, wd, cin = x.shape
+        cout = w.shape[0]
+        assert w.shape[1] == cin, "dense partial conv needs groups == 1"
+        ho, wo = g.out_hw(h, wd)
+        y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+        L = _lib.lib()
+        nbytes = L.tsii_dense_ws_bytes(cin, cout, g.kh, g.kw)
+        ws = _ws(nbytes, x)
+        call("tsii_dense_fwd", ptr(x), ptr(mfull), ptr(r0), int(split), ptr(r1), ptr(w), ptr(bias),
+             ptr(denom), ptr(keep), n, h, wd, cin, cout, *g, ho, wo, ptr(y), ptr(ws), nbytes, _lib.stream())
+        ctx.save_for_backward(x, w, mfull, r0, r1, inv, keep)
+        ctx.g, ctx.split, ctx.has_bias = g, int(split), bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, mfull, r0, r1, inv, keep = ctx.saved_tensors
+        g = ctx.g
+        gy = gy.contiguous()
+        n, h, wd, cin = x.shape
+        cout = w.shape[0]
+        ho, wo = g.out_hw(h, wd)
+        L, st = _lib.lib(), _lib.stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            nbytes = L.tsii_dense_ws_bytes(cin, cout, g.kh, g.kw)
+            ws = _ws(nbytes, x)
+            call("tsii_dense_bwd_dx", ptr(gy), ptr(inv), ptr(w), ptr(mfull), ptr(r0), ctx.split, ptr(r1),
+                 n, h, wd, cin, cout, *g, ho, wo, ptr(dx), ptr(ws), nbytes, st)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(w)
+            db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            nbytes = L.tsii_dense_bwd_dw_ws_bytes(n, ho, wo, cin, cout, g.kh, g.kw)
+            ws = _ws(nbytes, x)
+            call("tsii_dense_bwd_dw", ptr(gy), ptr(inv), ptr(keep), ptr(x), ptr(mfull), ptr(r0), ctx.split, ptr(r1),
+                 n, h, wd, cin, cout, *g, ho, wo, ptr(dw), ptr(db), ptr(ws), nbytes, st)
+        return dx, dw, db, None, None, None, None, None, None, None, None
+
+
+def pconv_dense(x, w, bias, mfull, r0, split, r1, denom, keep, inv, g: Geom):
+    return _Dense.apply(x, w, bias, mfull, r0, r1, denom, keep, inv, split, g)
+
+
+# ---------------------------------------------------------------------------------------
+# K6 BatchNorm (+activation, +residual)
+# ---------------------------------------------------------------------------------------
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, slope):
+        _lib.check_device(y)
+        y = y.contiguous()
+        c = y.shape[-1]
+        m = y.numel() // c
+        st = _lib.stream()
+        if training:
+            mean = torch.empty(c, dtype=torch.float32, device=y.device)
+            var = torch.empty(c, dtype=torch.float32, device=y.device)
+            nbytes = _lib.lib().tsii_bn_ws_bytes(m, c)
+            ws = _ws(nbytes, y)
+            call("tsii_bn_stats", ptr(y), m, c, ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
+                 float(momentum), ptr(ws), nbytes, st)
+        else:
+            mean, var = running_mean, running_var
+        residual = _c(residual)
+        out = torch.empty_like(y)
+        call("tsii_bn_act_fwd", ptr(y), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), int(act),
+             float(slope), ptr(residual), ptr(out), st)
+        ctx.save_for_backward(y, mean, var, gamma, beta)
+        ctx.cfg = (bool(training), float(eps), int(act), float(slope), residual is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        y, mean, var, gamma, beta = ctx.saved_tensors
+        training, eps, act, slope, has_res = ctx.cfg
+        gout = gout.contiguous()
+        c = y.shape[-1]
+        m = y.numel() // c
+        dy = torch.empty_like(y)
+        dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
+        nbytes = _lib.lib().tsii_bn_ws_bytes(m, c)
+        ws = _ws(nbytes, y)
+        call("tsii_bn_act_bwd", ptr(gout), ptr(y), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), eps, act,
+             slope, int(training), ptr(dy), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _lib.stream())
+        return dy, dgamma, dbeta, None, None, (gout if has_res else None), None, None, None, None, None
+
+
+def bn_act(y, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5,
+           act=ACT_NONE, slope=0.0, residual=None):
+    return _BNAct.apply(y, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, slope)
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        _lib.check_device(x)
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        call("tsii_act_fwd", ptr(x), x.numel(), int(act), float(slope), ptr(out), _lib.stream())
+        ctx.save_for_backward(x)
+        ctx.cfg = (int(act), float(slope))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (x,) = ctx.saved_tensors
+        gout = gout.contiguous()
+        dx = torch.empty_like(x)
+        call("tsii_act_bwd", ptr(gout), ptr(x), x.numel(), ctx.cfg[0], ctx.cfg[1], ptr(dx), _lib.stream())
+        return dx, None, None
+
+
+def activation(x, act, slope=0.0):
+    return _Act.apply(x, act, slope)
+
+
+# ---------------------------------------------------------------------------------------
+# K7 nearest x2 up-sampling + concat
+# ---------------------------------------------------------------------------------------
+class _UpCat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, low, skip):
+        _lib.check_device(low)
+        low, skip = low.contiguous(), skip.contiguous()
+        n, h, w, c1 = low.shape
+        assert skip.shape[0] == n and skip.shape[1] == 2 * h and skip.shape[2] == 2 * w, "upcat: shape mismatch"
+        c2 = skip.shape[3]
+        out = torch.empty((n, 2 * h, 2 * w, c1 + c2), dtype=torch.float32, device=low.device)
+        call("tsii_upcat_fwd", ptr(low), ptr(skip), n, h, w, c1, c2, ptr(out), _lib.stream())
+        ctx.dims = (n, h, w, c1, c2)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        n, h, w, c1, c2 = ctx.dims
+        gout = gout.contiguous()
+        dlow = torch.empty((n, h, w, c1), dtype=torch.float32, device=gout.device) if ctx.needs_input_grad[0] else None
+        dskip = torch.empty((n, 2 * h, 2 * w, c2), dtype=torch.float32, device=gout.device) if ctx.needs_input_grad[1] else None
+        if dlow is not None or dskip is not None:
+            call("tsii_upcat_bwd", ptr(gout), n, h, w, c1, c2, ptr(dlow), ptr(dskip), _lib.stream())
+        return dlow, dskip
+
+
+def upcat(low, skip):
+    return _UpCat.apply(low, skip)
+
+
+class _Up2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _lib.check_device(x)
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        out = torch.empty((n, 2 * h, 2 * w, c), dtype=torch.float32, device=x.device)
+        call("tsii_upcat_fwd", ptr(x), None, n, h, w, c, 0, ptr(out), _lib.stream())
+        ctx.dims = (n, h, w, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        n, h, w, c = ctx.dims
+        gout = gout.contiguous()
+        dlow = torch.empty((n, h, w, c), dtype=torch.float32, device=gout.device)
+        call("tsii_upcat_bwd", ptr(gout), n, h, w, c, 0, ptr(dlow), None, _lib.stream())
+        return dlow
+
+
+def upsample2x(x):
+    """nearest x2 of an NHWC tensor (DoubleUpSample on x, models/partial_convolution.py:231)."""
+    return _Up2x.apply(x)
+
+
+# ---------------------------------------------------------------------------------------
+# general per-channel mask multiply and mean-L1 loss
+# ---------------------------------------------------------------------------------------
+class _MulMask(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask):
+        _lib.check_device(x)
+        x, mask = x.contiguous(), mask.contiguous()
+        assert x.shape == mask.shape
+        out = torch.empty_like(x)
+        call("tsii_mul_mask", ptr(x), ptr(mask), x.numel(), ptr(out), _lib.stream())
+        ctx.save_for_backward(mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (mask,) = ctx.saved_tensors
+        gout = gout.contiguous()
+        dx = torch.empty_like(gout)
+        call("tsii_mul_mask", ptr(gout), ptr(mask), gout.numel(), ptr(dx), _lib.stream())
+        return dx, None
+
+
+def mul_mask(x, mask_full):
+    return _MulMask.apply(x, mask_full)
+
+
+class _L1Mean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _lib.check_device(a)
+        a, b = a.contiguous(), b.contiguous()
+        assert a.shape == b.shape
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        nbytes = _lib.lib().tsii_l1_ws_bytes(a.numel())
+        ws = _ws(nbytes, a)
+        call("tsii_l1_mean_fwd", ptr(a), ptr(b), a.numel(), ptr(loss), ptr(ws), nbytes, _lib.stream())
+        ctx.save_for_backward(a, b)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.reshape(1).contiguous()
+        da = torch.empty_like(a)
+        call("tsii_l1_mean_bwd", ptr(a), ptr(b), a.numel(), ptr(g), ptr(da), _lib.stream())
+        return da, None
+
+
+def l1_mean(a, b):
+    """mean(|a - b|); both NHWC-contiguous with identical shape."""
+    return _L1Mean.apply(a, b)
+
+
+def sgd_nesterov_(p, grad, buf, lr, momentum, weight_decay):
+    _lib.check_device(p)
+    assert p.is_contiguous() and grad.is_contiguous() and buf.is_contiguous()
+    call("tsii_sgd_nesterov", ptr(p), ptr(grad), ptr(buf), p.numel(), float(lr), float(momentum),
+         float(weight_decay), _lib.stream())

@@ -1,0 +1,205 @@
+"""Host-side mirror of the reference's hard-gated partial convolution family
+(models/partial_convolution.py:20-231): same class names, constructor signatures,
+``forward((x, mask)) -> (out, new_mask)`` surface and ``state_dict`` keys
+(``feature_conv.weight/bias``, frozen all-ones ``mask_conv.weight``, ``bn_act.0.*``).
+
+The nn.Conv2d / nn.BatchNorm2d members only hold parameters (so keys, shapes and default
+initialisation match the reference); they are never called.  ``forward`` dispatches to the
+HIP kernels through ops.py: the all-ones mask convolution is replaced by the K1 box count on
+mask planes, x*mask / division / hole zeroing are fused into the conv kernels.
+Each module also has ``forward_nhwc(x_nhwc, MaskParts)``, the zero-copy internal protocol
+used by the mirrored networks.
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .BaseModels import BaseModule, act_code, to_nchw, to_nhwc
+from .masks import MaskParts, as_parts
+
+inplace_batch_norm = False  # reference: optional un-vendored InPlaceABN (:12-17); never available
+
+
+def _public_forward(module, args, **kw):
+    x, mask = args
+    keep_parts = isinstance(mask, MaskParts)
+    y, mp = module.forward_nhwc(to_nhwc(x), as_parts(mask), **kw)
+    return to_nchw(y), (mp if keep_parts else mp.as_tensor())
+
+
+class PartialConv(BaseModule):
+    # mask is binary, 0 is holes; 1 is not            (models/partial_convolution.py:20-80)
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1,
+                 padding=0, dilation=1, groups=1, bias=True, same_holes=False):
+        super().__init__()
+        self.feature_conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride,
+                                      padding, dilation, groups, bias)
+        nn.init.kaiming_normal_(self.feature_conv.weight)                       # :35
+        self.same_holes = same_holes
+        mask_in = 1 if same_holes else in_channels                              # :38-40
+        mask_out = 1 if same_holes else out_channels
+        mask_groups = 1 if same_holes else groups
+        self.mask_conv = nn.Conv2d(mask_in, mask_out, kernel_size, stride,
+                                   padding, dilation, mask_groups, bias=False)
+        torch.nn.init.constant_(self.mask_conv.weight, 1.0)                     # :44-47
+        for param in self.mask_conv.parameters():
+            param.requires_grad = False
+
+    fill_holes = True
+
+    def _geom(self):
+        fc = self.feature_conv
+        return ops.make_geom(fc.kernel_size, fc.stride, fc.padding, fc.dilation)
+
+    def forward_nhwc(self, x, mp):
+        fc = self.feature_conv
+        w, b = fc.weight, fc.bias
+        cin, cout, groups = fc.in_channels, fc.out_channels, fc.groups
+        g = self._geom()
+        if x.shape[-1] != cin or mp.channels != cin:
+            raise RuntimeError(f"PartialConv expects {cin} input channels, got x:{x.shape[-1]} mask:{mp.channels}")
+        # K1: valid-input count -> denom / new mask / reciprocal planes          (:57-66,74-75)
+        if self.same_holes:
+            p0, a0, p1, a1, post = mp.first_channel_plane(), 1.0, None, 0.0, float(cin)   # :59-61
+        elif groups == 1:
+            (p0, a0, p1, a1), post = mp.count_operands(), 1.0                            # :63
+        else:
+            raise NotImplementedError("grouped PartialConv without same_holes (per-group mask counts, "
+                                      "models/partial_convolution.py:63) is not used by any reference "
+                                      "network and has no HIP kernel")
+        denom, new_mask, inv = ops.mask_update(p0, a0, p1, a1, g, post, self.fill_holes)
+        keep = new_mask if self.fill_holes else None
+        pointwise = tuple(g) == (1, 1, 1, 1, 0, 0, 1, 1)
+        if groups == 1:
+            if mp.fusable:
+                r0, split, r1 = mp.row_scale()
+                if pointwise:
+                    y = ops.pconv_pointwise(x, w, b, r0, split, r1, denom, keep, inv)
+                else:
+                    y = ops.pconv_dense(x, w, b, None, r0, split, r1, denom, keep, inv, g)
+            else:
+                mfull = mp.full_nhwc()
+                if pointwise:
+                    y = ops.pconv_pointwise(ops.mul_mask(x, mfull), w, b, None, 0, None, denom, keep, inv)
+                else:
+                    y = ops.pconv_dense(x, w, b, mfull, None, 0, None, denom, keep, inv, g)
+        elif groups == cin == cout:
+            if mp.fusable and len(mp.parts) == 1:
+                y = ops.pconv_depthwise(x, w, b, mp.parts[0].plane, denom, keep, inv, g)
+            else:
+                y = ops.pconv_depthwise(ops.mul_mask(x, mp.full_nhwc()), w, b, None, denom, keep, inv, g)
+        else:
+            raise NotImplementedError(f"PartialConv groups={groups} (neither 1 nor depth-wise) has no HIP kernel")
+        return y, MaskParts.from_plane(new_mask, cout)                                  # :74-77
+
+    def forward(self, args):
+        return _public_forward(self, args)
+
+
+class PartialConv1x1(BaseModule):
+    """Plain 1x1 conv of x (no x*mask); mask = channel 0 expanded (models/partial_convolution.py:83-105)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1,
+                 padding=0, dilation=1, groups=1, bias=True):
+        super().__init__()
+        assert kernel_size == 1 and stride == 1 and padding == 0                 # :96
+        self.feature_conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride,
+                                      padding, dilation, groups, bias)
+        nn.init.kaiming_normal_(self.feature_conv.weight)
+
+    def forward_nhwc(self, x, mp):
+        fc = self.feature_conv
+        if fc.groups != 1:
+            raise NotImplementedError("grouped PartialConv1x1 has no HIP kernel")
+        y = ops.pconv_pointwise(x, fc.weight, fc.bias)
+        return y, MaskParts.from_plane(mp.first_channel_plane(), fc.out_channels)  # :104
+
+    def forward(self, args):
+        return _public_forward(self, args)
+
+
+class PartialConvNoHoles(PartialConv):
+    """No hole handling (0/0 -> NaN), new mask all ones (models/partial_convolution.py:108-137)."""
+
+    fill_holes = False
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1,
+                 padding=0, dilation=1, groups=1, bias=True):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+        assert self.feature_conv.groups == 1                                     # :119
+
+
+class PartialActivatedBN(BaseModule):
+    """(BatchNorm2d -> activation)(x), mask passthrough (models/partial_convolution.py:183-201)."""
+
+    def __init__(self, channel, act_fn):
+        super().__init__()
+        if act_fn:
+            self.bn_act = nn.Sequential(nn.BatchNorm2d(channel), act_fn)         # :195
+        else:
+            self.bn_act = nn.Sequential(nn.BatchNorm2d(channel))                 # :197
+
+    def forward_nhwc(self, x, mp, residual=None):
+        bn = self.bn_act[0]
+        act, slope = act_code(self.bn_act[1] if len(self.bn_act) > 1 else None)
+        training = bn.training or bn.running_mean is None
+        if training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        momentum = 0.1 if bn.momentum is None else bn.momentum
+        y = ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
+                       momentum, bn.eps, act, slope, residual)
+        return y, mp
+
+    def forward(self, args):
+        return _public_forward(self, args)
+
+
+class PartialActivation(BaseModule):
+    def __init__(self, activation):                                              # :204-211
+        super().__init__()
+        self.act_fn = activation
+
+    def forward_nhwc(self, x, mp):
+        act, slope = act_code(self.act_fn)
+        return ops.activation(x, act, slope), mp
+
+    def forward(self, args):
+        return _public_forward(self, args)
+
+
+class DoubleUpSample(nn.Module):
+    """Nearest x2 on x and on the mask (models/partial_convolution.py:224-231)."""
+
+    def __init__(self, scale_factor, mode="nearest"):
+        super().__init__()
+        if scale_factor != 2 or mode != "nearest":
+            raise NotImplementedError("only the nearest x2 up-sampling the reference networks use has a HIP kernel")
+        self.upsample = nn.Upsample(scale_factor=scale_factor, mode=mode)  # attribute kept for parity; never called
+
+    def forward_nhwc(self, x, mp):
+        if not (mp.fusable and len(mp.parts) == 1 and mp.parts[0].planar):
+            # general per-channel mask: up-sample it like a feature map
+            up = ops.upsample2x(mp.full_nhwc())
+            from .masks import Part
+            return ops.upsample2x(x), MaskParts([Part(mp.channels, full=up)])
+        return ops.upsample2x(x), mp.upsample2x()
+
+    def forward(self, args):
+        return _public_forward(self, args)
+
+
+def partial_convolution_block(in_channels, out_channels, kernel_size, stride=1, padding=0,
+                              dilation=1, groups=1, bias=False, BN=True, activation=True,
+                              use_1_conv=False, no_holes_1_conv=False, same_holes=False):
+    """models/partial_convolution.py:163-180 (note: same_holes only reaches PartialConv, :173-174)."""
+    if use_1_conv:
+        m = [PartialConv1x1(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)]
+    elif no_holes_1_conv:
+        m = [PartialConvNoHoles(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)]
+    else:
+        m = [PartialConv(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, same_holes)]
+    if BN:
+        m += [PartialActivatedBN(out_channels, activation)]
+    if not BN and activation:
+        m += [PartialActivation(activation)]
+    return nn.Sequential(*m)
