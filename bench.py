@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): imgs/s of the partial-conv inpainting training step
+(ImageFill, 512x512, batch 32 per GPU, train-mode BN, fwd + bwd + gradient all-reduce + fused
+SGD update) on N MI355X of one node, with the roofline of the dominant kernel and the CPU
+baseline (the oracle timed on the host cores) in the same JSON line.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 vector = fp32 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_TBS = 8.0         # HBM3E spec
+# ImageFill 512^2 forward = 58.8 GFLOP and 2934 MB (train-mode BN) per image; fwd+bwd = 3x
+ALG_GFLOP_PER_IMG = 3 * 58.8
+ALG_GB_PER_IMG = 3 * 2.934
+
+
+def nt_variant(n_cols: int) -> str:
+    """Tile variant gemm.hip picks for an NT GEMM with this many output columns."""
+    if n_cols % 128 == 0 or n_cols > 192:
+        return "gemm_nt<128x128>"
+    return "gemm_nt<128x64>" if n_cols > 32 else "gemm_nt<128x32>"
+
+
+def cpu_baseline(size: int, threads: int):
+    """Oracle (stock-PyTorch CPU restatement of the reference) on a bounded sample of the workload."""
+    from oracle import pconv_oracle as O
+    from text_segmentation_image_inpainting_amd.synthetic import make_batch
+    import text_segmentation_image_inpainting_amd as T
+    torch.set_num_threads(threads)
+    bs = 2
+    torch.manual_seed(0)
+    ref_like = T.ImageFill()  # parameter container only (default init); the oracle does the math on CPU
+    sd = {k: v.detach().clone() for k, v in ref_like.state_dict().items()}
+    for k, p in ref_like.named_parameters():
+        if p.requires_grad:
+            sd[k].requires_grad_(True)
+    corrupted, mask, clean = make_batch(bs, size, seed0=10_000)
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        out = O.image_fill(sd, corrupted, mask, training=True)
+        loss = O.l1_mean(out, clean)
+        loss.backward()
+        for v in sd.values():
+            if v.grad is not None:
+                v.grad = None
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[0]
+    return {"value": bs / t, "unit": "imgs/s", "cores": threads, "kind": "port",
+            "sample": f"ImageFill {size}x{size} bs {bs} fwd+bwd (train-mode BN, L1 loss), 1 warm-up + 2 timed steps, best"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--model", default="ImageFill", choices=["ImageFill", "ImageFillOrigin", "ImageFillOriginV2"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bernoulli-masks", action="store_true", help="stress variant: i.i.d. per-channel masks")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import text_segmentation_image_inpainting_amd as T
+    from text_segmentation_image_inpainting_amd import _lib
+    from text_segmentation_image_inpainting_amd.BaseModels import to_nhwc
+    from text_segmentation_image_inpainting_amd.synthetic import make_batch
+    from text_segmentation_image_inpainting_amd.train_step import FlatSGDTrainer
+
+    _lib.lib()
+    torch.manual_seed(0)  # identical random-init weights on every rank
+    model = getattr(T, args.model)().to(dev).train()
+    trainer = FlatSGDTrainer(model, lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    trainer.broadcast_parameters()
+
+    corrupted, mask, clean = make_batch(args.batch, args.size, seed0=rank * args.batch, bernoulli=args.bernoulli_masks)
+    corrupted, mask = corrupted.to(dev), mask.to(dev)   # inputs resident in HBM before the timed region
+    clean_nhwc = to_nhwc(clean.to(dev))
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = trainer.step(corrupted, mask, clean_nhwc)
+    sync()
+    _lib.start_timing(["tsii_pw_fwd", "tsii_pw_bwd_dx"])
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(corrupted, mask, clean_nhwc)
+    sync()
+    elapsed = time.perf_counter() - t0
+    timed = _lib.stop_timing()
+    final_loss = float(loss.item())
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        imgs = world * args.batch * args.steps
+        value = imgs / elapsed
+        # roofline of the dominant kernel: NT fp32-MFMA GEMM, 128x128 tile (forward 1x1 convs and dX)
+        agg = {}
+        for name, recs in timed.items():
+            for ms, a in recs:
+                m, p, q = a[0], a[1], a[2]       # (M, K, N) for pw_fwd ; (M, N, K) for pw_bwd_dx
+                out_cols = q if name == "tsii_pw_fwd" else q
+                v = nt_variant(out_cols)
+                d = agg.setdefault(v, {"ms": 0.0, "flop": 0.0, "launches": 0})
+                d["ms"] += ms
+                d["flop"] += 2.0 * m * p * q
+                d["launches"] += 1
+        dom = max(agg.items(), key=lambda kv: kv[1]["ms"]) if agg else None
+        roofline = None
+        if dom:
+            k, d = dom
+            ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                        "launches_per_step": d["launches"] // args.steps,
+                        "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                        "ms_per_step_in_kernel": round(d["ms"] / args.steps, 3),
+                        "all_gemm_variants": {kk: {"TFLOP/s": round(dd["flop"] / (dd["ms"] * 1e-3) / 1e12, 2),
+                                                    "ms_per_step": round(dd["ms"] / args.steps, 3)} for kk, dd in agg.items()}}
+        ms_per_img = elapsed / imgs * world * 1e3  # per-GPU ms per image
+        whole = None
+        if args.model == "ImageFill" and args.size == 512:
+            t_hbm = ALG_GB_PER_IMG / (PEAK_HBM_TBS * 1e3) * 1e3
+            t_flop = ALG_GFLOP_PER_IMG / (PEAK_FP32_TFLOPS * 1e3) * 1e3
+            whole = {"alg_gflop_per_img": ALG_GFLOP_PER_IMG, "alg_gb_per_img": round(ALG_GB_PER_IMG, 3),
+                     "t_min_ms_per_img_hbm": round(t_hbm, 3), "t_min_ms_per_img_flop": round(t_flop, 3),
+                     "frac_of_roofline": round(max(t_hbm, t_flop) / ms_per_img, 4)}
+        line = {
+            "metric": "imgs/sec fwd+bwd on 512x512 partial-conv inpaint",
+            "value": round(value, 2), "unit": "imgs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.model} {args.size}x{args.size} partial-conv inpainting train step "
+                                   f"(fwd+bwd, train-mode BN, L1 loss, grad all-reduce, fused SGD), "
+                                   f"{args.batch} imgs/GPU, random line/ellipse hole masks",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}"},
+            "roofline": roofline, "whole_step_roofline": whole, "final_loss": final_loss,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.size, os.cpu_count() or 1)
+        elif world == 1:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

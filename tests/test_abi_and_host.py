@@ -1,0 +1,94 @@
+"""CPU-side checks: the C-ABI library loads and exports exactly what include/tsii_hip.h declares,
+the ctypes table mirrors the header, the module mirror keeps the reference's state_dict layout,
+and the product path refuses to run without a GPU (no silent CPU fallback)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import text_segmentation_image_inpainting_amd as T
+from text_segmentation_image_inpainting_amd import _lib, build_ext, masks, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "tsii_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tsii_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_matches_ctypes_table():
+    assert _header_symbols() == sorted(_lib.SIGNATURES)
+
+
+def test_library_exports_every_symbol():
+    lib = build_ext.build(verbose=False)  # hipcc cross-compiles for gfx950 without a GPU
+    cdll = ctypes.CDLL(lib)
+    for name in _header_symbols():
+        assert hasattr(cdll, name), f"{name} declared in include/tsii_hip.h but not exported"
+    _lib.bind(cdll)
+    assert cdll.tsii_version() == 1
+
+
+def test_state_dict_layout_matches_reference(golden_dir):
+    keys = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))
+    for name in ("ImageFill", "ImageFillOrigin", "ImageFillOriginV2"):
+        m = getattr(T, name)()
+        assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == keys[name]
+        assert [k for k, p in m.named_parameters() if p.requires_grad] == keys[name + ".trainable"]
+        for k, v in m.state_dict().items():
+            if k.endswith("mask_conv.weight"):
+                assert bool((v == 1).all())
+
+
+def test_no_cpu_fallback():
+    m = T.PartialConv(3, 4, 3, 1, 1)
+    x = torch.randn(1, 3, 8, 8)
+    with pytest.raises(RuntimeError, match="no CPU path|GPU"):
+        m((x, torch.ones_like(x)))
+
+
+def test_tolerant_load_state_dict(capsys):
+    m = T.PartialConv(3, 4, 3, 1, 1)
+    sd = {"feature_conv.weight": torch.zeros(4, 3, 3, 3), "nonexistent.key": torch.zeros(1),
+          "feature_conv.bias": torch.zeros(5)}
+    m.load_state_dict(sd)  # never raises (models/BaseModels.py:41-52)
+    out = capsys.readouterr().out
+    assert "is not in the model" in out and "fails to load" in out
+    assert float(m.feature_conv.weight.abs().sum()) == 0.0
+
+
+def test_mask_parts_roundtrip():
+    plane = (torch.rand(2, 5, 6) > 0.5).float()
+    t = plane.unsqueeze(1).expand(-1, 7, -1, -1)
+    mp = masks.MaskParts.from_tensor(t)
+    assert mp.planar and mp.channels == 7
+    back = mp.as_tensor()
+    assert back.shape == t.shape and back.stride(1) == 0 and torch.equal(back, t)
+    full = (torch.rand(2, 3, 5, 6) > 0.5).float()
+    mp2 = masks.MaskParts.from_tensor(full)
+    assert not mp2.planar and torch.equal(mp2.as_tensor(), full)
+
+
+def test_synthetic_dataset_contract():
+    c, m, cl = synthetic.make_batch(2, 128, seed0=3)
+    assert c.shape == m.shape == cl.shape == (2, 3, 128, 128) and c.dtype == torch.float32
+    assert set(np.unique(m.numpy())) <= {0.0, 1.0}
+    assert torch.equal(c, cl * m)                                # Dataloader.py:131
+    assert torch.equal(m[:, 0], m[:, 1]) and torch.equal(m[:, 0], m[:, 2])
+    c2, m2, _ = synthetic.make_batch(2, 128, seed0=3)
+    assert torch.equal(m, m2) and torch.equal(c, c2)             # seeded
+
+
+def test_dilate_known_answer():
+    """10x10 dilation, anchor (5,5): a single pixel grows to rows/cols -4..+5 around it."""
+    a = np.zeros((32, 32), np.uint8)
+    a[16, 16] = 255
+    d = synthetic.dilate_10x10(a)
+    ys, xs = np.nonzero(d)
+    assert (ys.min(), ys.max(), xs.min(), xs.max()) == (12, 21, 12, 21) and d.sum() == 255 * 100

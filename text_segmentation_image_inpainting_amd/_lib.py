@@ -91,8 +91,35 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+# Optional per-entry-point timing with HIP events on the launch stream (bench.py's roofline leg):
+# _TIMED maps an entry-point name to a list of (start_event, end_event, scalar_args).
+_TIMED = None
+
+
+def start_timing(names):
+    """Record a HIP event pair (on torch's current stream, where the kernels are enqueued) around
+    every call of the given entry points until ``stop_timing()``."""
+    global _TIMED
+    _TIMED = {n: [] for n in names}
+
+
+def stop_timing():
+    """-> {name: [(milliseconds, scalar_args), ...]} ; synchronises the device."""
+    global _TIMED
+    rec, _TIMED = _TIMED, None
+    torch.cuda.synchronize()
+    return {n: [(a.elapsed_time(b), args) for a, b, args in lst] for n, lst in (rec or {}).items()}
+
+
 def call(name, *args):
     L = lib()
+    timed = _TIMED is not None and name in _TIMED
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = getattr(L, name)(*args)
+    if timed:
+        e1.record()
+        _TIMED[name].append((e0, e1, tuple(a for a in args if isinstance(a, (int, float)))))
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {L.tsii_last_error().decode(errors='replace')}")
