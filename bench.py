@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--model", default="ImageFill", choices=["ImageFill", "ImageFillOrigin", "ImageFillOriginV2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads for the CPU-baseline leg (default: min(host cores, 32); a 2-image batch "
+                         "does not scale past that -- 256 threads ran 50x slower than 32)")
     ap.add_argument("--bernoulli-masks", action="store_true", help="stress variant: i.i.d. per-channel masks")
     args = ap.parse_args()
 
@@ -172,7 +175,7 @@ def main():
             "roofline": roofline, "whole_step_roofline": whole, "final_loss": final_loss,
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.size, os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(args.size, args.cpu_threads or min(os.cpu_count() or 1, 32))
         elif world == 1:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -1,0 +1,72 @@
+"""Kernel-level checks through the C ABI on the TEST-ONLY emulator (tests/emu): the fp32-MFMA GEMMs
+(fragment layout, tile tails, row scales, LDS-staged epilogue) against float64 numpy."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from text_segmentation_image_inpainting_amd import _lib
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from tests.emu import build_emu
+    if not build_emu.available():
+        pytest.skip("host clang++ not available")
+    return _lib.bind(ctypes.CDLL(build_emu.build()))
+
+
+def P(a):
+    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+@pytest.mark.parametrize("M,K,N,bias,masked", [(300, 64, 128, True, True), (257, 96, 192, True, False),
+                                               (130, 40, 32, False, True), (70, 6, 5, True, True),
+                                               (260, 128, 256, False, False), (200, 36, 136, True, True)])
+def test_pointwise_gemms(emu, M, K, N, bias, masked):
+    L = emu
+    rng = np.random.default_rng(M + K + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = rng.standard_normal((N, K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32) if bias else None
+    split = (K // 2 // 4) * 4 if K >= 8 else K // 2
+    r0 = (rng.uniform(size=M) > 0.3).astype(np.float32) if masked else None
+    r1 = (rng.uniform(size=M) > 0.3).astype(np.float32) if masked else None
+    denom = rng.integers(1, 9, size=M).astype(np.float32) if masked else None
+    keep = (rng.uniform(size=M) > 0.2).astype(np.float32) if masked else None
+    y = np.zeros((M, N), np.float32)
+    assert L.tsii_pw_fwd(P(x), M, K, P(w), N, P(b), P(r0), split, P(r1), P(denom), P(keep), P(y), None) == 0, L.tsii_last_error()
+    xm = x.astype(np.float64).copy()
+    if masked:
+        xm[:, :split] *= r0[:, None]
+        xm[:, split:] *= r1[:, None]
+    ref = xm @ w.T.astype(np.float64)
+    if masked:
+        ref = ref / denom[:, None]
+    if bias:
+        ref = ref + b
+    if masked:
+        ref = ref * keep[:, None]
+    assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max()
+
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    inv = (keep / denom).astype(np.float32) if masked else None
+    dx = np.zeros((M, K), np.float32)
+    wt = np.zeros(K * N, np.float32)
+    assert L.tsii_pw_bwd_dx(P(dy), M, N, P(w), K, P(inv), P(r0), split, P(r1), P(dx), P(wt), None) == 0, L.tsii_last_error()
+    g = dy.astype(np.float64) * (inv[:, None] if masked else 1.0)
+    rdx = g @ w.astype(np.float64)
+    if masked:
+        rdx[:, :split] *= r0[:, None]
+        rdx[:, split:] *= r1[:, None]
+    assert np.abs(dx - rdx).max() <= 1e-5 * np.abs(rdx).max()
+
+    nbytes = L.tsii_pw_bwd_dw_ws_bytes(M, N, K)
+    ws = np.zeros(nbytes // 4 + 4, np.float32)
+    dw = np.zeros((N, K), np.float32)
+    db = np.zeros(N, np.float32)
+    assert L.tsii_pw_bwd_dw(P(dy), P(x), M, N, K, P(inv), P(keep), P(r0), split, P(r1), P(dw), P(db), P(ws), nbytes, None) == 0, L.tsii_last_error()
+    rdw = g.T @ xm
+    assert np.abs(dw - rdw).max() <= 1e-5 * np.abs(rdw).max()
+    rdb = (dy.astype(np.float64) * (keep[:, None] if masked else 1.0)).sum(0)
+    assert np.abs(db - rdb).max() <= 1e-5 * np.abs(rdb).max()

@@ -36,15 +36,38 @@ __global__ void bn_stats_partial_kernel(const float* __restrict__ y, int64_t M, 
     }
 }
 
-__global__ void bn_stats_final_kernel(const float* __restrict__ y, const float* __restrict__ part, int R, int64_t M, int C,
-                                      float* __restrict__ mean, float* __restrict__ var,
-                                      float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int r = 0; r < R; ++r) {
-            s1 += (double)part[(int64_t)r * 2 * C + c];
-            s2 += (double)part[(int64_t)r * 2 * C + C + c];
+// combine the R partial rows: block = 32 channels x 8 row lanes, 4 independent loads in flight per lane
+__device__ __forceinline__ void reduce_part_rows(const float* __restrict__ part, int R, int C, int c, int ty,
+                                                 double& o1, double& o2) {
+    double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    for (int r = ty; r < R; r += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + 8 * u;
+            if (rr < R) {
+                a1[u] += (double)part[(int64_t)rr * 2 * C + c];
+                a2[u] += (double)part[(int64_t)rr * 2 * C + C + c];
+            }
         }
+    }
+    o1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    o2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+}
+
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ y, const float* __restrict__ part,
+                                                             int R, int64_t M, int C, float* __restrict__ mean,
+                                                             float* __restrict__ var, float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var, float momentum) {
+    __shared__ double sh[2][8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) reduce_part_rows(part, R, C, c, ty, s1, s2);
+    sh[0][ty][tx] = s1; sh[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        s1 = 0.0; s2 = 0.0;
+        for (int j = 0; j < 8; ++j) { s1 += sh[0][j][tx]; s2 += sh[1][j][tx]; }
         const double e1 = s1 / (double)M;
         double v = s2 / (double)M - e1 * e1;
         if (v < 0.0) v = 0.0;
@@ -59,23 +82,32 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ y, const float* 
     }
 }
 
+// launched with chan_grid(): (gridDim*blockDim) % CG == 0, so each thread's channel group is fixed
 template <int W>
 __global__ void bn_act_fwd_kernel(const float* __restrict__ y, int64_t M, int C, const float* __restrict__ mean,
                                   const float* __restrict__ var, const float* __restrict__ gamma,
                                   const float* __restrict__ beta, float eps, int act, float slope,
                                   const float* __restrict__ residual, float* __restrict__ out) {
-    const int CG = C / W;
+    const unsigned CG = (unsigned)(C / W);
     const int64_t total = M * CG;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % CG) * W;
-        const int64_t off = (idx / CG) * C + c;
+    const unsigned gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int c = (int)(gt % CG) * W;
+    float mu[W], sc[W], be[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        mu[i] = mean[c + i];
+        sc[i] = (1.0f / sqrtf(var[c + i] + eps)) * gamma[c + i];
+        be[i] = beta[c + i];
+    }
+    for (int64_t idx = gt; idx < total; idx += stride) {
+        const int64_t off = idx * W;
         VecF<W> v = vload<W>(y + off);
         VecF<W> res;
         if (residual != nullptr) res = vload<W>(residual + off);
 #pragma unroll
         for (int i = 0; i < W; ++i) {
-            const float istd = 1.0f / sqrtf(var[c + i] + eps);
-            float z = (v.v[i] - mean[c + i]) * istd * gamma[c + i] + beta[c + i];
+            float z = (v.v[i] - mu[i]) * sc[i] + be[i];
             z = apply_act(z, act, slope);
             if (residual != nullptr) z += res.v[i];
             v.v[i] = z;
@@ -119,14 +151,18 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ dout, const floa
     }
 }
 
-__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int R, int C, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int r = 0; r < R; ++r) {
-            s1 += (double)part[(int64_t)r * 2 * C + c];
-            s2 += (double)part[(int64_t)r * 2 * C + C + c];
-        }
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ part, int R, int C,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double sh[2][8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) reduce_part_rows(part, R, C, c, ty, s1, s2);
+    sh[0][ty][tx] = s1; sh[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        s1 = 0.0; s2 = 0.0;
+        for (int j = 0; j < 8; ++j) { s1 += sh[0][j][tx]; s2 += sh[1][j][tx]; }
         dbeta[c] = (float)s1;
         dgamma[c] = (float)s2;
     }
@@ -139,22 +175,33 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dout, const float*
                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                     int act, float slope, int training, const float* __restrict__ dgamma,
                                     const float* __restrict__ dbeta, float* __restrict__ dy) {
-    const int CG = C / W;
+    const unsigned CG = (unsigned)(C / W);
     const int64_t total = M * CG;
+    const unsigned gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int c = (int)(gt % CG) * W;
     const float invM = 1.0f / (float)M;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % CG) * W;
-        const int64_t off = (idx / CG) * C + c;
+    float mu[W], istd[W], ga[W], be[W], k1[W], k2[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        mu[i] = mean[c + i];
+        istd[i] = 1.0f / sqrtf(var[c + i] + eps);
+        ga[i] = gamma[c + i];
+        be[i] = beta[c + i];
+        k1[i] = training ? dbeta[c + i] * invM : 0.f;
+        k2[i] = training ? dgamma[c + i] * invM : 0.f;
+    }
+    for (int64_t idx = gt; idx < total; idx += stride) {
+        const int64_t off = idx * W;
         const VecF<W> yv = vload<W>(y + off);
         VecF<W> dv = vload<W>(dout + off);
 #pragma unroll
         for (int i = 0; i < W; ++i) {
-            const float istd = 1.0f / sqrtf(var[c + i] + eps);
-            const float xh = (yv.v[i] - mean[c + i]) * istd;
-            const float z = xh * gamma[c + i] + beta[c + i];
+            const float xh = (yv.v[i] - mu[i]) * istd[i];
+            const float z = xh * ga[i] + be[i];
             float dz = dv.v[i] * act_grad(z, act, slope);
-            if (training) dz = dz - dbeta[c + i] * invM - xh * dgamma[c + i] * invM;
-            dv.v[i] = dz * gamma[c + i] * istd;
+            dz = dz - k1[i] - xh * k2[i];
+            dv.v[i] = dz * ga[i] * istd[i];
         }
         vstore<W>(dy + off, dv);
     }
@@ -206,7 +253,7 @@ extern "C" int tsii_bn_stats(const float* y, int64_t m, int c, float* mean, floa
     else hipLaunchKernelGGL((bn_stats_partial_kernel<1>), dim3(stream_grid(tasks, 256)), dim3(256), 0, st, y, m, c, R, part);
     int rc = check_launch("bn_stats_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, y, part, R, m, c, mean, var,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(c, 32)), dim3(256), 0, st, y, part, R, m, c, mean, var,
                        running_mean, running_var, momentum);
     return check_launch("bn_stats_final");
 }
@@ -220,8 +267,9 @@ extern "C" int tsii_bn_act_fwd(const float* y, int64_t m, int c, const float* me
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(out) && (residual == nullptr || aligned16(residual));
     const int64_t total = m * (vec ? c / 4 : c);
-    if (vec) hipLaunchKernelGGL((bn_act_fwd_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, st, y, m, c, mean, var, gamma, beta, eps, act, slope, residual, out);
-    else hipLaunchKernelGGL((bn_act_fwd_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, st, y, m, c, mean, var, gamma, beta, eps, act, slope, residual, out);
+    const unsigned grid = chan_grid(total, vec ? c / 4 : c, 256);
+    if (vec) hipLaunchKernelGGL((bn_act_fwd_kernel<4>), dim3(grid), dim3(256), 0, st, y, m, c, mean, var, gamma, beta, eps, act, slope, residual, out);
+    else hipLaunchKernelGGL((bn_act_fwd_kernel<1>), dim3(grid), dim3(256), 0, st, y, m, c, mean, var, gamma, beta, eps, act, slope, residual, out);
     return check_launch("bn_act_fwd");
 }
 
@@ -241,12 +289,13 @@ extern "C" int tsii_bn_act_bwd(const float* dout, const float* y, int64_t m, int
     else hipLaunchKernelGGL((bn_bwd_partial_kernel<1>), dim3(stream_grid(tasks, 256)), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta, eps, act, slope, R, part);
     int rc = check_launch("bn_bwd_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, part, R, c, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(c, 32)), dim3(256), 0, st, part, R, c, dgamma, dbeta);
     rc = check_launch("bn_bwd_final");
     if (rc) return rc;
     const int64_t total = m * (vec ? c / 4 : c);
-    if (vec) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta, eps, act, slope, training, dgamma, dbeta, dy);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta, eps, act, slope, training, dgamma, dbeta, dy);
+    const unsigned grid = chan_grid(total, vec ? c / 4 : c, 256);
+    if (vec) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(grid), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta, eps, act, slope, training, dgamma, dbeta, dy);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(grid), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta, eps, act, slope, training, dgamma, dbeta, dy);
     return check_launch("bn_bwd_apply");
 }
 

@@ -61,29 +61,43 @@ int launch_transpose(const float* in, int rows_in, int cols_in, float* out, hipS
 }
 
 // ---- scaled column sums (bias gradients) -----------------------------------------
-__global__ void colsum_partial_kernel(const float* __restrict__ a, const float* __restrict__ rowmul, int64_t M, int N,
-                                      int64_t rows_per_block, float* __restrict__ part) {
+// block = NB columns x L row lanes (NB = min(N,256), L = 256/NB); the [rows, N] slab of a block is one
+// contiguous stream; lanes are combined through LDS.  part[block][n]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, const float* __restrict__ rowmul,
+                                                             int64_t M, int N, int NB, int L, int64_t rows_per_block,
+                                                             float* __restrict__ part) {
+    __shared__ float sh[256];
+    const int col0 = blockIdx.y * NB;
+    const int cl = threadIdx.x % NB, lane = threadIdx.x / NB;
+    const int col = col0 + cl;
     const int64_t mbeg = (int64_t)blockIdx.x * rows_per_block;
     const int64_t mend = (mbeg + rows_per_block < M) ? mbeg + rows_per_block : M;
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
-        float s = 0.f;
-        for (int64_t m = mbeg; m < mend; ++m) {
-            float v = a[m * N + n];
+    float s = 0.f;
+    if (lane < L && col < N) {
+        for (int64_t m = mbeg + lane; m < mend; m += L) {
+            float v = a[m * N + col];
             if (rowmul != nullptr) v *= rowmul[m];
             s += v;
         }
-        part[(int64_t)blockIdx.x * N + n] = s;
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (lane == 0 && col < N) {
+        float t = 0.f;
+        for (int l = 0; l < L; ++l) t += sh[l * NB + cl];
+        part[(int64_t)blockIdx.x * N + col] = t;
     }
 }
 
-static inline int64_t colsum_rpb(int64_t M) { int64_t r = cdiv64(M, 512); return r < 64 ? 64 : r; }
+static inline int64_t colsum_rpb(int64_t M) { int64_t r = cdiv64(M, 1024); return r < 64 ? 64 : r; }
 size_t colsum_ws_floats(int64_t M, int N) { return (size_t)cdiv64(M, colsum_rpb(M)) * N; }
 
 int launch_colsum_scaled(const float* a, const float* rowmul, int64_t M, int N, float* out, float* ws,
                          hipStream_t stream) {
     const int64_t rpb = colsum_rpb(M);
     const int rows = (int)cdiv64(M, rpb);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(rows), dim3(256), 0, stream, a, rowmul, M, N, rpb, ws);
+    const int NB = N < 256 ? N : 256, L = 256 / NB;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(rows, cdiv(N, NB)), dim3(256), 0, stream, a, rowmul, M, N, NB, L, rpb, ws);
     int rc = check_launch("colsum_partial");
     if (rc) return rc;
     return launch_reduce_rows(ws, rows, N, out, stream);

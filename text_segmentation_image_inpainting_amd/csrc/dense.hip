@@ -212,6 +212,183 @@ __global__ __launch_bounds__(256) void dense_bwd_dw_kernel(const float* __restri
     }
 }
 
+// ---- few-output-channel path (Cout <= 4; ImageFill's final 35->3 layer) ---------------------
+// A block owns an 8 x 32 tile of output pixels.  The masked input patch is staged once into LDS
+// with fully coalesced row reads (NHWC rows are contiguous), so the 140-byte pixel stride of the
+// 35-channel tensor never reaches the memory pipeline; each thread then walks its kh*kw*Cin
+// window out of LDS (lane stride sw*Cin floats: conflict-free for odd Cin) against wave-uniform
+// weights.
+static constexpr int DS_TH = 8, DS_TW = 32, DS_LDS = 16384;
+
+struct SmallPlan {
+    bool ok;
+    int PH, PW;
+};
+static SmallPlan plan_small(const ConvGeom& g) {
+    SmallPlan p;
+    p.PH = (DS_TH - 1) * g.sh + (g.kh - 1) * g.dh + 1;
+    p.PW = (DS_TW - 1) * g.sw + (g.kw - 1) * g.dw + 1;
+    p.ok = g.cout <= 4 && (int64_t)p.PH * p.PW * g.cin <= DS_LDS && g.kh * g.kw * g.cin <= 1024;
+    return p;
+}
+
+// w[co][ci][t] -> w4[(t*cin + ci)*4 + co], zero padded to 4 output channels
+__global__ void dense_prep_small_kernel(const float* __restrict__ w, int cin, int cout, int T, float* __restrict__ w4) {
+    const int total = T * cin * 4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i & 3;
+        const int k = i >> 2;
+        const int ci = k % cin, t = k / cin;
+        w4[i] = co < cout ? w[((int64_t)co * cin + ci) * T + t] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void stage_patch(float* __restrict__ tile, const float* __restrict__ x,
+                                            const float* __restrict__ mfull, const RowScale& rs, const ConvGeom& g,
+                                            int64_t n, int iy0, int ix0, int PH, int PW) {
+    const int rowlen = PW * g.cin;
+    for (int py = 0; py < PH; ++py) {
+        const int iy = iy0 + py;
+        const bool yin = (iy >= 0 && iy < g.h);
+        int px = threadIdx.x / g.cin, ci = threadIdx.x % g.cin;
+        const int dpx = 256 / g.cin, dci = 256 % g.cin;
+        for (int e = threadIdx.x; e < rowlen; e += 256) {
+            const int ix = ix0 + px;
+            float v = 0.f;
+            if (yin && ix >= 0 && ix < g.w) {
+                const int64_t ipix = (n * g.h + iy) * g.w + ix;
+                v = x[ipix * g.cin + ci] * in_mask(mfull, rs, ipix, g.cin, ci);
+            }
+            tile[py * rowlen + e] = v;
+            px += dpx; ci += dci;
+            if (ci >= g.cin) { ci -= g.cin; ++px; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dense_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mfull,
+                                                              RowScale rs, const float* __restrict__ w4,
+                                                              const float* __restrict__ bias, const float* __restrict__ denom,
+                                                              const float* __restrict__ keep, ConvGeom g, int PH, int PW,
+                                                              float* __restrict__ y) {
+    __shared__ __attribute__((aligned(16))) float tile[DS_LDS];
+    const int64_t n = blockIdx.z;
+    const int oy0 = blockIdx.y * DS_TH, ox0 = blockIdx.x * DS_TW;
+    stage_patch(tile, x, mfull, rs, g, n, oy0 * g.sh - g.ph, ox0 * g.sw - g.pw, PH, PW);
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy >= g.ho || ox >= g.wo) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int ky = 0; ky < g.kh; ++ky)
+        for (int kx = 0; kx < g.kw; ++kx) {
+            const float* tp = tile + ((ty * g.sh + ky * g.dh) * PW + tx * g.sw + kx * g.dw) * g.cin;
+            const float* wp = w4 + (ky * g.kw + kx) * g.cin * 4;
+            for (int ci = 0; ci < g.cin; ++ci) {
+                const float xv = tp[ci];
+                a0 = fmaf(xv, wp[ci * 4 + 0], a0); a1 = fmaf(xv, wp[ci * 4 + 1], a1);
+                a2 = fmaf(xv, wp[ci * 4 + 2], a2); a3 = fmaf(xv, wp[ci * 4 + 3], a3);
+            }
+        }
+    const int64_t pix = (n * g.ho + oy) * g.wo + ox;
+    const bool kp = keep != nullptr ? (keep[pix] != 0.f) : true;
+    const float dn = denom != nullptr ? denom[pix] : 1.f;
+    const float out[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (e >= g.cout) break;
+        float v = out[e];
+        if (kp) {
+            if (denom != nullptr) v = v / dn;
+            if (bias != nullptr) v += bias[e];
+        } else {
+            v = 0.f;
+        }
+        y[pix * g.cout + e] = v;
+    }
+}
+
+// dW partials for the few-output-channel path: persistent blocks walk tiles; thread t owns im2col
+// columns t, t+256, ... (column = (tap, ci)) x 4 output channels in registers.
+static constexpr int DS_NP = 4;
+__global__ __launch_bounds__(256) void dense_small_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
+                                                                 const float* __restrict__ x, const float* __restrict__ mfull,
+                                                                 RowScale rs, ConvGeom g, int PH, int PW, int tiles_per_block,
+                                                                 float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float tile[DS_LDS];
+    __shared__ __attribute__((aligned(16))) float gs[DS_TH * DS_TW * 4];
+    const int T = g.kh * g.kw, KK = T * g.cin;
+    const int ntx = (g.wo + DS_TW - 1) / DS_TW, nty = (g.ho + DS_TH - 1) / DS_TH;
+    const int total_tiles = g.n * nty * ntx;
+    int toff[DS_NP], tci[DS_NP];
+#pragma unroll
+    for (int q = 0; q < DS_NP; ++q) {
+        const int k = threadIdx.x + 256 * q;
+        const int t = k < KK ? k / g.cin : 0;
+        tci[q] = k < KK ? k % g.cin : 0;
+        toff[q] = ((t / g.kw) * g.dh * PW + (t % g.kw) * g.dw) * g.cin + tci[q];
+    }
+    float acc[DS_NP][4];
+#pragma unroll
+    for (int q = 0; q < DS_NP; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[q][e] = 0.f;
+
+    const int t_beg = blockIdx.x * tiles_per_block;
+    const int t_end = t_beg + tiles_per_block < total_tiles ? t_beg + tiles_per_block : total_tiles;
+    for (int tl = t_beg; tl < t_end; ++tl) {
+        const int bx = tl % ntx, by = (tl / ntx) % nty;
+        const int64_t n = tl / (ntx * nty);
+        const int oy0 = by * DS_TH, ox0 = bx * DS_TW;
+        __syncthreads();
+        stage_patch(tile, x, mfull, rs, g, n, oy0 * g.sh - g.ph, ox0 * g.sw - g.pw, PH, PW);
+        {
+            const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+            const int oy = oy0 + ty, ox = ox0 + tx;
+            float gv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (oy < g.ho && ox < g.wo) {
+                const int64_t pix = (n * g.ho + oy) * g.wo + ox;
+                const float sc = inv != nullptr ? inv[pix] : 1.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < g.cout) gv[e] = dy[pix * g.cout + e] * sc;
+            }
+            *reinterpret_cast<float4*>(gs + threadIdx.x * 4) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        }
+        __syncthreads();
+        for (int py = 0; py < DS_TH; ++py)
+            for (int px = 0; px < DS_TW; ++px) {
+                const float4 gq = *reinterpret_cast<const float4*>(gs + (py * DS_TW + px) * 4);
+                const int base = (py * g.sh * PW + px * g.sw) * g.cin;
+#pragma unroll
+                for (int q = 0; q < DS_NP; ++q) {
+                    if (threadIdx.x + 256 * q >= KK) break;
+                    const float xv = tile[base + toff[q]];
+                    acc[q][0] = fmaf(xv, gq.x, acc[q][0]); acc[q][1] = fmaf(xv, gq.y, acc[q][1]);
+                    acc[q][2] = fmaf(xv, gq.z, acc[q][2]); acc[q][3] = fmaf(xv, gq.w, acc[q][3]);
+                }
+            }
+    }
+    float* pz = part + (int64_t)blockIdx.x * g.cout * g.cin * T;
+#pragma unroll
+    for (int q = 0; q < DS_NP; ++q) {
+        const int k = threadIdx.x + 256 * q;
+        if (k >= KK) break;
+        const int t = k / g.cin;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < g.cout) pz[((int64_t)e * g.cin + tci[q]) * T + t] = acc[q][e];
+    }
+}
+
+static int small_dw_blocks(const ConvGeom& g, int* tiles_per_block) {
+    const int ntx = cdiv(g.wo, DS_TW), nty = cdiv(g.ho, DS_TH);
+    const int total = g.n * nty * ntx;
+    int blocks = total < 1024 ? total : 1024;
+    *tiles_per_block = cdiv(total, blocks);
+    return cdiv(total, *tiles_per_block);
+}
+
 static int check_conv_geom(const ConvGeom& g, const char* who) {
     TSII_REQUIRE(g.n > 0 && g.h > 0 && g.w > 0 && g.cin > 0 && g.cout > 0 && g.kh > 0 && g.kw > 0 && g.sh > 0 &&
                  g.sw > 0 && g.dh > 0 && g.dw > 0 && g.ph >= 0 && g.pw >= 0, "%s: bad geometry", who);
@@ -251,7 +428,7 @@ using namespace tsii;
 
 extern "C" size_t tsii_dense_ws_bytes(int cin, int cout, int kh, int kw) {
     if (cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0) return 0;
-    const size_t a = (size_t)kh * kw * cin * pad4(cout);
+    const size_t a = (size_t)kh * kw * cin * (pad4(cout) < 4 ? 4 : pad4(cout));
     const size_t b = (size_t)kh * kw * cout * pad4(cin);
     return (a > b ? a : b) * sizeof(float);
 }
@@ -268,6 +445,16 @@ extern "C" int tsii_dense_fwd(const float* x, const float* mfull, const float* r
     hipStream_t st = (hipStream_t)stream;
     const int coutp = pad4(cout), T = kh * kw;
     float* wf = (float*)ws;
+    const SmallPlan sp = plan_small(g);
+    if (sp.ok && ho <= 65535 * DS_TH && n <= 65535) {
+        hipLaunchKernelGGL(dense_prep_small_kernel, dim3(cdiv(T * cin * 4, 256)), dim3(256), 0, st, w, cin, cout, T, wf);
+        int rc0 = check_launch("dense_prep_small");
+        if (rc0) return rc0;
+        RowScale rs0 = {r0, r1, split};
+        hipLaunchKernelGGL(dense_small_fwd_kernel, dim3(cdiv(wo, DS_TW), cdiv(ho, DS_TH), n), dim3(256), 0, st, x, mfull,
+                           rs0, wf, bias, denom, keep, g, sp.PH, sp.PW, y);
+        return check_launch("dense_small_fwd");
+    }
     hipLaunchKernelGGL(dense_prep_fwd_kernel, dim3(stream_grid((int64_t)T * cin * coutp, 256)), dim3(256), 0, st,
                        w, cin, cout, T, coutp, wf);
     int rc = check_launch("dense_prep_fwd");
@@ -306,7 +493,10 @@ extern "C" size_t tsii_dense_bwd_dw_ws_bytes(int n, int ho, int wo, int cin, int
     if (n <= 0 || ho <= 0 || wo <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0) return 0;
     ConvGeom g = {n, 0, 0, cin, cout, kh, kw, 1, 1, 0, 0, 1, 1, ho, wo};
     DdPlan p = plan_dd(g);
-    return ((size_t)p.chunks * cout * cin * kh * kw + colsum_ws_floats((int64_t)n * ho * wo, cout)) * sizeof(float);
+    int tpb = 0;
+    const int small_rows = small_dw_blocks(g, &tpb);
+    const int rows = p.chunks > small_rows ? p.chunks : small_rows;
+    return ((size_t)rows * cout * cin * kh * kw + colsum_ws_floats((int64_t)n * ho * wo, cout)) * sizeof(float);
 }
 
 extern "C" int tsii_dense_bwd_dw(const float* dy, const float* inv, const float* keep, const float* x, const float* mfull,
@@ -321,6 +511,21 @@ extern "C" int tsii_dense_bwd_dw(const float* dy, const float* inv, const float*
     DdPlan p = plan_dd(g);
     RowScale rs = {r0, r1, split};
     float* part = (float*)ws;
+    const SmallPlan sp = plan_small(g);
+    if (sp.ok) {
+        int tpb = 0;
+        const int blocks = small_dw_blocks(g, &tpb);
+        hipLaunchKernelGGL(dense_small_bwd_dw_kernel, dim3(blocks), dim3(256), 0, st, dy, inv, x, mfull, rs, g, sp.PH,
+                           sp.PW, tpb, part);
+        int rc1 = check_launch("dense_small_bwd_dw");
+        if (rc1) return rc1;
+        const int64_t len1 = (int64_t)cout * cin * kh * kw;
+        rc1 = launch_reduce_rows(part, blocks, len1, dwgt, st);
+        if (rc1) return rc1;
+        if (dbias != nullptr)
+            rc1 = launch_colsum_scaled(dy, keep, (int64_t)n * ho * wo, cout, dbias, part + (size_t)blocks * len1, st);
+        return rc1;
+    }
     hipLaunchKernelGGL(dense_bwd_dw_kernel, dim3(p.kblocks, p.coblocks, p.chunks), dim3(256), 0, st, dy, inv, x, mfull,
                        rs, g, p.chunk, part);
     int rc = check_launch("dense_bwd_dw");

@@ -28,6 +28,7 @@ struct Epilogue {
     const float* keep;   // [M] 0 -> output 0
     const float* bias;   // [N]
     RowScale cs;         // output scale per (row, col)
+    int vec_store;       // C rows are 16-byte aligned (ldc % 4 == 0, base aligned)
 };
 
 // ---- tile loaders ----------------------------------------------------------------------
@@ -157,27 +158,54 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
         }
     }
 
-    // epilogue: D[row=(r&3)+8*(r>>2)+4*hi][col=lane&31]
+    // epilogue: accumulators (D[row=(r&3)+8*(r>>2)+4*hi][col=lane&31]) are staged through LDS one
+    // 32-row band per wave-row at a time, so rows leave as 16-byte stores (the dword-per-lane form is
+    // store-issue bound for the short-K layers); count division / bias / hole zeroing ride along.
+    constexpr int CS = BN + 4;                       // padded LDS row stride (floats), keeps float4 alignment
+    constexpr int BAND_ROWS = WM * 32;
+    constexpr int F4_PER_ROW = BN / 4;
+    constexpr int F4_PER_THREAD = BAND_ROWS * F4_PER_ROW / 256;
+    static_assert(BAND_ROWS * CS <= (BM + BN) * GEMM_LDS, "epilogue band must fit the operand LDS");
+    float* Cs = smem;
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t row = m0 + (wm * TM + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (row >= M) continue;
-            const float dn = ep.denom != nullptr ? ep.denom[row] : 1.f;
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * CS + (wn * TN + u) * 32 + li] = acc[t][u][r];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < F4_PER_THREAD; ++i) {
+            const int f = tid + 256 * i;
+            const int rr = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
+            const int64_t row = m0 + ((rr >> 5) * TM + t) * 32 + (rr & 31);
+            const int col = n0 + c4 * 4;
+            if (row >= M || col >= N) continue;
+            const float4 q = *reinterpret_cast<const float4*>(Cs + rr * CS + c4 * 4);
+            float v[4] = {q.x, q.y, q.z, q.w};
             const bool kp = ep.keep != nullptr ? (ep.keep[row] != 0.f) : true;
+            if (ep.denom != nullptr) {
+                const float dn = ep.denom[row];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] / dn;
+            }
             float c0 = 1.f, c1 = 1.f;
             if (ep.cs.r0 != nullptr) { c0 = ep.cs.r0[row]; c1 = ep.cs.r1 != nullptr ? ep.cs.r1[row] : 1.f; }
 #pragma unroll
-            for (int u = 0; u < TN; ++u) {
-                const int col = n0 + (wn * TN + u) * 32 + li;
-                if (col >= N) continue;
-                float v = acc[t][u][r];
-                if (ep.denom != nullptr) v = v / dn;
-                if (ep.bias != nullptr) v += ep.bias[col];
-                if (!kp) v = 0.f;
-                if (ep.cs.r0 != nullptr) v *= (col < ep.cs.split) ? c0 : c1;
-                C[row * ldc + col] = v;
+            for (int e = 0; e < 4; ++e) {
+                if (ep.bias != nullptr && col + e < N) v[e] += ep.bias[col + e];
+                if (!kp) v[e] = 0.f;
+                if (ep.cs.r0 != nullptr) v[e] *= (col + e < ep.cs.split) ? c0 : c1;
+            }
+            float* cp = C + row * ldc + col;
+            if (ep.vec_store && col + 3 < N) {
+                *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < N) cp[e] = v[e];
             }
         }
     }
@@ -330,6 +358,7 @@ static int launch_nt_cfg(const float* A, int64_t lda, RowScale as, const float* 
 static int launch_nt(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, float* C, int64_t ldc,
                      int64_t M, int N, int K, Epilogue ep, hipStream_t stream) {
     const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && aligned16(A) && aligned16(B);
+    ep.vec_store = (ldc % 4 == 0) && aligned16(C);
     if (N % 128 == 0 || N > 192) return launch_nt_cfg<2, 2, 2, 2>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, vec, stream);
     if (N > 32) return launch_nt_cfg<2, 2, 2, 1>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, vec, stream);
     return launch_nt_cfg<4, 1, 1, 1>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, vec, stream);
@@ -366,7 +395,7 @@ extern "C" int tsii_pw_fwd(const float* x, int64_t m, int k, const float* w, int
     TSII_REQUIRE(x && w && y, "pw_fwd: null pointer");
     TSII_REQUIRE(m > 0 && k > 0 && n > 0, "pw_fwd: bad shape m=%lld k=%d n=%d", (long long)m, k, n);
     RowScale as = {r0, r1, split};
-    Epilogue ep = {denom, keep, bias, {nullptr, nullptr, 0}};
+    Epilogue ep = {denom, keep, bias, {nullptr, nullptr, 0}, 0};
     return launch_nt(x, k, as, w, k, y, n, m, n, k, ep, (hipStream_t)stream);
 }
 
@@ -378,7 +407,7 @@ extern "C" int tsii_pw_bwd_dx(const float* dy, int64_t m, int n, const float* w,
     int rc = launch_transpose(w, n, k, wt_ws, (hipStream_t)stream);
     if (rc) return rc;
     RowScale as = {inv, nullptr, n};  // g = dy * inv[m]
-    Epilogue ep = {nullptr, nullptr, nullptr, {r0, r1, split}};
+    Epilogue ep = {nullptr, nullptr, nullptr, {r0, r1, split}, 0};
     return launch_nt(dy, n, as, wt_ws, n, dx, k, m, k, n, ep, (hipStream_t)stream);
 }
 

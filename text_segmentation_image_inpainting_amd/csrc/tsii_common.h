@@ -71,6 +71,20 @@ static inline int partial_rows(int64_t M, int CG) {
     return (int)r;
 }
 
+// Grid for flat streaming kernels whose threads keep a FIXED channel group across the grid-stride
+// loop: (grid * block) is a multiple of CG, so (global thread id % CG) never changes and the
+// per-channel constants live in registers (no per-element div/mod).
+static inline unsigned chan_grid(int64_t items, int CG, int block) {
+    int a = CG, b = block;
+    while (b) { int t = a % b; a = b; b = t; }
+    const int unit = CG / a;                 // grid must be a multiple of this
+    int64_t want = cdiv64(items, block);
+    if (want > 2048) want = 2048;
+    int64_t k = want / unit;
+    if (k < 1) k = 1;
+    return (unsigned)(k * unit);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
