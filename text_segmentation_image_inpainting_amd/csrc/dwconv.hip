@@ -102,70 +102,77 @@ __global__ __launch_bounds__(256) void dw_bwd_dx_kernel(const float* __restrict_
     vstore<W>(dx + pix * g.c + c, acc);
 }
 
-// dW partials.  Block = CGB channel groups x L pixel lanes; it walks `rpb` output rows (n,oy), lane l
-// taking ox = l, l+L, ...; 9 taps x W channels (+ bias) stay in registers.  part[by*L + l][(T+1)][C].
+// dW partials.  Block = CGB (<= 32) channel groups x L pixel lanes; it walks `rpb` output rows (n,oy),
+// lane l taking ox = l, l+L, ...; 9 taps x W channels (+ bias) stay in registers, the L lanes are
+// combined through LDS, so each block emits ONE partial row: part[by][(T+1)][C].
 static constexpr int DW_TAPS = 9;
 template <int W>
 __global__ __launch_bounds__(256) void dw_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
                                                         const float* __restrict__ keep, const float* __restrict__ x,
                                                         const float* __restrict__ rmask, DwGeom g, int CGB, int L,
                                                         int rpb, float* __restrict__ part) {
+    __shared__ float red[256];
     const int CG = g.c / W;
     const int T = g.kh * g.kw;
     const int cgl = threadIdx.x % CGB, lane = threadIdx.x / CGB;
     const int cg = blockIdx.x * CGB + cgl;
-    if (lane >= L || cg >= CG) return;
+    const bool active = (lane < L) && (cg < CG);
     const int c = cg * W;
     const int rows_total = g.n * g.ho;
     const int row0 = blockIdx.y * rpb;
     const int row1 = row0 + rpb < rows_total ? row0 + rpb : rows_total;
-    float* prow = part + ((int64_t)blockIdx.y * L + lane) * (T + 1) * g.c;
+    float* prow = part + (int64_t)blockIdx.y * (T + 1) * g.c;
     for (int t0 = 0; t0 < T; t0 += DW_TAPS) {
-        float acc[DW_TAPS][W];
-        float accb[W];
+        float acc[DW_TAPS + 1][W];   // last entry: bias gradient
 #pragma unroll
-        for (int t = 0; t < DW_TAPS; ++t)
+        for (int t = 0; t <= DW_TAPS; ++t)
 #pragma unroll
             for (int i = 0; i < W; ++i) acc[t][i] = 0.f;
+        if (active) {
+            for (int row = row0; row < row1; ++row) {
+                const int64_t n = row / g.ho;
+                const int oy = row % g.ho;
+                for (int ox = lane; ox < g.wo; ox += L) {
+                    const int64_t pix = (int64_t)row * g.wo + ox;
+                    if (keep != nullptr && keep[pix] == 0.f) continue;  // hole: no gradient (partial_convolution.py:72)
+                    const float s = inv != nullptr ? inv[pix] : 1.f;
+                    VecF<W> gv = vload<W>(dy + pix * g.c + c);
 #pragma unroll
-        for (int i = 0; i < W; ++i) accb[i] = 0.f;
-        for (int row = row0; row < row1; ++row) {
-            const int64_t n = row / g.ho;
-            const int oy = row % g.ho;
-            for (int ox = lane; ox < g.wo; ox += L) {
-                const int64_t pix = (int64_t)row * g.wo + ox;
-                if (keep != nullptr && keep[pix] == 0.f) continue;  // hole: no gradient (partial_convolution.py:72)
-                const float s = inv != nullptr ? inv[pix] : 1.f;
-                VecF<W> gv = vload<W>(dy + pix * g.c + c);
+                    for (int i = 0; i < W; ++i) { acc[DW_TAPS][i] += gv.v[i]; gv.v[i] *= s; }  // bias is added after the division
 #pragma unroll
-                for (int i = 0; i < W; ++i) { accb[i] += gv.v[i]; gv.v[i] *= s; }  // bias is added after the division
+                    for (int t = 0; t < DW_TAPS; ++t) {
+                        const int tt = t0 + t;
+                        if (tt >= T) break;
+                        const int ky = tt / g.kw, kx = tt % g.kw;
+                        const int iy = oy * g.sh - g.ph + ky * g.dh;
+                        const int ix = ox * g.sw - g.pw + kx * g.dw;
+                        if (iy < 0 || iy >= g.h || ix < 0 || ix >= g.w) continue;
+                        const int64_t ipix = (n * g.h + iy) * g.w + ix;
+                        const float m = rmask != nullptr ? rmask[ipix] : 1.f;
+                        if (m == 0.f) continue;
+                        const VecF<W> xv = vload<W>(x + ipix * g.c + c);
 #pragma unroll
-                for (int t = 0; t < DW_TAPS; ++t) {
-                    const int tt = t0 + t;
-                    if (tt >= T) break;
-                    const int ky = tt / g.kw, kx = tt % g.kw;
-                    const int iy = oy * g.sh - g.ph + ky * g.dh;
-                    const int ix = ox * g.sw - g.pw + kx * g.dw;
-                    if (iy < 0 || iy >= g.h || ix < 0 || ix >= g.w) continue;
-                    const int64_t ipix = (n * g.h + iy) * g.w + ix;
-                    const float m = rmask != nullptr ? rmask[ipix] : 1.f;
-                    if (m == 0.f) continue;
-                    const VecF<W> xv = vload<W>(x + ipix * g.c + c);
-#pragma unroll
-                    for (int i = 0; i < W; ++i) acc[t][i] = fmaf(gv.v[i], xv.v[i] * m, acc[t][i]);
+                        for (int i = 0; i < W; ++i) acc[t][i] = fmaf(gv.v[i], xv.v[i] * m, acc[t][i]);
+                    }
                 }
             }
         }
+        // combine the pixel lanes: one value per (tap, channel) at a time through LDS
 #pragma unroll
-        for (int t = 0; t < DW_TAPS; ++t) {
-            const int tt = t0 + t;
-            if (tt >= T) break;
+        for (int t = 0; t <= DW_TAPS; ++t) {
+            const int tt = (t == DW_TAPS) ? T : t0 + t;
+            const bool emit = (t == DW_TAPS) ? (t0 == 0) : (tt < T);
 #pragma unroll
-            for (int i = 0; i < W; ++i) prow[(int64_t)tt * g.c + c + i] = acc[t][i];
-        }
-        if (t0 == 0) {
-#pragma unroll
-            for (int i = 0; i < W; ++i) prow[(int64_t)T * g.c + c + i] = accb[i];
+            for (int i = 0; i < W; ++i) {
+                __syncthreads();
+                red[threadIdx.x] = acc[t][i];
+                __syncthreads();
+                if (emit && active && lane == 0) {
+                    float sum = 0.f;
+                    for (int l = 0; l < L; ++l) sum += red[l * CGB + cgl];
+                    prow[(int64_t)tt * g.c + c + i] = sum;
+                }
+            }
         }
     }
 }
@@ -206,16 +213,16 @@ static DwPlan plan_dw(int n, int ho, int c, bool vec) {
     DwPlan p;
     p.W = vec ? 4 : 1;
     p.CG = c / p.W;
-    p.CGB = p.CG < 256 ? p.CG : 256;
+    p.CGB = p.CG < 32 ? p.CG : 32;
     p.L = 256 / p.CGB;
     p.gx = cdiv(p.CG, p.CGB);
     const int rows_total = n * ho;
-    int gy = 1024 / p.gx;
+    int gy = 2048 / p.gx;
     if (gy < 1) gy = 1;
     if (gy > rows_total) gy = rows_total;
     p.rpb = cdiv(rows_total, gy);
     p.gy = cdiv(rows_total, p.rpb);
-    p.R = p.gy * p.L;
+    p.R = p.gy;
     return p;
 }
 

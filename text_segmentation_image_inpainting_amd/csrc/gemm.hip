@@ -32,10 +32,12 @@ struct Epilogue {
 };
 
 // ---- tile loaders ----------------------------------------------------------------------
-// NT: tile of ROWS x 32 floats from a row-major matrix (K contiguous); 8 float4 per row.
+// NT: tile of ROWS x 32 floats from a row-major matrix (K contiguous); 8 float4 per row.  A thread
+// touches the same ROWS/32 rows in every K-tile, so its row scales (s0 for k < split, s1 after)
+// are loaded once before the K loop.
 template <int ROWS, bool VEC>
 __device__ __forceinline__ void nt_load(const float* __restrict__ P, int64_t ld, int64_t row0, int64_t nrows,
-                                        int k0, int K, const RowScale& rs, float4 (&regs)[ROWS / 32]) {
+                                        int k0, int K, float4 (&regs)[ROWS / 32]) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i) {
@@ -54,27 +56,43 @@ __device__ __forceinline__ void nt_load(const float* __restrict__ P, int64_t ld,
                 if (k + 2 < K) v.z = p[2];
                 if (k + 3 < K) v.w = p[3];
             }
-            if (rs.r0 != nullptr) {
-                const float s0 = rs.r0[row];
-                const float s1 = rs.r1 != nullptr ? rs.r1[row] : 1.f;
-                v.x *= (k + 0 < rs.split) ? s0 : s1;
-                v.y *= (k + 1 < rs.split) ? s0 : s1;
-                v.z *= (k + 2 < rs.split) ? s0 : s1;
-                v.w *= (k + 3 < rs.split) ? s0 : s1;
-            }
         }
-        regs[i] = v;
+        regs[i] = v;   // NOT scaled here: a use of the loaded value would force vmcnt(0) before the MFMAs
     }
 }
 
 template <int ROWS>
-__device__ __forceinline__ void nt_store(float* __restrict__ S, const float4 (&regs)[ROWS / 32]) {
+__device__ __forceinline__ void nt_row_scales(const RowScale& rs, int64_t row0, int64_t nrows,
+                                              float (&s0)[ROWS / 32], float (&s1)[ROWS / 32]) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int64_t row = row0 + ((threadIdx.x + 256 * i) >> 3);
+        s0[i] = 1.f; s1[i] = 1.f;
+        if (rs.r0 != nullptr && row < nrows) {
+            s0[i] = rs.r0[row];
+            s1[i] = rs.r1 != nullptr ? rs.r1[row] : 1.f;
+        }
+    }
+}
+
+// registers -> LDS after the MFMA phase; the x*mask row scale (s0 for k < split, s1 after) rides here
+template <int ROWS, bool SCALED>
+__device__ __forceinline__ void nt_store(float* __restrict__ S, const float4 (&regs)[ROWS / 32], int k0, int split,
+                                         const float (&s0)[ROWS / 32], const float (&s1)[ROWS / 32]) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i) {
         const int f = tid + 256 * i;
         const int r = f >> 3, c4 = f & 7;
-        *reinterpret_cast<float4*>(S + r * GEMM_LDS + c4 * 4) = regs[i];
+        float4 v = regs[i];
+        if (SCALED) {
+            const int k = k0 + c4 * 4;
+            v.x *= (k + 0 < split) ? s0[i] : s1[i];
+            v.y *= (k + 1 < split) ? s0[i] : s1[i];
+            v.z *= (k + 2 < split) ? s0[i] : s1[i];
+            v.w *= (k + 3 < split) ? s0[i] : s1[i];
+        }
+        *reinterpret_cast<float4*>(S + r * GEMM_LDS + c4 * 4) = v;
     }
 }
 
@@ -115,19 +133,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
 
     float4 ra[BM / 32], rb[BN / 32];
-    const RowScale none = {nullptr, nullptr, 0};
-    nt_load<BM, VEC>(A, lda, m0, M, 0, K, as, ra);
-    nt_load<BN, VEC>(B, ldb, n0, N, 0, K, none, rb);
-    nt_store<BM>(As, ra);
-    nt_store<BN>(Bs, rb);
+    float sa0[BM / 32], sa1[BM / 32], sb0[BN / 32], sb1[BN / 32];
+    nt_row_scales<BM>(as, m0, M, sa0, sa1);
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) { sb0[i] = 1.f; sb1[i] = 1.f; }
+    nt_load<BM, VEC>(A, lda, m0, M, 0, K, ra);
+    nt_load<BN, VEC>(B, ldb, n0, N, 0, K, rb);
+    nt_store<BM, true>(As, ra, 0, as.split, sa0, sa1);
+    nt_store<BN, false>(Bs, rb, 0, 0, sb0, sb1);
     __syncthreads();
 
     const int nk = (K + GEMM_BK - 1) / GEMM_BK;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = (kt + 1 < nk);
         if (more) {  // next tile's global loads fly during the MFMA phase
-            nt_load<BM, VEC>(A, lda, m0, M, (kt + 1) * GEMM_BK, K, as, ra);
-            nt_load<BN, VEC>(B, ldb, n0, N, (kt + 1) * GEMM_BK, K, none, rb);
+            nt_load<BM, VEC>(A, lda, m0, M, (kt + 1) * GEMM_BK, K, ra);
+            nt_load<BN, VEC>(B, ldb, n0, N, (kt + 1) * GEMM_BK, K, rb);
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -152,8 +173,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
         }
         __syncthreads();
         if (more) {
-            nt_store<BM>(As, ra);
-            nt_store<BN>(Bs, rb);
+            nt_store<BM, true>(As, ra, (kt + 1) * GEMM_BK, as.split, sa0, sa1);
+            nt_store<BN, false>(Bs, rb, 0, 0, sb0, sb1);
             __syncthreads();
         }
     }
@@ -212,10 +233,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 }
 
 // ---- TN (dW): reduction over rows m, operands are [m][channel] --------------------------
+// TN tile: 32 rows (m) x COLS channels.  Loads are raw; the per-row factors (rowmul, and the two-plane
+// row scale) are fetched into `f0`/`f1` next to them and applied by tn_store after the MFMA phase.
 template <int COLS, bool VEC>
 __device__ __forceinline__ void tn_load(const float* __restrict__ P, int64_t ld, int64_t m0, int64_t mend,
                                         int c0, int ncols, const float* __restrict__ rowmul, const RowScale& rs,
-                                        float4 (&regs)[COLS / 32]) {
+                                        float4 (&regs)[COLS / 32], float (&f0)[COLS / 32], float (&f1)[COLS / 32]) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < COLS / 32; ++i) {
@@ -224,6 +247,7 @@ __device__ __forceinline__ void tn_load(const float* __restrict__ P, int64_t ld,
         const int64_t row = m0 + r;
         const int c = c0 + c4 * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float a0 = 1.f, a1 = 1.f;
         if (row < mend) {
             const float* p = P + row * ld + c;
             if (VEC) {
@@ -234,31 +258,33 @@ __device__ __forceinline__ void tn_load(const float* __restrict__ P, int64_t ld,
                 if (c + 2 < ncols) v.z = p[2];
                 if (c + 3 < ncols) v.w = p[3];
             }
-            if (rowmul != nullptr) {
-                const float s = rowmul[row];
-                v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-            }
+            if (rowmul != nullptr) { a0 = rowmul[row]; a1 = a0; }
             if (rs.r0 != nullptr) {
-                const float s0 = rs.r0[row];
-                const float s1 = rs.r1 != nullptr ? rs.r1[row] : 1.f;
-                v.x *= (c + 0 < rs.split) ? s0 : s1;
-                v.y *= (c + 1 < rs.split) ? s0 : s1;
-                v.z *= (c + 2 < rs.split) ? s0 : s1;
-                v.w *= (c + 3 < rs.split) ? s0 : s1;
+                a0 *= rs.r0[row];
+                a1 *= rs.r1 != nullptr ? rs.r1[row] : 1.f;
             }
         }
         regs[i] = v;
+        f0[i] = a0;
+        f1[i] = a1;
     }
 }
 
 template <int COLS>
-__device__ __forceinline__ void tn_store(float* __restrict__ S, const float4 (&regs)[COLS / 32]) {
+__device__ __forceinline__ void tn_store(float* __restrict__ S, const float4 (&regs)[COLS / 32], int c0, int split,
+                                         bool split_active, const float (&f0)[COLS / 32], const float (&f1)[COLS / 32]) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < COLS / 32; ++i) {
         const int f = tid + 256 * i;
         const int r = f / (COLS / 4), c4 = f % (COLS / 4);
-        *reinterpret_cast<float4*>(S + r * COLS + c4 * 4) = regs[i];
+        const int c = c0 + c4 * 4;
+        float4 v = regs[i];
+        v.x *= (!split_active || c + 0 < split) ? f0[i] : f1[i];
+        v.y *= (!split_active || c + 1 < split) ? f0[i] : f1[i];
+        v.z *= (!split_active || c + 2 < split) ? f0[i] : f1[i];
+        v.w *= (!split_active || c + 3 < split) ? f0[i] : f1[i];
+        *reinterpret_cast<float4*>(S + r * COLS + c4 * 4) = v;
     }
 }
 
@@ -289,18 +315,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
 
     float4 ra[BM / 32], rb[BN / 32];
+    float fa0[BM / 32], fa1[BM / 32], fb0[BN / 32], fb1[BN / 32];
     const RowScale none = {nullptr, nullptr, 0};
-    tn_load<BM, VEC>(A, lda, mbeg, mend, p0, P, sa, none, ra);
-    tn_load<BN, VEC>(B, ldb, mbeg, mend, q0, Q, nullptr, sb, rb);
-    tn_store<BM>(As, ra);
-    tn_store<BN>(Bs, rb);
+    const bool sb_active = sb.r0 != nullptr;
+    tn_load<BM, VEC>(A, lda, mbeg, mend, p0, P, sa, none, ra, fa0, fa1);
+    tn_load<BN, VEC>(B, ldb, mbeg, mend, q0, Q, nullptr, sb, rb, fb0, fb1);
+    tn_store<BM>(As, ra, p0, 0, false, fa0, fa1);
+    tn_store<BN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1);
     __syncthreads();
 
     for (int64_t mt = mbeg; mt < mend; mt += GEMM_BK) {
         const bool more = (mt + GEMM_BK < mend);
         if (more) {
-            tn_load<BM, VEC>(A, lda, mt + GEMM_BK, mend, p0, P, sa, none, ra);
-            tn_load<BN, VEC>(B, ldb, mt + GEMM_BK, mend, q0, Q, nullptr, sb, rb);
+            tn_load<BM, VEC>(A, lda, mt + GEMM_BK, mend, p0, P, sa, none, ra, fa0, fa1);
+            tn_load<BN, VEC>(B, ldb, mt + GEMM_BK, mend, q0, Q, nullptr, sb, rb, fb0, fb1);
         }
 #pragma unroll
         for (int kk = 0; kk < GEMM_BK / 2; ++kk) {
@@ -317,8 +345,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         }
         __syncthreads();
         if (more) {
-            tn_store<BM>(As, ra);
-            tn_store<BN>(Bs, rb);
+            tn_store<BM>(As, ra, p0, 0, false, fa0, fa1);
+            tn_store<BN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1);
             __syncthreads();
         }
     }
