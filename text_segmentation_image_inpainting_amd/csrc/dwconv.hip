@@ -15,98 +15,135 @@ struct DwGeom {
 };
 
 // weights arrive as [C][T] (reference layout [C,1,kh,kw]); kernels read wT[T][C].
-// Grids are (x: pixels-of-a-row x channel groups, y: row, z: image): all index math is 32-bit and
-// the only division is by the channel-group count.
-template <int W>
+// Grids are (x: pixel groups of a row x channel groups, y: row, z: image): index math is 32-bit.
+// Every tap is an UNCONDITIONAL load from a clamped address followed by a select (never `x * 0`: a
+// clamped address may hold NaN/Inf) -- data-dependent `continue`s would chain the loads of a pixel
+// one after the other; this way a thread keeps PX * taps independent 16-byte loads in flight.
+template <bool K3> struct DwPx { static constexpr int value = K3 ? 2 : 4; };  // pixels per thread along x
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <int W, bool K3>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ rmask,
                                                      const float* __restrict__ wT, const float* __restrict__ bias,
                                                      const float* __restrict__ denom, const float* __restrict__ keep,
                                                      DwGeom g, float* __restrict__ y) {
+    constexpr int DW_PX = DwPx<K3>::value;
     const unsigned CG = (unsigned)(g.c / W);
-    const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= (unsigned)g.wo * CG) return;
-    const int ox = (int)(j / CG);
+    const unsigned nxg = (unsigned)((g.wo + DW_PX - 1) / DW_PX);
+    const unsigned gx = (nxg * CG + 255u) / 256u;               // blocks per output row
+    const unsigned b = xcd_remap(blockIdx.x, gridDim.x);        // each XCD gets a contiguous band of rows
+    const unsigned j = (b % gx) * blockDim.x + threadIdx.x;
+    if (j >= nxg * CG) return;
+    const unsigned row = b / gx;
+    const int ox0 = (int)(j / CG) * DW_PX;
     const int c = (int)(j % CG) * W;
-    const int oy = blockIdx.y;
-    const int64_t n = blockIdx.z;
-    const int64_t pix = (n * g.ho + oy) * g.wo + ox;
-    VecF<W> acc;
+    const int oy = (int)(row % (unsigned)g.ho);
+    const int64_t n = row / (unsigned)g.ho;
+    float acc[DW_PX][W];
 #pragma unroll
-    for (int i = 0; i < W; ++i) acc.v[i] = 0.f;
-    const bool kp = keep != nullptr ? (keep[pix] != 0.f) : true;
-    if (kp) {
-        for (int ky = 0; ky < g.kh; ++ky) {
-            const int iy = oy * g.sh - g.ph + ky * g.dh;
-            if (iy < 0 || iy >= g.h) continue;
-            for (int kx = 0; kx < g.kw; ++kx) {
-                const int ix = ox * g.sw - g.pw + kx * g.dw;
-                if (ix < 0 || ix >= g.w) continue;
-                const int64_t ipix = (n * g.h + iy) * g.w + ix;
+    for (int p = 0; p < DW_PX; ++p)
+#pragma unroll
+        for (int i = 0; i < W; ++i) acc[p][i] = 0.f;
+    const int KH = K3 ? 3 : g.kh, KW = K3 ? 3 : g.kw;   // compile-time 3x3: loops unroll, every tap load issues up-front
+#pragma unroll
+    for (int ky = 0; ky < KH; ++ky) {
+        const int iy = oy * g.sh - g.ph + ky * g.dh;
+        const bool yin = (iy >= 0 && iy < g.h);
+        const int64_t rowbase = (n * g.h + clampi(iy, 0, g.h - 1)) * g.w;
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            const VecF<W> wv = vload<W>(wT + (ky * KW + kx) * g.c + c);
+#pragma unroll
+            for (int p = 0; p < DW_PX; ++p) {
+                const int ix = (ox0 + p) * g.sw - g.pw + kx * g.dw;
+                const bool inb = yin && ix >= 0 && ix < g.w;
+                const int64_t ipix = rowbase + clampi(ix, 0, g.w - 1);
                 const float m = rmask != nullptr ? rmask[ipix] : 1.f;
                 const VecF<W> xv = vload<W>(x + ipix * g.c + c);
-                const VecF<W> wv = vload<W>(wT + (ky * g.kw + kx) * g.c + c);
 #pragma unroll
-                for (int i = 0; i < W; ++i) acc.v[i] = fmaf(xv.v[i] * m, wv.v[i], acc.v[i]);
+                for (int i = 0; i < W; ++i) acc[p][i] = fmaf(inb ? xv.v[i] * m : 0.f, wv.v[i], acc[p][i]);
             }
         }
+    }
+#pragma unroll
+    for (int p = 0; p < DW_PX; ++p) {
+        const int ox = ox0 + p;
+        if (ox >= g.wo) break;
+        const int64_t pix = (n * g.ho + oy) * g.wo + ox;
+        const bool kp = keep != nullptr ? (keep[pix] != 0.f) : true;
         const float dn = denom != nullptr ? denom[pix] : 1.f;
+        VecF<W> o;
 #pragma unroll
         for (int i = 0; i < W; ++i) {
-            float v = acc.v[i];
+            float v = acc[p][i];
             if (denom != nullptr) v = v / dn;
             if (bias != nullptr) v += bias[c + i];
-            acc.v[i] = v;
+            o.v[i] = kp ? v : 0.f;
         }
+        vstore<W>(y + pix * g.c + c, o);
     }
-    vstore<W>(y + pix * g.c + c, acc);
 }
 
-template <int W>
+template <int W, bool K3>
 __global__ __launch_bounds__(256) void dw_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
                                                         const float* __restrict__ wT, const float* __restrict__ rmask,
                                                         DwGeom g, float* __restrict__ dx) {
+    constexpr int DW_PX = DwPx<K3>::value;
     const unsigned CG = (unsigned)(g.c / W);
-    const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= (unsigned)g.w * CG) return;
-    const int ix = (int)(j / CG);
+    const unsigned nxg = (unsigned)((g.w + DW_PX - 1) / DW_PX);
+    const unsigned gx = (nxg * CG + 255u) / 256u;
+    const unsigned b = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned j = (b % gx) * blockDim.x + threadIdx.x;
+    if (j >= nxg * CG) return;
+    const unsigned row = b / gx;
+    const int ix0 = (int)(j / CG) * DW_PX;
     const int c = (int)(j % CG) * W;
-    const int iy = blockIdx.y;
-    const int64_t n = blockIdx.z;
-    const int64_t pix = (n * g.h + iy) * g.w + ix;
-    VecF<W> acc;
+    const int iy = (int)(row % (unsigned)g.h);
+    const int64_t n = row / (unsigned)g.h;
+    float acc[DW_PX][W];
 #pragma unroll
-    for (int i = 0; i < W; ++i) acc.v[i] = 0.f;
-    const float m = rmask != nullptr ? rmask[pix] : 1.f;
-    if (m != 0.f) {
-        for (int ky = 0; ky < g.kh; ++ky) {
-            const int ty = iy + g.ph - ky * g.dh;
-            if (ty < 0 || (ty % g.sh) != 0) continue;
-            const int oy = ty / g.sh;
-            if (oy >= g.ho) continue;
-            for (int kx = 0; kx < g.kw; ++kx) {
-                const int tx = ix + g.pw - kx * g.dw;
-                if (tx < 0 || (tx % g.sw) != 0) continue;
-                const int ox = tx / g.sw;
-                if (ox >= g.wo) continue;
-                const int64_t opix = (n * g.ho + oy) * g.wo + ox;
-                const float s = inv != nullptr ? inv[opix] : 1.f;
+    for (int p = 0; p < DW_PX; ++p)
+#pragma unroll
+        for (int i = 0; i < W; ++i) acc[p][i] = 0.f;
+    const int KH = K3 ? 3 : g.kh, KW = K3 ? 3 : g.kw;
+#pragma unroll
+    for (int ky = 0; ky < KH; ++ky) {
+        const int ty = iy + g.ph - ky * g.dh;
+        const bool vy = ty >= 0 && (ty % g.sh) == 0 && (ty / g.sh) < g.ho;
+        const int64_t rowbase = (n * g.ho + clampi(ty / g.sh, 0, g.ho - 1)) * g.wo;
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            const VecF<W> wv = vload<W>(wT + (ky * KW + kx) * g.c + c);
+#pragma unroll
+            for (int p = 0; p < DW_PX; ++p) {
+                const int tx = ix0 + p + g.pw - kx * g.dw;
+                const bool v = vy && tx >= 0 && (tx % g.sw) == 0 && (tx / g.sw) < g.wo;
+                const int64_t opix = rowbase + clampi(tx / g.sw, 0, g.wo - 1);
+                const float sc = inv != nullptr ? inv[opix] : 1.f;
                 const VecF<W> gv = vload<W>(dy + opix * g.c + c);
-                const VecF<W> wv = vload<W>(wT + (ky * g.kw + kx) * g.c + c);
 #pragma unroll
-                for (int i = 0; i < W; ++i) acc.v[i] = fmaf(gv.v[i] * s, wv.v[i], acc.v[i]);
+                for (int i = 0; i < W; ++i) acc[p][i] = fmaf(v ? gv.v[i] * sc : 0.f, wv.v[i], acc[p][i]);
             }
         }
-#pragma unroll
-        for (int i = 0; i < W; ++i) acc.v[i] *= m;
     }
-    vstore<W>(dx + pix * g.c + c, acc);
+#pragma unroll
+    for (int p = 0; p < DW_PX; ++p) {
+        const int ix = ix0 + p;
+        if (ix >= g.w) break;
+        const int64_t pix = (n * g.h + iy) * g.w + ix;
+        const float m = rmask != nullptr ? rmask[pix] : 1.f;
+        VecF<W> o;
+#pragma unroll
+        for (int i = 0; i < W; ++i) o.v[i] = (m != 0.f) ? acc[p][i] * m : 0.f;
+        vstore<W>(dx + pix * g.c + c, o);
+    }
 }
 
 // dW partials.  Block = CGB (<= 32) channel groups x L pixel lanes; it walks `rpb` output rows (n,oy),
 // lane l taking ox = l, l+L, ...; 9 taps x W channels (+ bias) stay in registers, the L lanes are
-// combined through LDS, so each block emits ONE partial row: part[by][(T+1)][C].
+// combined through LDS, so each block emits ONE partial row: part[by][(T+1)][C].  Branch-free taps.
 static constexpr int DW_TAPS = 9;
-template <int W>
+template <int W, bool K3>
 __global__ __launch_bounds__(256) void dw_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
                                                         const float* __restrict__ keep, const float* __restrict__ x,
                                                         const float* __restrict__ rmask, DwGeom g, int CGB, int L,
@@ -115,13 +152,16 @@ __global__ __launch_bounds__(256) void dw_bwd_dw_kernel(const float* __restrict_
     const int CG = g.c / W;
     const int T = g.kh * g.kw;
     const int cgl = threadIdx.x % CGB, lane = threadIdx.x / CGB;
-    const int cg = blockIdx.x * CGB + cgl;
+    const unsigned gxb = (unsigned)((CG + CGB - 1) / CGB);
+    const unsigned b = xcd_remap(blockIdx.x, gridDim.x);        // contiguous row chunks per XCD
+    const int bx = (int)(b % gxb), by = (int)(b / gxb);
+    const int cg = bx * CGB + cgl;
     const bool active = (lane < L) && (cg < CG);
     const int c = cg * W;
     const int rows_total = g.n * g.ho;
-    const int row0 = blockIdx.y * rpb;
+    const int row0 = by * rpb;
     const int row1 = row0 + rpb < rows_total ? row0 + rpb : rows_total;
-    float* prow = part + (int64_t)blockIdx.y * (T + 1) * g.c;
+    float* prow = part + (int64_t)by * (T + 1) * g.c;
     for (int t0 = 0; t0 < T; t0 += DW_TAPS) {
         float acc[DW_TAPS + 1][W];   // last entry: bias gradient
 #pragma unroll
@@ -134,25 +174,28 @@ __global__ __launch_bounds__(256) void dw_bwd_dw_kernel(const float* __restrict_
                 const int oy = row % g.ho;
                 for (int ox = lane; ox < g.wo; ox += L) {
                     const int64_t pix = (int64_t)row * g.wo + ox;
-                    if (keep != nullptr && keep[pix] == 0.f) continue;  // hole: no gradient (partial_convolution.py:72)
+                    const bool kp = keep != nullptr ? (keep[pix] != 0.f) : true;   // hole: no gradient (:72)
                     const float s = inv != nullptr ? inv[pix] : 1.f;
-                    VecF<W> gv = vload<W>(dy + pix * g.c + c);
+                    const VecF<W> graw = vload<W>(dy + pix * g.c + c);
+                    float gv[W];
 #pragma unroll
-                    for (int i = 0; i < W; ++i) { acc[DW_TAPS][i] += gv.v[i]; gv.v[i] *= s; }  // bias is added after the division
+                    for (int i = 0; i < W; ++i) {
+                        acc[DW_TAPS][i] += kp ? graw.v[i] : 0.f;          // bias is added after the division
+                        gv[i] = kp ? graw.v[i] * s : 0.f;
+                    }
 #pragma unroll
                     for (int t = 0; t < DW_TAPS; ++t) {
-                        const int tt = t0 + t;
-                        if (tt >= T) break;
-                        const int ky = tt / g.kw, kx = tt % g.kw;
+                        const int tt = K3 ? t : ((t0 + t < T) ? t0 + t : T - 1);
+                        const bool tv = K3 ? true : (t0 + t < T);
+                        const int ky = K3 ? t / 3 : tt / g.kw, kx = K3 ? t % 3 : tt % g.kw;
                         const int iy = oy * g.sh - g.ph + ky * g.dh;
                         const int ix = ox * g.sw - g.pw + kx * g.dw;
-                        if (iy < 0 || iy >= g.h || ix < 0 || ix >= g.w) continue;
-                        const int64_t ipix = (n * g.h + iy) * g.w + ix;
+                        const bool inb = tv && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w;
+                        const int64_t ipix = (n * g.h + clampi(iy, 0, g.h - 1)) * g.w + clampi(ix, 0, g.w - 1);
                         const float m = rmask != nullptr ? rmask[ipix] : 1.f;
-                        if (m == 0.f) continue;
                         const VecF<W> xv = vload<W>(x + ipix * g.c + c);
 #pragma unroll
-                        for (int i = 0; i < W; ++i) acc[t][i] = fmaf(gv.v[i], xv.v[i] * m, acc[t][i]);
+                        for (int i = 0; i < W; ++i) acc[t][i] = fmaf(gv[i], inb ? xv.v[i] * m : 0.f, acc[t][i]);
                     }
                 }
             }
@@ -252,10 +295,14 @@ extern "C" int tsii_dw_fwd(const float* x, const float* rmask, const float* w, c
     int rc = launch_transpose(w, c, kh * kw, ws, st);  // [C][T] -> [T][C]
     if (rc) return rc;
     const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(ws);
-    TSII_REQUIRE(ho <= 65535 && n <= 65535, "dw_fwd: grid limit");
-    const dim3 grid(cdiv(wo * (vec ? c / 4 : c), 256), ho, n);
-    if (vec) hipLaunchKernelGGL((dw_fwd_kernel<4>), grid, dim3(256), 0, st, x, rmask, ws, bias, denom, keep, g, y);
-    else hipLaunchKernelGGL((dw_fwd_kernel<1>), grid, dim3(256), 0, st, x, rmask, ws, bias, denom, keep, g, y);
+    const bool k3 = (kh == 3 && kw == 3);
+    const int px = (vec && k3) ? DwPx<true>::value : DwPx<false>::value;
+    const int64_t nblk = (int64_t)cdiv(cdiv(wo, px) * (vec ? c / 4 : c), 256) * ho * n;
+    TSII_REQUIRE(nblk < (1ll << 31), "dw_fwd: grid limit");
+    const dim3 grid((unsigned)nblk);
+    if (vec && k3) hipLaunchKernelGGL((dw_fwd_kernel<4, true>), grid, dim3(256), 0, st, x, rmask, ws, bias, denom, keep, g, y);
+    else if (vec) hipLaunchKernelGGL((dw_fwd_kernel<4, false>), grid, dim3(256), 0, st, x, rmask, ws, bias, denom, keep, g, y);
+    else hipLaunchKernelGGL((dw_fwd_kernel<1, false>), grid, dim3(256), 0, st, x, rmask, ws, bias, denom, keep, g, y);
     return check_launch("dw_fwd");
 }
 
@@ -269,10 +316,14 @@ extern "C" int tsii_dw_bwd_dx(const float* dy, const float* inv, const float* w,
     int rc = launch_transpose(w, c, kh * kw, ws, st);
     if (rc) return rc;
     const bool vec = (c % 4 == 0) && aligned16(dy) && aligned16(dx) && aligned16(ws);
-    TSII_REQUIRE(h <= 65535 && n <= 65535, "dw_bwd_dx: grid limit");
-    const dim3 grid(cdiv(wd * (vec ? c / 4 : c), 256), h, n);
-    if (vec) hipLaunchKernelGGL((dw_bwd_dx_kernel<4>), grid, dim3(256), 0, st, dy, inv, ws, rmask, g, dx);
-    else hipLaunchKernelGGL((dw_bwd_dx_kernel<1>), grid, dim3(256), 0, st, dy, inv, ws, rmask, g, dx);
+    const bool k3 = (kh == 3 && kw == 3);
+    const int px = (vec && k3) ? DwPx<true>::value : DwPx<false>::value;
+    const int64_t nblk = (int64_t)cdiv(cdiv(wd, px) * (vec ? c / 4 : c), 256) * h * n;
+    TSII_REQUIRE(nblk < (1ll << 31), "dw_bwd_dx: grid limit");
+    const dim3 grid((unsigned)nblk);
+    if (vec && k3) hipLaunchKernelGGL((dw_bwd_dx_kernel<4, true>), grid, dim3(256), 0, st, dy, inv, ws, rmask, g, dx);
+    else if (vec) hipLaunchKernelGGL((dw_bwd_dx_kernel<4, false>), grid, dim3(256), 0, st, dy, inv, ws, rmask, g, dx);
+    else hipLaunchKernelGGL((dw_bwd_dx_kernel<1, false>), grid, dim3(256), 0, st, dy, inv, ws, rmask, g, dx);
     return check_launch("dw_bwd_dx");
 }
 
@@ -296,9 +347,11 @@ extern "C" int tsii_dw_bwd_dw(const float* dy, const float* inv, const float* ke
     const bool vec = (c % 4 == 0) && aligned16(dy) && aligned16(x);
     const DwPlan p = plan_dw(n, ho, c, vec);
     float* part = (float*)ws;
-    const dim3 grid(p.gx, p.gy);
-    if (vec) hipLaunchKernelGGL((dw_bwd_dw_kernel<4>), grid, dim3(256), 0, st, dy, inv, keep, x, rmask, g, p.CGB, p.L, p.rpb, part);
-    else hipLaunchKernelGGL((dw_bwd_dw_kernel<1>), grid, dim3(256), 0, st, dy, inv, keep, x, rmask, g, p.CGB, p.L, p.rpb, part);
+    const dim3 grid((unsigned)(p.gx * p.gy));
+    const bool k3 = (kh == 3 && kw == 3);
+    if (vec && k3) hipLaunchKernelGGL((dw_bwd_dw_kernel<4, true>), grid, dim3(256), 0, st, dy, inv, keep, x, rmask, g, p.CGB, p.L, p.rpb, part);
+    else if (vec) hipLaunchKernelGGL((dw_bwd_dw_kernel<4, false>), grid, dim3(256), 0, st, dy, inv, keep, x, rmask, g, p.CGB, p.L, p.rpb, part);
+    else hipLaunchKernelGGL((dw_bwd_dw_kernel<1, false>), grid, dim3(256), 0, st, dy, inv, keep, x, rmask, g, p.CGB, p.L, p.rpb, part);
     int rc = check_launch("dw_bwd_dw");
     if (rc) return rc;
     const int T = kh * kw;

@@ -96,15 +96,6 @@ __device__ __forceinline__ void nt_store(float* __restrict__ S, const float4 (&r
     }
 }
 
-// XCD-aware bijective block remap: consecutive logical tiles (which share an A row panel)
-// land on the same XCD / L2 instead of being dealt round-robin over the 8 XCDs.
-__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
-    const unsigned xcd = bid & 7u, local = bid >> 3;
-    const unsigned q = nblocks >> 3, r = nblocks & 7u;
-    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + local;
-}
-
 template <int WM, int WN, int TM, int TN, bool VEC>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda, RowScale as,
                                                       const float* __restrict__ B, int64_t ldb,

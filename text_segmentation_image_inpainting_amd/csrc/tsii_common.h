@@ -85,6 +85,17 @@ static inline unsigned chan_grid(int64_t items, int CG, int block) {
     return (unsigned)(k * unit);
 }
 
+// XCD-aware bijective block remap.  The dispatcher deals consecutive block ids round-robin to the 8
+// XCDs (private L2 each); this maps block id -> logical tile so that every XCD works on ONE contiguous
+// range of logical tiles (neighbouring tiles share operand panels / stencil rows in that XCD's L2).
+// Placement only affects speed, never correctness.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
+    const unsigned xcd = bid & 7u, local = bid >> 3;
+    const unsigned q = nblocks >> 3, r = nblocks & 7u;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
