@@ -35,6 +35,20 @@ def nt_variant(n_cols: int) -> str:
     return "gemm_nt<128x64>" if n_cols > 32 else "gemm_nt<128x32>"
 
 
+def pmc_traffic(kernel_label: str):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, x2 read correction; see the file's `_how`)."""
+    path = os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic_bs32.json")
+    names = {"gemm_nt<128x128>": "tsii::gemm_nt_kernel<2, 2, 2, 2, true>",
+             "gemm_nt<128x64>": "tsii::gemm_nt_kernel<2, 2, 2, 1, true>",
+             "gemm_nt<128x32>": "tsii::gemm_nt_kernel<4, 1, 1, 1, true>"}
+    try:
+        rec = json.load(open(path))["kernels"][names[kernel_label]]
+        return rec["bytes_per_launch"]
+    except Exception:  # noqa: BLE001 - no summary committed for this kernel/config
+        return None
+
+
 def cpu_baseline(size: int, threads: int):
     """Oracle (stock-PyTorch CPU restatement of the reference) on a bounded sample of the workload."""
     from oracle import pconv_oracle as O
@@ -139,9 +153,10 @@ def main():
                 m, p, q = a[0], a[1], a[2]       # (M, K, N) for pw_fwd ; (M, N, K) for pw_bwd_dx
                 out_cols = q if name == "tsii_pw_fwd" else q
                 v = nt_variant(out_cols)
-                d = agg.setdefault(v, {"ms": 0.0, "flop": 0.0, "launches": 0})
+                d = agg.setdefault(v, {"ms": 0.0, "flop": 0.0, "launches": 0, "alg_bytes": 0.0})
                 d["ms"] += ms
                 d["flop"] += 2.0 * m * p * q
+                d["alg_bytes"] += 4.0 * m * (p + q)   # read the [M, K] operand once, write [M, N] once
                 d["launches"] += 1
         dom = max(agg.items(), key=lambda kv: kv[1]["ms"]) if agg else None
         roofline = None
@@ -149,7 +164,11 @@ def main():
             k, d = dom
             ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
+                        "traffic": (pmc_traffic(k) if (args.batch == 32 and args.size == 512 and args.model == "ImageFill") else None),
+                        "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_c_pmc_hbm_traffic_bs32.json)",
+                        "alg_bytes_per_launch": round(d["alg_bytes"] / d["launches"]),
+                        "alg_flop_per_launch": round(d["flop"] / d["launches"]),
                         "launches_per_step": d["launches"] // args.steps,
                         "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                         "ms_per_step_in_kernel": round(d["ms"] / args.steps, 3),

@@ -295,7 +295,9 @@ extern "C" int tsii_dw_fwd(const float* x, const float* rmask, const float* w, c
     int rc = launch_transpose(w, c, kh * kw, ws, st);  // [C][T] -> [T][C]
     if (rc) return rc;
     const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(ws);
-    const bool k3 = (kh == 3 && kw == 3);
+    // measured on MI355X: the fully unrolled 3x3 form (more loads in flight) is SLOWER here -- these
+    // stencils are bound by vector-memory instruction issue, not latency -- so it stays disabled
+    const bool k3 = false;
     const int px = (vec && k3) ? DwPx<true>::value : DwPx<false>::value;
     const int64_t nblk = (int64_t)cdiv(cdiv(wo, px) * (vec ? c / 4 : c), 256) * ho * n;
     TSII_REQUIRE(nblk < (1ll << 31), "dw_fwd: grid limit");
@@ -316,7 +318,7 @@ extern "C" int tsii_dw_bwd_dx(const float* dy, const float* inv, const float* w,
     int rc = launch_transpose(w, c, kh * kw, ws, st);
     if (rc) return rc;
     const bool vec = (c % 4 == 0) && aligned16(dy) && aligned16(dx) && aligned16(ws);
-    const bool k3 = (kh == 3 && kw == 3);
+    const bool k3 = false;  // see dw_fwd
     const int px = (vec && k3) ? DwPx<true>::value : DwPx<false>::value;
     const int64_t nblk = (int64_t)cdiv(cdiv(wd, px) * (vec ? c / 4 : c), 256) * h * n;
     TSII_REQUIRE(nblk < (1ll << 31), "dw_bwd_dx: grid limit");
