@@ -38,6 +38,7 @@ extern "C" {
 #define TSII_ACT_RELU 1
 #define TSII_ACT_LEAKY 2 /* slope argument */
 #define TSII_ACT_RELU6 3
+#define TSII_ACT_SIGMOID 4
 
 int tsii_version(void);
 const char* tsii_last_error(void);
@@ -168,6 +169,33 @@ int tsii_l1_mean_bwd(const float* a, const float* b, int64_t numel, const float*
  * checkpoints/ReadME.md:4): g += wd*p; buf = mom*buf + g; p -= lr*(g + mom*buf) */
 int tsii_sgd_nesterov(float* p, const float* g, float* buf, int64_t numel,
                       float lr, float momentum, float weight_decay, void* stream);
+
+/* ---- segmentation path (models/common.py, models/text_segmentation.py, loss.py) ------- */
+/* out = act(a + b): residual adds `x + self.conv(x)` (models/MobileNetV2.py:146-147, models/Xception.py:44)
+ * and `act_fn(rfb_pool + resi)` (models/common.py:156).  Backward: tsii_act_bwd(dout, out, ...) twice. */
+int tsii_add_act_fwd(const float* a, const float* b, int64_t numel, int act, float slope, float* out, void* stream);
+/* channel concat / slice on [M, C] NHWC rows (torch.cat dim=1, models/text_segmentation.py:68,75,80,111;
+ * models/common.py:91,151):  to_dst != 0: big[m, coff + c] = small[m, c];  else small[m, c] = big[m, coff + c] */
+int tsii_copy_channels(float* big, int64_t m, int cbig, int coff, float* small_, int csmall, int to_dst, void* stream);
+/* bilinear up-sampling by an integer factor, align_corners=False (F.interpolate / nn.Upsample,
+ * models/text_segmentation.py:54,76,109,113); x is [n,h,w,c], y is [n,h*s,w*s,c] */
+int tsii_bilinear_up_fwd(const float* x, int n, int h, int w, int c, int scale, float* y, void* stream);
+int tsii_bilinear_up_bwd(const float* dy, int n, int h, int w, int c, int scale, float* dx, void* stream);
+/* global average pool (nn.AdaptiveAvgPool2d(1), models/common.py:19,35): gap[n,c] = mean_hw x[n,hw,c] */
+size_t tsii_gap_ws_bytes(int n, int hw, int c);
+int tsii_gap_fwd(const float* x, int n, int hw, int c, float* gap, void* ws, size_t ws_bytes, void* stream);
+int tsii_gap_bwd(const float* dgap, int n, int hw, int c, float* dx, void* stream);
+/* scSE combine (models/common.py:38-43): out = x*cse[n,c] + x*sse[n,hw];
+ * backward: dx = g*(cse+sse), dcse[n,c] = sum_hw g*x, dsse[n,hw] = sum_c g*x */
+int tsii_scse_fwd(const float* x, const float* cse, const float* sse, int n, int hw, int c, float* out, void* stream);
+int tsii_scse_bwd(const float* g, const float* x, const float* cse, const float* sse, int n, int hw, int c,
+                  float* dx, float* dcse, float* dsse, void* ws, size_t ws_bytes, void* stream);
+/* BinaryFocalLoss (loss.py:58-75): mean( exp(gamma*logsigmoid(-x*(2t-1))) * w*BCEwithlogits(x,t) ),
+ * w = words_w if t > 0 else background_w.  ws: tsii_l1_ws_bytes(numel). */
+int tsii_bce_focal_fwd(const float* x, const float* t, int64_t numel, float gamma, float background_w, float words_w,
+                       float* loss, void* ws, size_t ws_bytes, void* stream);
+int tsii_bce_focal_bwd(const float* x, const float* t, int64_t numel, float gamma, float background_w, float words_w,
+                       const float* gscale, float* dx, void* stream);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ def _rng(key: str, seed: int) -> np.random.Generator:
     return np.random.default_rng((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF)
 
 
-def fill_tensor(key: str, shape, seed: int = 0) -> np.ndarray:
+def fill_tensor(key: str, shape, seed: int = 0, gain: float = 2.0) -> np.ndarray:
     """Value for state_dict entry ``key`` of ``shape`` (float32 / int64)."""
     r = _rng(key, seed)
     shape = tuple(shape)
@@ -37,25 +37,25 @@ def fill_tensor(key: str, shape, seed: int = 0) -> np.ndarray:
         return r.uniform(0.5, 1.5, shape).astype(np.float32)
     if key.endswith(".weight") and len(shape) >= 2:  # conv / linear
         fan_in = int(np.prod(shape[1:]))
-        std = (2.0 / max(fan_in, 1)) ** 0.5
+        std = (gain / max(fan_in, 1)) ** 0.5   # gain 2 = He init; deep eval-mode nets use 1 to stay O(1)
         return (std * r.standard_normal(shape)).astype(np.float32)
     return (0.1 * r.standard_normal(shape)).astype(np.float32)
 
 
-def fill_state_dict_(state_dict, seed: int = 0):
+def fill_state_dict_(state_dict, seed: int = 0, gain: float = 2.0):
     """In-place fill of every tensor of a ``state_dict`` (reference or product)."""
     with torch.no_grad():
         for k, v in state_dict.items():
-            val = torch.from_numpy(fill_tensor(k, v.shape, seed))
+            val = torch.from_numpy(fill_tensor(k, v.shape, seed, gain))
             v.copy_(val.to(v.dtype).reshape(v.shape))
     return state_dict
 
 
-def make_state_dict(key_shapes, seed: int = 0, dtype=torch.float32):
+def make_state_dict(key_shapes, seed: int = 0, dtype=torch.float32, gain: float = 2.0):
     """Build a fresh filled state_dict from ``[(key, shape), ...]``."""
     out = {}
     for k, shape in key_shapes:
-        t = torch.from_numpy(fill_tensor(k, shape, seed))
+        t = torch.from_numpy(fill_tensor(k, shape, seed, gain))
         out[k] = t if t.dtype == torch.int64 else t.to(dtype)
     return out
 

@@ -47,6 +47,17 @@ SIGNATURES = {
     "tsii_l1_mean_fwd": (_i, [_p, _p, _l, _p, _p, _z, _p]),
     "tsii_l1_mean_bwd": (_i, [_p, _p, _l, _p, _p, _p]),
     "tsii_sgd_nesterov": (_i, [_p, _p, _p, _l, _f, _f, _f, _p]),
+    "tsii_add_act_fwd": (_i, [_p, _p, _l, _i, _f, _p, _p]),
+    "tsii_copy_channels": (_i, [_p, _l, _i, _i, _p, _i, _i, _p]),
+    "tsii_bilinear_up_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "tsii_bilinear_up_bwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "tsii_gap_ws_bytes": (_z, [_i, _i, _i]),
+    "tsii_gap_fwd": (_i, [_p, _i, _i, _i, _p, _p, _z, _p]),
+    "tsii_gap_bwd": (_i, [_p, _i, _i, _i, _p, _p]),
+    "tsii_scse_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
+    "tsii_scse_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _z, _p]),
+    "tsii_bce_focal_fwd": (_i, [_p, _p, _l, _f, _f, _f, _p, _p, _z, _p]),
+    "tsii_bce_focal_bwd": (_i, [_p, _p, _l, _f, _f, _f, _p, _p, _p]),
 }
 
 _LIB = None

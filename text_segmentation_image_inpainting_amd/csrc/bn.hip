@@ -263,7 +263,7 @@ extern "C" int tsii_bn_act_fwd(const float* y, int64_t m, int c, const float* me
                                const float* residual, float* out, void* stream) {
     TSII_REQUIRE(y && mean && var && gamma && beta && out, "bn_act_fwd: null pointer");
     TSII_REQUIRE(m > 0 && c > 0, "bn_act_fwd: bad shape");
-    TSII_REQUIRE(act >= 0 && act <= 3, "bn_act_fwd: unknown activation %d", act);
+    TSII_REQUIRE(act >= 0 && act <= 4, "bn_act_fwd: unknown activation %d", act);
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(out) && (residual == nullptr || aligned16(residual));
     const int64_t total = m * (vec ? c / 4 : c);
@@ -301,7 +301,7 @@ extern "C" int tsii_bn_act_bwd(const float* dout, const float* y, int64_t m, int
 
 extern "C" int tsii_act_fwd(const float* x, int64_t numel, int act, float slope, float* out, void* stream) {
     TSII_REQUIRE(x && out && numel > 0, "act_fwd: bad arguments");
-    TSII_REQUIRE(act >= 0 && act <= 3, "act_fwd: unknown activation %d", act);
+    TSII_REQUIRE(act >= 0 && act <= 4, "act_fwd: unknown activation %d", act);
     hipStream_t st = (hipStream_t)stream;
     if (numel % 4 == 0 && aligned16(x) && aligned16(out))
         hipLaunchKernelGGL((act_fwd_kernel<4>), dim3(stream_grid(numel / 4, 256)), dim3(256), 0, st, x, numel / 4, act, slope, out);

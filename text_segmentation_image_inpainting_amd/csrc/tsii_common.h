@@ -29,6 +29,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     if (act == TSII_ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == TSII_ACT_LEAKY) return v > 0.f ? v : v * slope;
     if (act == TSII_ACT_RELU6) return v < 0.f ? 0.f : (v > 6.f ? 6.f : v);
+    if (act == TSII_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
     return v;
 }
 // derivative as a function of the pre-activation value (torch semantics: 0 at v <= 0,
@@ -37,6 +38,7 @@ __device__ __forceinline__ float act_grad(float v, int act, float slope) {
     if (act == TSII_ACT_RELU) return v > 0.f ? 1.f : 0.f;
     if (act == TSII_ACT_LEAKY) return v > 0.f ? 1.f : slope;
     if (act == TSII_ACT_RELU6) return (v > 0.f && v < 6.f) ? 1.f : 0.f;
+    if (act == TSII_ACT_SIGMOID) { const float sg = 1.f / (1.f + expf(-v)); return sg * (1.f - sg); }
     return 1.f;
 }
 
