@@ -1,0 +1,105 @@
+"""Parity of the HIP segmentation path with reference-generated fixtures (tests/golden/make_golden_seg.py):
+building blocks (InvertedResidual+scSE, scSE, RFB, ASP, Xception ResidualBlock), BinaryFocalLoss, and the two
+whole nets.  1e-3 max-normalised tolerance."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import text_segmentation_image_inpainting_amd as T
+from oracle.filler import fill_state_dict_
+from tests.backends import BACKENDS, both_backends
+from tests.util import assert_close
+
+TOL = 1e-3
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def build_block(c):
+    act = torch.nn.LeakyReLU(0.3)
+    kw, kind = dict(c["kw"]), c["kind"]
+    if kind == "ir":
+        return T.InvertedResidual(activation=act, bias=False, **kw)
+    if kind == "scse":
+        return T.SpatialChannelSqueezeExcitation(kw["in_channel"], activation=act)
+    if kind == "rfb":
+        return T.RFB(kw["in_channel"], kw["out_channel"], activation=act, add_sece=True)
+    if kind == "asp":
+        return T.ASP(kw["in_channel"], kw["out_channel"], act_fn=act, asp_rate=tuple(kw["asp_rate"]))
+    return T.ResidualBlock(bias=False, BN=True, activation=act, **kw)
+
+
+@both_backends
+def test_golden_seg_blocks(backend):
+    meta = json.load(open(os.path.join(GOLD, "seg_blocks.json")))
+    G = np.load(os.path.join(GOLD, "seg_blocks.npz"))
+    with BACKENDS[backend]() as dev:
+        for c in meta:
+            i = c["idx"]
+            pre = f"blk{i}."
+            m = build_block(c)
+            assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == c["keys"], f"blk{i} state_dict layout"
+            fill_state_dict_(m.state_dict(), seed=300 + i)
+            m = m.to(dev).train()
+            x = torch.from_numpy(G[pre + "x"]).to(dev).requires_grad_(True)
+            y = m(x)
+            assert_close(y, G[pre + "y"], TOL, f"blk{i} {c['kind']} y")
+            y.backward(torch.from_numpy(G[pre + "gy"]).to(dev))
+            assert_close(x.grad, G[pre + "dx"], TOL, f"blk{i} {c['kind']} dx")
+            params, sd = dict(m.named_parameters()), m.state_dict()
+            gmax = max(float(np.abs(G[k]).max()) for k in G.files if k.startswith(pre + "grad."))
+            for k in G.files:
+                if k.startswith(pre + "grad."):
+                    assert_close(params[k[len(pre) + 5:]].grad, G[k], 2e-3, k, floor=1e-3 * gmax)
+                if k.startswith(pre + "buf."):
+                    assert_close(sd[k[len(pre) + 4:]], G[k], TOL, k)
+
+
+@both_backends
+def test_golden_focal_loss(backend):
+    G = np.load(os.path.join(GOLD, "focal_loss.npz"))
+    with BACKENDS[backend]() as dev:
+        t = torch.from_numpy(G["t"]).to(dev)
+        for j in range(4):
+            g, bw, ww = (float(v) for v in G[f"c{j}.cfg"])
+            x = torch.from_numpy(G["x"]).to(dev).requires_grad_(True)
+            loss = T.BinaryFocalLoss(g, bw, ww)(x, t)
+            assert abs(loss.item() - float(G[f"c{j}.loss"])) <= 1e-5 * max(1.0, abs(float(G[f"c{j}.loss"])))
+            loss.backward()
+            assert_close(x.grad, G[f"c{j}.dx"], TOL, f"focal c{j} dx")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["TextSegament", "XceptionTextSegment"])
+def test_golden_seg_nets_64_gpu(name):
+    keys = json.load(open(os.path.join(GOLD, "seg_state_dict_keys.json")))[name]
+    G = np.load(os.path.join(GOLD, name.lower() + "_64.npz"))
+    with BACKENDS["gpu"]() as dev:
+        m = getattr(T, name)()
+        assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == keys
+        fill_state_dict_(m.state_dict(), seed=41, gain=1.0)
+        m = m.to(dev)
+        x, t = torch.from_numpy(G["x"]).to(dev), torch.from_numpy(G["t"]).to(dev)
+        m.eval()
+        with torch.no_grad():
+            ye = m(x)
+        assert tuple(ye.shape) == (2, 1, 64, 64)
+        assert_close(ye, G["y_eval"], TOL, name + " eval")
+        assert_close(ye, G["y_eval_f64"], TOL, name + " eval vs the reference's fp64 run")
+        m.train()
+        y = m(x)
+        assert_close(y, G["y_train"], TOL, name + " train")
+        loss = T.BinaryFocalLoss(0, 1, 2)(y, t)
+        assert abs(loss.item() - float(G["loss"])) < 1e-4
+        loss.backward()
+        params = dict(m.named_parameters())
+        gmax = max(float(np.abs(G[k]).max()) for k in G.files if k.startswith("grad."))
+        n = 0
+        for k in G.files:
+            if k.startswith("grad."):
+                assert_close(params[k[5:]].grad, G[k], 3e-3, k, floor=1e-3 * gmax)
+                n += 1
+        assert n >= 12

@@ -98,6 +98,104 @@ def act_code(act):
     raise NotImplementedError(f"activation {act!r} has no HIP kernel (ReLU / ReLU6 / LeakyReLU only)")
 
 
+# +++++++++++++++++++++++++++++++++++++
+#           Convolution Wrappers   (models/BaseModels.py:91-127)
+# -------------------------------------
+# The reference builds its nets from torch.nn building blocks inside nn.Sequential containers; the
+# subclasses below keep the parameter names / container indices (so state_dict keys match) and route
+# forward() to the HIP kernels.  Tensors between modules are NCHW-shaped with channels_last memory,
+# so the NHWC views the kernels want are free.
+class Conv2d(nn.Conv2d):
+    def forward(self, x):
+        if self.padding_mode != "zeros":
+            raise NotImplementedError("only zero padding has a HIP kernel")
+        g = ops.make_geom(self.kernel_size, self.stride, self.padding, self.dilation)
+        return to_nchw(ops.conv2d(to_nhwc(x), self.weight, self.bias, g, self.groups))
+
+
+class BNAct(nn.Sequential):
+    """nn.Sequential(nn.BatchNorm2d(c)[, activation]) (models/BaseModels.py:95-99) as ONE fused kernel."""
+
+    def forward(self, x, residual=None):
+        bn = self[0]
+        act, slope = act_code(self[1] if len(self) > 1 else None)
+        training = bn.training or bn.running_mean is None
+        if training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        momentum = 0.1 if bn.momentum is None else bn.momentum
+        res = None if residual is None else to_nhwc(residual)
+        y = ops.bn_act(to_nhwc(x), bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps,
+                       act, slope, res)
+        return to_nchw(y)
+
+
+class Activation(nn.Module):
+    """A bare activation placed in a Sequential (models/BaseModels.py:100-101)."""
+
+    def __init__(self, act):
+        super().__init__()
+        self.act = act
+
+    def forward(self, x):
+        code, slope = act_code(self.act)
+        return to_nchw(ops.activation(to_nhwc(x), code, slope))
+
+
+class AvgPool2d(nn.AvgPool2d):
+    def forward(self, x):
+        k, s, p = self.kernel_size, self.stride, self.padding
+        if not (isinstance(k, int) and isinstance(s, int) and isinstance(p, int)) or self.ceil_mode or not self.count_include_pad:
+            raise NotImplementedError("only square AvgPool2d with count_include_pad=True has a HIP kernel")
+        return to_nchw(ops.avg_pool(to_nhwc(x), k, s, p))
+
+
+class Upsample(nn.Upsample):
+    def forward(self, x):
+        if self.mode != "bilinear" or self.align_corners or int(self.scale_factor) != self.scale_factor:
+            raise NotImplementedError("only integer-factor bilinear (align_corners=False) up-sampling has a HIP kernel")
+        return to_nchw(ops.bilinear_up(to_nhwc(x), int(self.scale_factor)))
+
+
+def interpolate_bilinear(x, scale_factor):
+    """F.interpolate(x, scale_factor=s, mode='bilinear', align_corners=False)."""
+    return to_nchw(ops.bilinear_up(to_nhwc(x), int(scale_factor)))
+
+
+def cat_channels(xs):
+    """torch.cat(xs, dim=1) on NCHW-shaped tensors."""
+    return to_nchw(ops.concat([to_nhwc(x) for x in xs]))
+
+
+def Conv_block(in_channels, out_channels, kernel_size, stride=1, padding=0,
+               dilation=1, groups=1, bias=True, BN=False, activation=None):
+    m = [Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)]
+    if BN:
+        if activation:
+            m += [BNAct(nn.BatchNorm2d(out_channels), activation)]
+        else:
+            m += [BNAct(nn.BatchNorm2d(out_channels))]
+    if BN is False and activation is not None:
+        m += [Activation(activation)]
+    return m
+
+
+class DSConvBlock(BaseModule):
+    """depth-wise separable convolution (models/BaseModels.py:105-127)"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0,
+                 dilation=1, bias=True, BN=False, activation_dep=None, activation_point=None):
+        super().__init__()
+        self.depth_wise_conv = nn.Sequential(
+            *Conv_block(in_channels, in_channels, kernel_size, stride, padding,
+                        dilation, in_channels, bias, BN=BN, activation=activation_dep))
+        self.point_wise_conv = nn.Sequential(
+            *Conv_block(in_channels, out_channels, kernel_size=1, stride=1, padding=0,
+                        dilation=1, bias=bias, BN=BN, activation=activation_point))
+
+    def forward(self, x):
+        return self.point_wise_conv(self.depth_wise_conv(x))
+
+
 def run_nhwc(layer, x, mp):
     """Run a mirrored module / nn.Sequential of them on (NHWC tensor, MaskParts)."""
     if hasattr(layer, "forward_nhwc"):

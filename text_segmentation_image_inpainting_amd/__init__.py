@@ -5,3 +5,8 @@ from .image_inpainting import DoublePartialResidual, ImageFill, ImageFillOrigin,
 from .MobileNetV2 import PartialInvertedResidual  # noqa: F401
 from .partial_convolution import (DoubleUpSample, PartialActivatedBN, PartialActivation, PartialConv,  # noqa: F401
                                   PartialConv1x1, PartialConvNoHoles, partial_convolution_block)
+from .MobileNetV2 import DilatedMobileNetV2, InvertedResidual, MobileNetV2  # noqa: F401,E402
+from .Xception import ResidualBlock, Xception  # noqa: F401,E402
+from .common import ASP, RFB, SpatialChannelSqueezeExcitation  # noqa: F401,E402
+from .text_segmentation import TextSegament, XceptionTextSegment  # noqa: F401,E402
+from .loss import BinaryFocalLoss  # noqa: F401,E402

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import call, ptr
 
-ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_RELU6 = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3, 4
 
 
 class Geom(NamedTuple):
@@ -420,3 +420,209 @@ def sgd_nesterov_(p, grad, buf, lr, momentum, weight_decay):
     assert p.is_contiguous() and grad.is_contiguous() and buf.is_contiguous()
     call("tsii_sgd_nesterov", ptr(p), ptr(grad), ptr(buf), p.numel(), float(lr), float(momentum),
          float(weight_decay), _lib.stream())
+
+
+# ---------------------------------------------------------------------------------------
+# segmentation path (models/common.py, models/text_segmentation.py, loss.py:58-83)
+# ---------------------------------------------------------------------------------------
+def conv2d(x, w, b, g: Geom, groups: int):
+    """Plain nn.Conv2d on NHWC data through the partial-conv kernels with no mask planes."""
+    cin, cout = x.shape[-1], w.shape[0]
+    if groups == 1:
+        if tuple(g)[:6] == (1, 1, 1, 1, 0, 0):
+            return pconv_pointwise(x, w, b)
+        return pconv_dense(x, w, b, None, None, 0, None, None, None, None, g)
+    if groups == cin == cout:
+        return pconv_depthwise(x, w, b, None, None, None, None, g)
+    raise NotImplementedError(f"conv2d groups={groups} (neither 1 nor depth-wise) has no HIP kernel")
+
+
+_POOL_W = {}
+
+
+def avg_pool(x, k: int, stride: int, padding: int):
+    """nn.AvgPool2d(k, stride, padding), count_include_pad=True: a depth-wise conv with weights 1/k^2."""
+    c = x.shape[-1]
+    key = (c, k, x.device)
+    w = _POOL_W.get(key)
+    if w is None:
+        w = _POOL_W[key] = torch.full((c, 1, k, k), 1.0 / (k * k), dtype=torch.float32, device=x.device)
+    return pconv_depthwise(x, w, None, None, None, None, None, make_geom(k, stride, padding, 1))
+
+
+class _AddAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, act, slope):
+        _lib.check_device(a)
+        a, b = a.contiguous(), b.contiguous()
+        assert a.shape == b.shape
+        out = torch.empty_like(a)
+        call("tsii_add_act_fwd", ptr(a), ptr(b), a.numel(), int(act), float(slope), ptr(out), _lib.stream())
+        ctx.cfg = (int(act), float(slope))
+        if act != ACT_NONE:
+            ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        act, slope = ctx.cfg
+        gout = gout.contiguous()
+        if act == ACT_NONE:
+            return gout, gout, None, None
+        if act == ACT_SIGMOID:
+            raise NotImplementedError("add+sigmoid backward is not used by the reference networks")
+        (out,) = ctx.saved_tensors   # sign / range of the output decides the ReLU-family derivative
+        g = torch.empty_like(gout)
+        call("tsii_act_bwd", ptr(gout), ptr(out), out.numel(), act, slope, ptr(g), _lib.stream())
+        return g, g, None, None
+
+
+def add_act(a, b, act=ACT_NONE, slope=0.0):
+    return _AddAct.apply(a, b, act, slope)
+
+
+class _Concat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        _lib.check_device(xs[0])
+        xs = [x.contiguous() for x in xs]
+        lead = xs[0].shape[:-1]
+        chans = [x.shape[-1] for x in xs]
+        m = xs[0].numel() // chans[0]
+        out = torch.empty(lead + (sum(chans),), dtype=torch.float32, device=xs[0].device)
+        off = 0
+        for x, c in zip(xs, chans):
+            assert x.shape[:-1] == lead
+            call("tsii_copy_channels", ptr(out), m, sum(chans), off, ptr(x), c, 1, _lib.stream())
+            off += c
+        ctx.chans, ctx.lead = chans, lead
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        gout = gout.contiguous()
+        chans, lead = ctx.chans, ctx.lead
+        m = gout.numel() // sum(chans)
+        grads, off = [], 0
+        for i, c in enumerate(chans):
+            if ctx.needs_input_grad[i]:
+                g = torch.empty(lead + (c,), dtype=torch.float32, device=gout.device)
+                call("tsii_copy_channels", ptr(gout), m, sum(chans), off, ptr(g), c, 0, _lib.stream())
+                grads.append(g)
+            else:
+                grads.append(None)
+            off += c
+        return tuple(grads)
+
+
+def concat(xs):
+    """torch.cat(dim=1) of NCHW == concat of the last (channel) axis in NHWC."""
+    return _Concat.apply(*xs)
+
+
+class _BilinearUp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        _lib.check_device(x)
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        y = torch.empty((n, h * scale, w * scale, c), dtype=torch.float32, device=x.device)
+        call("tsii_bilinear_up_fwd", ptr(x), n, h, w, c, int(scale), ptr(y), _lib.stream())
+        ctx.dims = (n, h, w, c, int(scale))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        n, h, w, c, scale = ctx.dims
+        gy = gy.contiguous()
+        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=gy.device)
+        call("tsii_bilinear_up_bwd", ptr(gy), n, h, w, c, scale, ptr(dx), _lib.stream())
+        return dx, None
+
+
+def bilinear_up(x, scale: int):
+    """F.interpolate(scale_factor=scale, mode='bilinear', align_corners=False) on NHWC."""
+    return _BilinearUp.apply(x, scale)
+
+
+class _GAP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _lib.check_device(x)
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        nbytes = _lib.lib().tsii_gap_ws_bytes(n, h * w, c)
+        ws = _ws(nbytes, x)
+        call("tsii_gap_fwd", ptr(x), n, h * w, c, ptr(out), ptr(ws), nbytes, _lib.stream())
+        ctx.dims = (n, h, w, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, c = ctx.dims
+        g = g.contiguous()
+        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=g.device)
+        call("tsii_gap_bwd", ptr(g), n, h * w, c, ptr(dx), _lib.stream())
+        return dx
+
+
+def global_avg_pool(x):
+    return _GAP.apply(x)
+
+
+class _SCSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cse, sse):
+        _lib.check_device(x)
+        x, cse, sse = x.contiguous(), cse.contiguous(), sse.contiguous()
+        n, h, w, c = x.shape
+        out = torch.empty_like(x)
+        call("tsii_scse_fwd", ptr(x), ptr(cse), ptr(sse), n, h * w, c, ptr(out), _lib.stream())
+        ctx.save_for_backward(x, cse, sse)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, cse, sse = ctx.saved_tensors
+        g = g.contiguous()
+        n, h, w, c = x.shape
+        dx, dcse, dsse = torch.empty_like(x), torch.empty_like(cse), torch.empty_like(sse)
+        nbytes = _lib.lib().tsii_gap_ws_bytes(n, h * w, c)
+        ws = _ws(nbytes, x)
+        call("tsii_scse_bwd", ptr(g), ptr(x), ptr(cse), ptr(sse), n, h * w, c, ptr(dx), ptr(dcse), ptr(dsse),
+             ptr(ws), nbytes, _lib.stream())
+        return dx, dcse, dsse
+
+
+def scse_combine(x, cse, sse):
+    """x*cse[n,c] + x*sse[n,h,w]  (models/common.py:38-43)."""
+    return _SCSE.apply(x, cse, sse)
+
+
+class _BCEFocal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, t, gamma, bw, ww):
+        _lib.check_device(x)
+        x, t = x.contiguous(), t.contiguous()
+        assert x.numel() == t.numel()
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        nbytes = _lib.lib().tsii_l1_ws_bytes(x.numel())
+        ws = _ws(nbytes, x)
+        call("tsii_bce_focal_fwd", ptr(x), ptr(t), x.numel(), float(gamma), float(bw), float(ww), ptr(loss), ptr(ws),
+             nbytes, _lib.stream())
+        ctx.save_for_backward(x, t)
+        ctx.cfg = (float(gamma), float(bw), float(ww))
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t = ctx.saved_tensors
+        g = g.reshape(1).contiguous()
+        dx = torch.empty_like(x)
+        call("tsii_bce_focal_bwd", ptr(x), ptr(t), x.numel(), *ctx.cfg, ptr(g), ptr(dx), _lib.stream())
+        return dx, None, None, None, None
+
+
+def bce_focal(x, t, gamma=0.0, background_w=1.0, words_w=2.0):
+    return _BCEFocal.apply(x, t, gamma, background_w, words_w)
