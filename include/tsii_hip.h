@@ -197,6 +197,19 @@ int tsii_bce_focal_fwd(const float* x, const float* t, int64_t numel, float gamm
 int tsii_bce_focal_bwd(const float* x, const float* t, int64_t numel, float gamma, float background_w, float words_w,
                        const float* gscale, float* dx, void* stream);
 
+/* ---- InpaintingLoss pieces (loss.py:195-225,303-307) ------------------------------------ */
+/* comp = mask*raw + (1-mask)*out (loss.py:196); backward: dout = dcomp*(1-mask) */
+int tsii_compose_fwd(const float* raw, const float* mask, const float* out, int64_t numel, float* comp, void* stream);
+int tsii_compose_bwd(const float* dcomp, const float* mask, int64_t numel, float* dout, void* stream);
+/* loss = w_valid*mean|m*out - m*gt| + w_hole*mean|(1-m)*out - (1-m)*gt|  (loss.py:199-200,223); ws: tsii_l1_ws_bytes */
+int tsii_masked_l1_fwd(const float* out, const float* gt, const float* mask, int64_t numel, float w_valid, float w_hole,
+                       float* loss, void* ws, size_t ws_bytes, void* stream);
+int tsii_masked_l1_bwd(const float* out, const float* gt, const float* mask, int64_t numel, float w_valid, float w_hole,
+                       const float* gscale, float* dout, void* stream);
+/* total_variation_loss (loss.py:303-307) on NHWC [n,h,w,c]: mean|x[:,:,:,:-1]-x[:,:,:,1:]| + mean|x[:,:,:-1,:]-x[:,:,1:,:]| */
+int tsii_tv_fwd(const float* x, int n, int h, int w, int c, float* loss, void* ws, size_t ws_bytes, void* stream);
+int tsii_tv_bwd(const float* x, int n, int h, int w, int c, const float* gscale, float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -215,4 +215,40 @@ def binary_focal_loss(logits, target, gamma=0.0, background_weights=1.0, words_w
     return ((pt * gamma).exp() * loss).mean()
 
 
+def gram_matrix(feat):
+    """loss.py:294-300."""
+    b, ch, h, w = feat.shape
+    f = feat.reshape(b, ch, h * w)
+    return torch.bmm(f, f.transpose(1, 2)) / (ch * h * w)
+
+
+def total_variation_loss(image):
+    """loss.py:303-307."""
+    return (image[:, :, :, :-1] - image[:, :, :, 1:]).abs().mean() + (image[:, :, :-1, :] - image[:, :, 1:, :]).abs().mean()
+
+
+def inpainting_loss(sd, raw_input, mask, output, origin, width_mult=1, feature_range=3, training=True):
+    """``InpaintingLoss.forward`` (loss.py:195-225) with ``FeatureExtractor`` over the first stages of a
+    MobileNetV2 (``sd`` keys: ``feature_encoder.layers.<i>....``; ReLU6, no scSE -- MobileNetV2 defaults)."""
+    relu6 = F.relu6
+
+    def feats(x):
+        out = []
+        for idx in range(feature_range):
+            x = mobilenet_feature(sd, "feature_encoder.layers.", idx, x, width_mult, relu6, False, training)
+            out.append(x)
+        return out
+
+    l1 = lambda a, b: (a - b).abs().mean()
+    comp = mask * raw_input + (1 - mask) * output
+    loss_validate = l1(mask * output, mask * origin)
+    loss_hole = l1((1 - mask) * output, (1 - mask) * origin)
+    loss_tv = total_variation_loss(comp)
+    f_comp, f_out, f_org = feats(comp), feats(output), feats(origin)
+    loss_perc = sum(l1(x, y) for x, y in zip(f_comp, f_org)) + sum(l1(x, y) for x, y in zip(f_out, f_org))
+    loss_style = sum(l1(gram_matrix(x), gram_matrix(y)) for x, y in zip(f_out, f_org)) + \
+        sum(l1(gram_matrix(x), gram_matrix(y)) for x, y in zip(f_comp, f_org))
+    return 1.0 * loss_validate + 6.0 * loss_hole + 0.1 * loss_tv + 0.05 * loss_perc + 120 * loss_style
+
+
 SEG_MODELS = {"TextSegament": text_segament, "XceptionTextSegment": xception_text_segment}

@@ -92,3 +92,15 @@ def test_seg_nets_64(golden_dir, name):
             assert_close(sd[k[5:]].grad, G[k], 1e-3, k, floor=1e-4 * gmax)
             n += 1
     assert n >= 12
+
+
+def test_inpainting_loss(golden_dir):
+    G = np.load(os.path.join(golden_dir, "inpainting_loss.npz"))
+    keys = json.loads(str(G["keys"]))
+    sd = make_state_dict([(k, s) for k, s in keys], seed=77)
+    gt, mask = torch.from_numpy(G["gt"]), torch.from_numpy(G["mask"])
+    out = torch.from_numpy(G["out"]).requires_grad_(True)
+    l = S.inpainting_loss(sd, gt * mask, mask, out, gt, width_mult=1, feature_range=3, training=True)
+    assert abs(l.item() - float(G["loss"])) < 1e-5 * abs(float(G["loss"]))
+    l.backward()
+    assert_close(out.grad, G["dout"], 1e-4, "InpaintingLoss d/d(output)")

@@ -100,6 +100,31 @@ def test_golden_seg_nets_64_gpu(name):
         n = 0
         for k in G.files:
             if k.startswith("grad."):
-                assert_close(params[k[5:]].grad, G[k], 3e-3, k, floor=1e-3 * gmax)
+                # tolerance: 3e-3, or 4x the reference's own fp32-vs-fp64 discrepancy for this tensor when that is
+                # larger (train-mode BN chains amplify rounding noise)
+                ref64 = G["grad64." + k[5:]]
+                scale = max(float(np.abs(G[k]).max()), 1e-3 * gmax)
+                noise = float(np.abs(G[k] - ref64).max()) / scale
+                assert_close(params[k[5:]].grad, G[k], max(3e-3, 4 * noise), k, floor=1e-3 * gmax)
                 n += 1
         assert n >= 12
+
+
+@both_backends
+def test_golden_inpainting_loss(backend):
+    """a20: InpaintingLoss (pixel + TV + perceptual + style terms, frozen MobileNetV2 feature extractor) vs the
+    fixture the reference produced: loss value and gradient w.r.t. the network output."""
+    G = np.load(os.path.join(GOLD, "inpainting_loss.npz"))
+    keys = json.loads(str(G["keys"]))
+    with BACKENDS[backend]() as dev:
+        crit = T.InpaintingLoss(T.MobileNetV2(width_mult=1), feature_range=3)
+        assert [[k, list(v.shape)] for k, v in crit.state_dict().items()] == keys
+        fill_state_dict_(crit.state_dict(), seed=77)
+        crit = crit.to(dev)
+        gt, mask = torch.from_numpy(G["gt"]).to(dev), torch.from_numpy(G["mask"]).to(dev)
+        out = torch.from_numpy(G["out"]).to(dev).requires_grad_(True)
+        raw = torch.from_numpy(G["gt"] * G["mask"]).to(dev)
+        loss = crit(raw, mask, out, gt)
+        assert abs(loss.item() - float(G["loss"])) <= 1e-4 * abs(float(G["loss"]))
+        loss.backward()
+        assert_close(out.grad, G["dout"], TOL, "InpaintingLoss d/d(output)")

@@ -626,3 +626,125 @@ class _BCEFocal(torch.autograd.Function):
 
 def bce_focal(x, t, gamma=0.0, background_w=1.0, words_w=2.0):
     return _BCEFocal.apply(x, t, gamma, background_w, words_w)
+
+
+# ---------------------------------------------------------------------------------------
+# InpaintingLoss pieces (loss.py:185-225,294-307)
+# ---------------------------------------------------------------------------------------
+class _Compose(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, mask, out):
+        _lib.check_device(out)
+        raw, mask, out = raw.contiguous(), mask.contiguous(), out.contiguous()
+        assert raw.shape == mask.shape == out.shape
+        comp = torch.empty_like(out)
+        call("tsii_compose_fwd", ptr(raw), ptr(mask), ptr(out), out.numel(), ptr(comp), _lib.stream())
+        ctx.save_for_backward(mask)
+        return comp
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        g = g.contiguous()
+        dout = torch.empty_like(g)
+        call("tsii_compose_bwd", ptr(g), ptr(mask), g.numel(), ptr(dout), _lib.stream())
+        return None, None, dout
+
+
+def compose(raw, mask, out):
+    """mask*raw + (1-mask)*out; gradient flows to ``out`` only (raw / mask are data)."""
+    return _Compose.apply(raw, mask, out)
+
+
+class _MaskedL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, gt, mask, wv, wh):
+        _lib.check_device(out)
+        out, gt, mask = out.contiguous(), gt.contiguous(), mask.contiguous()
+        assert out.shape == gt.shape == mask.shape
+        loss = torch.empty(1, dtype=torch.float32, device=out.device)
+        nbytes = _lib.lib().tsii_l1_ws_bytes(out.numel())
+        ws = _ws(nbytes, out)
+        call("tsii_masked_l1_fwd", ptr(out), ptr(gt), ptr(mask), out.numel(), float(wv), float(wh), ptr(loss), ptr(ws),
+             nbytes, _lib.stream())
+        ctx.save_for_backward(out, gt, mask)
+        ctx.w = (float(wv), float(wh))
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        out, gt, mask = ctx.saved_tensors
+        g = g.reshape(1).contiguous()
+        dout = torch.empty_like(out)
+        call("tsii_masked_l1_bwd", ptr(out), ptr(gt), ptr(mask), out.numel(), *ctx.w, ptr(g), ptr(dout), _lib.stream())
+        return dout, None, None, None, None
+
+
+def masked_l1(out, gt, mask, w_valid=1.0, w_hole=6.0):
+    """w_valid*L1(m*out, m*gt) + w_hole*L1((1-m)*out, (1-m)*gt)  (loss.py:199-200,223)."""
+    return _MaskedL1.apply(out, gt, mask, w_valid, w_hole)
+
+
+class _TV(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _lib.check_device(x)
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        nbytes = 2 * _lib.lib().tsii_l1_ws_bytes(x.numel())
+        ws = _ws(nbytes, x)
+        call("tsii_tv_fwd", ptr(x), n, h, w, c, ptr(loss), ptr(ws), nbytes, _lib.stream())
+        ctx.save_for_backward(x)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        n, h, w, c = x.shape
+        g = g.reshape(1).contiguous()
+        dx = torch.empty_like(x)
+        call("tsii_tv_bwd", ptr(x), n, h, w, c, ptr(g), ptr(dx), _lib.stream())
+        return dx
+
+
+def total_variation(x):
+    return _TV.apply(x)
+
+
+class _Gram(torch.autograd.Function):
+    """gram[n] = F_n^T F_n / (C*H*W) for NHWC features: the TN GEMM (dW form) per sample; backward is the NT GEMM
+    dF_n = F_n (dG + dG^T) / (C*H*W)."""
+
+    @staticmethod
+    def forward(ctx, f):
+        _lib.check_device(f)
+        f = f.contiguous()
+        n, h, w, c = f.shape
+        hw = h * w
+        gram = torch.empty((n, c, c), dtype=torch.float32, device=f.device)
+        L, st = _lib.lib(), _lib.stream()
+        nbytes = L.tsii_pw_bwd_dw_ws_bytes(hw, c, c)
+        ws = _ws(nbytes, f)
+        for i in range(n):
+            fi = f[i]
+            call("tsii_pw_bwd_dw", ptr(fi), ptr(fi), hw, c, c, None, None, None, 0, None, ptr(gram[i]), None, ptr(ws), nbytes, st)
+        ctx.save_for_backward(f)
+        ctx.scale = 1.0 / (c * hw)
+        return gram * ctx.scale
+
+    @staticmethod
+    def backward(ctx, dg):
+        (f,) = ctx.saved_tensors
+        n, h, w, c = f.shape
+        hw = h * w
+        sym = ((dg + dg.transpose(1, 2)) * ctx.scale).contiguous()   # tiny [n,c,c]
+        df = torch.empty_like(f)
+        st = _lib.stream()
+        for i in range(n):
+            call("tsii_pw_fwd", ptr(f[i]), hw, c, ptr(sym[i]), c, None, None, 0, None, None, None, ptr(df[i]), st)
+        return df
+
+
+def gram_matrix(f_nhwc):
+    return _Gram.apply(f_nhwc)

@@ -22,7 +22,8 @@ class FlatSGDTrainer:
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if self.distributed else 1
         numel = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         # flat parameter storage: every trainable parameter becomes a view into one buffer
@@ -41,7 +42,7 @@ class FlatSGDTrainer:
         self.loss_fn = loss_fn or (lambda out_nchw, clean_nhwc: ops.l1_mean(to_nhwc(out_nchw), clean_nhwc))
 
     def broadcast_parameters(self, src=0):
-        if self.world > 1:
+        if self.distributed:
             dist.broadcast(self.flat_param, src=src, group=self.pg)
 
     def forward_backward(self, corrupted, mask, clean_nhwc):
@@ -55,7 +56,7 @@ class FlatSGDTrainer:
 
     def reduce_gradients(self):
         torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat_grad)
-        if self.world > 1:
+        if self.distributed:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
         for p, (off, n) in zip(self.params, self.slices):
             p.grad = self.flat_grad[off:off + n].view_as(p)
