@@ -8,6 +8,8 @@
 // The valid count comes from K1 (mask.hip) as the `denom`/`keep`/`inv` planes.
 #include "tsii_common.h"
 
+#include <stdlib.h>
+
 namespace tsii {
 
 struct DwGeom {
@@ -220,6 +222,234 @@ __global__ __launch_bounds__(256) void dw_bwd_dw_kernel(const float* __restrict_
     }
 }
 
+// ---- LDS-tiled 3x3 stencil (forward, and dX for stride 1 with flipped taps) --------------------------
+// The direct kernels above issue ~20 vector-memory instructions per output pixel and are bound by VMEM
+// issue (measured ~2.5 TB/s).  Here a block stages the (TH*s+2d) x (TW*s+2d) x 32-channel input patch ONCE
+// (pre-multiplied by its per-pixel plane: the mask for forward, 1/count for dX) with coalesced 16-byte loads,
+// then every thread walks its taps out of LDS (pixel stride 128 B: x-adjacent pixels of a 16-lane group sit in
+// the two halves of the 256-byte bank row, conflict-free) with the 9 weights in registers.
+//   y[o] = post[o] ? (sum_t w[t] * pre[i_t] * in[i_t]) / denom[o] + bias : 0,   i_t = o*s - pad + t*d
+// tile variants (TH x TW output pixels, CB channels, LDS floats); chosen per call, see try_launch_dw_tile
+
+struct DtGeom {
+    int n, hin, win, c, s, d, pad_h, pad_w, hout, wout, flip;
+};
+
+template <int DT_TH, int DT_TW, int DT_CB, int DT_LDS_FLOATS>
+__global__ __launch_bounds__(256) void dw_tile_kernel(const float* __restrict__ in, const float* __restrict__ pre,
+                                                      const float* __restrict__ wT, const float* __restrict__ bias,
+                                                      const float* __restrict__ denom, const float* __restrict__ keep,
+                                                      const float* __restrict__ post_mul, DtGeom g, int PH, int PW,
+                                                      unsigned tiles_x, unsigned tiles_y, unsigned cblocks,
+                                                      float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float tile[DT_LDS_FLOATS];
+    unsigned b = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned cb = b % cblocks; b /= cblocks;
+    const unsigned tx0 = b % tiles_x; b /= tiles_x;
+    const unsigned ty0 = b % tiles_y;
+    const int64_t n = b / tiles_y;
+    const int c0 = (int)cb * DT_CB;
+    const int oy0 = (int)ty0 * DT_TH, ox0 = (int)tx0 * DT_TW;
+    const int iy0 = oy0 * g.s - g.pad_h, ix0 = ox0 * g.s - g.pad_w;
+    // stage the patch: element = (pixel, 4-channel group); 8 groups per pixel
+    const int npix = PH * PW;
+    constexpr int CGS = DT_CB / 4;                 // channel groups per pixel
+    constexpr int LANES = 256 / CGS;               // pixel lanes
+    for (int e = threadIdx.x; e < npix * CGS; e += 256) {
+        const int cg = e % CGS, p = e / CGS;
+        const int py = p / PW, px = p - py * PW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win && c0 + cg * 4 < g.c) {
+            const int64_t ipix = (n * g.hin + iy) * g.win + ix;
+            v = *reinterpret_cast<const float4*>(in + ipix * g.c + c0 + cg * 4);
+            if (pre != nullptr) { const float m = pre[ipix]; v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
+        }
+        *reinterpret_cast<float4*>(tile + p * DT_CB + cg * 4) = v;
+    }
+    const int cg = threadIdx.x % CGS, lane = threadIdx.x / CGS;
+    const int c = c0 + cg * 4;
+    float4 w[9];
+    if (c < g.c) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const float4*>(wT + (g.flip ? 8 - t : t) * g.c + c);
+    }
+    __syncthreads();
+    if (c >= g.c) return;
+#pragma unroll
+    for (int k = 0; k < DT_TH * DT_TW / LANES; ++k) {
+        const int p = lane + LANES * k;              // x-adjacent lanes -> conflict-free LDS reads
+        const int ty = p / DT_TW, tx = p % DT_TW;
+        const int oy = oy0 + ty, ox = ox0 + tx;
+        if (oy >= g.hout || ox >= g.wout) continue;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 v = *reinterpret_cast<const float4*>(tile + ((ty * g.s + ky * g.d) * PW + tx * g.s + kx * g.d) * DT_CB + cg * 4);
+                const float4 ww = w[ky * 3 + kx];
+                a.x = fmaf(v.x, ww.x, a.x); a.y = fmaf(v.y, ww.y, a.y); a.z = fmaf(v.z, ww.z, a.z); a.w = fmaf(v.w, ww.w, a.w);
+            }
+        const int64_t opix = (n * g.hout + oy) * g.wout + ox;
+        const bool kp = keep != nullptr ? (keep[opix] != 0.f) : true;
+        if (denom != nullptr) { const float dn = denom[opix]; a.x /= dn; a.y /= dn; a.z /= dn; a.w /= dn; }
+        if (bias != nullptr) { a.x += bias[c]; a.y += bias[c + 1]; a.z += bias[c + 2]; a.w += bias[c + 3]; }
+        if (post_mul != nullptr) {
+            const float pm = post_mul[opix];
+            a.x = pm != 0.f ? a.x * pm : 0.f; a.y = pm != 0.f ? a.y * pm : 0.f;
+            a.z = pm != 0.f ? a.z * pm : 0.f; a.w = pm != 0.f ? a.w * pm : 0.f;
+        }
+        if (!kp) a = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(out + opix * g.c + c) = a;
+    }
+}
+
+// -> 0 launched, 1 not applicable (caller falls back to the direct kernel), <0 error
+template <int TH, int TW, int CB, int LDSF>
+static int launch_dw_tile_variant(const float* in, const float* pre, const float* wT, const float* bias, const float* denom,
+                                  const float* keep, const float* post_mul, DtGeom g, float* out, hipStream_t st) {
+    const int PH = (TH - 1) * g.s + 2 * g.d + 1, PW = (TW - 1) * g.s + 2 * g.d + 1;
+    if (PH * PW * CB > LDSF) return 1;
+    const unsigned tiles_x = cdiv(g.wout, TW), tiles_y = cdiv(g.hout, TH), cblocks = cdiv(g.c, CB);
+    const int64_t nblk = (int64_t)tiles_x * tiles_y * cblocks * g.n;
+    if (nblk >= (1ll << 31)) return 1;
+    hipLaunchKernelGGL((dw_tile_kernel<TH, TW, CB, LDSF>), dim3((unsigned)nblk), dim3(256), 0, st, in, pre, wT, bias, denom, keep,
+                       post_mul, g, PH, PW, tiles_x, tiles_y, cblocks, out);
+    return check_launch("dw_tile");
+}
+
+static int try_launch_dw_tile(const float* in, const float* pre, const float* wT, const float* bias, const float* denom,
+                              const float* keep, const float* post_mul, DtGeom g, float* out, hipStream_t st) {
+    if (g.c % 4 != 0 || !aligned16(in) || !aligned16(out) || !aligned16(wT)) return 1;
+    static int variant = -1;   // TSII_DW_TILE: tuning knob for A/B runs (0 = default)
+    if (variant < 0) { const char* e = getenv("TSII_DW_TILE"); variant = e ? atoi(e) : 0; }
+    int rc = 1;
+    if (variant == 1) rc = launch_dw_tile_variant<8, 16, 32, 10240>(in, pre, wT, bias, denom, keep, post_mul, g, out, st);
+    else if (variant == 2) rc = launch_dw_tile_variant<8, 8, 64, 6656>(in, pre, wT, bias, denom, keep, post_mul, g, out, st);
+    else if (variant == 3) rc = launch_dw_tile_variant<4, 32, 32, 6656>(in, pre, wT, bias, denom, keep, post_mul, g, out, st);
+    else if (variant == 4) rc = launch_dw_tile_variant<16, 16, 32, 10240>(in, pre, wT, bias, denom, keep, post_mul, g, out, st);
+    else if (variant == 9) return 1;   // direct kernel
+    else rc = launch_dw_tile_variant<8, 16, 32, 6144>(in, pre, wT, bias, denom, keep, post_mul, g, out, st);
+    if (rc == 1 && variant != 1) rc = launch_dw_tile_variant<8, 16, 32, 10240>(in, pre, wT, bias, denom, keep, post_mul, g, out, st);
+    return rc;
+}
+
+// ---- LDS-tiled dW for 3x3 kernels -----------------------------------------------------------------
+// Persistent block (g, cb): walks spatial tiles of ONE 32-channel block, stages the masked input patch in LDS,
+// reads its own dy pixels straight from HBM, keeps 9 taps x 4 channels (+ bias) in registers across all its
+// tiles, combines the 32 pixel lanes through LDS at the end and writes its 32-channel slice of partial row g.
+__global__ __launch_bounds__(256) void dw_tile_dw_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
+                                                         const float* __restrict__ keep, const float* __restrict__ x,
+                                                         const float* __restrict__ rmask, DtGeom g, int PH, int PW,
+                                                         unsigned tiles_x, unsigned tiles_y, unsigned cblocks,
+                                                         unsigned tiles_per_block, float* __restrict__ part) {
+    constexpr int TH = 8, TW = 16, CB = 32, CGS = 8, LANES = 32;
+    __shared__ __attribute__((aligned(16))) float tile[6144];
+    __shared__ float red[256];
+    const unsigned cb = blockIdx.x % cblocks, gi = blockIdx.x / cblocks;
+    const int c0 = (int)cb * CB;
+    const int cg = threadIdx.x % CGS, lane = threadIdx.x / CGS;
+    const int c = c0 + cg * 4;
+    const bool cok = c < g.c;
+    const unsigned total_tiles = tiles_x * tiles_y * (unsigned)g.n;
+    const unsigned t_beg = gi * tiles_per_block;
+    const unsigned t_end = t_beg + tiles_per_block < total_tiles ? t_beg + tiles_per_block : total_tiles;
+    float4 acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int npix = PH * PW;
+    for (unsigned tl = t_beg; tl < t_end; ++tl) {
+        const unsigned tx0 = tl % tiles_x, ty0 = (tl / tiles_x) % tiles_y;
+        const int64_t n = tl / (tiles_x * tiles_y);
+        const int oy0 = (int)ty0 * TH, ox0 = (int)tx0 * TW;
+        const int iy0 = oy0 * g.s - g.pad_h, ix0 = ox0 * g.s - g.pad_w;
+        __syncthreads();
+        for (int e = threadIdx.x; e < npix * CGS; e += 256) {
+            const int ecg = e % CGS, p = e / CGS;
+            const int py = p / PW, px = p - py * PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win && c0 + ecg * 4 < g.c) {
+                const int64_t ipix = (n * g.hin + iy) * g.win + ix;
+                v = *reinterpret_cast<const float4*>(x + ipix * g.c + c0 + ecg * 4);
+                if (rmask != nullptr) { const float m = rmask[ipix]; v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
+            }
+            *reinterpret_cast<float4*>(tile + p * CB + ecg * 4) = v;
+        }
+        // this thread's dy pixels (registers), issued before the barrier so they overlap the staging
+        float4 gv[TH * TW / LANES];
+        float gs[TH * TW / LANES];
+        bool gk[TH * TW / LANES];
+#pragma unroll
+        for (int k = 0; k < TH * TW / LANES; ++k) {
+            const int p = lane + LANES * k;
+            const int oy = oy0 + p / TW, ox = ox0 + p % TW;
+            gv[k] = make_float4(0.f, 0.f, 0.f, 0.f); gs[k] = 0.f; gk[k] = false;
+            if (cok && oy < g.hout && ox < g.wout) {
+                const int64_t opix = (n * g.hout + oy) * g.wout + ox;
+                gk[k] = keep != nullptr ? (keep[opix] != 0.f) : true;
+                gs[k] = inv != nullptr ? inv[opix] : 1.f;
+                gv[k] = *reinterpret_cast<const float4*>(dy + opix * g.c + c);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TH * TW / LANES; ++k) {
+            if (!gk[k]) continue;                     // hole / out of range: no gradient (partial_convolution.py:72)
+            const int p = lane + LANES * k;
+            const int ty = p / TW, tx = p % TW;
+            float4 gq = gv[k];
+            acc[9].x += gq.x; acc[9].y += gq.y; acc[9].z += gq.z; acc[9].w += gq.w;   // bias: added after the division
+            gq.x *= gs[k]; gq.y *= gs[k]; gq.z *= gs[k]; gq.w *= gs[k];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float4 v = *reinterpret_cast<const float4*>(tile + ((ty * g.s + ky * g.d) * PW + tx * g.s + kx * g.d) * CB + cg * 4);
+                    float4& a = acc[ky * 3 + kx];
+                    a.x = fmaf(gq.x, v.x, a.x); a.y = fmaf(gq.y, v.y, a.y); a.z = fmaf(gq.z, v.z, a.z); a.w = fmaf(gq.w, v.w, a.w);
+                }
+        }
+    }
+    // combine the 32 pixel lanes; partial row gi, columns [t][c0 .. c0+31]
+    float* prow = part + (int64_t)gi * 10 * g.c;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+        const float vals[4] = {acc[t].x, acc[t].y, acc[t].z, acc[t].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __syncthreads();
+            red[threadIdx.x] = vals[i];
+            __syncthreads();
+            if (lane == 0 && cok) {
+                float sum = 0.f;
+                for (int l = 0; l < LANES; ++l) sum += red[l * CGS + cg];
+                prow[(int64_t)t * g.c + c + i] = sum;
+            }
+        }
+    }
+}
+
+struct DtDwPlan {
+    bool ok;
+    int PH, PW;
+    unsigned tiles_x, tiles_y, cblocks, groups, tiles_per_block;
+};
+static DtDwPlan plan_dt_dw(int n, int ho, int wo, int c, int s, int d) {
+    DtDwPlan p;
+    p.PH = 7 * s + 2 * d + 1; p.PW = 15 * s + 2 * d + 1;
+    p.ok = (c % 4 == 0) && p.PH * p.PW * 32 <= 6144;
+    p.tiles_x = cdiv(wo, 16); p.tiles_y = cdiv(ho, 8); p.cblocks = cdiv(c, 32);
+    const unsigned total = p.tiles_x * p.tiles_y * (unsigned)n;
+    unsigned groups = 4096 / p.cblocks;
+    if (groups < 1) groups = 1;
+    if (groups > total) groups = total;
+    p.tiles_per_block = cdiv((int)total, (int)groups);
+    p.groups = cdiv((int)total, (int)p.tiles_per_block);
+    return p;
+}
+
 // sum the R partial rows (block = 32 columns x 8 row lanes, 4 loads in flight) and scatter back to the
 // reference layout dw[c][t], db[c]
 __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ part, int R, int T, int C,
@@ -295,6 +525,11 @@ extern "C" int tsii_dw_fwd(const float* x, const float* rmask, const float* w, c
     int rc = launch_transpose(w, c, kh * kw, ws, st);  // [C][T] -> [T][C]
     if (rc) return rc;
     const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(ws);
+    if (kh == 3 && kw == 3 && sh == sw && dh == dw) {   // LDS-tiled 3x3 stencil
+        DtGeom tg = {n, h, wd, c, sh, dh, ph, pw, ho, wo, 0};
+        rc = try_launch_dw_tile(x, rmask, ws, bias, denom, keep, nullptr, tg, y, st);
+        if (rc <= 0) return rc;
+    }
     // measured on MI355X: the fully unrolled 3x3 form (more loads in flight) is SLOWER here -- these
     // stencils are bound by vector-memory instruction issue, not latency -- so it stays disabled
     const bool k3 = false;
@@ -318,6 +553,12 @@ extern "C" int tsii_dw_bwd_dx(const float* dy, const float* inv, const float* w,
     int rc = launch_transpose(w, c, kh * kw, ws, st);
     if (rc) return rc;
     const bool vec = (c % 4 == 0) && aligned16(dy) && aligned16(dx) && aligned16(ws);
+    if (kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == dw) {
+        // stride 1: dx[i] = rmask[i] * sum_t w[t] * (dy*inv)[i + pad - t*d] -- the forward stencil with flipped taps
+        DtGeom tg = {n, ho, wo, c, 1, dh, 2 * dh - ph, 2 * dw - pw, h, wd, 1};
+        rc = try_launch_dw_tile(dy, inv, ws, nullptr, nullptr, nullptr, rmask, tg, dx, st);
+        if (rc <= 0) return rc;
+    }
     const bool k3 = false;  // see dw_fwd
     const int px = (vec && k3) ? DwPx<true>::value : DwPx<false>::value;
     const int64_t nblk = (int64_t)cdiv(cdiv(wd, px) * (vec ? c / 4 : c), 256) * h * n;
@@ -333,7 +574,11 @@ extern "C" size_t tsii_dw_bwd_dw_ws_bytes(int n, int ho, int wo, int c, int kh, 
     if (n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || kh <= 0 || kw <= 0) return 0;
     // the scalar plan (taken when c % 4 != 0 or a pointer is unaligned) never needs more rows
     const DwPlan a = plan_dw(n, ho, c, c % 4 == 0), b = plan_dw(n, ho, c, false);
-    const int R = a.R > b.R ? a.R : b.R;
+    int R = a.R > b.R ? a.R : b.R;
+    if (kh == 3 && kw == 3) {   // LDS-tiled plan (any stride/dilation: upper bound over both)
+        const int g1 = (int)plan_dt_dw(n, ho, wo, c, 1, 1).groups;
+        if (g1 > R) R = g1;
+    }
     return (size_t)R * (size_t)(kh * kw + 1) * c * sizeof(float);
 }
 
@@ -347,8 +592,20 @@ extern "C" int tsii_dw_bwd_dw(const float* dy, const float* inv, const float* ke
     TSII_REQUIRE(ws_bytes >= tsii_dw_bwd_dw_ws_bytes(n, ho, wo, c, kh, kw), "dw_bwd_dw: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (c % 4 == 0) && aligned16(dy) && aligned16(x);
-    const DwPlan p = plan_dw(n, ho, c, vec);
     float* part = (float*)ws;
+    if (vec && kh == 3 && kw == 3 && sh == sw && dh == dw) {
+        const DtDwPlan tp = plan_dt_dw(n, ho, wo, c, sh, dh);
+        if (tp.ok) {
+            DtGeom tg = {n, h, wd, c, sh, dh, ph, pw, ho, wo, 0};
+            hipLaunchKernelGGL(dw_tile_dw_kernel, dim3(tp.groups * tp.cblocks), dim3(256), 0, st, dy, inv, keep, x, rmask, tg,
+                               tp.PH, tp.PW, tp.tiles_x, tp.tiles_y, tp.cblocks, tp.tiles_per_block, part);
+            int rc0 = check_launch("dw_tile_dw");
+            if (rc0) return rc0;
+            hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)cdiv64((int64_t)10 * c, 32)), dim3(256), 0, st, part, (int)tp.groups, 9, c, dwgt, dbias);
+            return check_launch("dw_reduce");
+        }
+    }
+    const DwPlan p = plan_dw(n, ho, c, vec);
     const dim3 grid((unsigned)(p.gx * p.gy));
     const bool k3 = (kh == 3 && kw == 3);
     if (vec && k3) hipLaunchKernelGGL((dw_bwd_dw_kernel<4, true>), grid, dim3(256), 0, st, dy, inv, keep, x, rmask, g, p.CGB, p.L, p.rpb, part);

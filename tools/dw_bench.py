@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the depth-wise entry points on ImageFill's largest layers."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from text_segmentation_image_inpainting_amd import _lib
+from text_segmentation_image_inpainting_amd._lib import call, ptr
+L = _lib.lib(); dev = torch.device("cuda:0"); st = _lib.stream()
+def timeit(fn, it=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / it
+for (n, h, w, c, s, d) in [(32, 256, 256, 384, 1, 1), (32, 128, 128, 768, 1, 1), (32, 64, 64, 1024, 1, 1), (32, 256, 256, 256, 2, 1)]:
+    ho, wo = (h + 2 * d - 2 * d - 1) // s + 1, (w + 2 * d - 2 * d - 1) // s + 1
+    x = torch.randn(n, h, w, c, device=dev); wt = torch.randn(c, 1, 3, 3, device=dev)
+    m = (torch.rand(n, h, w, device=dev) > 0.05).float()
+    den = torch.full((n, ho, wo), 9.0 * c, device=dev); keep = torch.ones(n, ho, wo, device=dev); inv = 1 / den
+    y = torch.empty(n, ho, wo, c, device=dev); dy = torch.randn(n, ho, wo, c, device=dev); dx = torch.empty_like(x)
+    ws = torch.empty(c * 9 + 16, device=dev)
+    g = (3, 3, s, s, d, d, d, d)
+    tf = timeit(lambda: call("tsii_dw_fwd", ptr(x), ptr(m), ptr(wt), None, ptr(den), ptr(keep), n, h, w, c, *g, ho, wo, ptr(y), ptr(ws), st))
+    tb = timeit(lambda: call("tsii_dw_bwd_dx", ptr(dy), ptr(inv), ptr(wt), ptr(m), n, h, w, c, *g, ho, wo, ptr(dx), ptr(ws), st))
+    nb = L.tsii_dw_bwd_dw_ws_bytes(n, ho, wo, c, 3, 3); w2 = torch.empty(nb // 4 + 4, device=dev); dwg = torch.empty_like(wt)
+    tw = timeit(lambda: call("tsii_dw_bwd_dw", ptr(dy), ptr(inv), ptr(keep), ptr(x), ptr(m), n, h, w, c, *g, ho, wo, ptr(dwg), None, ptr(w2), nb, st))
+    gb = (x.numel() + y.numel()) * 4 / 1e9
+    print(f"dw n{n} {h}x{w} c{c} s{s} d{d}: fwd {tf:6.3f} ms {gb / tf:5.2f} TB/s | dx {tb:6.3f} ms {gb / tb:5.2f} TB/s | dw {tw:6.3f} ms {gb / tw:5.2f} TB/s", flush=True)
