@@ -97,7 +97,7 @@ __device__ __forceinline__ void nt_store(float* __restrict__ S, const float4 (&r
 }
 
 template <int WM, int WN, int TM, int TN, bool VEC>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda, RowScale as,
+__global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda, RowScale as,
                                                       const float* __restrict__ B, int64_t ldb,
                                                       float* __restrict__ C, int64_t ldc,
                                                       int64_t M, int N, int K, Epilogue ep, unsigned ntn) {
@@ -280,7 +280,7 @@ __device__ __forceinline__ void tn_store(float* __restrict__ S, const float4 (&r
 }
 
 template <int WM, int WN, int TM, int TN, bool VEC>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ sa,
+__global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ sa,
                                                       const float* __restrict__ B, int64_t ldb, RowScale sb,
                                                       float* __restrict__ Cws, int64_t M, int P, int Q, int64_t chunk) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
