@@ -219,3 +219,52 @@ def test_origin_models_golden_256_gpu(name):
         for k, p in model.named_parameters():
             if p.requires_grad:
                 assert_close(p.grad, sd[k].grad, 3e-3, "grad " + k, floor=1e-6)
+
+
+# cin, cout, k, s, p, d, bias, same_holes, two_plane, H
+CONV_GEMM_CASES = [
+    (8, 16, 3, 1, 1, 1, True, True, False, 12),      # encoder flavour (same_holes), implicit GEMM
+    (16, 32, 3, 2, 1, 1, False, True, False, 13),    # stride 2, odd size
+    (8, 16, 5, 2, 2, 1, False, True, False, 12),     # 5x5 s2 (ImageFillOrigin encoder)
+    (12, 16, 3, 1, 2, 2, True, False, True, 10),     # dilated, decoder flavour: two mask planes, non-same-holes
+    (16, 24, (1, 3), 1, (0, 1), 1, False, False, False, 9),   # RFB (1 x k)
+    (40, 136, 3, 1, 1, 1, True, False, True, 9),     # > 128 output channels, K = 360 (tile tails)
+]
+
+
+@both_backends
+def test_dense_conv_implicit_gemm_vs_oracle(backend):
+    """K4 on the MFMA path (gather loaders of the NT / TN GEMM kernels): forward, new_mask, dX, dW, db vs the oracle."""
+    with BACKENDS[backend]() as dev:
+        for idx, (cin, cout, k, s, p, d, bias, same, two, H) in enumerate(CONV_GEMM_CASES):
+            m = T.PartialConv(cin, cout, k, s, p, d, 1, bias, same)
+            fill_state_dict_(m.state_dict(), seed=500 + idx)
+            rng = np.random.default_rng(500 + idx)
+            x = torch.from_numpy(rng.standard_normal((2, cin, H, H)).astype(np.float32))
+            pa = (torch.from_numpy(rng.uniform(size=(2, 1, H, H))) > 0.3).float()
+            if two:
+                c1 = cin // 2
+                pb = (torch.from_numpy(rng.uniform(size=(2, 1, H, H))) > 0.3).float()
+                mask = torch.cat([pa.expand(-1, c1, -1, -1), pb.expand(-1, cin - c1, -1, -1)], 1).contiguous()
+                from text_segmentation_image_inpainting_amd.masks import MaskParts, Part
+                mparts = MaskParts([Part(c1, plane=pa[:, 0].contiguous().to(dev)), Part(cin - c1, plane=pb[:, 0].contiguous().to(dev))])
+            else:
+                mask = pa.expand(-1, cin, -1, -1).contiguous()
+                mparts = pa.expand(-1, cin, -1, -1).to(dev)          # stride-0 view -> planar fast path
+            w = m.feature_conv.weight.detach().clone().requires_grad_(True)
+            b = m.feature_conv.bias.detach().clone().requires_grad_(True) if bias else None
+            xo = x.clone().requires_grad_(True)
+            yo, nmo = O.partial_conv(xo, mask, w, b, m.feature_conv.stride, m.feature_conv.padding, m.feature_conv.dilation, 1, same)
+            gy = torch.from_numpy(rng.standard_normal(tuple(yo.shape)).astype(np.float32))
+            yo.backward(gy)
+            m = m.to(dev)
+            xd = x.to(dev).requires_grad_(True)
+            y, nm = m((xd, mparts))
+            nm_t = nm.as_tensor() if hasattr(nm, "as_tensor") else nm
+            assert_close(y, yo, TOL, f"conv-gemm case {idx} y")
+            assert np.array_equal(nm_t.detach().cpu().numpy(), nmo.detach().numpy()), f"case {idx} new_mask"
+            y.backward(gy.to(dev))
+            assert_close(xd.grad, xo.grad, TOL, f"conv-gemm case {idx} dx")
+            assert_close(m.feature_conv.weight.grad, w.grad, TOL, f"conv-gemm case {idx} dw")
+            if bias:
+                assert_close(m.feature_conv.bias.grad, b.grad, TOL, f"conv-gemm case {idx} db")

@@ -389,6 +389,23 @@ static int small_dw_blocks(const ConvGeom& g, int* tiles_per_block) {
     return cdiv(total, *tiles_per_block);
 }
 
+// weight re-layouts for the implicit-GEMM path: w[co][ci][t] -> wr[co][t*cin + ci]  /  wd[ci][t*cout + co]
+__global__ void conv_w_layout_kernel(const float* __restrict__ w, int cin, int cout, int T, int dx_layout, float* __restrict__ out) {
+    const int64_t total = (int64_t)cout * cin * T;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % T);
+        const int ci = (int)((i / T) % cin);
+        const int64_t co = i / ((int64_t)T * cin);
+        const int64_t dst = dx_layout ? ((int64_t)ci * T + t) * cout + co : (co * T + t) * cin + ci;
+        out[dst] = w[i];
+    }
+}
+
+static bool use_conv_gemm(const ConvGeom& g, const float* mfull, const void* a, const void* b, const void* c) {
+    const ConvGemmGeom cg = {g.n, g.h, g.w, g.cin, g.cout, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw, g.dh, g.dw, g.ho, g.wo};
+    return mfull == nullptr && conv_gemm_ok(cg) && aligned16(a) && aligned16(b) && aligned16(c);
+}
+
 static int check_conv_geom(const ConvGeom& g, const char* who) {
     TSII_REQUIRE(g.n > 0 && g.h > 0 && g.w > 0 && g.cin > 0 && g.cout > 0 && g.kh > 0 && g.kw > 0 && g.sh > 0 &&
                  g.sw > 0 && g.dh > 0 && g.dw > 0 && g.ph >= 0 && g.pw >= 0, "%s: bad geometry", who);
@@ -455,6 +472,14 @@ extern "C" int tsii_dense_fwd(const float* x, const float* mfull, const float* r
                            rs0, wf, bias, denom, keep, g, sp.PH, sp.PW, y);
         return check_launch("dense_small_fwd");
     }
+    if (use_conv_gemm(g, mfull, x, y, ws)) {   // MFMA implicit GEMM
+        hipLaunchKernelGGL(conv_w_layout_kernel, dim3(stream_grid((int64_t)T * cin * cout, 256)), dim3(256), 0, st, w, cin, cout, T, 0, wf);
+        int rcg = check_launch("conv_w_layout");
+        if (rcg) return rcg;
+        const ConvGemmGeom cgg = {n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo};
+        RowScale rsg = {r0, r1, split};
+        return launch_conv_gemm_fwd(x, rsg, wf, bias, denom, keep, cgg, y, st);
+    }
     hipLaunchKernelGGL(dense_prep_fwd_kernel, dim3(stream_grid((int64_t)T * cin * coutp, 256)), dim3(256), 0, st,
                        w, cin, cout, T, coutp, wf);
     int rc = check_launch("dense_prep_fwd");
@@ -478,6 +503,14 @@ extern "C" int tsii_dense_bwd_dx(const float* dy, const float* inv, const float*
     hipStream_t st = (hipStream_t)stream;
     const int cinp = pad4(cin), T = kh * kw;
     float* wb = (float*)ws;
+    if (use_conv_gemm(g, mfull, dy, dx, ws) && cin >= 16) {
+        hipLaunchKernelGGL(conv_w_layout_kernel, dim3(stream_grid((int64_t)T * cin * cout, 256)), dim3(256), 0, st, w, cin, cout, T, 1, wb);
+        int rcg = check_launch("conv_w_layout");
+        if (rcg) return rcg;
+        const ConvGemmGeom cgg = {n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo};
+        RowScale rsg = {r0, r1, split};
+        return launch_conv_gemm_dx(dy, inv, wb, rsg, cgg, dx, st);
+    }
     hipLaunchKernelGGL(dense_prep_dx_kernel, dim3(stream_grid((int64_t)T * cout * cinp, 256)), dim3(256), 0, st,
                        w, cin, cout, T, cinp, wb);
     int rc = check_launch("dense_prep_dx");
@@ -496,7 +529,10 @@ extern "C" size_t tsii_dense_bwd_dw_ws_bytes(int n, int ho, int wo, int cin, int
     int tpb = 0;
     const int small_rows = small_dw_blocks(g, &tpb);
     const int rows = p.chunks > small_rows ? p.chunks : small_rows;
-    return ((size_t)rows * cout * cin * kh * kw + colsum_ws_floats((int64_t)n * ho * wo, cout)) * sizeof(float);
+    size_t main_floats = (size_t)rows * cout * cin * kh * kw;
+    const ConvGemmGeom cgg = {n, 0, 0, cin, cout, kh, kw, 1, 1, 0, 0, 1, 1, ho, wo};
+    if (conv_gemm_ok(cgg) && conv_gemm_dw_ws_floats(cgg) > main_floats) main_floats = conv_gemm_dw_ws_floats(cgg);
+    return (main_floats + colsum_ws_floats((int64_t)n * ho * wo, cout)) * sizeof(float);
 }
 
 extern "C" int tsii_dense_bwd_dw(const float* dy, const float* inv, const float* keep, const float* x, const float* mfull,
@@ -511,6 +547,14 @@ extern "C" int tsii_dense_bwd_dw(const float* dy, const float* inv, const float*
     DdPlan p = plan_dd(g);
     RowScale rs = {r0, r1, split};
     float* part = (float*)ws;
+    if (use_conv_gemm(g, mfull, dy, x, ws)) {
+        const ConvGemmGeom cgg = {n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo};
+        int rcg = launch_conv_gemm_dw(dy, inv, x, rs, cgg, dwgt, part, st);
+        if (rcg) return rcg;
+        if (dbias != nullptr)
+            rcg = launch_colsum_scaled(dy, keep, (int64_t)n * ho * wo, cout, dbias, part + conv_gemm_dw_ws_floats(cgg), st);
+        return rcg;
+    }
     const SmallPlan sp = plan_small(g);
     if (sp.ok) {
         int tpb = 0;

@@ -96,11 +96,97 @@ __device__ __forceinline__ void nt_store(float* __restrict__ S, const float4 (&r
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC>
+// ---- implicit-GEMM gather (dense k x k convolutions on the MFMA path) ------------------------------
+// The A operand of the NT kernel (and the B operand of the TN kernel) can be an im2col VIEW of an NHWC tensor:
+// row m = a pixel of the row grid [n, rh, rw], column k = (tap t, source channel ci), t = ky*kw + kx.
+//   AMODE 1 (forward / dW):  source pixel = (ry*sh - ph + ky*dh, rx*sw - pw + kx*dw)
+//   AMODE 2 (dX):            source pixel = ((ry + ph - ky*dh)/sh, (rx + pw - kx*dw)/sw) when divisible
+// Out-of-range taps contribute zeros (zero padding).  p0/p1: per-source-pixel planes multiplied in at the LDS
+// store (x*mask with a channel split for forward/dW, 1/count for dX).
+struct ConvGather {
+    int h, w, c;     // source tensor [n, h, w, c]
+    int rh, rw;      // row grid
+    int kw;          // kernel width
+    int sh, sw, ph, pw, dh, dw;
+    const float* p0;
+    const float* p1;
+    int split;       // channels < split use p0, the rest p1 (p1 == nullptr -> 1.0)
+};
+
+template <int AMODE>
+__device__ __forceinline__ bool conv_src(const ConvGather& cg, int ry, int rx, int ky, int kx, int& sy, int& sx) {
+    if (AMODE == 1) {
+        sy = ry * cg.sh - cg.ph + ky * cg.dh;
+        sx = rx * cg.sw - cg.pw + kx * cg.dw;
+        return sy >= 0 && sy < cg.h && sx >= 0 && sx < cg.w;
+    }
+    const int ty = ry + cg.ph - ky * cg.dh, tx = rx + cg.pw - kx * cg.dw;
+    if (ty < 0 || tx < 0 || (ty % cg.sh) != 0 || (tx % cg.sw) != 0) return false;
+    sy = ty / cg.sh; sx = tx / cg.sw;
+    return sy < cg.h && sx < cg.w;
+}
+
+// rows of this thread (fixed across K tiles): image index (or -1), y, x on the row grid
+template <int ROWS>
+__device__ __forceinline__ void conv_rows(const ConvGather& cg, int64_t row0, int64_t nrows, int (&rn)[ROWS / 32],
+                                          int (&ry)[ROWS / 32], int (&rx)[ROWS / 32]) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int64_t row = row0 + ((threadIdx.x + 256 * i) >> 3);
+        rn[i] = -1; ry[i] = 0; rx[i] = 0;
+        if (row < nrows) {
+            rx[i] = (int)(row % cg.rw);
+            ry[i] = (int)((row / cg.rw) % cg.rh);
+            rn[i] = (int)(row / ((int64_t)cg.rw * cg.rh));
+        }
+    }
+}
+
+template <int ROWS, int AMODE>
+__device__ __forceinline__ void conv_load(const float* __restrict__ src, const ConvGather& cg, const int (&rn)[ROWS / 32],
+                                          const int (&ry)[ROWS / 32], const int (&rx)[ROWS / 32], int k0, int K,
+                                          float4 (&regs)[ROWS / 32], float (&f0)[ROWS / 32], float (&f1)[ROWS / 32]) {
+    const int k = k0 + (threadIdx.x & 7) * 4;          // same column group for all of this thread's rows
+    const int t = k / cg.c, ci = k - t * cg.c;
+    const int ky = t / cg.kw, kx = t - ky * cg.kw;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float a0 = 1.f, a1 = 1.f;
+        int sy, sx;
+        if (k < K && rn[i] >= 0 && conv_src<AMODE>(cg, ry[i], rx[i], ky, kx, sy, sx)) {
+            const int64_t spix = ((int64_t)rn[i] * cg.h + sy) * cg.w + sx;
+            v = *reinterpret_cast<const float4*>(src + spix * cg.c + ci);
+            if (cg.p0 != nullptr) { a0 = cg.p0[spix]; a1 = cg.p1 != nullptr ? cg.p1[spix] : 1.f; }
+        }
+        regs[i] = v; f0[i] = a0; f1[i] = a1;
+    }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void conv_store(float* __restrict__ S, const float4 (&regs)[ROWS / 32], const ConvGather& cg, int k0,
+                                           const float (&f0)[ROWS / 32], const float (&f1)[ROWS / 32]) {
+    const int tid = threadIdx.x;
+    const int c4 = tid & 7;
+    const int ci = (k0 + c4 * 4) % cg.c;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int r = (tid + 256 * i) >> 3;
+        float4 v = regs[i];
+        v.x *= (ci + 0 < cg.split) ? f0[i] : f1[i];
+        v.y *= (ci + 1 < cg.split) ? f0[i] : f1[i];
+        v.z *= (ci + 2 < cg.split) ? f0[i] : f1[i];
+        v.w *= (ci + 3 < cg.split) ? f0[i] : f1[i];
+        *reinterpret_cast<float4*>(S + r * GEMM_LDS + c4 * 4) = v;
+    }
+}
+
+template <int WM, int WN, int TM, int TN, bool VEC, int AMODE>
 __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda, RowScale as,
                                                       const float* __restrict__ B, int64_t ldb,
                                                       float* __restrict__ C, int64_t ldc,
-                                                      int64_t M, int N, int K, Epilogue ep, unsigned ntn) {
+                                                      int64_t M, int N, int K, Epilogue ep, unsigned ntn,
+                                                      ConvGather cg) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per block");
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * GEMM_LDS];
@@ -125,12 +211,19 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
 
     float4 ra[BM / 32], rb[BN / 32];
     float sa0[BM / 32], sa1[BM / 32], sb0[BN / 32], sb1[BN / 32];
-    nt_row_scales<BM>(as, m0, M, sa0, sa1);
+    int rn[BM / 32], ry[BM / 32], rx[BM / 32];
 #pragma unroll
     for (int i = 0; i < BN / 32; ++i) { sb0[i] = 1.f; sb1[i] = 1.f; }
-    nt_load<BM, VEC>(A, lda, m0, M, 0, K, ra);
+    if constexpr (AMODE == 0) {
+        nt_row_scales<BM>(as, m0, M, sa0, sa1);
+        nt_load<BM, VEC>(A, lda, m0, M, 0, K, ra);
+    } else {
+        conv_rows<BM>(cg, m0, M, rn, ry, rx);
+        conv_load<BM, AMODE>(A, cg, rn, ry, rx, 0, K, ra, sa0, sa1);
+    }
     nt_load<BN, VEC>(B, ldb, n0, N, 0, K, rb);
-    nt_store<BM, true>(As, ra, 0, as.split, sa0, sa1);
+    if constexpr (AMODE == 0) nt_store<BM, true>(As, ra, 0, as.split, sa0, sa1);
+    else conv_store<BM>(As, ra, cg, 0, sa0, sa1);
     nt_store<BN, false>(Bs, rb, 0, 0, sb0, sb1);
     __syncthreads();
 
@@ -138,7 +231,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = (kt + 1 < nk);
         if (more) {  // next tile's global loads fly during the MFMA phase
-            nt_load<BM, VEC>(A, lda, m0, M, (kt + 1) * GEMM_BK, K, ra);
+            if constexpr (AMODE == 0) nt_load<BM, VEC>(A, lda, m0, M, (kt + 1) * GEMM_BK, K, ra);
+            else conv_load<BM, AMODE>(A, cg, rn, ry, rx, (kt + 1) * GEMM_BK, K, ra, sa0, sa1);
             nt_load<BN, VEC>(B, ldb, n0, N, (kt + 1) * GEMM_BK, K, rb);
         }
 #pragma unroll
@@ -164,7 +258,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
         }
         __syncthreads();
         if (more) {
-            nt_store<BM, true>(As, ra, (kt + 1) * GEMM_BK, as.split, sa0, sa1);
+            if constexpr (AMODE == 0) nt_store<BM, true>(As, ra, (kt + 1) * GEMM_BK, as.split, sa0, sa1);
+            else conv_store<BM>(As, ra, cg, (kt + 1) * GEMM_BK, sa0, sa1);
             nt_store<BN, false>(Bs, rb, 0, 0, sb0, sb1);
             __syncthreads();
         }
@@ -279,10 +374,56 @@ __device__ __forceinline__ void tn_store(float* __restrict__ S, const float4 (&r
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC>
+// gathered B operand of the TN kernel (dW of a dense conv): rows m = output pixels, columns k = (tap, ci) of x
+template <int COLS>
+__device__ __forceinline__ void conv_tn_load(const float* __restrict__ src, const ConvGather& cg, int64_t m0, int64_t mend,
+                                             int q0, int Q, float4 (&regs)[COLS / 32], float (&f0)[COLS / 32],
+                                             float (&f1)[COLS / 32]) {
+    const int tid = threadIdx.x;
+    const int k = q0 + (tid % (COLS / 4)) * 4;        // 256 % (COLS/4) == 0: one column group per thread
+    const int t = k / cg.c, ci = k - t * cg.c;
+    const int ky = t / cg.kw, kx = t - ky * cg.kw;
+#pragma unroll
+    for (int i = 0; i < COLS / 32; ++i) {
+        const int64_t row = m0 + (tid + 256 * i) / (COLS / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float a0 = 1.f, a1 = 1.f;
+        if (row < mend && k < Q) {
+            const int rx = (int)(row % cg.rw), ry = (int)((row / cg.rw) % cg.rh);
+            const int64_t n = row / ((int64_t)cg.rw * cg.rh);
+            int sy, sx;
+            if (conv_src<1>(cg, ry, rx, ky, kx, sy, sx)) {
+                const int64_t spix = (n * cg.h + sy) * cg.w + sx;
+                v = *reinterpret_cast<const float4*>(src + spix * cg.c + ci);
+                if (cg.p0 != nullptr) { a0 = cg.p0[spix]; a1 = cg.p1 != nullptr ? cg.p1[spix] : 1.f; }
+            }
+        }
+        regs[i] = v; f0[i] = a0; f1[i] = a1;
+    }
+}
+template <int COLS>
+__device__ __forceinline__ void conv_tn_store(float* __restrict__ S, const float4 (&regs)[COLS / 32], const ConvGather& cg, int q0,
+                                              const float (&f0)[COLS / 32], const float (&f1)[COLS / 32]) {
+    const int tid = threadIdx.x;
+    const int c4 = tid % (COLS / 4);
+    const int ci = (q0 + c4 * 4) % cg.c;
+#pragma unroll
+    for (int i = 0; i < COLS / 32; ++i) {
+        const int r = (tid + 256 * i) / (COLS / 4);
+        float4 v = regs[i];
+        v.x *= (ci + 0 < cg.split) ? f0[i] : f1[i];
+        v.y *= (ci + 1 < cg.split) ? f0[i] : f1[i];
+        v.z *= (ci + 2 < cg.split) ? f0[i] : f1[i];
+        v.w *= (ci + 3 < cg.split) ? f0[i] : f1[i];
+        *reinterpret_cast<float4*>(S + r * COLS + c4 * 4) = v;
+    }
+}
+
+template <int WM, int WN, int TM, int TN, bool VEC, bool BCONV>
 __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ sa,
                                                       const float* __restrict__ B, int64_t ldb, RowScale sb,
-                                                      float* __restrict__ Cws, int64_t M, int P, int Q, int64_t chunk) {
+                                                      float* __restrict__ Cws, int64_t M, int P, int Q, int64_t chunk,
+                                                      ConvGather cg) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per block");
     __shared__ __attribute__((aligned(16))) float smem[GEMM_BK * (BM + BN)];
@@ -310,16 +451,19 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
     const RowScale none = {nullptr, nullptr, 0};
     const bool sb_active = sb.r0 != nullptr;
     tn_load<BM, VEC>(A, lda, mbeg, mend, p0, P, sa, none, ra, fa0, fa1);
-    tn_load<BN, VEC>(B, ldb, mbeg, mend, q0, Q, nullptr, sb, rb, fb0, fb1);
+    if constexpr (BCONV) conv_tn_load<BN>(B, cg, mbeg, mend, q0, Q, rb, fb0, fb1);
+    else tn_load<BN, VEC>(B, ldb, mbeg, mend, q0, Q, nullptr, sb, rb, fb0, fb1);
     tn_store<BM>(As, ra, p0, 0, false, fa0, fa1);
-    tn_store<BN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1);
+    if constexpr (BCONV) conv_tn_store<BN>(Bs, rb, cg, q0, fb0, fb1);
+    else tn_store<BN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1);
     __syncthreads();
 
     for (int64_t mt = mbeg; mt < mend; mt += GEMM_BK) {
         const bool more = (mt + GEMM_BK < mend);
         if (more) {
             tn_load<BM, VEC>(A, lda, mt + GEMM_BK, mend, p0, P, sa, none, ra, fa0, fa1);
-            tn_load<BN, VEC>(B, ldb, mt + GEMM_BK, mend, q0, Q, nullptr, sb, rb, fb0, fb1);
+            if constexpr (BCONV) conv_tn_load<BN>(B, cg, mt + GEMM_BK, mend, q0, Q, rb, fb0, fb1);
+            else tn_load<BN, VEC>(B, ldb, mt + GEMM_BK, mend, q0, Q, nullptr, sb, rb, fb0, fb1);
         }
 #pragma unroll
         for (int kk = 0; kk < GEMM_BK / 2; ++kk) {
@@ -337,7 +481,8 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
         __syncthreads();
         if (more) {
             tn_store<BM>(As, ra, p0, 0, false, fa0, fa1);
-            tn_store<BN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1);
+            if constexpr (BCONV) conv_tn_store<BN>(Bs, rb, cg, q0, fb0, fb1);
+            else tn_store<BN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1);
             __syncthreads();
         }
     }
@@ -358,6 +503,29 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
 }
 
 // ---- host-side dispatch ----------------------------------------------------------------
+static const ConvGather kNoConv = {0, 0, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, nullptr, nullptr, 0};
+
+template <int WM, int WN, int TM, int TN, int AMODE>
+static int launch_nt_conv_cfg(const float* A, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                              Epilogue ep, ConvGather cg, hipStream_t stream) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const unsigned ntn = (unsigned)cdiv(N, BN);
+    const int64_t nblocks = cdiv64(M, BM) * ntn;
+    TSII_REQUIRE(nblocks < (1ll << 31), "conv gemm: grid too large");
+    const RowScale none = {nullptr, nullptr, 0};
+    hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, true, AMODE>), dim3((unsigned)nblocks), dim3(256), 0, stream,
+                       A, (int64_t)0, none, B, ldb, C, ldc, M, N, K, ep, ntn, cg);
+    return check_launch("conv_gemm_nt");
+}
+template <int AMODE>
+static int launch_nt_conv(const float* A, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                          Epilogue ep, ConvGather cg, hipStream_t stream) {
+    ep.vec_store = (ldc % 4 == 0) && aligned16(C);
+    if (N % 128 == 0 || N > 192) return launch_nt_conv_cfg<2, 2, 2, 2, AMODE>(A, B, ldb, C, ldc, M, N, K, ep, cg, stream);
+    if (N > 32) return launch_nt_conv_cfg<2, 2, 2, 1, AMODE>(A, B, ldb, C, ldc, M, N, K, ep, cg, stream);
+    return launch_nt_conv_cfg<4, 1, 1, 1, AMODE>(A, B, ldb, C, ldc, M, N, K, ep, cg, stream);
+}
+
 template <int WM, int WN, int TM, int TN>
 static int launch_nt_cfg(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, float* C, int64_t ldc,
                          int64_t M, int N, int K, Epilogue ep, bool vec, hipStream_t stream) {
@@ -366,11 +534,11 @@ static int launch_nt_cfg(const float* A, int64_t lda, RowScale as, const float* 
     const int64_t nblocks = cdiv64(M, BM) * ntn;
     TSII_REQUIRE(nblocks < (1ll << 31), "gemm_nt: grid too large");
     if (vec)
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, true>), dim3((unsigned)nblocks), dim3(256), 0, stream,
-                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, true, 0>), dim3((unsigned)nblocks), dim3(256), 0, stream,
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, kNoConv);
     else
-        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, false>), dim3((unsigned)nblocks), dim3(256), 0, stream,
-                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn);
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, false, 0>), dim3((unsigned)nblocks), dim3(256), 0, stream,
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, kNoConv);
     return check_launch("gemm_nt");
 }
 
@@ -402,6 +570,73 @@ static TnPlan plan_tn(int64_t M, int P, int Q) {
     pl.chunk = chunk;
     pl.splits = (int)cdiv64(M, chunk);
     return pl;
+}
+
+// ---- dense convolution on the GEMM kernels (called from dense.hip) ------------------------------------
+static ConvGather make_gather(const ConvGemmGeom& g, bool dx_mode, const float* p0, const float* p1, int split) {
+    ConvGather cg;
+    if (!dx_mode) { cg.h = g.h; cg.w = g.w; cg.c = g.cin; cg.rh = g.ho; cg.rw = g.wo; }
+    else { cg.h = g.ho; cg.w = g.wo; cg.c = g.cout; cg.rh = g.h; cg.rw = g.w; }
+    cg.kw = g.kw; cg.sh = g.sh; cg.sw = g.sw; cg.ph = g.ph; cg.pw = g.pw; cg.dh = g.dh; cg.dw = g.dw;
+    cg.p0 = p0; cg.p1 = p1; cg.split = split;
+    return cg;
+}
+
+bool conv_gemm_ok(const ConvGemmGeom& g) {
+    return g.cin % 4 == 0 && g.cout % 4 == 0 && g.kh * g.kw * g.cin >= 32 && g.cout >= 16;
+}
+
+int launch_conv_gemm_fwd(const float* x, RowScale rs, const float* wr, const float* bias, const float* denom,
+                         const float* keep, const ConvGemmGeom& g, float* y, hipStream_t st) {
+    const int K = g.kh * g.kw * g.cin;
+    const int64_t M = (int64_t)g.n * g.ho * g.wo;
+    Epilogue ep = {denom, keep, bias, {nullptr, nullptr, 0}, 0};
+    const ConvGather cg = make_gather(g, false, rs.r0, rs.r1, rs.r0 != nullptr ? rs.split : 0);
+    return launch_nt_conv<1>(x, wr, K, y, g.cout, M, g.cout, K, ep, cg, st);
+}
+
+int launch_conv_gemm_dx(const float* dy, const float* inv, const float* wd, RowScale rs_out, const ConvGemmGeom& g,
+                        float* dx, hipStream_t st) {
+    const int K = g.kh * g.kw * g.cout;
+    const int64_t M = (int64_t)g.n * g.h * g.w;
+    Epilogue ep = {nullptr, nullptr, nullptr, rs_out, 0};
+    const ConvGather cg = make_gather(g, true, inv, nullptr, 0x7fffffff);
+    return launch_nt_conv<2>(dy, wd, K, dx, g.cin, M, g.cin, K, ep, cg, st);
+}
+
+__global__ void conv_dw_reduce_kernel(const float* __restrict__ part, int S, int cout, int cin, int T, float* __restrict__ dw) {
+    const int64_t len = (int64_t)cout * cin * T;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < len; j += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(j % T);
+        const int ci = (int)((j / T) % cin);
+        const int64_t co = j / ((int64_t)T * cin);
+        const int64_t src = (co * T + t) * cin + ci;     // partial layout [co][(t, ci)]
+        double a = 0.0;
+        for (int z = 0; z < S; ++z) a += (double)part[(int64_t)z * len + src];
+        dw[j] = (float)a;
+    }
+}
+
+size_t conv_gemm_dw_ws_floats(const ConvGemmGeom& g) {
+    const int K = g.kh * g.kw * g.cin;
+    const TnPlan pl = plan_tn((int64_t)g.n * g.ho * g.wo, g.cout, K);
+    return (size_t)pl.splits * g.cout * K;
+}
+
+int launch_conv_gemm_dw(const float* dy, const float* inv, const float* x, RowScale rs, const ConvGemmGeom& g, float* dwgt,
+                        float* ws, hipStream_t st) {
+    const int K = g.kh * g.kw * g.cin, T = g.kh * g.kw;
+    const int64_t M = (int64_t)g.n * g.ho * g.wo;
+    const TnPlan pl = plan_tn(M, g.cout, K);
+    const ConvGather cg = make_gather(g, false, rs.r0, rs.r1, rs.r0 != nullptr ? rs.split : 0);
+    const RowScale none = {nullptr, nullptr, 0};
+    dim3 grid(cdiv(K, pl.bn), cdiv(g.cout, pl.bm), pl.splits);
+    if (pl.big) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, true>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg);
+    else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, true>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg);
+    int rc = check_launch("conv_gemm_tn");
+    if (rc) return rc;
+    hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3(stream_grid((int64_t)g.cout * K, 256)), dim3(256), 0, st, ws, pl.splits, g.cout, g.cin, T, dwgt);
+    return check_launch("conv_dw_reduce");
 }
 
 }  // namespace tsii
@@ -449,11 +684,11 @@ extern "C" int tsii_pw_bwd_dw(const float* dy, const float* x, int64_t m, int n,
     const bool vec = (n % 4 == 0) && (k % 4 == 0) && aligned16(dy) && aligned16(x);
     dim3 grid(cdiv(k, pl.bn), cdiv(n, pl.bm), pl.splits);
     if (pl.big) {
-        if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk);
-        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, false>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk);
+        if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, false>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv);
+        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, false, false>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv);
     } else {
-        if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk);
-        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, false>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk);
+        if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, false>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv);
+        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, false, false>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv);
     }
     int rc = check_launch("gemm_tn");
     if (rc) return rc;

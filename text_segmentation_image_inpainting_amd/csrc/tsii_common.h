@@ -64,6 +64,20 @@ size_t colsum_ws_floats(int64_t M, int N);
 int launch_colsum_scaled(const float* a, const float* rowmul, int64_t M, int N, float* out, float* ws,
                          hipStream_t stream);
 
+// dense convolution as implicit GEMM on the MFMA kernels (gemm.hip); weights must be pre-laid-out:
+//   forward / dW: wr[co][t*cin + ci];   dX: wd[ci][t*cout + co]
+struct ConvGemmGeom {
+    int n, h, w, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo;
+};
+bool conv_gemm_ok(const ConvGemmGeom& g);
+int launch_conv_gemm_fwd(const float* x, RowScale rs, const float* wr, const float* bias, const float* denom,
+                         const float* keep, const ConvGemmGeom& g, float* y, hipStream_t st);
+int launch_conv_gemm_dx(const float* dy, const float* inv, const float* wd, RowScale rs_out, const ConvGemmGeom& g,
+                        float* dx, hipStream_t st);
+size_t conv_gemm_dw_ws_floats(const ConvGemmGeom& g);
+int launch_conv_gemm_dw(const float* dy, const float* inv, const float* x, RowScale rs, const ConvGemmGeom& g, float* dwgt,
+                        float* ws, hipStream_t st);
+
 // number of partial rows for per-channel reductions over M rows with CG channel groups
 static inline int partial_rows(int64_t M, int CG) {
     int64_t r = 131072 / (CG > 0 ? CG : 1);
