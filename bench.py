@@ -39,9 +39,9 @@ def pmc_traffic(kernel_label: str):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, x2 read correction; see the file's `_how`)."""
     path = os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic_bs32.json")
-    names = {"gemm_nt<128x128>": "tsii::gemm_nt_kernel<2, 2, 2, 2, true>",
-             "gemm_nt<128x64>": "tsii::gemm_nt_kernel<2, 2, 2, 1, true>",
-             "gemm_nt<128x32>": "tsii::gemm_nt_kernel<4, 1, 1, 1, true>"}
+    names = {"gemm_nt<128x128>": "tsii::gemm_nt_kernel<2, 2, 2, 2, true, 0>",
+             "gemm_nt<128x64>": "tsii::gemm_nt_kernel<2, 2, 2, 1, true, 0>",
+             "gemm_nt<128x32>": "tsii::gemm_nt_kernel<4, 1, 1, 1, true, 0>"}
     try:
         rec = json.load(open(path))["kernels"][names[kernel_label]]
         return rec["bytes_per_launch"]
