@@ -268,3 +268,49 @@ def test_dense_conv_implicit_gemm_vs_oracle(backend):
             assert_close(m.feature_conv.weight.grad, w.grad, TOL, f"conv-gemm case {idx} dw")
             if bias:
                 assert_close(m.feature_conv.bias.grad, b.grad, TOL, f"conv-gemm case {idx} db")
+
+
+@both_backends
+def test_stem_conv_elementwise_gather_vs_oracle(backend):
+    """3-channel stems on the implicit-GEMM path (element-wise gather): per-channel mask (ImageFill stem),
+    same_holes plane mask (ImageFillOrigin stem) and a plain 3x3 s2 conv (MobileNetV2 / Xception first layer)."""
+    from text_segmentation_image_inpainting_amd.BaseModels import Conv2d
+    with BACKENDS[backend]() as dev:
+        for idx, (cout, k, s, p, bias, same, pcm) in enumerate([(16, 7, 2, 3, True, False, True), (32, 7, 2, 3, True, True, False),
+                                                              (24, 5, 2, 2, False, True, False)]):
+            rng = np.random.default_rng(700 + idx)
+            H = 18
+            m = T.PartialConv(3, cout, k, s, p, 1, 1, bias, same)
+            fill_state_dict_(m.state_dict(), seed=700 + idx)
+            x = torch.from_numpy(rng.standard_normal((2, 3, H, H)).astype(np.float32))
+            if pcm:
+                mask = (torch.from_numpy(rng.uniform(size=(2, 3, H, H))) > 0.35).float()
+                mask[:, :, 4:9, 5:11] = 0
+            else:
+                mask = (torch.from_numpy(rng.uniform(size=(2, 1, H, H))) > 0.35).float().expand(-1, 3, -1, -1).contiguous()
+            w = m.feature_conv.weight.detach().clone().requires_grad_(True)
+            b = m.feature_conv.bias.detach().clone().requires_grad_(True) if bias else None
+            yo, nmo = O.partial_conv(x, mask, w, b, s, p, 1, 1, same)
+            gy = torch.from_numpy(rng.standard_normal(tuple(yo.shape)).astype(np.float32))
+            yo.backward(gy)
+            m = m.to(dev)
+            y, nm = m((x.to(dev), mask.to(dev)))
+            assert_close(y, yo, TOL, f"stem {idx} y")
+            assert np.array_equal(nm.detach().cpu().numpy(), nmo.detach().numpy()), f"stem {idx} new_mask"
+            y.backward(gy.to(dev))
+            assert_close(m.feature_conv.weight.grad, w.grad, TOL, f"stem {idx} dw")
+            if bias:
+                assert_close(m.feature_conv.bias.grad, b.grad, TOL, f"stem {idx} db")
+        # plain conv (no mask): MobileNetV2 first layer 3 -> 32, 3x3 s2
+        conv = Conv2d(3, 32, 3, 2, 1, bias=False)
+        fill_state_dict_(conv.state_dict(), seed=710)
+        x = torch.from_numpy(np.random.default_rng(710).standard_normal((2, 3, 17, 17)).astype(np.float32))
+        w = conv.weight.detach().clone().requires_grad_(True)
+        yo = torch.nn.functional.conv2d(x, w, None, 2, 1)
+        gy = torch.from_numpy(np.random.default_rng(711).standard_normal(tuple(yo.shape)).astype(np.float32))
+        yo.backward(gy)
+        conv = conv.to(dev)
+        y = conv(x.to(dev))
+        assert_close(y, yo, TOL, "plain stem y")
+        y.backward(gy.to(dev))
+        assert_close(conv.weight.grad, w.grad, TOL, "plain stem dw")

@@ -401,9 +401,16 @@ __global__ void conv_w_layout_kernel(const float* __restrict__ w, int cin, int c
     }
 }
 
+// fwd / dW: vector gather when the channels allow it, element-wise gather for stems / per-channel masks
 static bool use_conv_gemm(const ConvGeom& g, const float* mfull, const void* a, const void* b, const void* c) {
     const ConvGemmGeom cg = {g.n, g.h, g.w, g.cin, g.cout, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw, g.dh, g.dw, g.ho, g.wo};
-    return mfull == nullptr && conv_gemm_ok(cg) && aligned16(a) && aligned16(b) && aligned16(c);
+    if (!(aligned16(a) && aligned16(b) && aligned16(c))) return false;
+    if (mfull == nullptr && conv_gemm_ok(cg)) return true;
+    return conv_gemm_elem_ok(cg);
+}
+static bool use_conv_gemm_dx(const ConvGeom& g, const float* mfull, const void* a, const void* b, const void* c) {
+    const ConvGemmGeom cg = {g.n, g.h, g.w, g.cin, g.cout, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw, g.dh, g.dw, g.ho, g.wo};
+    return mfull == nullptr && conv_gemm_ok(cg) && g.cin >= 16 && aligned16(a) && aligned16(b) && aligned16(c);
 }
 
 static int check_conv_geom(const ConvGeom& g, const char* who) {
@@ -478,7 +485,7 @@ extern "C" int tsii_dense_fwd(const float* x, const float* mfull, const float* r
         if (rcg) return rcg;
         const ConvGemmGeom cgg = {n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo};
         RowScale rsg = {r0, r1, split};
-        return launch_conv_gemm_fwd(x, rsg, wf, bias, denom, keep, cgg, y, st);
+        return launch_conv_gemm_fwd(x, mfull, rsg, wf, bias, denom, keep, cgg, y, st);
     }
     hipLaunchKernelGGL(dense_prep_fwd_kernel, dim3(stream_grid((int64_t)T * cin * coutp, 256)), dim3(256), 0, st,
                        w, cin, cout, T, coutp, wf);
@@ -503,7 +510,7 @@ extern "C" int tsii_dense_bwd_dx(const float* dy, const float* inv, const float*
     hipStream_t st = (hipStream_t)stream;
     const int cinp = pad4(cin), T = kh * kw;
     float* wb = (float*)ws;
-    if (use_conv_gemm(g, mfull, dy, dx, ws) && cin >= 16) {
+    if (use_conv_gemm_dx(g, mfull, dy, dx, ws)) {
         hipLaunchKernelGGL(conv_w_layout_kernel, dim3(stream_grid((int64_t)T * cin * cout, 256)), dim3(256), 0, st, w, cin, cout, T, 1, wb);
         int rcg = check_launch("conv_w_layout");
         if (rcg) return rcg;
@@ -531,7 +538,7 @@ extern "C" size_t tsii_dense_bwd_dw_ws_bytes(int n, int ho, int wo, int cin, int
     const int rows = p.chunks > small_rows ? p.chunks : small_rows;
     size_t main_floats = (size_t)rows * cout * cin * kh * kw;
     const ConvGemmGeom cgg = {n, 0, 0, cin, cout, kh, kw, 1, 1, 0, 0, 1, 1, ho, wo};
-    if (conv_gemm_ok(cgg) && conv_gemm_dw_ws_floats(cgg) > main_floats) main_floats = conv_gemm_dw_ws_floats(cgg);
+    if ((conv_gemm_ok(cgg) || conv_gemm_elem_ok(cgg)) && conv_gemm_dw_ws_floats(cgg) > main_floats) main_floats = conv_gemm_dw_ws_floats(cgg);
     return (main_floats + colsum_ws_floats((int64_t)n * ho * wo, cout)) * sizeof(float);
 }
 
@@ -549,7 +556,7 @@ extern "C" int tsii_dense_bwd_dw(const float* dy, const float* inv, const float*
     float* part = (float*)ws;
     if (use_conv_gemm(g, mfull, dy, x, ws)) {
         const ConvGemmGeom cgg = {n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo};
-        int rcg = launch_conv_gemm_dw(dy, inv, x, rs, cgg, dwgt, part, st);
+        int rcg = launch_conv_gemm_dw(dy, inv, x, mfull, rs, cgg, dwgt, part, st);
         if (rcg) return rcg;
         if (dbias != nullptr)
             rcg = launch_colsum_scaled(dy, keep, (int64_t)n * ho * wo, cout, dbias, part + conv_gemm_dw_ws_floats(cgg), st);

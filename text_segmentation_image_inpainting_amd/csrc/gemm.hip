@@ -111,6 +111,7 @@ struct ConvGather {
     const float* p0;
     const float* p1;
     int split;       // channels < split use p0, the rest p1 (p1 == nullptr -> 1.0)
+    const float* pfull;  // general per-channel mask with the source tensor's shape (element-wise gather only)
 };
 
 template <int AMODE>
@@ -124,6 +125,21 @@ __device__ __forceinline__ bool conv_src(const ConvGather& cg, int ry, int rx, i
     if (ty < 0 || tx < 0 || (ty % cg.sh) != 0 || (tx % cg.sw) != 0) return false;
     sy = ty / cg.sh; sx = tx / cg.sw;
     return sy < cg.h && sx < cg.w;
+}
+
+// element-wise form of the gather for channel counts that are not a multiple of 4 (3-channel stems) and for
+// per-channel masks: every k decodes its own (tap, channel); the mask factor is applied at once (the K loop of
+// such layers is a handful of tiles, so the early use of the loaded value does not matter).
+__device__ __forceinline__ float conv_gather_elem(const float* __restrict__ src, const ConvGather& cg, int n, int ry, int rx, int k) {
+    const int t = k / cg.c, ci = k - t * cg.c;
+    const int ky = t / cg.kw, kx = t - ky * cg.kw;
+    int sy, sx;
+    if (!conv_src<1>(cg, ry, rx, ky, kx, sy, sx)) return 0.f;
+    const int64_t spix = ((int64_t)n * cg.h + sy) * cg.w + sx;
+    float v = src[spix * cg.c + ci];
+    if (cg.pfull != nullptr) v *= cg.pfull[spix * cg.c + ci];
+    else if (cg.p0 != nullptr) v *= (ci < cg.split) ? cg.p0[spix] : (cg.p1 != nullptr ? cg.p1[spix] : 1.f);
+    return v;
 }
 
 // rows of this thread (fixed across K tiles): image index (or -1), y, x on the row grid
@@ -147,6 +163,20 @@ __device__ __forceinline__ void conv_load(const float* __restrict__ src, const C
                                           const int (&ry)[ROWS / 32], const int (&rx)[ROWS / 32], int k0, int K,
                                           float4 (&regs)[ROWS / 32], float (&f0)[ROWS / 32], float (&f1)[ROWS / 32]) {
     const int k = k0 + (threadIdx.x & 7) * 4;          // same column group for all of this thread's rows
+    if constexpr (AMODE == 3) {
+#pragma unroll
+        for (int i = 0; i < ROWS / 32; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rn[i] >= 0) {
+                if (k + 0 < K) v.x = conv_gather_elem(src, cg, rn[i], ry[i], rx[i], k + 0);
+                if (k + 1 < K) v.y = conv_gather_elem(src, cg, rn[i], ry[i], rx[i], k + 1);
+                if (k + 2 < K) v.z = conv_gather_elem(src, cg, rn[i], ry[i], rx[i], k + 2);
+                if (k + 3 < K) v.w = conv_gather_elem(src, cg, rn[i], ry[i], rx[i], k + 3);
+            }
+            regs[i] = v; f0[i] = 1.f; f1[i] = 1.f;
+        }
+        return;
+    }
     const int t = k / cg.c, ci = k - t * cg.c;
     const int ky = t / cg.kw, kx = t - ky * cg.kw;
 #pragma unroll
@@ -154,7 +184,7 @@ __device__ __forceinline__ void conv_load(const float* __restrict__ src, const C
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         float a0 = 1.f, a1 = 1.f;
         int sy, sx;
-        if (k < K && rn[i] >= 0 && conv_src<AMODE>(cg, ry[i], rx[i], ky, kx, sy, sx)) {
+        if (k < K && rn[i] >= 0 && conv_src<(AMODE == 2 ? 2 : 1)>(cg, ry[i], rx[i], ky, kx, sy, sx)) {
             const int64_t spix = ((int64_t)rn[i] * cg.h + sy) * cg.w + sx;
             v = *reinterpret_cast<const float4*>(src + spix * cg.c + ci);
             if (cg.p0 != nullptr) { a0 = cg.p0[spix]; a1 = cg.p1 != nullptr ? cg.p1[spix] : 1.f; }
@@ -375,12 +405,29 @@ __device__ __forceinline__ void tn_store(float* __restrict__ S, const float4 (&r
 }
 
 // gathered B operand of the TN kernel (dW of a dense conv): rows m = output pixels, columns k = (tap, ci) of x
-template <int COLS>
+template <int COLS, bool ELEM>
 __device__ __forceinline__ void conv_tn_load(const float* __restrict__ src, const ConvGather& cg, int64_t m0, int64_t mend,
                                              int q0, int Q, float4 (&regs)[COLS / 32], float (&f0)[COLS / 32],
                                              float (&f1)[COLS / 32]) {
     const int tid = threadIdx.x;
     const int k = q0 + (tid % (COLS / 4)) * 4;        // 256 % (COLS/4) == 0: one column group per thread
+    if constexpr (ELEM) {
+#pragma unroll
+        for (int i = 0; i < COLS / 32; ++i) {
+            const int64_t row = m0 + (tid + 256 * i) / (COLS / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < mend) {
+                const int rx = (int)(row % cg.rw), ry = (int)((row / cg.rw) % cg.rh);
+                const int n = (int)(row / ((int64_t)cg.rw * cg.rh));
+                if (k + 0 < Q) v.x = conv_gather_elem(src, cg, n, ry, rx, k + 0);
+                if (k + 1 < Q) v.y = conv_gather_elem(src, cg, n, ry, rx, k + 1);
+                if (k + 2 < Q) v.z = conv_gather_elem(src, cg, n, ry, rx, k + 2);
+                if (k + 3 < Q) v.w = conv_gather_elem(src, cg, n, ry, rx, k + 3);
+            }
+            regs[i] = v; f0[i] = 1.f; f1[i] = 1.f;
+        }
+        return;
+    }
     const int t = k / cg.c, ci = k - t * cg.c;
     const int ky = t / cg.kw, kx = t - ky * cg.kw;
 #pragma unroll
@@ -419,7 +466,7 @@ __device__ __forceinline__ void conv_tn_store(float* __restrict__ S, const float
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC, bool BCONV>
+template <int WM, int WN, int TM, int TN, bool VEC, int BCONV>
 __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ sa,
                                                       const float* __restrict__ B, int64_t ldb, RowScale sb,
                                                       float* __restrict__ Cws, int64_t M, int P, int Q, int64_t chunk,
@@ -451,10 +498,10 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
     const RowScale none = {nullptr, nullptr, 0};
     const bool sb_active = sb.r0 != nullptr;
     tn_load<BM, VEC>(A, lda, mbeg, mend, p0, P, sa, none, ra, fa0, fa1);
-    if constexpr (BCONV) conv_tn_load<BN>(B, cg, mbeg, mend, q0, Q, rb, fb0, fb1);
+    if constexpr (BCONV != 0) conv_tn_load<BN, BCONV == 2>(B, cg, mbeg, mend, q0, Q, rb, fb0, fb1);
     else tn_load<BN, VEC>(B, ldb, mbeg, mend, q0, Q, nullptr, sb, rb, fb0, fb1);
     tn_store<BM>(As, ra, p0, 0, false, fa0, fa1);
-    if constexpr (BCONV) conv_tn_store<BN>(Bs, rb, cg, q0, fb0, fb1);
+    if constexpr (BCONV != 0) conv_tn_store<BN>(Bs, rb, cg, q0, fb0, fb1);
     else tn_store<BN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1);
     __syncthreads();
 
@@ -462,7 +509,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
         const bool more = (mt + GEMM_BK < mend);
         if (more) {
             tn_load<BM, VEC>(A, lda, mt + GEMM_BK, mend, p0, P, sa, none, ra, fa0, fa1);
-            if constexpr (BCONV) conv_tn_load<BN>(B, cg, mt + GEMM_BK, mend, q0, Q, rb, fb0, fb1);
+            if constexpr (BCONV != 0) conv_tn_load<BN, BCONV == 2>(B, cg, mt + GEMM_BK, mend, q0, Q, rb, fb0, fb1);
             else tn_load<BN, VEC>(B, ldb, mt + GEMM_BK, mend, q0, Q, nullptr, sb, rb, fb0, fb1);
         }
 #pragma unroll
@@ -481,7 +528,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
         __syncthreads();
         if (more) {
             tn_store<BM>(As, ra, p0, 0, false, fa0, fa1);
-            if constexpr (BCONV) conv_tn_store<BN>(Bs, rb, cg, q0, fb0, fb1);
+            if constexpr (BCONV != 0) conv_tn_store<BN>(Bs, rb, cg, q0, fb0, fb1);
             else tn_store<BN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1);
             __syncthreads();
         }
@@ -503,7 +550,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
 }
 
 // ---- host-side dispatch ----------------------------------------------------------------
-static const ConvGather kNoConv = {0, 0, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, nullptr, nullptr, 0};
+static const ConvGather kNoConv = {0, 0, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, nullptr, nullptr, 0, nullptr};
 
 template <int WM, int WN, int TM, int TN, int AMODE>
 static int launch_nt_conv_cfg(const float* A, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
@@ -573,8 +620,10 @@ static TnPlan plan_tn(int64_t M, int P, int Q) {
 }
 
 // ---- dense convolution on the GEMM kernels (called from dense.hip) ------------------------------------
-static ConvGather make_gather(const ConvGemmGeom& g, bool dx_mode, const float* p0, const float* p1, int split) {
+static ConvGather make_gather(const ConvGemmGeom& g, bool dx_mode, const float* p0, const float* p1, int split,
+                              const float* pfull = nullptr) {
     ConvGather cg;
+    cg.pfull = pfull;
     if (!dx_mode) { cg.h = g.h; cg.w = g.w; cg.c = g.cin; cg.rh = g.ho; cg.rw = g.wo; }
     else { cg.h = g.ho; cg.w = g.wo; cg.c = g.cout; cg.rh = g.h; cg.rw = g.w; }
     cg.kw = g.kw; cg.sh = g.sh; cg.sw = g.sw; cg.ph = g.ph; cg.pw = g.pw; cg.dh = g.dh; cg.dw = g.dw;
@@ -582,16 +631,20 @@ static ConvGather make_gather(const ConvGemmGeom& g, bool dx_mode, const float* 
     return cg;
 }
 
-bool conv_gemm_ok(const ConvGemmGeom& g) {
+bool conv_gemm_ok(const ConvGemmGeom& g) {   // vector gather (16-byte loads along the channels)
     return g.cin % 4 == 0 && g.cout % 4 == 0 && g.kh * g.kw * g.cin >= 32 && g.cout >= 16;
 }
+bool conv_gemm_elem_ok(const ConvGemmGeom& g) {   // element-wise gather: few input channels (stems), per-channel masks
+    return g.cout % 4 == 0 && g.cout >= 16 && g.kh * g.kw * g.cin >= 24 && g.cin <= 16;
+}
 
-int launch_conv_gemm_fwd(const float* x, RowScale rs, const float* wr, const float* bias, const float* denom,
-                         const float* keep, const ConvGemmGeom& g, float* y, hipStream_t st) {
+int launch_conv_gemm_fwd(const float* x, const float* mfull, RowScale rs, const float* wr, const float* bias,
+                         const float* denom, const float* keep, const ConvGemmGeom& g, float* y, hipStream_t st) {
     const int K = g.kh * g.kw * g.cin;
     const int64_t M = (int64_t)g.n * g.ho * g.wo;
     Epilogue ep = {denom, keep, bias, {nullptr, nullptr, 0}, 0};
-    const ConvGather cg = make_gather(g, false, rs.r0, rs.r1, rs.r0 != nullptr ? rs.split : 0);
+    const ConvGather cg = make_gather(g, false, rs.r0, rs.r1, rs.r0 != nullptr ? rs.split : 0, mfull);
+    if (mfull != nullptr || g.cin % 4 != 0) return launch_nt_conv<3>(x, wr, K, y, g.cout, M, g.cout, K, ep, cg, st);
     return launch_nt_conv<1>(x, wr, K, y, g.cout, M, g.cout, K, ep, cg, st);
 }
 
@@ -623,16 +676,19 @@ size_t conv_gemm_dw_ws_floats(const ConvGemmGeom& g) {
     return (size_t)pl.splits * g.cout * K;
 }
 
-int launch_conv_gemm_dw(const float* dy, const float* inv, const float* x, RowScale rs, const ConvGemmGeom& g, float* dwgt,
-                        float* ws, hipStream_t st) {
+int launch_conv_gemm_dw(const float* dy, const float* inv, const float* x, const float* mfull, RowScale rs,
+                        const ConvGemmGeom& g, float* dwgt, float* ws, hipStream_t st) {
     const int K = g.kh * g.kw * g.cin, T = g.kh * g.kw;
     const int64_t M = (int64_t)g.n * g.ho * g.wo;
     const TnPlan pl = plan_tn(M, g.cout, K);
-    const ConvGather cg = make_gather(g, false, rs.r0, rs.r1, rs.r0 != nullptr ? rs.split : 0);
+    const ConvGather cg = make_gather(g, false, rs.r0, rs.r1, rs.r0 != nullptr ? rs.split : 0, mfull);
     const RowScale none = {nullptr, nullptr, 0};
     dim3 grid(cdiv(K, pl.bn), cdiv(g.cout, pl.bm), pl.splits);
-    if (pl.big) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, true>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg);
-    else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, true>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg);
+    const bool elem = (mfull != nullptr || g.cin % 4 != 0);
+    if (pl.big && !elem) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 1>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg);
+    else if (!elem) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, 1>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg);
+    else if (pl.big) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 2>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg);
+    else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, 2>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg);
     int rc = check_launch("conv_gemm_tn");
     if (rc) return rc;
     hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3(stream_grid((int64_t)g.cout * K, 256)), dim3(256), 0, st, ws, pl.splits, g.cout, g.cin, T, dwgt);
@@ -684,11 +740,11 @@ extern "C" int tsii_pw_bwd_dw(const float* dy, const float* x, int64_t m, int n,
     const bool vec = (n % 4 == 0) && (k % 4 == 0) && aligned16(dy) && aligned16(x);
     dim3 grid(cdiv(k, pl.bn), cdiv(n, pl.bm), pl.splits);
     if (pl.big) {
-        if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, false>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv);
-        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, false, false>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv);
+        if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 0>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv);
+        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, false, 0>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv);
     } else {
-        if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, false>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv);
-        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, false, false>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv);
+        if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, 0>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv);
+        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, false, 0>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv);
     }
     int rc = check_launch("gemm_tn");
     if (rc) return rc;

@@ -69,14 +69,15 @@ int launch_colsum_scaled(const float* a, const float* rowmul, int64_t M, int N, 
 struct ConvGemmGeom {
     int n, h, w, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo;
 };
-bool conv_gemm_ok(const ConvGemmGeom& g);
-int launch_conv_gemm_fwd(const float* x, RowScale rs, const float* wr, const float* bias, const float* denom,
-                         const float* keep, const ConvGemmGeom& g, float* y, hipStream_t st);
+bool conv_gemm_ok(const ConvGemmGeom& g);        // vector gather: cin % 4 == 0, no per-channel mask
+bool conv_gemm_elem_ok(const ConvGemmGeom& g);   // element-wise gather: few input channels / per-channel mask
+int launch_conv_gemm_fwd(const float* x, const float* mfull, RowScale rs, const float* wr, const float* bias,
+                         const float* denom, const float* keep, const ConvGemmGeom& g, float* y, hipStream_t st);
 int launch_conv_gemm_dx(const float* dy, const float* inv, const float* wd, RowScale rs_out, const ConvGemmGeom& g,
                         float* dx, hipStream_t st);
 size_t conv_gemm_dw_ws_floats(const ConvGemmGeom& g);
-int launch_conv_gemm_dw(const float* dy, const float* inv, const float* x, RowScale rs, const ConvGemmGeom& g, float* dwgt,
-                        float* ws, hipStream_t st);
+int launch_conv_gemm_dw(const float* dy, const float* inv, const float* x, const float* mfull, RowScale rs,
+                        const ConvGemmGeom& g, float* dwgt, float* ws, hipStream_t st);
 
 // number of partial rows for per-channel reductions over M rows with CG channel groups
 static inline int partial_rows(int64_t M, int CG) {
