@@ -229,6 +229,8 @@ CONV_GEMM_CASES = [
     (12, 16, 3, 1, 2, 2, True, False, True, 10),     # dilated, decoder flavour: two mask planes, non-same-holes
     (16, 24, (1, 3), 1, (0, 1), 1, False, False, False, 9),   # RFB (1 x k)
     (40, 136, 3, 1, 1, 1, True, False, True, 9),     # > 128 output channels, K = 360 (tile tails)
+    (67, 3, 3, 1, 1, 1, True, False, True, 9),       # ImageFillOrigin final layer: LDS-tiled Cout<=4 path, 16-wide tile
+    (35, 3, 3, 1, 1, 1, True, False, True, 40),      # ImageFill final layer: 32-wide tile, several tiles
 ]
 
 

@@ -218,17 +218,21 @@ __global__ __launch_bounds__(256) void dense_bwd_dw_kernel(const float* __restri
 // 35-channel tensor never reaches the memory pipeline; each thread then walks its kh*kw*Cin
 // window out of LDS (lane stride sw*Cin floats: conflict-free for odd Cin) against wave-uniform
 // weights.
-static constexpr int DS_TH = 8, DS_TW = 32, DS_LDS = 16384;
+static constexpr int DS_TH = 8, DS_LDS = 12288;   // 48 KB patch budget -> 3 blocks per CU; tile width 32 or 16
 
 struct SmallPlan {
     bool ok;
-    int PH, PW;
+    int PH, PW, TW;
 };
 static SmallPlan plan_small(const ConvGeom& g) {
     SmallPlan p;
     p.PH = (DS_TH - 1) * g.sh + (g.kh - 1) * g.dh + 1;
-    p.PW = (DS_TW - 1) * g.sw + (g.kw - 1) * g.dw + 1;
-    p.ok = g.cout <= 4 && (int64_t)p.PH * p.PW * g.cin <= DS_LDS && g.kh * g.kw * g.cin <= 1024;
+    p.ok = false;
+    for (int tw = 32; tw >= 16 && !p.ok; tw /= 2) {
+        p.TW = tw;
+        p.PW = (tw - 1) * g.sw + (g.kw - 1) * g.dw + 1;
+        p.ok = g.cout <= 4 && (int64_t)p.PH * p.PW * g.cin <= DS_LDS && g.kh * g.kw * g.cin <= 1024;
+    }
     return p;
 }
 
@@ -243,29 +247,34 @@ __global__ void dense_prep_small_kernel(const float* __restrict__ w, int cin, in
     }
 }
 
+// 8 patch rows at a time x 32 lanes striding one row: (px, ci) advance incrementally (no divisions) and the loads of
+// a lane are independent, so many are in flight
 __device__ __forceinline__ void stage_patch(float* __restrict__ tile, const float* __restrict__ x,
                                             const float* __restrict__ mfull, const RowScale& rs, const ConvGeom& g,
                                             int64_t n, int iy0, int ix0, int PH, int PW) {
     const int rowlen = PW * g.cin;
-    for (int py = 0; py < PH; ++py) {
+    const int lane = threadIdx.x & 31, prow = threadIdx.x >> 5;
+    const int dpx = 32 / g.cin, dci = 32 % g.cin;
+    for (int py = prow; py < PH; py += 8) {
         const int iy = iy0 + py;
         const bool yin = (iy >= 0 && iy < g.h);
-        int px = threadIdx.x / g.cin, ci = threadIdx.x % g.cin;
-        const int dpx = 256 / g.cin, dci = 256 % g.cin;
-        for (int e = threadIdx.x; e < rowlen; e += 256) {
+        int px = lane / g.cin, ci = lane % g.cin;
+        float* trow = tile + py * rowlen;
+        for (int e = lane; e < rowlen; e += 32) {
             const int ix = ix0 + px;
             float v = 0.f;
             if (yin && ix >= 0 && ix < g.w) {
                 const int64_t ipix = (n * g.h + iy) * g.w + ix;
                 v = x[ipix * g.cin + ci] * in_mask(mfull, rs, ipix, g.cin, ci);
             }
-            tile[py * rowlen + e] = v;
+            trow[e] = v;
             px += dpx; ci += dci;
             if (ci >= g.cin) { ci -= g.cin; ++px; }
         }
     }
 }
 
+template <int DS_TW>
 __global__ __launch_bounds__(256) void dense_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mfull,
                                                               RowScale rs, const float* __restrict__ w4,
                                                               const float* __restrict__ bias, const float* __restrict__ denom,
@@ -276,9 +285,9 @@ __global__ __launch_bounds__(256) void dense_small_fwd_kernel(const float* __res
     const int oy0 = blockIdx.y * DS_TH, ox0 = blockIdx.x * DS_TW;
     stage_patch(tile, x, mfull, rs, g, n, oy0 * g.sh - g.ph, ox0 * g.sw - g.pw, PH, PW);
     __syncthreads();
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tx = threadIdx.x % DS_TW, ty = threadIdx.x / DS_TW;
     const int oy = oy0 + ty, ox = ox0 + tx;
-    if (oy >= g.ho || ox >= g.wo) return;
+    if (ty >= DS_TH || oy >= g.ho || ox >= g.wo) return;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int ky = 0; ky < g.kh; ++ky)
         for (int kx = 0; kx < g.kw; ++kx) {
@@ -311,12 +320,13 @@ __global__ __launch_bounds__(256) void dense_small_fwd_kernel(const float* __res
 // dW partials for the few-output-channel path: persistent blocks walk tiles; thread t owns im2col
 // columns t, t+256, ... (column = (tap, ci)) x 4 output channels in registers.
 static constexpr int DS_NP = 4;
+template <int DS_TW>
 __global__ __launch_bounds__(256) void dense_small_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
                                                                  const float* __restrict__ x, const float* __restrict__ mfull,
                                                                  RowScale rs, ConvGeom g, int PH, int PW, int tiles_per_block,
                                                                  float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) float tile[DS_LDS];
-    __shared__ __attribute__((aligned(16))) float gs[DS_TH * DS_TW * 4];
+    __shared__ __attribute__((aligned(16))) float gs[DS_TH * 32 * 4];
     const int T = g.kh * g.kw, KK = T * g.cin;
     const int ntx = (g.wo + DS_TW - 1) / DS_TW, nty = (g.ho + DS_TH - 1) / DS_TH;
     const int total_tiles = g.n * nty * ntx;
@@ -343,17 +353,17 @@ __global__ __launch_bounds__(256) void dense_small_bwd_dw_kernel(const float* __
         __syncthreads();
         stage_patch(tile, x, mfull, rs, g, n, oy0 * g.sh - g.ph, ox0 * g.sw - g.pw, PH, PW);
         {
-            const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+            const int tx = threadIdx.x % DS_TW, ty = threadIdx.x / DS_TW;
             const int oy = oy0 + ty, ox = ox0 + tx;
             float gv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (oy < g.ho && ox < g.wo) {
+            if (ty < DS_TH && oy < g.ho && ox < g.wo) {
                 const int64_t pix = (n * g.ho + oy) * g.wo + ox;
                 const float sc = inv != nullptr ? inv[pix] : 1.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (e < g.cout) gv[e] = dy[pix * g.cout + e] * sc;
             }
-            *reinterpret_cast<float4*>(gs + threadIdx.x * 4) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+            if (ty < DS_TH) *reinterpret_cast<float4*>(gs + threadIdx.x * 4) = make_float4(gv[0], gv[1], gv[2], gv[3]);
         }
         __syncthreads();
         for (int py = 0; py < DS_TH; ++py)
@@ -381,8 +391,8 @@ __global__ __launch_bounds__(256) void dense_small_bwd_dw_kernel(const float* __
     }
 }
 
-static int small_dw_blocks(const ConvGeom& g, int* tiles_per_block) {
-    const int ntx = cdiv(g.wo, DS_TW), nty = cdiv(g.ho, DS_TH);
+static int small_dw_blocks(const ConvGeom& g, int tw, int* tiles_per_block) {
+    const int ntx = cdiv(g.wo, tw), nty = cdiv(g.ho, DS_TH);
     const int total = g.n * nty * ntx;
     int blocks = total < 1024 ? total : 1024;
     *tiles_per_block = cdiv(total, blocks);
@@ -470,13 +480,15 @@ extern "C" int tsii_dense_fwd(const float* x, const float* mfull, const float* r
     const int coutp = pad4(cout), T = kh * kw;
     float* wf = (float*)ws;
     const SmallPlan sp = plan_small(g);
-    if (sp.ok && ho <= 65535 * DS_TH && n <= 65535) {
+    if (sp.ok && cdiv(ho, DS_TH) <= 65535 && n <= 65535) {
         hipLaunchKernelGGL(dense_prep_small_kernel, dim3(cdiv(T * cin * 4, 256)), dim3(256), 0, st, w, cin, cout, T, wf);
         int rc0 = check_launch("dense_prep_small");
         if (rc0) return rc0;
         RowScale rs0 = {r0, r1, split};
-        hipLaunchKernelGGL(dense_small_fwd_kernel, dim3(cdiv(wo, DS_TW), cdiv(ho, DS_TH), n), dim3(256), 0, st, x, mfull,
-                           rs0, wf, bias, denom, keep, g, sp.PH, sp.PW, y);
+        if (sp.TW == 32) hipLaunchKernelGGL((dense_small_fwd_kernel<32>), dim3(cdiv(wo, 32), cdiv(ho, DS_TH), n), dim3(256), 0, st, x, mfull,
+                                            rs0, wf, bias, denom, keep, g, sp.PH, sp.PW, y);
+        else hipLaunchKernelGGL((dense_small_fwd_kernel<16>), dim3(cdiv(wo, 16), cdiv(ho, DS_TH), n), dim3(256), 0, st, x, mfull,
+                                rs0, wf, bias, denom, keep, g, sp.PH, sp.PW, y);
         return check_launch("dense_small_fwd");
     }
     if (use_conv_gemm(g, mfull, x, y, ws)) {   // MFMA implicit GEMM
@@ -534,7 +546,7 @@ extern "C" size_t tsii_dense_bwd_dw_ws_bytes(int n, int ho, int wo, int cin, int
     ConvGeom g = {n, 0, 0, cin, cout, kh, kw, 1, 1, 0, 0, 1, 1, ho, wo};
     DdPlan p = plan_dd(g);
     int tpb = 0;
-    const int small_rows = small_dw_blocks(g, &tpb);
+    const int small_rows = small_dw_blocks(g, 16, &tpb);   // upper bound over both tile widths
     const int rows = p.chunks > small_rows ? p.chunks : small_rows;
     size_t main_floats = (size_t)rows * cout * cin * kh * kw;
     const ConvGemmGeom cgg = {n, 0, 0, cin, cout, kh, kw, 1, 1, 0, 0, 1, 1, ho, wo};
@@ -565,9 +577,11 @@ extern "C" int tsii_dense_bwd_dw(const float* dy, const float* inv, const float*
     const SmallPlan sp = plan_small(g);
     if (sp.ok) {
         int tpb = 0;
-        const int blocks = small_dw_blocks(g, &tpb);
-        hipLaunchKernelGGL(dense_small_bwd_dw_kernel, dim3(blocks), dim3(256), 0, st, dy, inv, x, mfull, rs, g, sp.PH,
-                           sp.PW, tpb, part);
+        const int blocks = small_dw_blocks(g, sp.TW, &tpb);
+        if (sp.TW == 32) hipLaunchKernelGGL((dense_small_bwd_dw_kernel<32>), dim3(blocks), dim3(256), 0, st, dy, inv, x, mfull, rs, g, sp.PH,
+                                            sp.PW, tpb, part);
+        else hipLaunchKernelGGL((dense_small_bwd_dw_kernel<16>), dim3(blocks), dim3(256), 0, st, dy, inv, x, mfull, rs, g, sp.PH,
+                                sp.PW, tpb, part);
         int rc1 = check_launch("dense_small_bwd_dw");
         if (rc1) return rc1;
         const int64_t len1 = (int64_t)cout * cin * kh * kw;
