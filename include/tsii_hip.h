@@ -197,6 +197,11 @@ int tsii_bce_focal_fwd(const float* x, const float* t, int64_t numel, float gamm
 int tsii_bce_focal_bwd(const float* x, const float* t, int64_t numel, float gamma, float background_w, float words_w,
                        const float* gscale, float* dx, void* stream);
 
+/* pixel shuffle by r on NHWC (the reference only mentions it in its README; semantics =
+ * torch.nn.PixelShuffle on NCHW): x [n,h,w,c*r*r] -> y [n,h*r,w*r,c], y[n,h*r+i,w*r+j,c] = x[n,h,w,c*r*r+i*r+j].
+ * inverse != 0 runs the adjoint / un-shuffle (y -> x). */
+int tsii_pixel_shuffle(const float* src, int n, int h, int w, int c, int r, int inverse, float* dst, void* stream);
+
 /* ---- InpaintingLoss pieces (loss.py:195-225,303-307) ------------------------------------ */
 /* comp = mask*raw + (1-mask)*out (loss.py:196); backward: dout = dcomp*(1-mask) */
 int tsii_compose_fwd(const float* raw, const float* mask, const float* out, int64_t numel, float* comp, void* stream);

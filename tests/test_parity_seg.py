@@ -128,3 +128,21 @@ def test_golden_inpainting_loss(backend):
         assert abs(loss.item() - float(G["loss"])) <= 1e-4 * abs(float(G["loss"]))
         loss.backward()
         assert_close(out.grad, G["dout"], TOL, "InpaintingLoss d/d(output)")
+
+
+@both_backends
+def test_pixel_shuffle_vs_torch(backend):
+    """K12: no reference code -- oracle is stock torch.nn.PixelShuffle on CPU; exact permutation."""
+    from text_segmentation_image_inpainting_amd.BaseModels import PixelShuffle
+    with BACKENDS[backend]() as dev:
+        for r, c in ((2, 3), (4, 1), (2, 8)):
+            x = torch.randn(2, c * r * r, 5, 6)
+            xo = x.clone().requires_grad_(True)
+            yo = torch.nn.PixelShuffle(r)(xo)
+            gy = torch.randn_like(yo)
+            yo.backward(gy)
+            xd = x.to(dev).requires_grad_(True)
+            y = PixelShuffle(r)(xd)
+            assert torch.equal(y.detach().cpu(), yo.detach())
+            y.backward(gy.to(dev))
+            assert torch.equal(xd.grad.cpu(), xo.grad)

@@ -156,6 +156,13 @@ class Upsample(nn.Upsample):
         return to_nchw(ops.bilinear_up(to_nhwc(x), int(self.scale_factor)))
 
 
+class PixelShuffle(nn.PixelShuffle):
+    """nn.PixelShuffle on the HIP path (no counterpart in the reference's code -- only its README)."""
+
+    def forward(self, x):
+        return to_nchw(ops.pixel_shuffle(to_nhwc(x), self.upscale_factor))
+
+
 def interpolate_bilinear(x, scale_factor):
     """F.interpolate(x, scale_factor=s, mode='bilinear', align_corners=False)."""
     return to_nchw(ops.bilinear_up(to_nhwc(x), int(scale_factor)))

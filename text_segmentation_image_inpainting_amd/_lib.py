@@ -58,6 +58,7 @@ SIGNATURES = {
     "tsii_scse_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _z, _p]),
     "tsii_bce_focal_fwd": (_i, [_p, _p, _l, _f, _f, _f, _p, _p, _z, _p]),
     "tsii_bce_focal_bwd": (_i, [_p, _p, _l, _f, _f, _f, _p, _p, _p]),
+    "tsii_pixel_shuffle": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "tsii_compose_fwd": (_i, [_p, _p, _p, _l, _p, _p]),
     "tsii_compose_bwd": (_i, [_p, _p, _l, _p, _p]),
     "tsii_masked_l1_fwd": (_i, [_p, _p, _p, _l, _f, _f, _p, _p, _z, _p]),

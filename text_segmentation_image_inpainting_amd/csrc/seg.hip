@@ -205,6 +205,21 @@ __global__ __launch_bounds__(256) void scse_dsse_kernel(const float* __restrict_
     }
 }
 
+// pixel shuffle (K12): pure permutation; lanes walk the OUTPUT channels so the wide side is coalesced
+__global__ void pixel_shuffle_kernel(const float* __restrict__ src, int64_t total, int h, int w, int c, int r, int inverse,
+                                     float* __restrict__ dst) {
+    const int hr = h * r, wr = w * r, crr = c * r * r;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % c);
+        const int64_t opix = idx / c;
+        const int ox = (int)(opix % wr), oy = (int)((opix / wr) % hr);
+        const int64_t b = opix / ((int64_t)wr * hr);
+        const int64_t lo = ((b * h + oy / r) * w + ox / r) * crr + (int64_t)ch * r * r + (oy % r) * r + (ox % r);
+        if (inverse) dst[lo] = src[idx];
+        else dst[idx] = src[lo];
+    }
+}
+
 // BinaryFocalLoss element (loss.py:66-75)
 __device__ __forceinline__ float softplus_neg_abs(float x) { return log1pf(expf(-fabsf(x))); }
 __device__ __forceinline__ float focal_elem(float x, float t, float gamma, float bw, float ww) {
@@ -253,6 +268,14 @@ __global__ void bce_focal_bwd_kernel(const float* __restrict__ x, const float* _
 }  // namespace tsii
 
 using namespace tsii;
+
+extern "C" int tsii_pixel_shuffle(const float* src, int n, int h, int w, int c, int r, int inverse, float* dst, void* stream) {
+    TSII_REQUIRE(src && dst && n > 0 && h > 0 && w > 0 && c > 0 && r >= 1, "pixel_shuffle: bad arguments");
+    const int64_t total = (int64_t)n * h * r * w * r * c;
+    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, src, total, h, w, c, r,
+                       inverse, dst);
+    return check_launch("pixel_shuffle");
+}
 
 extern "C" int tsii_add_act_fwd(const float* a, const float* b, int64_t numel, int act, float slope, float* out, void* stream) {
     TSII_REQUIRE(a && b && out && numel > 0, "add_act_fwd: bad arguments");

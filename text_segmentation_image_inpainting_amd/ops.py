@@ -748,3 +748,30 @@ class _Gram(torch.autograd.Function):
 
 def gram_matrix(f_nhwc):
     return _Gram.apply(f_nhwc)
+
+
+class _PixelShuffle(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, r):
+        _lib.check_device(x)
+        x = x.contiguous()
+        n, h, w, crr = x.shape
+        assert crr % (r * r) == 0
+        c = crr // (r * r)
+        y = torch.empty((n, h * r, w * r, c), dtype=torch.float32, device=x.device)
+        call("tsii_pixel_shuffle", ptr(x), n, h, w, c, int(r), 0, ptr(y), _lib.stream())
+        ctx.dims = (n, h, w, c, int(r))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        n, h, w, c, r = ctx.dims
+        gy = gy.contiguous()
+        dx = torch.empty((n, h, w, c * r * r), dtype=torch.float32, device=gy.device)
+        call("tsii_pixel_shuffle", ptr(gy), n, h, w, c, r, 1, ptr(dx), _lib.stream())
+        return dx, None
+
+
+def pixel_shuffle(x, r: int):
+    """torch.nn.PixelShuffle(r) semantics on NHWC data (K12; perf-only variant of the decoder head)."""
+    return _PixelShuffle.apply(x, r)
