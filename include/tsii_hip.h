@@ -143,6 +143,47 @@ int tsii_bn_act_bwd(const float* dout, const float* y, int64_t m, int c,
                     const float* mean, const float* var, const float* gamma, const float* beta,
                     float eps, int act, float slope, int training,
                     float* dy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- K6b: BatchNorm folded into the neighbouring convolutions (training-time fusion of the reference's
+ *           Sequential(conv, BatchNorm2d, act, conv ...) chains, e.g. models/MobileNetV2.py:168-179) -----
+ * Producer side ("stat_part"): the conv kernel also writes, per block of output rows and per channel, the
+ *   partial sums (sum(y - p), sum((y - p)^2)), p = bias[c] (0 without bias), as float [rows][2][c_out];
+ *   rows = tsii_pw_stat_rows(m) / tsii_dw_stat_rows(...).  tsii_bn_finalize() folds them (fp64) into the
+ *   batch mean / biased variance, updates the running statistics like nn.BatchNorm2d and emits
+ *   scale = gamma/sqrt(var+eps), shift = beta - mean*scale -- no separate pass over y.
+ * Consumer side ("in_scale/in_shift"): the next conv applies a = act(in_scale[c]*v + in_shift[c]) to every
+ *   element it loads (before the x*mask multiply; zero padding pads a), so the normalised activation is never
+ *   written to HBM.  in_scale == NULL: plain input.  The *_bwd_dw_bn forms recompute a the same way;
+ *   dX is unchanged (it is the gradient w.r.t. a) and feeds tsii_bn_act_bwd together with the raw y. */
+int64_t tsii_pw_stat_rows(int64_t m);
+int tsii_pw_fwd_bn(const float* x, int64_t m, int k, const float* w, int n, const float* bias,
+                   const float* r0, int split, const float* r1, const float* denom, const float* keep,
+                   const float* in_scale, const float* in_shift, int in_act, float in_slope,
+                   float* stat_part, float* y, void* stream);
+int tsii_pw_bwd_dw_bn(const float* dy, const float* x, int64_t m, int n, int k, const float* inv, const float* keep,
+                      const float* r0, int split, const float* r1,
+                      const float* in_scale, const float* in_shift, int in_act, float in_slope,
+                      float* dw, float* dbias, void* ws, size_t ws_bytes, void* stream);
+/* 0 when the geometry has no LDS-tiled kernel (then only the unfused entry points apply) */
+int64_t tsii_dw_stat_rows(int n, int ho, int wo, int c, int kh, int kw, int sh, int sw, int dh, int dw);
+int tsii_dw_fwd_bn(const float* x, const float* rmask, const float* w, const float* bias,
+                   const float* denom, const float* keep,
+                   int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                   int ho, int wo, const float* in_scale, const float* in_shift, int in_act, float in_slope,
+                   float* stat_part, float* y, float* ws, void* stream);
+int tsii_dw_bwd_dw_bn(const float* dy, const float* inv, const float* keep, const float* x, const float* rmask,
+                      int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                      int ho, int wo, const float* in_scale, const float* in_shift, int in_act, float in_slope,
+                      float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream);
+size_t tsii_bn_finalize_ws_bytes(int64_t rows, int c);
+/* pivot = the producer's bias (NULL = 0); scale/shift may be NULL (then gamma/beta may be too) */
+int tsii_bn_finalize(const float* stat_part, int64_t rows, int c, int64_t m, const float* pivot,
+                     float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                     const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                     void* ws, size_t ws_bytes, void* stream);
+/* eval mode: (scale, shift) from the running statistics */
+int tsii_bn_scale_shift(const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                        int c, float* scale, float* shift, void* stream);
 /* activation only (PartialActivation :204-211): out = act(x); dx = dout*act'(x) */
 int tsii_act_fwd(const float* x, int64_t numel, int act, float slope, float* out, void* stream);
 int tsii_act_bwd(const float* dout, const float* x, int64_t numel, int act, float slope, float* dx, void* stream);

@@ -208,6 +208,9 @@ def run_nhwc(layer, x, mp):
     if hasattr(layer, "forward_nhwc"):
         return layer.forward_nhwc(x, mp)
     if isinstance(layer, nn.Sequential):
+        from .partial_convolution import PartialActivatedBN, PartialConv, PartialConv1x1, run_block
+        if len(layer) == 2 and isinstance(layer[0], (PartialConv, PartialConv1x1)) and isinstance(layer[1], PartialActivatedBN):
+            return run_block(layer, x, mp)      # conv + BatchNorm: statistics fused into the conv (K6b)
         for m in layer:
             x, mp = run_nhwc(m, x, mp)
         return x, mp

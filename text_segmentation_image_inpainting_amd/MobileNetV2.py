@@ -6,10 +6,10 @@ from torch import nn
 from torch.utils.checkpoint import checkpoint
 
 from . import ops
-from .BaseModels import BaseModule, Conv_block, run_nhwc, to_nchw, to_nhwc
+from .BaseModels import BaseModule, Conv_block, run_nhwc, to_nchw, to_nhwc  # noqa: F401
 from .common import SpatialChannelSqueezeExcitation
 from .masks import MaskParts, as_parts
-from .partial_convolution import PartialActivatedBN, partial_convolution_block
+from .partial_convolution import PartialActivatedBN, partial_convolution_block, run_block  # noqa: F401
 
 
 class MobileNetV2(BaseModule):
@@ -159,18 +159,11 @@ class PartialInvertedResidual(BaseModule):
         return nn.Sequential(*layer)
 
     def forward_nhwc(self, x, mp):
-        h, m = run_nhwc(self.conv[0], x, mp)
-        h, m = run_nhwc(self.conv[1], h, m)
-        last = self.conv[2]
-        if self.res_connect and len(last) == 2 and isinstance(last[1], PartialActivatedBN):
-            # residual add (:186-187) fused into the BN-apply kernel of the linear bottleneck
-            h, m = last[0].forward_nhwc(h, m)
-            h, m = last[1].forward_nhwc(h, m, residual=x)
-            return h, m
-        h, m = run_nhwc(last, h, m)
-        if self.res_connect:
-            h = x + h
-        return h, m
+        # expand -> depth-wise -> project with every BatchNorm folded into its neighbours (K6b): the two wide
+        # activations are never written, the residual add (:186-187) rides in the last BatchNorm's apply kernel
+        h, m = run_block(self.conv[0], x, mp, allow_lazy=True)
+        h, m = run_block(self.conv[1], h, m, allow_lazy=True)
+        return run_block(self.conv[2], h, m, residual=x if self.res_connect else None)
 
     def forward(self, args):
         x, mask = args

@@ -82,6 +82,87 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
     }
 }
 
+// K6b: statistics from the partial sums the producing conv kernel left behind (one row per 128-row GEMM block /
+// per 8x16 stencil tile: up to 16 K rows), taken about pivot[c] = the conv bias (0 if none).  Level 1 folds
+// 128-row chunks into fp64 (sum, sum of squares); the final kernel turns them into mean / biased variance,
+// updates the running statistics and emits the (scale, shift) pair the consumer applies on load.
+__global__ __launch_bounds__(256) void bn_parts_l1_kernel(const float* __restrict__ part, int64_t R, int C, int chunk_rows,
+                                                          double* __restrict__ out) {
+    __shared__ double sh[2][8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    const int64_t r0 = (int64_t)blockIdx.y * chunk_rows;
+    const int64_t r1 = r0 + chunk_rows < R ? r0 + chunk_rows : R;
+    double a1[2] = {0, 0}, a2[2] = {0, 0};
+    if (c < C) {
+        for (int64_t r = r0 + ty; r < r1; r += 16) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t rr = r + 8 * u;
+                if (rr < r1) {
+                    a1[u] += (double)part[rr * 2 * C + c];
+                    a2[u] += (double)part[rr * 2 * C + C + c];
+                }
+            }
+        }
+    }
+    sh[0][ty][tx] = a1[0] + a1[1]; sh[1][ty][tx] = a2[0] + a2[1];
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int j = 0; j < 8; ++j) { s1 += sh[0][j][tx]; s2 += sh[1][j][tx]; }
+        out[(int64_t)blockIdx.y * 2 * C + c] = s1;
+        out[(int64_t)blockIdx.y * 2 * C + C + c] = s2;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_parts_final_kernel(const double* __restrict__ l1, int chunks, int64_t M, int C,
+                                                             const float* __restrict__ pivot, float* __restrict__ mean,
+                                                             float* __restrict__ var, float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var, float momentum,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float eps, float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double sh[2][8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int r = ty; r < chunks; r += 8) { s1 += l1[(int64_t)r * 2 * C + c]; s2 += l1[(int64_t)r * 2 * C + C + c]; }
+    sh[0][ty][tx] = s1; sh[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        s1 = 0.0; s2 = 0.0;
+        for (int j = 0; j < 8; ++j) { s1 += sh[0][j][tx]; s2 += sh[1][j][tx]; }
+        const double e1 = s1 / (double)M;
+        double v = s2 / (double)M - e1 * e1;
+        if (v < 0.0) v = 0.0;
+        const double mu = (pivot != nullptr ? (double)pivot[c] : 0.0) + e1;
+        mean[c] = (float)mu;
+        var[c] = (float)v;
+        if (running_mean != nullptr) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        if (running_var != nullptr) {
+            const double unb = M > 1 ? v * (double)M / (double)(M - 1) : v;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+        if (scale != nullptr) {
+            const float sc = (1.0f / sqrtf((float)v + eps)) * gamma[c];
+            scale[c] = sc;
+            shift[c] = beta[c] - (float)mu * sc;
+        }
+    }
+}
+
+__global__ void bn_scale_shift_kernel(const float* __restrict__ mean, const float* __restrict__ var,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int C,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float sc = (1.0f / sqrtf(var[c] + eps)) * gamma[c];
+        scale[c] = sc;
+        shift[c] = beta[c] - mean[c] * sc;
+    }
+}
+
 // launched with chan_grid(): (gridDim*blockDim) % CG == 0, so each thread's channel group is fixed
 template <int W>
 __global__ void bn_act_fwd_kernel(const float* __restrict__ y, int64_t M, int C, const float* __restrict__ mean,
@@ -256,6 +337,40 @@ extern "C" int tsii_bn_stats(const float* y, int64_t m, int c, float* mean, floa
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(c, 32)), dim3(256), 0, st, y, part, R, m, c, mean, var,
                        running_mean, running_var, momentum);
     return check_launch("bn_stats_final");
+}
+
+static inline int bn_l1_chunks(int64_t rows) { return (int)cdiv64(rows, 128); }
+
+extern "C" size_t tsii_bn_finalize_ws_bytes(int64_t rows, int c) {
+    if (rows <= 0 || c <= 0) return 0;
+    return (size_t)bn_l1_chunks(rows) * 2 * c * sizeof(double);
+}
+
+extern "C" int tsii_bn_finalize(const float* stat_part, int64_t rows, int c, int64_t m, const float* pivot,
+                                float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                                const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                                void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(stat_part && mean && var && ws, "bn_finalize: null pointer");
+    TSII_REQUIRE(rows > 0 && c > 0 && m > 0, "bn_finalize: bad shape");
+    TSII_REQUIRE((scale == nullptr) == (shift == nullptr), "bn_finalize: scale / shift go together");
+    TSII_REQUIRE(scale == nullptr || (gamma && beta), "bn_finalize: scale / shift need gamma and beta");
+    TSII_REQUIRE(ws_bytes >= tsii_bn_finalize_ws_bytes(rows, c), "bn_finalize: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int chunks = bn_l1_chunks(rows);
+    hipLaunchKernelGGL(bn_parts_l1_kernel, dim3(cdiv(c, 32), chunks), dim3(256), 0, st, stat_part, rows, c, 128, (double*)ws);
+    int rc = check_launch("bn_parts_l1");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_parts_final_kernel, dim3(cdiv(c, 32)), dim3(256), 0, st, (const double*)ws, chunks, m, c, pivot, mean,
+                       var, running_mean, running_var, momentum, gamma, beta, eps, scale, shift);
+    return check_launch("bn_parts_final");
+}
+
+extern "C" int tsii_bn_scale_shift(const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                                   int c, float* scale, float* shift, void* stream) {
+    TSII_REQUIRE(mean && var && gamma && beta && scale && shift && c > 0, "bn_scale_shift: bad arguments");
+    hipLaunchKernelGGL(bn_scale_shift_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, mean, var, gamma, beta, eps,
+                       c, scale, shift);
+    return check_launch("bn_scale_shift");
 }
 
 extern "C" int tsii_bn_act_fwd(const float* y, int64_t m, int c, const float* mean, const float* var,

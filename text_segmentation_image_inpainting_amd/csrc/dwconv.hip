@@ -235,13 +235,22 @@ struct DtGeom {
     int n, hin, win, c, s, d, pad_h, pad_w, hout, wout, flip;
 };
 
+// BatchNorm(+activation) of the producer applied to the staged input (K6b): a = act(sc[c]*v + sh[c]); zero padding
+// stays zero (it pads the activated tensor).  sc == nullptr: none.
+struct DwBN {
+    const float* sc;
+    const float* sh;
+    int act;
+    float slope;
+};
+
 template <int DT_TH, int DT_TW, int DT_CB, int DT_LDS_FLOATS>
 __global__ __launch_bounds__(256) void dw_tile_kernel(const float* __restrict__ in, const float* __restrict__ pre,
                                                       const float* __restrict__ wT, const float* __restrict__ bias,
                                                       const float* __restrict__ denom, const float* __restrict__ keep,
                                                       const float* __restrict__ post_mul, DtGeom g, int PH, int PW,
                                                       unsigned tiles_x, unsigned tiles_y, unsigned cblocks,
-                                                      float* __restrict__ out) {
+                                                      DwBN ib, float* __restrict__ stats, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float tile[DT_LDS_FLOATS];
     unsigned b = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned cb = b % cblocks; b /= cblocks;
@@ -255,33 +264,58 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const float* __restrict__ 
     const int npix = PH * PW;
     constexpr int CGS = DT_CB / 4;                 // channel groups per pixel
     constexpr int LANES = 256 / CGS;               // pixel lanes
+    const int cg = threadIdx.x % CGS, lane = threadIdx.x / CGS;   // 256 % CGS == 0: the staging loop keeps this thread's cg
+    const int c = c0 + cg * 4;
+    float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool bn_in = ib.sc != nullptr;
+    if (bn_in && c < g.c) { isc = *reinterpret_cast<const float4*>(ib.sc + c); ish = *reinterpret_cast<const float4*>(ib.sh + c); }
     for (int e = threadIdx.x; e < npix * CGS; e += 256) {
-        const int cg = e % CGS, p = e / CGS;
+        const int p = e / CGS;
         const int py = p / PW, px = p - py * PW;
         const int iy = iy0 + py, ix = ix0 + px;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win && c0 + cg * 4 < g.c) {
+        if (iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win && c < g.c) {
             const int64_t ipix = (n * g.hin + iy) * g.win + ix;
-            v = *reinterpret_cast<const float4*>(in + ipix * g.c + c0 + cg * 4);
+            v = *reinterpret_cast<const float4*>(in + ipix * g.c + c);
+            if (bn_in) {
+                v.x = apply_act(fmaf(v.x, isc.x, ish.x), ib.act, ib.slope); v.y = apply_act(fmaf(v.y, isc.y, ish.y), ib.act, ib.slope);
+                v.z = apply_act(fmaf(v.z, isc.z, ish.z), ib.act, ib.slope); v.w = apply_act(fmaf(v.w, isc.w, ish.w), ib.act, ib.slope);
+            }
             if (pre != nullptr) { const float m = pre[ipix]; v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
         }
         *reinterpret_cast<float4*>(tile + p * DT_CB + cg * 4) = v;
     }
-    const int cg = threadIdx.x % CGS, lane = threadIdx.x / CGS;
-    const int c = c0 + cg * 4;
     float4 w[9];
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < g.c) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const float4*>(wT + (g.flip ? 8 - t : t) * g.c + c);
+        if (bias != nullptr) bq = make_float4(bias[c], bias[c + 1], bias[c + 2], bias[c + 3]);   // bias may be 4-byte aligned only
+    }
+    // per-pixel side values of this thread's pixels, issued before the barrier (their latency hides behind the
+    // staging; loading them next to their use serialised ~4 L2 round trips per pixel)
+    constexpr int NP = DT_TH * DT_TW / LANES;
+    float kpv[NP], dnv[NP], pmv[NP];
+    int64_t opv[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int p = lane + LANES * k;
+        const int oy = oy0 + p / DT_TW, ox = ox0 + p % DT_TW;
+        const bool ok = oy < g.hout && ox < g.wout;
+        opv[k] = ok ? (n * g.hout + oy) * g.wout + ox : -1;
+        const int64_t q = ok ? opv[k] : (n * g.hout + oy0) * g.wout + ox0;   // clamp: the tile origin is always valid
+        kpv[k] = keep != nullptr ? keep[q] : 1.f;
+        dnv[k] = denom != nullptr ? denom[q] : 1.f;
+        pmv[k] = post_mul != nullptr ? post_mul[q] : 1.f;
     }
     __syncthreads();
-    if (c >= g.c) return;
+    const bool cok = c < g.c;
+    float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;   // BatchNorm partial sums of the outputs about the bias
 #pragma unroll
-    for (int k = 0; k < DT_TH * DT_TW / LANES; ++k) {
+    for (int k = 0; k < NP; ++k) {
         const int p = lane + LANES * k;              // x-adjacent lanes -> conflict-free LDS reads
         const int ty = p / DT_TW, tx = p % DT_TW;
-        const int oy = oy0 + ty, ox = ox0 + tx;
-        if (oy >= g.hout || ox >= g.wout) continue;
+        if (opv[k] < 0 || !cok) continue;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -291,47 +325,80 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const float* __restrict__ 
                 const float4 ww = w[ky * 3 + kx];
                 a.x = fmaf(v.x, ww.x, a.x); a.y = fmaf(v.y, ww.y, a.y); a.z = fmaf(v.z, ww.z, a.z); a.w = fmaf(v.w, ww.w, a.w);
             }
-        const int64_t opix = (n * g.hout + oy) * g.wout + ox;
-        const bool kp = keep != nullptr ? (keep[opix] != 0.f) : true;
-        if (denom != nullptr) { const float dn = denom[opix]; a.x /= dn; a.y /= dn; a.z /= dn; a.w /= dn; }
-        if (bias != nullptr) { a.x += bias[c]; a.y += bias[c + 1]; a.z += bias[c + 2]; a.w += bias[c + 3]; }
+        if (denom != nullptr) { const float dn = dnv[k]; a.x /= dn; a.y /= dn; a.z /= dn; a.w /= dn; }
+        a.x += bq.x; a.y += bq.y; a.z += bq.z; a.w += bq.w;
         if (post_mul != nullptr) {
-            const float pm = post_mul[opix];
+            const float pm = pmv[k];
             a.x = pm != 0.f ? a.x * pm : 0.f; a.y = pm != 0.f ? a.y * pm : 0.f;
             a.z = pm != 0.f ? a.z * pm : 0.f; a.w = pm != 0.f ? a.w * pm : 0.f;
         }
-        if (!kp) a = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(out + opix * g.c + c) = a;
+        if (kpv[k] == 0.f) a = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(out + opv[k] * g.c + c) = a;
+        if (stats != nullptr) {
+            const float dx = a.x - bq.x, dy = a.y - bq.y, dz = a.z - bq.z, dw = a.w - bq.w;
+            t1.x += dx; t1.y += dy; t1.z += dz; t1.w += dw;
+            t2.x = fmaf(dx, dx, t2.x); t2.y = fmaf(dy, dy, t2.y); t2.z = fmaf(dz, dz, t2.z); t2.w = fmaf(dw, dw, t2.w);
+        }
+    }
+    if (stats != nullptr) {
+        // lanes of one channel group are CGS apart inside a wave: xor-shuffle them together, then the 4 waves through LDS
+        float vals[8] = {t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int off = CGS; off < 64; off <<= 1) vals[i] += __shfl_xor(vals[i], off, 64);
+        __syncthreads();                               // the patch is dead: reuse it
+        const int wl = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (wl < CGS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                tile[(wave * 2 + 0) * DT_CB + wl * 4 + i] = vals[i];
+                tile[(wave * 2 + 1) * DT_CB + wl * 4 + i] = vals[4 + i];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * DT_CB) {
+            const int which = threadIdx.x / DT_CB, ch = threadIdx.x % DT_CB;
+            if (c0 + ch < g.c) {
+                const float sum = (tile[(0 * 2 + which) * DT_CB + ch] + tile[(1 * 2 + which) * DT_CB + ch]) +
+                                  (tile[(2 * 2 + which) * DT_CB + ch] + tile[(3 * 2 + which) * DT_CB + ch]);
+                const int64_t prow = (n * tiles_y + ty0) * tiles_x + tx0;      // one partial row per spatial tile
+                stats[(prow * 2 + which) * g.c + c0 + ch] = sum;
+            }
+        }
     }
 }
 
 // -> 0 launched, 1 not applicable (caller falls back to the direct kernel), <0 error
+static const DwBN kNoDwBN = {nullptr, nullptr, 0, 0.f};
+static constexpr int DT_TH0 = 8, DT_TW0 = 16;     // output tile of every variant (also the BatchNorm partial-row grain)
+
 template <int TH, int TW, int CB, int LDSF>
 static int launch_dw_tile_variant(const float* in, const float* pre, const float* wT, const float* bias, const float* denom,
-                                  const float* keep, const float* post_mul, DtGeom g, float* out, hipStream_t st) {
+                                  const float* keep, const float* post_mul, DtGeom g, DwBN ib, float* stats, float* out,
+                                  hipStream_t st) {
     const int PH = (TH - 1) * g.s + 2 * g.d + 1, PW = (TW - 1) * g.s + 2 * g.d + 1;
     if (PH * PW * CB > LDSF) return 1;
     const unsigned tiles_x = cdiv(g.wout, TW), tiles_y = cdiv(g.hout, TH), cblocks = cdiv(g.c, CB);
     const int64_t nblk = (int64_t)tiles_x * tiles_y * cblocks * g.n;
     if (nblk >= (1ll << 31)) return 1;
     hipLaunchKernelGGL((dw_tile_kernel<TH, TW, CB, LDSF>), dim3((unsigned)nblk), dim3(256), 0, st, in, pre, wT, bias, denom, keep,
-                       post_mul, g, PH, PW, tiles_x, tiles_y, cblocks, out);
+                       post_mul, g, PH, PW, tiles_x, tiles_y, cblocks, ib, stats, out);
     return check_launch("dw_tile");
 }
 
+static bool dw_tile_fits(int s, int d) {   // patch fits the forward AND the dW tile kernels (6144 floats)
+    const int PH = (DT_TH0 - 1) * s + 2 * d + 1, PW = (DT_TW0 - 1) * s + 2 * d + 1;
+    return PH * PW * 32 <= 6144;
+}
+
 static int try_launch_dw_tile(const float* in, const float* pre, const float* wT, const float* bias, const float* denom,
-                              const float* keep, const float* post_mul, DtGeom g, float* out, hipStream_t st) {
+                              const float* keep, const float* post_mul, DtGeom g, float* out, hipStream_t st,
+                              DwBN ib = kNoDwBN, float* stats = nullptr) {
     if (g.c % 4 != 0 || !aligned16(in) || !aligned16(out) || !aligned16(wT)) return 1;
-    static int variant = -1;   // TSII_DW_TILE: tuning knob for A/B runs (0 = default)
-    if (variant < 0) { const char* e = getenv("TSII_DW_TILE"); variant = e ? atoi(e) : 0; }
-    int rc = 1;
-    if (variant == 1) rc = launch_dw_tile_variant<8, 16, 32, 10240>(in, pre, wT, bias, denom, keep, post_mul, g, out, st);
-    else if (variant == 2) rc = launch_dw_tile_variant<8, 8, 64, 6656>(in, pre, wT, bias, denom, keep, post_mul, g, out, st);
-    else if (variant == 3) rc = launch_dw_tile_variant<4, 32, 32, 6656>(in, pre, wT, bias, denom, keep, post_mul, g, out, st);
-    else if (variant == 4) rc = launch_dw_tile_variant<16, 16, 32, 10240>(in, pre, wT, bias, denom, keep, post_mul, g, out, st);
-    else if (variant == 9) return 1;   // direct kernel
-    else rc = launch_dw_tile_variant<8, 16, 32, 6144>(in, pre, wT, bias, denom, keep, post_mul, g, out, st);
-    if (rc == 1 && variant != 1) rc = launch_dw_tile_variant<8, 16, 32, 10240>(in, pre, wT, bias, denom, keep, post_mul, g, out, st);
+    if (ib.sc != nullptr && (!aligned16(ib.sc) || !aligned16(ib.sh))) return 1;
+    int rc = launch_dw_tile_variant<DT_TH0, DT_TW0, 32, 6144>(in, pre, wT, bias, denom, keep, post_mul, g, ib, stats, out, st);
+    if (rc == 1) rc = launch_dw_tile_variant<DT_TH0, DT_TW0, 32, 10240>(in, pre, wT, bias, denom, keep, post_mul, g, ib, stats, out, st);
     return rc;
 }
 
@@ -343,7 +410,7 @@ __global__ __launch_bounds__(256) void dw_tile_dw_kernel(const float* __restrict
                                                          const float* __restrict__ keep, const float* __restrict__ x,
                                                          const float* __restrict__ rmask, DtGeom g, int PH, int PW,
                                                          unsigned tiles_x, unsigned tiles_y, unsigned cblocks,
-                                                         unsigned tiles_per_block, float* __restrict__ part) {
+                                                         unsigned tiles_per_block, DwBN ib, float* __restrict__ part) {
     constexpr int TH = 8, TW = 16, CB = 32, CGS = 8, LANES = 32;
     __shared__ __attribute__((aligned(16))) float tile[6144];
     __shared__ float red[256];
@@ -352,6 +419,9 @@ __global__ __launch_bounds__(256) void dw_tile_dw_kernel(const float* __restrict
     const int cg = threadIdx.x % CGS, lane = threadIdx.x / CGS;
     const int c = c0 + cg * 4;
     const bool cok = c < g.c;
+    float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool bn_in = ib.sc != nullptr;
+    if (bn_in && cok) { isc = *reinterpret_cast<const float4*>(ib.sc + c); ish = *reinterpret_cast<const float4*>(ib.sh + c); }
     const unsigned total_tiles = tiles_x * tiles_y * (unsigned)g.n;
     const unsigned t_beg = gi * tiles_per_block;
     const unsigned t_end = t_beg + tiles_per_block < total_tiles ? t_beg + tiles_per_block : total_tiles;
@@ -365,17 +435,21 @@ __global__ __launch_bounds__(256) void dw_tile_dw_kernel(const float* __restrict
         const int oy0 = (int)ty0 * TH, ox0 = (int)tx0 * TW;
         const int iy0 = oy0 * g.s - g.pad_h, ix0 = ox0 * g.s - g.pad_w;
         __syncthreads();
-        for (int e = threadIdx.x; e < npix * CGS; e += 256) {
-            const int ecg = e % CGS, p = e / CGS;
+        for (int e = threadIdx.x; e < npix * CGS; e += 256) {   // 256 % CGS == 0: e % CGS == cg
+            const int p = e / CGS;
             const int py = p / PW, px = p - py * PW;
             const int iy = iy0 + py, ix = ix0 + px;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win && c0 + ecg * 4 < g.c) {
+            if (iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win && cok) {
                 const int64_t ipix = (n * g.hin + iy) * g.win + ix;
-                v = *reinterpret_cast<const float4*>(x + ipix * g.c + c0 + ecg * 4);
+                v = *reinterpret_cast<const float4*>(x + ipix * g.c + c);
+                if (bn_in) {
+                    v.x = apply_act(fmaf(v.x, isc.x, ish.x), ib.act, ib.slope); v.y = apply_act(fmaf(v.y, isc.y, ish.y), ib.act, ib.slope);
+                    v.z = apply_act(fmaf(v.z, isc.z, ish.z), ib.act, ib.slope); v.w = apply_act(fmaf(v.w, isc.w, ish.w), ib.act, ib.slope);
+                }
                 if (rmask != nullptr) { const float m = rmask[ipix]; v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
             }
-            *reinterpret_cast<float4*>(tile + p * CB + ecg * 4) = v;
+            *reinterpret_cast<float4*>(tile + p * CB + cg * 4) = v;
         }
         // this thread's dy pixels (registers), issued before the barrier so they overlap the staging
         float4 gv[TH * TW / LANES];
@@ -514,10 +588,10 @@ using namespace tsii;
 
 #define DW_GEOM() DwGeom g = {n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo}
 
-extern "C" int tsii_dw_fwd(const float* x, const float* rmask, const float* w, const float* bias,
-                           const float* denom, const float* keep, int n, int h, int wd, int c, int kh, int kw,
-                           int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo, float* y, float* ws,
-                           void* stream) {
+static int dw_fwd_impl(const float* x, const float* rmask, const float* w, const float* bias,
+                       const float* denom, const float* keep, int n, int h, int wd, int c, int kh, int kw,
+                       int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo, DwBN ib, float* stats, float* y,
+                       float* ws, void* stream) {
     TSII_REQUIRE(x && w && y && ws, "dw_fwd: null pointer");
     DW_GEOM();
     if (check_geom(g, "dw_fwd")) return -1;
@@ -527,9 +601,11 @@ extern "C" int tsii_dw_fwd(const float* x, const float* rmask, const float* w, c
     const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(ws);
     if (kh == 3 && kw == 3 && sh == sw && dh == dw) {   // LDS-tiled 3x3 stencil
         DtGeom tg = {n, h, wd, c, sh, dh, ph, pw, ho, wo, 0};
-        rc = try_launch_dw_tile(x, rmask, ws, bias, denom, keep, nullptr, tg, y, st);
+        rc = try_launch_dw_tile(x, rmask, ws, bias, denom, keep, nullptr, tg, y, st, ib, stats);
         if (rc <= 0) return rc;
     }
+    TSII_REQUIRE(ib.sc == nullptr && stats == nullptr,
+                 "dw_fwd_bn: the fused BatchNorm forms need the LDS-tiled 3x3 path (tsii_dw_stat_rows() > 0, 16-byte aligned operands)");
     // measured on MI355X: the fully unrolled 3x3 form (more loads in flight) is SLOWER here -- these
     // stencils are bound by vector-memory instruction issue, not latency -- so it stays disabled
     const bool k3 = false;
@@ -541,6 +617,32 @@ extern "C" int tsii_dw_fwd(const float* x, const float* rmask, const float* w, c
     else if (vec) hipLaunchKernelGGL((dw_fwd_kernel<4, false>), grid, dim3(256), 0, st, x, rmask, ws, bias, denom, keep, g, y);
     else hipLaunchKernelGGL((dw_fwd_kernel<1, false>), grid, dim3(256), 0, st, x, rmask, ws, bias, denom, keep, g, y);
     return check_launch("dw_fwd");
+}
+
+extern "C" int tsii_dw_fwd(const float* x, const float* rmask, const float* w, const float* bias,
+                           const float* denom, const float* keep, int n, int h, int wd, int c, int kh, int kw,
+                           int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo, float* y, float* ws,
+                           void* stream) {
+    return dw_fwd_impl(x, rmask, w, bias, denom, keep, n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo, kNoDwBN, nullptr, y,
+                       ws, stream);
+}
+
+extern "C" int64_t tsii_dw_stat_rows(int n, int ho, int wo, int c, int kh, int kw, int sh, int sw, int dh, int dw) {
+    if (n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || c % 4 != 0) return 0;
+    if (!(kh == 3 && kw == 3 && sh == sw && dh == dw) || !dw_tile_fits(sh, dh)) return 0;
+    return (int64_t)n * cdiv(ho, DT_TH0) * cdiv(wo, DT_TW0);
+}
+
+extern "C" int tsii_dw_fwd_bn(const float* x, const float* rmask, const float* w, const float* bias,
+                              const float* denom, const float* keep, int n, int h, int wd, int c, int kh, int kw,
+                              int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo,
+                              const float* in_scale, const float* in_shift, int in_act, float in_slope,
+                              float* stat_part, float* y, float* ws, void* stream) {
+    TSII_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dw_fwd_bn: in_scale / in_shift go together");
+    TSII_REQUIRE(in_act >= 0 && in_act <= 4, "dw_fwd_bn: unknown activation %d", in_act);
+    const DwBN ib = {in_scale, in_shift, in_act, in_slope};
+    return dw_fwd_impl(x, rmask, w, bias, denom, keep, n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo, ib, stat_part, y, ws,
+                       stream);
 }
 
 extern "C" int tsii_dw_bwd_dx(const float* dy, const float* inv, const float* w, const float* rmask,
@@ -582,29 +684,30 @@ extern "C" size_t tsii_dw_bwd_dw_ws_bytes(int n, int ho, int wo, int c, int kh, 
     return (size_t)R * (size_t)(kh * kw + 1) * c * sizeof(float);
 }
 
-extern "C" int tsii_dw_bwd_dw(const float* dy, const float* inv, const float* keep, const float* x, const float* rmask,
-                              int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw,
-                              int dh, int dw, int ho, int wo, float* dwgt, float* dbias, void* ws, size_t ws_bytes,
-                              void* stream) {
+static int dw_bwd_dw_impl(const float* dy, const float* inv, const float* keep, const float* x, const float* rmask,
+                          int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw,
+                          int dh, int dw, int ho, int wo, DwBN ib, float* dwgt, float* dbias, void* ws, size_t ws_bytes,
+                          void* stream) {
     TSII_REQUIRE(dy && x && dwgt && ws, "dw_bwd_dw: null pointer");
     DW_GEOM();
     if (check_geom(g, "dw_bwd_dw")) return -1;
     TSII_REQUIRE(ws_bytes >= tsii_dw_bwd_dw_ws_bytes(n, ho, wo, c, kh, kw), "dw_bwd_dw: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    const bool vec = (c % 4 == 0) && aligned16(dy) && aligned16(x);
+    const bool vec = (c % 4 == 0) && aligned16(dy) && aligned16(x) && (ib.sc == nullptr || (aligned16(ib.sc) && aligned16(ib.sh)));
     float* part = (float*)ws;
     if (vec && kh == 3 && kw == 3 && sh == sw && dh == dw) {
         const DtDwPlan tp = plan_dt_dw(n, ho, wo, c, sh, dh);
         if (tp.ok) {
             DtGeom tg = {n, h, wd, c, sh, dh, ph, pw, ho, wo, 0};
             hipLaunchKernelGGL(dw_tile_dw_kernel, dim3(tp.groups * tp.cblocks), dim3(256), 0, st, dy, inv, keep, x, rmask, tg,
-                               tp.PH, tp.PW, tp.tiles_x, tp.tiles_y, tp.cblocks, tp.tiles_per_block, part);
+                               tp.PH, tp.PW, tp.tiles_x, tp.tiles_y, tp.cblocks, tp.tiles_per_block, ib, part);
             int rc0 = check_launch("dw_tile_dw");
             if (rc0) return rc0;
             hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)cdiv64((int64_t)10 * c, 32)), dim3(256), 0, st, part, (int)tp.groups, 9, c, dwgt, dbias);
             return check_launch("dw_reduce");
         }
     }
+    TSII_REQUIRE(ib.sc == nullptr, "dw_bwd_dw_bn: the fused BatchNorm form needs the LDS-tiled 3x3 path");
     const DwPlan p = plan_dw(n, ho, c, vec);
     const dim3 grid((unsigned)(p.gx * p.gy));
     const bool k3 = (kh == 3 && kw == 3);
@@ -616,4 +719,23 @@ extern "C" int tsii_dw_bwd_dw(const float* dy, const float* inv, const float* ke
     const int T = kh * kw;
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)cdiv64((int64_t)(T + 1) * c, 32)), dim3(256), 0, st, part, p.R, T, c, dwgt, dbias);
     return check_launch("dw_reduce");
+}
+
+extern "C" int tsii_dw_bwd_dw(const float* dy, const float* inv, const float* keep, const float* x, const float* rmask,
+                              int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw,
+                              int dh, int dw, int ho, int wo, float* dwgt, float* dbias, void* ws, size_t ws_bytes,
+                              void* stream) {
+    return dw_bwd_dw_impl(dy, inv, keep, x, rmask, n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo, kNoDwBN, dwgt, dbias, ws,
+                          ws_bytes, stream);
+}
+
+extern "C" int tsii_dw_bwd_dw_bn(const float* dy, const float* inv, const float* keep, const float* x, const float* rmask,
+                                 int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw,
+                                 int dh, int dw, int ho, int wo,
+                                 const float* in_scale, const float* in_shift, int in_act, float in_slope,
+                                 float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(in_scale && in_shift, "dw_bwd_dw_bn: null scale / shift");
+    const DwBN ib = {in_scale, in_shift, in_act, in_slope};
+    return dw_bwd_dw_impl(dy, inv, keep, x, rmask, n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo, ib, dwgt, dbias, ws,
+                          ws_bytes, stream);
 }

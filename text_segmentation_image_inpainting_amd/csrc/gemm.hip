@@ -29,6 +29,15 @@ struct Epilogue {
     const float* bias;   // [N]
     RowScale cs;         // output scale per (row, col)
     int vec_store;       // C rows are 16-byte aligned (ldc % 4 == 0, base aligned)
+    float* stats;        // [row blocks][2][N] BatchNorm partial sums of the stored values about the bias (or NULL)
+};
+
+// BatchNorm(+activation) of the producer folded into the A-operand load (K6b): a = act(sc[k]*v + sh[k])
+struct InBN {
+    const float* sc;
+    const float* sh;
+    int act;
+    float slope;
 };
 
 // ---- tile loaders ----------------------------------------------------------------------
@@ -92,6 +101,26 @@ __device__ __forceinline__ void nt_store(float* __restrict__ S, const float4 (&r
             v.z *= (k + 2 < split) ? s0[i] : s1[i];
             v.w *= (k + 3 < split) ? s0[i] : s1[i];
         }
+        *reinterpret_cast<float4*>(S + r * GEMM_LDS + c4 * 4) = v;
+    }
+}
+
+// nt_store with the producer's BatchNorm + activation applied first (psc/psh: this thread's 4 channels of the tile)
+template <int ROWS>
+__device__ __forceinline__ void nt_store_bn(float* __restrict__ S, const float4 (&regs)[ROWS / 32], int k0, int split,
+                                            const float (&s0)[ROWS / 32], const float (&s1)[ROWS / 32], const float4 psc,
+                                            const float4 psh, int act, float slope) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int f = tid + 256 * i;
+        const int r = f >> 3, c4 = f & 7;
+        const int k = k0 + c4 * 4;
+        float4 v = regs[i];
+        v.x = apply_act(fmaf(v.x, psc.x, psh.x), act, slope) * ((k + 0 < split) ? s0[i] : s1[i]);
+        v.y = apply_act(fmaf(v.y, psc.y, psh.y), act, slope) * ((k + 1 < split) ? s0[i] : s1[i]);
+        v.z = apply_act(fmaf(v.z, psc.z, psh.z), act, slope) * ((k + 2 < split) ? s0[i] : s1[i]);
+        v.w = apply_act(fmaf(v.w, psc.w, psh.w), act, slope) * ((k + 3 < split) ? s0[i] : s1[i]);
         *reinterpret_cast<float4*>(S + r * GEMM_LDS + c4 * 4) = v;
     }
 }
@@ -211,12 +240,13 @@ __device__ __forceinline__ void conv_store(float* __restrict__ S, const float4 (
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC, int AMODE>
+template <int WM, int WN, int TM, int TN, bool VEC, int AMODE, bool BNIN = false>
 __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda, RowScale as,
                                                       const float* __restrict__ B, int64_t ldb,
                                                       float* __restrict__ C, int64_t ldc,
                                                       int64_t M, int N, int K, Epilogue ep, unsigned ntn,
-                                                      ConvGather cg) {
+                                                      ConvGather cg, InBN ib) {
+    static_assert(!BNIN || (VEC && AMODE == 0), "input BatchNorm rides the plain vector loader");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per block");
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * GEMM_LDS];
@@ -252,7 +282,12 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
         conv_load<BM, AMODE>(A, cg, rn, ry, rx, 0, K, ra, sa0, sa1);
     }
     nt_load<BN, VEC>(B, ldb, n0, N, 0, K, rb);
-    if constexpr (AMODE == 0) nt_store<BM, true>(As, ra, 0, as.split, sa0, sa1);
+    float4 psc = make_float4(0.f, 0.f, 0.f, 0.f), psh = psc;   // BNIN: this thread's 4 channels of the tile in flight
+    const int pk = (tid & 7) * 4;
+    if constexpr (BNIN) {
+        if (pk < K) { psc = *reinterpret_cast<const float4*>(ib.sc + pk); psh = *reinterpret_cast<const float4*>(ib.sh + pk); }
+        nt_store_bn<BM>(As, ra, 0, as.split, sa0, sa1, psc, psh, ib.act, ib.slope);
+    } else if constexpr (AMODE == 0) nt_store<BM, true>(As, ra, 0, as.split, sa0, sa1);
     else conv_store<BM>(As, ra, cg, 0, sa0, sa1);
     nt_store<BN, false>(Bs, rb, 0, 0, sb0, sb1);
     __syncthreads();
@@ -264,6 +299,11 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
             if constexpr (AMODE == 0) nt_load<BM, VEC>(A, lda, m0, M, (kt + 1) * GEMM_BK, K, ra);
             else conv_load<BM, AMODE>(A, cg, rn, ry, rx, (kt + 1) * GEMM_BK, K, ra, sa0, sa1);
             nt_load<BN, VEC>(B, ldb, n0, N, (kt + 1) * GEMM_BK, K, rb);
+            if constexpr (BNIN) {
+                const int k = (kt + 1) * GEMM_BK + pk;
+                psc = make_float4(0.f, 0.f, 0.f, 0.f); psh = psc;
+                if (k < K) { psc = *reinterpret_cast<const float4*>(ib.sc + k); psh = *reinterpret_cast<const float4*>(ib.sh + k); }
+            }
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -288,7 +328,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
         }
         __syncthreads();
         if (more) {
-            if constexpr (AMODE == 0) nt_store<BM, true>(As, ra, (kt + 1) * GEMM_BK, as.split, sa0, sa1);
+            if constexpr (BNIN) nt_store_bn<BM>(As, ra, (kt + 1) * GEMM_BK, as.split, sa0, sa1, psc, psh, ib.act, ib.slope);
+            else if constexpr (AMODE == 0) nt_store<BM, true>(As, ra, (kt + 1) * GEMM_BK, as.split, sa0, sa1);
             else conv_store<BM>(As, ra, cg, (kt + 1) * GEMM_BK, sa0, sa1);
             nt_store<BN, false>(Bs, rb, 0, 0, sb0, sb1);
             __syncthreads();
@@ -298,14 +339,55 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
     // epilogue: accumulators (D[row=(r&3)+8*(r>>2)+4*hi][col=lane&31]) are staged through LDS one
     // 32-row band per wave-row at a time, so rows leave as 16-byte stores (the dword-per-lane form is
     // store-issue bound for the short-K layers); count division / bias / hole zeroing ride along.
+    // A thread owns ONE 4-column group (256 % F4_PER_ROW == 0) and F4_PER_THREAD rows per band; all the
+    // per-row side loads of a band are issued together before the first use -- interleaved load/use made
+    // the epilogue a chain of ~8 dependent L2 round trips per float4 and capped short-K layers at ~60 TF/s.
     constexpr int CS = BN + 4;                       // padded LDS row stride (floats), keeps float4 alignment
     constexpr int BAND_ROWS = WM * 32;
     constexpr int F4_PER_ROW = BN / 4;
     constexpr int F4_PER_THREAD = BAND_ROWS * F4_PER_ROW / 256;
+    constexpr int ROW_STEP = 256 / F4_PER_ROW;
     static_assert(BAND_ROWS * CS <= (BM + BN) * GEMM_LDS, "epilogue band must fit the operand LDS");
+    static_assert(256 % F4_PER_ROW == 0, "fixed column group per thread");
     float* Cs = smem;
+    const int c4 = tid % F4_PER_ROW, rr0 = tid / F4_PER_ROW;
+    const int col = n0 + c4 * 4;
+    const bool col_ok = col < N;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ep.bias != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (col + e < N) bv[e] = ep.bias[col + e];
+    }
+    const bool has_cs = ep.cs.r0 != nullptr;
+    float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};   // BatchNorm partial sums about the bias
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
+        // side loads of this band (clamped rows: no divergent branches, nothing is used until the tile is staged)
+        float kpv[F4_PER_THREAD], dnv[F4_PER_THREAD], c0v[F4_PER_THREAD], c1v[F4_PER_THREAD];
+        int64_t rowv[F4_PER_THREAD];
+#pragma unroll
+        for (int i = 0; i < F4_PER_THREAD; ++i) {
+            const int rr = rr0 + ROW_STEP * i;
+            rowv[i] = m0 + ((rr >> 5) * TM + t) * 32 + (rr & 31);
+            kpv[i] = 1.f; dnv[i] = 1.f; c0v[i] = 1.f; c1v[i] = 1.f;
+        }
+        if (ep.keep != nullptr) {
+#pragma unroll
+            for (int i = 0; i < F4_PER_THREAD; ++i) kpv[i] = ep.keep[rowv[i] < M ? rowv[i] : M - 1];
+        }
+        if (ep.denom != nullptr) {
+#pragma unroll
+            for (int i = 0; i < F4_PER_THREAD; ++i) dnv[i] = ep.denom[rowv[i] < M ? rowv[i] : M - 1];
+        }
+        if (has_cs) {
+#pragma unroll
+            for (int i = 0; i < F4_PER_THREAD; ++i) c0v[i] = ep.cs.r0[rowv[i] < M ? rowv[i] : M - 1];
+            if (ep.cs.r1 != nullptr) {
+#pragma unroll
+                for (int i = 0; i < F4_PER_THREAD; ++i) c1v[i] = ep.cs.r1[rowv[i] < M ? rowv[i] : M - 1];
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < TN; ++u)
@@ -315,26 +397,29 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < F4_PER_THREAD; ++i) {
-            const int f = tid + 256 * i;
-            const int rr = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
-            const int64_t row = m0 + ((rr >> 5) * TM + t) * 32 + (rr & 31);
-            const int col = n0 + c4 * 4;
-            if (row >= M || col >= N) continue;
+            const int rr = rr0 + ROW_STEP * i;
+            const int64_t row = rowv[i];
+            if (row >= M || !col_ok) continue;
             const float4 q = *reinterpret_cast<const float4*>(Cs + rr * CS + c4 * 4);
             float v[4] = {q.x, q.y, q.z, q.w};
-            const bool kp = ep.keep != nullptr ? (ep.keep[row] != 0.f) : true;
             if (ep.denom != nullptr) {
-                const float dn = ep.denom[row];
+                const float rd = 1.0f / dnv[i];      // one IEEE division per row, then multiplies (<= 1 ulp apart)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] / dn;
+                for (int e = 0; e < 4; ++e) v[e] *= rd;
             }
-            float c0 = 1.f, c1 = 1.f;
-            if (ep.cs.r0 != nullptr) { c0 = ep.cs.r0[row]; c1 = ep.cs.r1 != nullptr ? ep.cs.r1[row] : 1.f; }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (ep.bias != nullptr && col + e < N) v[e] += ep.bias[col + e];
-                if (!kp) v[e] = 0.f;
-                if (ep.cs.r0 != nullptr) v[e] *= (col + e < ep.cs.split) ? c0 : c1;
+                v[e] += bv[e];
+                if (kpv[i] == 0.f) v[e] = 0.f;
+                if (has_cs) v[e] *= (col + e < ep.cs.split) ? c0v[i] : c1v[i];
+            }
+            if (ep.stats != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[e] - bv[e];
+                    st1[e] += d;
+                    st2[e] = fmaf(d, d, st2[e]);
+                }
             }
             float* cp = C + row * ldc + col;
             if (ep.vec_store && col + 3 < N) {
@@ -346,61 +431,110 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
             }
         }
     }
+    if (ep.stats != nullptr) {
+        // ROW_STEP threads share a column group: combine through LDS, one partial row per row block
+        static_assert(ROW_STEP * BN * 2 <= (BM + BN) * GEMM_LDS, "stat reduction must fit the operand LDS");
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Cs[(rr0 * BN + c4 * 4 + e) * 2 + 0] = st1[e];
+            Cs[(rr0 * BN + c4 * 4 + e) * 2 + 1] = st2[e];
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < N) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll 4
+            for (int j = 0; j < ROW_STEP; ++j) { a1 += Cs[(j * BN + tid) * 2 + 0]; a2 += Cs[(j * BN + tid) * 2 + 1]; }
+            float* sp = ep.stats + (int64_t)(bid / ntn) * 2 * N;
+            sp[n0 + tid] = a1;
+            sp[N + n0 + tid] = a2;
+        }
+    }
 }
 
 // ---- TN (dW): reduction over rows m, operands are [m][channel] --------------------------
 // TN tile: 32 rows (m) x COLS channels.  Loads are raw; the per-row factors (rowmul, and the two-plane
 // row scale) are fetched into `f0`/`f1` next to them and applied by tn_store after the MFMA phase.
+// Thread (r = tid / 8, j = tid % 8) loads float4 columns j, j + 8, ... of ONE row, so it carries a single set of
+// per-row factors; LDS rows are COLS + 32 floats apart so the 16-lane ds_write_b128 groups (two rows of 8
+// float4) and the two half-waves of a fragment read (rows k, k + 1) land on disjoint banks.
+template <int COLS>
+struct TnLd { static constexpr int value = COLS + 32; };
+
 template <int COLS, bool VEC>
 __device__ __forceinline__ void tn_load(const float* __restrict__ P, int64_t ld, int64_t m0, int64_t mend,
                                         int c0, int ncols, const float* __restrict__ rowmul, const RowScale& rs,
-                                        float4 (&regs)[COLS / 32], float (&f0)[COLS / 32], float (&f1)[COLS / 32]) {
-    const int tid = threadIdx.x;
+                                        float4 (&regs)[COLS / 32], float& f0, float& f1) {
+    // wave-uniform 64-bit bases (SGPRs) + 32-bit per-thread offsets: 64-bit per-load address VGPRs made this
+    // kernel spill, and every spill reload put an s_waitcnt vmcnt(0) in the middle of the load issue
+    const int r = threadIdx.x >> 3, j = threadIdx.x & 7;
+    const float* __restrict__ base = P + m0 * ld;
+    const int left = (int)((mend - m0 < 32) ? (mend - m0) : 32);
+    const bool ok = r < left;
+    const float* p = base + (r * (int)ld + c0 + j * 4);
 #pragma unroll
     for (int i = 0; i < COLS / 32; ++i) {
-        const int f = tid + 256 * i;
-        const int r = f / (COLS / 4), c4 = f % (COLS / 4);
-        const int64_t row = m0 + r;
-        const int c = c0 + c4 * 4;
+        const int c = c0 + (j + 8 * i) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        float a0 = 1.f, a1 = 1.f;
-        if (row < mend) {
-            const float* p = P + row * ld + c;
+        if (ok) {
             if (VEC) {
-                if (c < ncols) v = *reinterpret_cast<const float4*>(p);
+                if (c < ncols) v = *reinterpret_cast<const float4*>(p + 32 * i);
             } else {
-                if (c + 0 < ncols) v.x = p[0];
-                if (c + 1 < ncols) v.y = p[1];
-                if (c + 2 < ncols) v.z = p[2];
-                if (c + 3 < ncols) v.w = p[3];
-            }
-            if (rowmul != nullptr) { a0 = rowmul[row]; a1 = a0; }
-            if (rs.r0 != nullptr) {
-                a0 *= rs.r0[row];
-                a1 *= rs.r1 != nullptr ? rs.r1[row] : 1.f;
+                if (c + 0 < ncols) v.x = p[32 * i + 0];
+                if (c + 1 < ncols) v.y = p[32 * i + 1];
+                if (c + 2 < ncols) v.z = p[32 * i + 2];
+                if (c + 3 < ncols) v.w = p[32 * i + 3];
             }
         }
         regs[i] = v;
-        f0[i] = a0;
-        f1[i] = a1;
     }
+    float a0 = 1.f, a1 = 1.f;
+    if (ok) {
+        if (rowmul != nullptr) { a0 = rowmul[m0 + r]; a1 = a0; }
+        if (rs.r0 != nullptr) {
+            a0 *= rs.r0[m0 + r];
+            a1 *= rs.r1 != nullptr ? rs.r1[m0 + r] : 1.f;
+        }
+    }
+    f0 = a0;
+    f1 = a1;
 }
 
 template <int COLS>
 __device__ __forceinline__ void tn_store(float* __restrict__ S, const float4 (&regs)[COLS / 32], int c0, int split,
-                                         bool split_active, const float (&f0)[COLS / 32], const float (&f1)[COLS / 32]) {
-    const int tid = threadIdx.x;
+                                         bool split_active, float f0, float f1) {
+    const int r = threadIdx.x >> 3, j = threadIdx.x & 7;
 #pragma unroll
     for (int i = 0; i < COLS / 32; ++i) {
-        const int f = tid + 256 * i;
-        const int r = f / (COLS / 4), c4 = f % (COLS / 4);
+        const int c4 = j + 8 * i;
         const int c = c0 + c4 * 4;
         float4 v = regs[i];
-        v.x *= (!split_active || c + 0 < split) ? f0[i] : f1[i];
-        v.y *= (!split_active || c + 1 < split) ? f0[i] : f1[i];
-        v.z *= (!split_active || c + 2 < split) ? f0[i] : f1[i];
-        v.w *= (!split_active || c + 3 < split) ? f0[i] : f1[i];
-        *reinterpret_cast<float4*>(S + r * COLS + c4 * 4) = v;
+        v.x *= (!split_active || c + 0 < split) ? f0 : f1;
+        v.y *= (!split_active || c + 1 < split) ? f0 : f1;
+        v.z *= (!split_active || c + 2 < split) ? f0 : f1;
+        v.w *= (!split_active || c + 3 < split) ? f0 : f1;
+        *reinterpret_cast<float4*>(S + r * TnLd<COLS>::value + c4 * 4) = v;
+    }
+}
+
+// tn_store with the producer's BatchNorm + activation applied first; tab = [sc[COLS] | sh[COLS]] of this block's columns
+template <int COLS>
+__device__ __forceinline__ void tn_store_bn(float* __restrict__ S, const float4 (&regs)[COLS / 32], int c0, int split,
+                                            bool split_active, float f0, float f1, const float* __restrict__ tab, int act,
+                                            float slope) {
+    const int r = threadIdx.x >> 3, j = threadIdx.x & 7;
+#pragma unroll
+    for (int i = 0; i < COLS / 32; ++i) {
+        const int c4 = j + 8 * i;
+        const int c = c0 + c4 * 4;
+        const float4 sc = *reinterpret_cast<const float4*>(tab + c4 * 4);
+        const float4 sh = *reinterpret_cast<const float4*>(tab + COLS + c4 * 4);
+        float4 v = regs[i];
+        v.x = apply_act(fmaf(v.x, sc.x, sh.x), act, slope) * ((!split_active || c + 0 < split) ? f0 : f1);
+        v.y = apply_act(fmaf(v.y, sc.y, sh.y), act, slope) * ((!split_active || c + 1 < split) ? f0 : f1);
+        v.z = apply_act(fmaf(v.z, sc.z, sh.z), act, slope) * ((!split_active || c + 2 < split) ? f0 : f1);
+        v.w = apply_act(fmaf(v.w, sc.w, sh.w), act, slope) * ((!split_active || c + 3 < split) ? f0 : f1);
+        *reinterpret_cast<float4*>(S + r * TnLd<COLS>::value + c4 * 4) = v;
     }
 }
 
@@ -462,20 +596,23 @@ __device__ __forceinline__ void conv_tn_store(float* __restrict__ S, const float
         v.y *= (ci + 1 < cg.split) ? f0[i] : f1[i];
         v.z *= (ci + 2 < cg.split) ? f0[i] : f1[i];
         v.w *= (ci + 3 < cg.split) ? f0[i] : f1[i];
-        *reinterpret_cast<float4*>(S + r * COLS + c4 * 4) = v;
+        *reinterpret_cast<float4*>(S + r * TnLd<COLS>::value + c4 * 4) = v;
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC, int BCONV>
+template <int WM, int WN, int TM, int TN, bool VEC, int BCONV, bool BNIN = false>
 __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ sa,
                                                       const float* __restrict__ B, int64_t ldb, RowScale sb,
                                                       float* __restrict__ Cws, int64_t M, int P, int Q, int64_t chunk,
-                                                      ConvGather cg) {
+                                                      ConvGather cg, InBN ib) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per block");
-    __shared__ __attribute__((aligned(16))) float smem[GEMM_BK * (BM + BN)];
+    static_assert(!BNIN || BCONV == 0, "input BatchNorm rides the plain loader");
+    __shared__ __attribute__((aligned(16))) float bnt[BNIN ? 2 * BN : 4];
+    constexpr int LDA = TnLd<BM>::value, LDB = TnLd<BN>::value;
+    __shared__ __attribute__((aligned(16))) float smem[GEMM_BK * (LDA + LDB)];
     float* As = smem;
-    float* Bs = smem + GEMM_BK * BM;
+    float* Bs = smem + GEMM_BK * LDA;
 
     const int q0 = blockIdx.x * BN, p0 = blockIdx.y * BM;
     const int64_t mbeg = (int64_t)blockIdx.z * chunk;
@@ -494,14 +631,24 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
 
     float4 ra[BM / 32], rb[BN / 32];
-    float fa0[BM / 32], fa1[BM / 32], fb0[BN / 32], fb1[BN / 32];
+    float fa0, fa1, fb0, fb1;
+    float gb0[BN / 32], gb1[BN / 32];   // gathered B operand: one factor pair per load
     const RowScale none = {nullptr, nullptr, 0};
     const bool sb_active = sb.r0 != nullptr;
+    if constexpr (BNIN) {   // (scale, shift) of this block's B columns; columns >= Q stay 0
+        if (tid < BN) {
+            const int q = q0 + tid;
+            bnt[tid] = q < Q ? ib.sc[q] : 0.f;
+            bnt[BN + tid] = q < Q ? ib.sh[q] : 0.f;
+        }
+        __syncthreads();
+    }
     tn_load<BM, VEC>(A, lda, mbeg, mend, p0, P, sa, none, ra, fa0, fa1);
-    if constexpr (BCONV != 0) conv_tn_load<BN, BCONV == 2>(B, cg, mbeg, mend, q0, Q, rb, fb0, fb1);
+    if constexpr (BCONV != 0) conv_tn_load<BN, BCONV == 2>(B, cg, mbeg, mend, q0, Q, rb, gb0, gb1);
     else tn_load<BN, VEC>(B, ldb, mbeg, mend, q0, Q, nullptr, sb, rb, fb0, fb1);
     tn_store<BM>(As, ra, p0, 0, false, fa0, fa1);
-    if constexpr (BCONV != 0) conv_tn_store<BN>(Bs, rb, cg, q0, fb0, fb1);
+    if constexpr (BCONV != 0) conv_tn_store<BN>(Bs, rb, cg, q0, gb0, gb1);
+    else if constexpr (BNIN) tn_store_bn<BN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1, bnt, ib.act, ib.slope);
     else tn_store<BN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1);
     __syncthreads();
 
@@ -509,16 +656,16 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
         const bool more = (mt + GEMM_BK < mend);
         if (more) {
             tn_load<BM, VEC>(A, lda, mt + GEMM_BK, mend, p0, P, sa, none, ra, fa0, fa1);
-            if constexpr (BCONV != 0) conv_tn_load<BN, BCONV == 2>(B, cg, mt + GEMM_BK, mend, q0, Q, rb, fb0, fb1);
+            if constexpr (BCONV != 0) conv_tn_load<BN, BCONV == 2>(B, cg, mt + GEMM_BK, mend, q0, Q, rb, gb0, gb1);
             else tn_load<BN, VEC>(B, ldb, mt + GEMM_BK, mend, q0, Q, nullptr, sb, rb, fb0, fb1);
         }
 #pragma unroll
         for (int kk = 0; kk < GEMM_BK / 2; ++kk) {
             float a[TM], b[TN];
 #pragma unroll
-            for (int t = 0; t < TM; ++t) a[t] = As[(2 * kk + hi) * BM + (wm * TM + t) * 32 + li];
+            for (int t = 0; t < TM; ++t) a[t] = As[(2 * kk + hi) * LDA + (wm * TM + t) * 32 + li];
 #pragma unroll
-            for (int u = 0; u < TN; ++u) b[u] = Bs[(2 * kk + hi) * BN + (wn * TN + u) * 32 + li];
+            for (int u = 0; u < TN; ++u) b[u] = Bs[(2 * kk + hi) * LDB + (wn * TN + u) * 32 + li];
 #pragma unroll
             for (int t = 0; t < TM; ++t)
 #pragma unroll
@@ -528,7 +675,8 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
         __syncthreads();
         if (more) {
             tn_store<BM>(As, ra, p0, 0, false, fa0, fa1);
-            if constexpr (BCONV != 0) conv_tn_store<BN>(Bs, rb, cg, q0, fb0, fb1);
+            if constexpr (BCONV != 0) conv_tn_store<BN>(Bs, rb, cg, q0, gb0, gb1);
+            else if constexpr (BNIN) tn_store_bn<BN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1, bnt, ib.act, ib.slope);
             else tn_store<BN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1);
             __syncthreads();
         }
@@ -551,6 +699,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
 
 // ---- host-side dispatch ----------------------------------------------------------------
 static const ConvGather kNoConv = {0, 0, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, nullptr, nullptr, 0, nullptr};
+static const InBN kNoBN = {nullptr, nullptr, 0, 0.f};
 
 template <int WM, int WN, int TM, int TN, int AMODE>
 static int launch_nt_conv_cfg(const float* A, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
@@ -561,7 +710,7 @@ static int launch_nt_conv_cfg(const float* A, const float* B, int64_t ldb, float
     TSII_REQUIRE(nblocks < (1ll << 31), "conv gemm: grid too large");
     const RowScale none = {nullptr, nullptr, 0};
     hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, true, AMODE>), dim3((unsigned)nblocks), dim3(256), 0, stream,
-                       A, (int64_t)0, none, B, ldb, C, ldc, M, N, K, ep, ntn, cg);
+                       A, (int64_t)0, none, B, ldb, C, ldc, M, N, K, ep, ntn, cg, kNoBN);
     return check_launch("conv_gemm_nt");
 }
 template <int AMODE>
@@ -575,27 +724,31 @@ static int launch_nt_conv(const float* A, const float* B, int64_t ldb, float* C,
 
 template <int WM, int WN, int TM, int TN>
 static int launch_nt_cfg(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, float* C, int64_t ldc,
-                         int64_t M, int N, int K, Epilogue ep, bool vec, hipStream_t stream) {
+                         int64_t M, int N, int K, Epilogue ep, bool vec, InBN ib, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const unsigned ntn = (unsigned)cdiv(N, BN);
     const int64_t nblocks = cdiv64(M, BM) * ntn;
     TSII_REQUIRE(nblocks < (1ll << 31), "gemm_nt: grid too large");
-    if (vec)
+    if (ib.sc != nullptr) {
+        TSII_REQUIRE(vec && aligned16(ib.sc) && aligned16(ib.sh), "gemm_nt: input BatchNorm needs K %% 4 == 0 and 16-byte aligned operands");
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, true, 0, true>), dim3((unsigned)nblocks), dim3(256), 0, stream,
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, kNoConv, ib);
+    } else if (vec)
         hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, true, 0>), dim3((unsigned)nblocks), dim3(256), 0, stream,
-                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, kNoConv);
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, kNoConv, kNoBN);
     else
         hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, false, 0>), dim3((unsigned)nblocks), dim3(256), 0, stream,
-                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, kNoConv);
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, kNoConv, kNoBN);
     return check_launch("gemm_nt");
 }
 
 static int launch_nt(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, float* C, int64_t ldc,
-                     int64_t M, int N, int K, Epilogue ep, hipStream_t stream) {
+                     int64_t M, int N, int K, Epilogue ep, hipStream_t stream, InBN ib = kNoBN) {
     const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && aligned16(A) && aligned16(B);
     ep.vec_store = (ldc % 4 == 0) && aligned16(C);
-    if (N % 128 == 0 || N > 192) return launch_nt_cfg<2, 2, 2, 2>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, vec, stream);
-    if (N > 32) return launch_nt_cfg<2, 2, 2, 1>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, vec, stream);
-    return launch_nt_cfg<4, 1, 1, 1>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, vec, stream);
+    if (N % 128 == 0 || N > 192) return launch_nt_cfg<2, 2, 2, 2>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, vec, ib, stream);
+    if (N > 32) return launch_nt_cfg<2, 2, 2, 1>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, vec, ib, stream);
+    return launch_nt_cfg<4, 1, 1, 1>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, vec, ib, stream);
 }
 
 struct TnPlan {
@@ -685,10 +838,10 @@ int launch_conv_gemm_dw(const float* dy, const float* inv, const float* x, const
     const RowScale none = {nullptr, nullptr, 0};
     dim3 grid(cdiv(K, pl.bn), cdiv(g.cout, pl.bm), pl.splits);
     const bool elem = (mfull != nullptr || g.cin % 4 != 0);
-    if (pl.big && !elem) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 1>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg);
-    else if (!elem) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, 1>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg);
-    else if (pl.big) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 2>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg);
-    else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, 2>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg);
+    if (pl.big && !elem) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 1>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg, kNoBN);
+    else if (!elem) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, 1>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg, kNoBN);
+    else if (pl.big) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 2>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg, kNoBN);
+    else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, 2>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg, kNoBN);
     int rc = check_launch("conv_gemm_tn");
     if (rc) return rc;
     hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3(stream_grid((int64_t)g.cout * K, 256)), dim3(256), 0, st, ws, pl.splits, g.cout, g.cin, T, dwgt);
@@ -699,14 +852,31 @@ int launch_conv_gemm_dw(const float* dy, const float* inv, const float* x, const
 
 using namespace tsii;
 
+static int pw_fwd_impl(const float* x, int64_t m, int k, const float* w, int n, const float* bias, const float* r0, int split,
+                       const float* r1, const float* denom, const float* keep, InBN ib, float* stats, float* y, void* stream) {
+    TSII_REQUIRE(x && w && y, "pw_fwd: null pointer");
+    TSII_REQUIRE(m > 0 && k > 0 && n > 0, "pw_fwd: bad shape m=%lld k=%d n=%d", (long long)m, k, n);
+    RowScale as = {r0, r1, r0 != nullptr ? split : 0};
+    Epilogue ep = {denom, keep, bias, {nullptr, nullptr, 0}, 0, stats};
+    return launch_nt(x, k, as, w, k, y, n, m, n, k, ep, (hipStream_t)stream, ib);
+}
+
 extern "C" int tsii_pw_fwd(const float* x, int64_t m, int k, const float* w, int n, const float* bias,
                            const float* r0, int split, const float* r1, const float* denom, const float* keep,
                            float* y, void* stream) {
-    TSII_REQUIRE(x && w && y, "pw_fwd: null pointer");
-    TSII_REQUIRE(m > 0 && k > 0 && n > 0, "pw_fwd: bad shape m=%lld k=%d n=%d", (long long)m, k, n);
-    RowScale as = {r0, r1, split};
-    Epilogue ep = {denom, keep, bias, {nullptr, nullptr, 0}, 0};
-    return launch_nt(x, k, as, w, k, y, n, m, n, k, ep, (hipStream_t)stream);
+    return pw_fwd_impl(x, m, k, w, n, bias, r0, split, r1, denom, keep, kNoBN, nullptr, y, stream);
+}
+
+extern "C" int64_t tsii_pw_stat_rows(int64_t m) { return m > 0 ? cdiv64(m, 128) : 0; }   // every NT tile variant has BM = 128
+
+extern "C" int tsii_pw_fwd_bn(const float* x, int64_t m, int k, const float* w, int n, const float* bias,
+                              const float* r0, int split, const float* r1, const float* denom, const float* keep,
+                              const float* in_scale, const float* in_shift, int in_act, float in_slope,
+                              float* stat_part, float* y, void* stream) {
+    TSII_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "pw_fwd_bn: in_scale / in_shift go together");
+    TSII_REQUIRE(in_act >= 0 && in_act <= 4, "pw_fwd_bn: unknown activation %d", in_act);
+    const InBN ib = {in_scale, in_shift, in_act, in_slope};
+    return pw_fwd_impl(x, m, k, w, n, bias, r0, split, r1, denom, keep, ib, stat_part, y, stream);
 }
 
 extern "C" int tsii_pw_bwd_dx(const float* dy, int64_t m, int n, const float* w, int k, const float* inv,
@@ -727,9 +897,9 @@ extern "C" size_t tsii_pw_bwd_dw_ws_bytes(int64_t m, int n, int k) {
     return ((size_t)pl.splits * n * k + colsum_ws_floats(m, n)) * sizeof(float);
 }
 
-extern "C" int tsii_pw_bwd_dw(const float* dy, const float* x, int64_t m, int n, int k, const float* inv,
-                              const float* keep, const float* r0, int split, const float* r1, float* dw, float* dbias,
-                              void* ws, size_t ws_bytes, void* stream) {
+static int pw_bwd_dw_impl(const float* dy, const float* x, int64_t m, int n, int k, const float* inv, const float* keep,
+                          const float* r0, int split, const float* r1, InBN ib, float* dw, float* dbias, void* ws,
+                          size_t ws_bytes, void* stream) {
     TSII_REQUIRE(dy && x && dw && ws, "pw_bwd_dw: null pointer");
     TSII_REQUIRE(m > 0 && k > 0 && n > 0, "pw_bwd_dw: bad shape");
     TSII_REQUIRE(ws_bytes >= tsii_pw_bwd_dw_ws_bytes(m, n, k), "pw_bwd_dw: workspace too small");
@@ -739,12 +909,16 @@ extern "C" int tsii_pw_bwd_dw(const float* dy, const float* x, int64_t m, int n,
     RowScale sb = {r0, r1, split};
     const bool vec = (n % 4 == 0) && (k % 4 == 0) && aligned16(dy) && aligned16(x);
     dim3 grid(cdiv(k, pl.bn), cdiv(n, pl.bm), pl.splits);
-    if (pl.big) {
-        if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 0>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv);
-        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, false, 0>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv);
+    if (ib.sc != nullptr) {
+        TSII_REQUIRE(vec, "pw_bwd_dw: input BatchNorm needs n, k %% 4 == 0 and 16-byte aligned operands");
+        if (pl.big) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 0, true>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv, ib);
+        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, 0, true>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv, ib);
+    } else if (pl.big) {
+        if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 0>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv, kNoBN);
+        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, false, 0>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv, kNoBN);
     } else {
-        if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, 0>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv);
-        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, false, 0>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv);
+        if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, 0>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv, kNoBN);
+        else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, false, 0>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv, kNoBN);
     }
     int rc = check_launch("gemm_tn");
     if (rc) return rc;
@@ -755,4 +929,19 @@ extern "C" int tsii_pw_bwd_dw(const float* dy, const float* x, int64_t m, int n,
         rc = launch_colsum_scaled(dy, keep, m, n, dbias, cpart, st);
     }
     return rc;
+}
+
+extern "C" int tsii_pw_bwd_dw(const float* dy, const float* x, int64_t m, int n, int k, const float* inv,
+                              const float* keep, const float* r0, int split, const float* r1, float* dw, float* dbias,
+                              void* ws, size_t ws_bytes, void* stream) {
+    return pw_bwd_dw_impl(dy, x, m, n, k, inv, keep, r0, split, r1, kNoBN, dw, dbias, ws, ws_bytes, stream);
+}
+
+extern "C" int tsii_pw_bwd_dw_bn(const float* dy, const float* x, int64_t m, int n, int k, const float* inv,
+                                 const float* keep, const float* r0, int split, const float* r1,
+                                 const float* in_scale, const float* in_shift, int in_act, float in_slope,
+                                 float* dw, float* dbias, void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(in_scale && in_shift, "pw_bwd_dw_bn: null scale / shift");
+    const InBN ib = {in_scale, in_shift, in_act, in_slope};
+    return pw_bwd_dw_impl(dy, x, m, n, k, inv, keep, r0, split, r1, ib, dw, dbias, ws, ws_bytes, stream);
 }

@@ -88,8 +88,12 @@ def plane_upsample2x(p: torch.Tensor) -> torch.Tensor:
 # K3 point-wise partial convolution
 # ---------------------------------------------------------------------------------------
 class _Pointwise(torch.autograd.Function):
+    """x may be the raw output of the previous conv whose BatchNorm(+act) is applied on load (in_scale / in_shift:
+    K6b, constants here -- the BatchNorm gradient flows through _BNLazy); want_stats adds the BatchNorm partial sums
+    of y as a second, non-differentiable output."""
+
     @staticmethod
-    def forward(ctx, x, w, bias, r0, r1, denom, keep, inv, split):
+    def forward(ctx, x, w, bias, r0, r1, denom, keep, inv, split, in_scale, in_shift, in_act, in_slope, want_stats):
         _lib.check_device(x)
         x, w = x.contiguous(), w.contiguous()
         n, h, wd, k = x.shape
@@ -97,15 +101,27 @@ class _Pointwise(torch.autograd.Function):
         assert w.shape[1] == k and w.shape[2] == 1 and w.shape[3] == 1, "point-wise weight must be [Cout,Cin,1,1]"
         m = n * h * wd
         y = torch.empty((n, h, wd, cout), dtype=torch.float32, device=x.device)
-        call("tsii_pw_fwd", ptr(x), m, k, ptr(w), cout, ptr(bias), ptr(r0), int(split), ptr(r1),
-             ptr(denom), ptr(keep), ptr(y), _lib.stream())
-        ctx.save_for_backward(x, w, r0, r1, inv, keep)
-        ctx.split, ctx.has_bias = int(split), bias is not None
+        part = None
+        if in_scale is None and not want_stats:
+            call("tsii_pw_fwd", ptr(x), m, k, ptr(w), cout, ptr(bias), ptr(r0), int(split), ptr(r1),
+                 ptr(denom), ptr(keep), ptr(y), _lib.stream())
+        else:
+            if want_stats:
+                rows = _lib.lib().tsii_pw_stat_rows(m)
+                part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+            call("tsii_pw_fwd_bn", ptr(x), m, k, ptr(w), cout, ptr(bias), ptr(r0), int(split), ptr(r1),
+                 ptr(denom), ptr(keep), ptr(in_scale), ptr(in_shift), int(in_act), float(in_slope), ptr(part), ptr(y),
+                 _lib.stream())
+        ctx.save_for_backward(x, w, r0, r1, inv, keep, in_scale, in_shift)
+        ctx.split, ctx.has_bias, ctx.in_cfg = int(split), bias is not None, (int(in_act), float(in_slope))
+        if want_stats:
+            ctx.mark_non_differentiable(part)
+            return y, part
         return y
 
     @staticmethod
-    def backward(ctx, gy):
-        x, w, r0, r1, inv, keep = ctx.saved_tensors
+    def backward(ctx, gy, *_):
+        x, w, r0, r1, inv, keep, in_scale, in_shift = ctx.saved_tensors
         gy = gy.contiguous()
         n, h, wd, k = x.shape
         cout = w.shape[0]
@@ -113,7 +129,7 @@ class _Pointwise(torch.autograd.Function):
         dx = dw = db = None
         st = _lib.stream()
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
+            dx = torch.empty_like(x)   # gradient w.r.t. the (virtual) normalised input when in_scale is set
             wt = _ws(4 * k * cout, x)
             call("tsii_pw_bwd_dx", ptr(gy), m, cout, ptr(w), k, ptr(inv), ptr(r0), ctx.split, ptr(r1),
                  ptr(dx), ptr(wt), st)
@@ -122,22 +138,41 @@ class _Pointwise(torch.autograd.Function):
             db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
             nbytes = _lib.lib().tsii_pw_bwd_dw_ws_bytes(m, cout, k)
             ws = _ws(nbytes, x)
-            call("tsii_pw_bwd_dw", ptr(gy), ptr(x), m, cout, k, ptr(inv), ptr(keep), ptr(r0), ctx.split, ptr(r1),
-                 ptr(dw), ptr(db), ptr(ws), nbytes, st)
-        return dx, dw, db, None, None, None, None, None, None
+            if in_scale is None:
+                call("tsii_pw_bwd_dw", ptr(gy), ptr(x), m, cout, k, ptr(inv), ptr(keep), ptr(r0), ctx.split, ptr(r1),
+                     ptr(dw), ptr(db), ptr(ws), nbytes, st)
+            else:
+                call("tsii_pw_bwd_dw_bn", ptr(gy), ptr(x), m, cout, k, ptr(inv), ptr(keep), ptr(r0), ctx.split, ptr(r1),
+                     ptr(in_scale), ptr(in_shift), ctx.in_cfg[0], ctx.in_cfg[1], ptr(dw), ptr(db), ptr(ws), nbytes, st)
+        return (dx, dw, db) + (None,) * 11
 
 
-def pconv_pointwise(x, w, bias=None, r0=None, split=0, r1=None, denom=None, keep=None, inv=None):
-    """y = keep ? (x*rs) @ w^T / denom + bias : 0   (include/tsii_hip.h, K3)."""
-    return _Pointwise.apply(x, w, bias, r0, r1, denom, keep, inv, split)
+def pconv_pointwise(x, w, bias=None, r0=None, split=0, r1=None, denom=None, keep=None, inv=None, want_stats=False):
+    """y = keep ? (x*rs) @ w^T / denom + bias : 0   (include/tsii_hip.h, K3).  ``x`` may be a LazyBN (K6b);
+    with ``want_stats`` returns (y, stat_part)."""
+    if isinstance(x, LazyBN):
+        if x.token.shape[-1] % 4 == 0:
+            return _Pointwise.apply(x.token, w, bias, r0, r1, denom, keep, inv, split, x.scale, x.shift, x.act, x.slope,
+                                    want_stats)
+        x = x.materialize()
+    return _Pointwise.apply(x, w, bias, r0, r1, denom, keep, inv, split, None, None, 0, 0.0, want_stats)
 
 
 # ---------------------------------------------------------------------------------------
 # K2 depth-wise partial convolution
 # ---------------------------------------------------------------------------------------
+def dw_stat_rows(x_shape, g: "Geom") -> int:
+    """Partial-sum rows of the fused depth-wise forms; 0 = geometry without the LDS-tiled kernel (unfused only)."""
+    n, h, wd, c = x_shape
+    ho, wo = g.out_hw(h, wd)
+    return int(_lib.lib().tsii_dw_stat_rows(n, ho, wo, c, g.kh, g.kw, g.sh, g.sw, g.dh, g.dw))
+
+
 class _Depthwise(torch.autograd.Function):
+    """See _Pointwise for in_scale / in_shift / want_stats (K6b)."""
+
     @staticmethod
-    def forward(ctx, x, w, bias, rmask, denom, keep, inv, g):
+    def forward(ctx, x, w, bias, rmask, denom, keep, inv, g, in_scale, in_shift, in_act, in_slope, want_stats):
         _lib.check_device(x)
         x, w = x.contiguous(), w.contiguous()
         n, h, wd, c = x.shape
@@ -145,15 +180,26 @@ class _Depthwise(torch.autograd.Function):
         ho, wo = g.out_hw(h, wd)
         y = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
         ws = _ws(4 * c * g.kh * g.kw, x)
-        call("tsii_dw_fwd", ptr(x), ptr(rmask), ptr(w), ptr(bias), ptr(denom), ptr(keep), n, h, wd, c, *g,
-             ho, wo, ptr(y), ptr(ws), _lib.stream())
-        ctx.save_for_backward(x, w, rmask, inv, keep)
-        ctx.g, ctx.has_bias = g, bias is not None
+        part = None
+        if in_scale is None and not want_stats:
+            call("tsii_dw_fwd", ptr(x), ptr(rmask), ptr(w), ptr(bias), ptr(denom), ptr(keep), n, h, wd, c, *g,
+                 ho, wo, ptr(y), ptr(ws), _lib.stream())
+        else:
+            if want_stats:
+                part = torch.empty((dw_stat_rows(x.shape, g), 2, c), dtype=torch.float32, device=x.device)
+            call("tsii_dw_fwd_bn", ptr(x), ptr(rmask), ptr(w), ptr(bias), ptr(denom), ptr(keep), n, h, wd, c, *g,
+                 ho, wo, ptr(in_scale), ptr(in_shift), int(in_act), float(in_slope), ptr(part), ptr(y), ptr(ws),
+                 _lib.stream())
+        ctx.save_for_backward(x, w, rmask, inv, keep, in_scale, in_shift)
+        ctx.g, ctx.has_bias, ctx.in_cfg = g, bias is not None, (int(in_act), float(in_slope))
+        if want_stats:
+            ctx.mark_non_differentiable(part)
+            return y, part
         return y
 
     @staticmethod
-    def backward(ctx, gy):
-        x, w, rmask, inv, keep = ctx.saved_tensors
+    def backward(ctx, gy, *_):
+        x, w, rmask, inv, keep, in_scale, in_shift = ctx.saved_tensors
         g = ctx.g
         gy = gy.contiguous()
         n, h, wd, c = x.shape
@@ -170,13 +216,30 @@ class _Depthwise(torch.autograd.Function):
             db = torch.empty(c, dtype=torch.float32, device=x.device) if ctx.has_bias else None
             nbytes = _lib.lib().tsii_dw_bwd_dw_ws_bytes(n, ho, wo, c, g.kh, g.kw)
             ws = _ws(nbytes, x)
-            call("tsii_dw_bwd_dw", ptr(gy), ptr(inv), ptr(keep), ptr(x), ptr(rmask), n, h, wd, c, *g, ho, wo,
-                 ptr(dw), ptr(db), ptr(ws), nbytes, st)
-        return dx, dw, db, None, None, None, None, None
+            if in_scale is None:
+                call("tsii_dw_bwd_dw", ptr(gy), ptr(inv), ptr(keep), ptr(x), ptr(rmask), n, h, wd, c, *g, ho, wo,
+                     ptr(dw), ptr(db), ptr(ws), nbytes, st)
+            else:
+                call("tsii_dw_bwd_dw_bn", ptr(gy), ptr(inv), ptr(keep), ptr(x), ptr(rmask), n, h, wd, c, *g, ho, wo,
+                     ptr(in_scale), ptr(in_shift), ctx.in_cfg[0], ctx.in_cfg[1], ptr(dw), ptr(db), ptr(ws), nbytes, st)
+        return (dx, dw, db) + (None,) * 10
 
 
-def pconv_depthwise(x, w, bias, rmask, denom, keep, inv, g: Geom):
-    return _Depthwise.apply(x, w, bias, rmask, denom, keep, inv, g)
+def pconv_depthwise(x, w, bias, rmask, denom, keep, inv, g: Geom, want_stats=False):
+    """``x`` may be a LazyBN; with ``want_stats`` returns (y, stat_part or None) -- None when the geometry has no
+    fused form (the caller then takes the statistics with the separate pass)."""
+    lazy = isinstance(x, LazyBN)
+    fusable = (lazy or want_stats) and dw_stat_rows((x.token if lazy else x).shape, g) > 0
+    if lazy and not fusable:
+        x, lazy = x.materialize(), False
+    stats = want_stats and fusable
+    if lazy:
+        out = _Depthwise.apply(x.token, w, bias, rmask, denom, keep, inv, g, x.scale, x.shift, x.act, x.slope, stats)
+    else:
+        out = _Depthwise.apply(x, w, bias, rmask, denom, keep, inv, g, None, None, 0, 0.0, stats)
+    if want_stats and not stats:
+        return out, None
+    return out
 
 
 # ---------------------------------------------------------------------------------------
@@ -279,6 +342,111 @@ class _BNAct(torch.autograd.Function):
 def bn_act(y, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5,
            act=ACT_NONE, slope=0.0, residual=None):
     return _BNAct.apply(y, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, slope)
+
+
+class LazyBN:
+    """BatchNorm(+activation) output that has not been written to memory (K6b): ``token`` aliases the RAW conv
+    output y and carries the autograd edge of the normalised activation a = act(scale*y + shift); consumers that
+    can apply (scale, shift, act) while loading take it as is, everything else calls ``materialize()``."""
+
+    __slots__ = ("token", "scale", "shift", "act", "slope", "mean", "var", "gamma", "beta", "eps")
+
+    def __init__(self, token, scale, shift, act, slope, mean, var, gamma, beta, eps):
+        self.token, self.scale, self.shift, self.act, self.slope = token, scale, shift, int(act), float(slope)
+        self.mean, self.var, self.gamma, self.beta, self.eps = mean, var, gamma, beta, float(eps)
+
+    @property
+    def shape(self):
+        return self.token.shape
+
+    def materialize(self, residual=None):
+        return _LazyApply.apply(self.token, self.mean, self.var, self.gamma, self.beta, self.eps, self.act, self.slope,
+                                residual)
+
+
+class _BNLazy(torch.autograd.Function):
+    """Statistics (from the producer's partial sums when given) + (scale, shift); the output token aliases y.
+    backward receives the gradient w.r.t. the normalised activation and is the full BatchNorm(+act) backward."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, part, pivot, training, momentum, eps, act, slope):
+        _lib.check_device(y)
+        y = y.contiguous()
+        c = y.shape[-1]
+        m = y.numel() // c
+        st = _lib.stream()
+        dev = y.device
+        scale = torch.empty(c, dtype=torch.float32, device=dev)
+        shift = torch.empty(c, dtype=torch.float32, device=dev)
+        if training:
+            mean = torch.empty(c, dtype=torch.float32, device=dev)
+            var = torch.empty(c, dtype=torch.float32, device=dev)
+            if part is not None:
+                rows = part.shape[0]
+                nbytes = _lib.lib().tsii_bn_finalize_ws_bytes(rows, c)
+                ws = _ws(nbytes, y)
+                call("tsii_bn_finalize", ptr(part), rows, c, m, ptr(pivot), ptr(mean), ptr(var), ptr(running_mean),
+                     ptr(running_var), float(momentum), ptr(gamma), ptr(beta), float(eps), ptr(scale), ptr(shift),
+                     ptr(ws), nbytes, st)
+            else:
+                nbytes = _lib.lib().tsii_bn_ws_bytes(m, c)
+                ws = _ws(nbytes, y)
+                call("tsii_bn_stats", ptr(y), m, c, ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
+                     float(momentum), ptr(ws), nbytes, st)
+                call("tsii_bn_scale_shift", ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), c, ptr(scale),
+                     ptr(shift), st)
+        else:
+            mean, var = running_mean, running_var
+            call("tsii_bn_scale_shift", ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), c, ptr(scale), ptr(shift), st)
+        ctx.save_for_backward(y, mean, var, gamma, beta)
+        ctx.cfg = (bool(training), float(eps), int(act), float(slope))
+        token = y.detach()          # same storage, fresh autograd identity
+        ctx.mark_non_differentiable(scale, shift, mean, var)
+        return token, scale, shift, mean, var
+
+    @staticmethod
+    def backward(ctx, ga, *_):
+        y, mean, var, gamma, beta = ctx.saved_tensors
+        training, eps, act, slope = ctx.cfg
+        ga = ga.contiguous()
+        c = y.shape[-1]
+        m = y.numel() // c
+        dy = torch.empty_like(y)
+        dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
+        nbytes = _lib.lib().tsii_bn_ws_bytes(m, c)
+        ws = _ws(nbytes, y)
+        call("tsii_bn_act_bwd", ptr(ga), ptr(y), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), eps, act,
+             slope, int(training), ptr(dy), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _lib.stream())
+        return (dy, dgamma, dbeta) + (None,) * 9
+
+
+class _LazyApply(torch.autograd.Function):
+    """Writes a = act(bn(y)) (+ residual) out; gradient-wise the identity on the token (the BatchNorm backward
+    lives in _BNLazy)."""
+
+    @staticmethod
+    def forward(ctx, token, mean, var, gamma, beta, eps, act, slope, residual):
+        c = token.shape[-1]
+        m = token.numel() // c
+        residual = _c(residual)
+        out = torch.empty_like(token)
+        call("tsii_bn_act_fwd", ptr(token), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), int(act),
+             float(slope), ptr(residual), ptr(out), _lib.stream())
+        ctx.has_res = residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        return (gout,) + (None,) * 7 + ((gout if ctx.has_res else None),)
+
+
+def bn_lazy(y, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, act=ACT_NONE, slope=0.0,
+            part=None, pivot=None) -> LazyBN:
+    """BatchNorm(+act) of a conv output as a LazyBN; ``part``/``pivot``: the conv's partial sums and its bias."""
+    token, scale, shift, mean, var = _BNLazy.apply(y, gamma, beta, running_mean, running_var, part, pivot, training,
+                                                   momentum, eps, act, slope)
+    return LazyBN(token, scale, shift, act, slope, mean, var, gamma.detach(), beta.detach(), eps)
 
 
 class _Act(torch.autograd.Function):

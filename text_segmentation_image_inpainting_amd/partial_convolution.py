@@ -51,7 +51,9 @@ class PartialConv(BaseModule):
         fc = self.feature_conv
         return ops.make_geom(fc.kernel_size, fc.stride, fc.padding, fc.dilation)
 
-    def forward_nhwc(self, x, mp):
+    def forward_nhwc(self, x, mp, want_stats=False):
+        """``x``: NHWC tensor or ops.LazyBN (a BatchNorm output still to be applied on load, K6b).  With
+        ``want_stats`` returns (y, mask, stat_part or None) for the BatchNorm that follows."""
         fc = self.feature_conv
         w, b = fc.weight, fc.bias
         cin, cout, groups = fc.in_channels, fc.out_channels, fc.groups
@@ -70,27 +72,38 @@ class PartialConv(BaseModule):
         denom, new_mask, inv = ops.mask_update(p0, a0, p1, a1, g, post, self.fill_holes)
         keep = new_mask if self.fill_holes else None
         pointwise = tuple(g) == (1, 1, 1, 1, 0, 0, 1, 1)
+        part = None
+        real = lambda t: t.materialize() if isinstance(t, ops.LazyBN) else t
         if groups == 1:
             if mp.fusable:
                 r0, split, r1 = mp.row_scale()
                 if pointwise:
-                    y = ops.pconv_pointwise(x, w, b, r0, split, r1, denom, keep, inv)
+                    y = ops.pconv_pointwise(x, w, b, r0, split, r1, denom, keep, inv, want_stats=want_stats)
+                    if want_stats:
+                        y, part = y
                 else:
-                    y = ops.pconv_dense(x, w, b, None, r0, split, r1, denom, keep, inv, g)
+                    y = ops.pconv_dense(real(x), w, b, None, r0, split, r1, denom, keep, inv, g)
             else:
                 mfull = mp.full_nhwc()
                 if pointwise:
-                    y = ops.pconv_pointwise(ops.mul_mask(x, mfull), w, b, None, 0, None, denom, keep, inv)
+                    y = ops.pconv_pointwise(ops.mul_mask(real(x), mfull), w, b, None, 0, None, denom, keep, inv,
+                                            want_stats=want_stats)
+                    if want_stats:
+                        y, part = y
                 else:
-                    y = ops.pconv_dense(x, w, b, mfull, None, 0, None, denom, keep, inv, g)
+                    y = ops.pconv_dense(real(x), w, b, mfull, None, 0, None, denom, keep, inv, g)
         elif groups == cin == cout:
             if mp.fusable and len(mp.parts) == 1:
-                y = ops.pconv_depthwise(x, w, b, mp.parts[0].plane, denom, keep, inv, g)
+                y = ops.pconv_depthwise(x, w, b, mp.parts[0].plane, denom, keep, inv, g, want_stats=want_stats)
             else:
-                y = ops.pconv_depthwise(ops.mul_mask(x, mp.full_nhwc()), w, b, None, denom, keep, inv, g)
+                y = ops.pconv_depthwise(ops.mul_mask(real(x), mp.full_nhwc()), w, b, None, denom, keep, inv, g,
+                                        want_stats=want_stats)
+            if want_stats:
+                y, part = y
         else:
             raise NotImplementedError(f"PartialConv groups={groups} (neither 1 nor depth-wise) has no HIP kernel")
-        return y, MaskParts.from_plane(new_mask, cout)                                  # :74-77
+        new_mp = MaskParts.from_plane(new_mask, cout)                                    # :74-77
+        return (y, new_mp, part) if want_stats else (y, new_mp)
 
     def forward(self, args):
         return _public_forward(self, args)
@@ -107,12 +120,15 @@ class PartialConv1x1(BaseModule):
                                       padding, dilation, groups, bias)
         nn.init.kaiming_normal_(self.feature_conv.weight)
 
-    def forward_nhwc(self, x, mp):
+    def forward_nhwc(self, x, mp, want_stats=False):
         fc = self.feature_conv
         if fc.groups != 1:
             raise NotImplementedError("grouped PartialConv1x1 has no HIP kernel")
-        y = ops.pconv_pointwise(x, fc.weight, fc.bias)
-        return y, MaskParts.from_plane(mp.first_channel_plane(), fc.out_channels)  # :104
+        y = ops.pconv_pointwise(x, fc.weight, fc.bias, want_stats=want_stats)
+        new_mp = MaskParts.from_plane(mp.first_channel_plane(), fc.out_channels)   # :104
+        if want_stats:
+            return y[0], new_mp, y[1]
+        return y, new_mp
 
     def forward(self, args):
         return _public_forward(self, args)
@@ -139,16 +155,32 @@ class PartialActivatedBN(BaseModule):
         else:
             self.bn_act = nn.Sequential(nn.BatchNorm2d(channel))                 # :197
 
-    def forward_nhwc(self, x, mp, residual=None):
+    def _cfg(self):
         bn = self.bn_act[0]
         act, slope = act_code(self.bn_act[1] if len(self.bn_act) > 1 else None)
         training = bn.training or bn.running_mean is None
         if training and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
         momentum = 0.1 if bn.momentum is None else bn.momentum
+        return bn, act, slope, training, momentum
+
+    def forward_nhwc(self, x, mp, residual=None):
+        bn, act, slope, training, momentum = self._cfg()
+        if isinstance(x, ops.LazyBN):
+            x = x.materialize()
         y = ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
                        momentum, bn.eps, act, slope, residual)
         return y, mp
+
+    def forward_lazy(self, y, mp, part=None, pivot=None):
+        """K6b: statistics from the producing conv's partial sums (``part``, taken about its bias ``pivot``); the
+        normalised activation stays virtual (ops.LazyBN) until a consumer loads it or ``materialize()`` writes it."""
+        bn, act, slope, training, momentum = self._cfg()
+        if bn.weight is None:
+            raise NotImplementedError("BatchNorm2d(affine=False) is not used by the reference networks")
+        lazy = ops.bn_lazy(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, act, slope,
+                           part if training else None, pivot)
+        return lazy, mp
 
     def forward(self, args):
         return _public_forward(self, args)
@@ -186,6 +218,31 @@ class DoubleUpSample(nn.Module):
 
     def forward(self, args):
         return _public_forward(self, args)
+
+
+def run_block(block, x, mp, allow_lazy=False, residual=None):
+    """Run a ``partial_convolution_block`` Sequential with its BatchNorm folded into the neighbouring convs (K6b):
+    the conv emits the BatchNorm partial sums, the BatchNorm becomes a LazyBN that the next conv applies on load.
+    ``allow_lazy``: hand the LazyBN to the caller instead of writing the activation; ``residual`` is added when the
+    trailing BatchNorm is written (MobileNetV2.py:186-187)."""
+    mods = list(block)
+    conv_types = (PartialConv, PartialConv1x1)
+    if len(mods) == 2 and isinstance(mods[0], conv_types) and isinstance(mods[1], PartialActivatedBN):
+        conv, bn = mods
+        y, m, part = conv.forward_nhwc(x, mp, want_stats=True)
+        lazy, m = bn.forward_lazy(y, m, part, conv.feature_conv.bias)
+        if allow_lazy and residual is None:
+            return lazy, m
+        return lazy.materialize(residual), m
+    for mod in mods:
+        if isinstance(x, ops.LazyBN) and not isinstance(mod, conv_types):
+            x = x.materialize()
+        x, mp = mod.forward_nhwc(x, mp)
+    if isinstance(x, ops.LazyBN):
+        x = x.materialize()
+    if residual is not None:
+        x = ops.add_act(x, residual)
+    return x, mp
 
 
 def partial_convolution_block(in_channels, out_channels, kernel_size, stride=1, padding=0,

@@ -24,10 +24,13 @@ class FlatSGDTrainer:
         self.pg = process_group
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if self.distributed else 1
-        numel = sum(p.numel() for p in self.params)
+        # every slice starts on a 64-float (256-byte) boundary: the kernels take their 16-byte vector paths
+        # only for aligned operands (an odd-sized tensor, e.g. the [3,35,3,3] head, would misalign the rest)
+        pad = lambda n: (n + 63) // 64 * 64
+        numel = sum(pad(p.numel()) for p in self.params)
         dev = self.params[0].device
         # flat parameter storage: every trainable parameter becomes a view into one buffer
-        self.flat_param = torch.empty(numel, dtype=torch.float32, device=dev)
+        self.flat_param = torch.zeros(numel, dtype=torch.float32, device=dev)
         off = 0
         self.slices = []
         with torch.no_grad():
@@ -36,9 +39,10 @@ class FlatSGDTrainer:
                 self.flat_param[off:off + n].copy_(p.reshape(-1))
                 p.data = self.flat_param[off:off + n].view_as(p)
                 self.slices.append((off, n))
-                off += n
-        self.flat_grad = torch.zeros(numel, dtype=torch.float32, device=dev)
+                off += pad(n)
+        self.flat_grad = torch.zeros(numel, dtype=torch.float32, device=dev)   # padding stays 0: no update there
         self.flat_buf = torch.zeros(numel, dtype=torch.float32, device=dev)
+        self.grad_views = [self.flat_grad[off:off + n].view_as(p) for p, (off, n) in zip(self.params, self.slices)]
         self.loss_fn = loss_fn or (lambda out_nchw, clean_nhwc: ops.l1_mean(to_nhwc(out_nchw), clean_nhwc))
 
     def broadcast_parameters(self, src=0):
@@ -55,11 +59,11 @@ class FlatSGDTrainer:
         return loss
 
     def reduce_gradients(self):
-        torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat_grad)
+        torch._foreach_copy_(self.grad_views, [p.grad for p in self.params])
         if self.distributed:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
-        for p, (off, n) in zip(self.params, self.slices):
-            p.grad = self.flat_grad[off:off + n].view_as(p)
+        for p, v in zip(self.params, self.grad_views):
+            p.grad = v
 
     def update(self):
         ops.sgd_nesterov_(self.flat_param, self.flat_grad, self.flat_buf, self.lr, self.momentum, self.weight_decay)
