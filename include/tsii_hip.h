@@ -146,9 +146,10 @@ int tsii_bn_act_bwd(const float* dout, const float* y, int64_t m, int c,
 
 /* ---- K6b: BatchNorm folded into the neighbouring convolutions (training-time fusion of the reference's
  *           Sequential(conv, BatchNorm2d, act, conv ...) chains, e.g. models/MobileNetV2.py:168-179) -----
- * Producer side ("stat_part"): the conv kernel also writes, per block of output rows and per channel, the
- *   partial sums (sum(y - p), sum((y - p)^2)), p = bias[c] (0 without bias), as float [rows][2][c_out];
- *   rows = tsii_pw_stat_rows(m) / tsii_dw_stat_rows(...).  tsii_bn_finalize() folds them (fp64) into the
+ * Producer side ("stat_part"): the conv kernel also writes, per block of output rows and per channel,
+ *   (count, p, sum(y - p), sum((y - p)^2)) with the pivot p a value of that block (no cancellation for
+ *   near-constant channels), as float [rows][4][c_out]; rows = tsii_pw_stat_rows(m) /
+ *   tsii_dw_stat_rows(...).  tsii_bn_finalize() combines them (fp64, parallel-variance formula) into the
  *   batch mean / biased variance, updates the running statistics like nn.BatchNorm2d and emits
  *   scale = gamma/sqrt(var+eps), shift = beta - mean*scale -- no separate pass over y.
  * Consumer side ("in_scale/in_shift"): the next conv applies a = act(in_scale[c]*v + in_shift[c]) to every
@@ -176,8 +177,8 @@ int tsii_dw_bwd_dw_bn(const float* dy, const float* inv, const float* keep, cons
                       int ho, int wo, const float* in_scale, const float* in_shift, int in_act, float in_slope,
                       float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream);
 size_t tsii_bn_finalize_ws_bytes(int64_t rows, int c);
-/* pivot = the producer's bias (NULL = 0); scale/shift may be NULL (then gamma/beta may be too) */
-int tsii_bn_finalize(const float* stat_part, int64_t rows, int c, int64_t m, const float* pivot,
+/* scale/shift may be NULL (then gamma/beta may be too) */
+int tsii_bn_finalize(const float* stat_part, int64_t rows, int c, int64_t m,
                      float* mean, float* var, float* running_mean, float* running_var, float momentum,
                      const float* gamma, const float* beta, float eps, float* scale, float* shift,
                      void* ws, size_t ws_bytes, void* stream);

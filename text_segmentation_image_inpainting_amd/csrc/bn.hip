@@ -82,61 +82,65 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
     }
 }
 
-// K6b: statistics from the partial sums the producing conv kernel left behind (one row per 128-row GEMM block /
-// per 8x16 stencil tile: up to 16 K rows), taken about pivot[c] = the conv bias (0 if none).  Level 1 folds
-// 128-row chunks into fp64 (sum, sum of squares); the final kernel turns them into mean / biased variance,
-// updates the running statistics and emits the (scale, shift) pair the consumer applies on load.
+// K6b: statistics from the partials the producing conv kernel left behind: per block of rows (128-row GEMM block /
+// 8x16 stencil tile; up to 16 K blocks) and channel (count n, pivot p, s1 = sum(y-p), s2 = sum((y-p)^2)) with p a
+// value of the block itself, so s2 - s1^2/n does not cancel even for near-constant channels.  Level 1 turns each
+// block into (n*mu_b, M2_b, n*mu_b^2) and folds 128-block chunks in fp64; the final kernel combines them
+// (var = (sum M2_b + sum n mu_b^2)/M - mean^2 in fp64), updates the running statistics and emits the
+// (scale, shift) pair the consumer applies on load.
 __global__ __launch_bounds__(256) void bn_parts_l1_kernel(const float* __restrict__ part, int64_t R, int C, int chunk_rows,
                                                           double* __restrict__ out) {
-    __shared__ double sh[2][8][33];
+    __shared__ double sh[3][8][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + tx;
     const int64_t r0 = (int64_t)blockIdx.y * chunk_rows;
     const int64_t r1 = r0 + chunk_rows < R ? r0 + chunk_rows : R;
-    double a1[2] = {0, 0}, a2[2] = {0, 0};
+    double a = 0.0, b = 0.0, q = 0.0;
     if (c < C) {
-        for (int64_t r = r0 + ty; r < r1; r += 16) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int64_t rr = r + 8 * u;
-                if (rr < r1) {
-                    a1[u] += (double)part[rr * 2 * C + c];
-                    a2[u] += (double)part[rr * 2 * C + C + c];
-                }
+        for (int64_t r = r0 + ty; r < r1; r += 8) {
+            const float* pr = part + r * 4 * C + c;
+            const double n = (double)pr[0], p = (double)pr[C], s1 = (double)pr[2 * (int64_t)C], s2 = (double)pr[3 * (int64_t)C];
+            if (n > 0.0) {
+                const double mu = p + s1 / n;
+                double m2 = s2 - s1 * s1 / n;
+                if (m2 < 0.0) m2 = 0.0;
+                a += n * mu; b += m2; q += n * mu * mu;
             }
         }
     }
-    sh[0][ty][tx] = a1[0] + a1[1]; sh[1][ty][tx] = a2[0] + a2[1];
+    sh[0][ty][tx] = a; sh[1][ty][tx] = b; sh[2][ty][tx] = q;
     __syncthreads();
     if (ty == 0 && c < C) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int j = 0; j < 8; ++j) { s1 += sh[0][j][tx]; s2 += sh[1][j][tx]; }
-        out[(int64_t)blockIdx.y * 2 * C + c] = s1;
-        out[(int64_t)blockIdx.y * 2 * C + C + c] = s2;
+        a = 0.0; b = 0.0; q = 0.0;
+        for (int j = 0; j < 8; ++j) { a += sh[0][j][tx]; b += sh[1][j][tx]; q += sh[2][j][tx]; }
+        double* o = out + (int64_t)blockIdx.y * 3 * C + c;
+        o[0] = a; o[C] = b; o[2 * (int64_t)C] = q;
     }
 }
 
 __global__ __launch_bounds__(256) void bn_parts_final_kernel(const double* __restrict__ l1, int chunks, int64_t M, int C,
-                                                             const float* __restrict__ pivot, float* __restrict__ mean,
+                                                             float* __restrict__ mean,
                                                              float* __restrict__ var, float* __restrict__ running_mean,
                                                              float* __restrict__ running_var, float momentum,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps, float* __restrict__ scale, float* __restrict__ shift) {
-    __shared__ double sh[2][8][33];
+    __shared__ double sh[3][8][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + tx;
-    double s1 = 0.0, s2 = 0.0;
+    double a = 0.0, b = 0.0, q = 0.0;
     if (c < C)
-        for (int r = ty; r < chunks; r += 8) { s1 += l1[(int64_t)r * 2 * C + c]; s2 += l1[(int64_t)r * 2 * C + C + c]; }
-    sh[0][ty][tx] = s1; sh[1][ty][tx] = s2;
+        for (int r = ty; r < chunks; r += 8) {
+            const double* p = l1 + (int64_t)r * 3 * C + c;
+            a += p[0]; b += p[C]; q += p[2 * (int64_t)C];
+        }
+    sh[0][ty][tx] = a; sh[1][ty][tx] = b; sh[2][ty][tx] = q;
     __syncthreads();
     if (ty == 0 && c < C) {
-        s1 = 0.0; s2 = 0.0;
-        for (int j = 0; j < 8; ++j) { s1 += sh[0][j][tx]; s2 += sh[1][j][tx]; }
-        const double e1 = s1 / (double)M;
-        double v = s2 / (double)M - e1 * e1;
+        a = 0.0; b = 0.0; q = 0.0;
+        for (int j = 0; j < 8; ++j) { a += sh[0][j][tx]; b += sh[1][j][tx]; q += sh[2][j][tx]; }
+        const double mu = a / (double)M;
+        double v = (b + q) / (double)M - mu * mu;
         if (v < 0.0) v = 0.0;
-        const double mu = (pivot != nullptr ? (double)pivot[c] : 0.0) + e1;
         mean[c] = (float)mu;
         var[c] = (float)v;
         if (running_mean != nullptr) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
@@ -343,10 +347,10 @@ static inline int bn_l1_chunks(int64_t rows) { return (int)cdiv64(rows, 128); }
 
 extern "C" size_t tsii_bn_finalize_ws_bytes(int64_t rows, int c) {
     if (rows <= 0 || c <= 0) return 0;
-    return (size_t)bn_l1_chunks(rows) * 2 * c * sizeof(double);
+    return (size_t)bn_l1_chunks(rows) * 3 * c * sizeof(double);
 }
 
-extern "C" int tsii_bn_finalize(const float* stat_part, int64_t rows, int c, int64_t m, const float* pivot,
+extern "C" int tsii_bn_finalize(const float* stat_part, int64_t rows, int c, int64_t m,
                                 float* mean, float* var, float* running_mean, float* running_var, float momentum,
                                 const float* gamma, const float* beta, float eps, float* scale, float* shift,
                                 void* ws, size_t ws_bytes, void* stream) {
@@ -360,7 +364,7 @@ extern "C" int tsii_bn_finalize(const float* stat_part, int64_t rows, int c, int
     hipLaunchKernelGGL(bn_parts_l1_kernel, dim3(cdiv(c, 32), chunks), dim3(256), 0, st, stat_part, rows, c, 128, (double*)ws);
     int rc = check_launch("bn_parts_l1");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_parts_final_kernel, dim3(cdiv(c, 32)), dim3(256), 0, st, (const double*)ws, chunks, m, c, pivot, mean,
+    hipLaunchKernelGGL(bn_parts_final_kernel, dim3(cdiv(c, 32)), dim3(256), 0, st, (const double*)ws, chunks, m, c, mean,
                        var, running_mean, running_var, momentum, gamma, beta, eps, scale, shift);
     return check_launch("bn_parts_final");
 }

@@ -310,9 +310,10 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const float* __restrict__ 
     }
     __syncthreads();
     const bool cok = c < g.c;
-    float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;   // BatchNorm partial sums of the outputs about the bias
+    float4 res[NP];                                  // outputs stay in registers for the BatchNorm partial sums
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
+        res[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int p = lane + LANES * k;              // x-adjacent lanes -> conflict-free LDS reads
         const int ty = p / DT_TW, tx = p % DT_TW;
         if (opv[k] < 0 || !cok) continue;
@@ -334,37 +335,53 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const float* __restrict__ 
         }
         if (kpv[k] == 0.f) a = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(out + opv[k] * g.c + c) = a;
-        if (stats != nullptr) {
-            const float dx = a.x - bq.x, dy = a.y - bq.y, dz = a.z - bq.z, dw = a.w - bq.w;
-            t1.x += dx; t1.y += dy; t1.z += dz; t1.w += dw;
-            t2.x = fmaf(dx, dx, t2.x); t2.y = fmaf(dy, dy, t2.y); t2.z = fmaf(dz, dz, t2.z); t2.w = fmaf(dw, dw, t2.w);
-        }
+        res[k] = a;
     }
     if (stats != nullptr) {
+        // (count, pivot, sum(y-pivot), sum((y-pivot)^2)) per channel for this tile; pivot = the tile's first output
+        // pixel (always valid), broadcast through the dead patch so every lane subtracts the same number
+        __syncthreads();
+        float* pv = tile;                              // [DT_CB]
+        float* wred = tile + DT_CB;                    // [4 waves][2][DT_CB]
+        if (lane == 0) *reinterpret_cast<float4*>(pv + cg * 4) = res[0];
+        __syncthreads();
+        const float4 P = *reinterpret_cast<const float4*>(pv + cg * 4);
+        float vals[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            if (opv[k] < 0 || !cok) continue;
+            const float dx = res[k].x - P.x, dy = res[k].y - P.y, dz = res[k].z - P.z, dw = res[k].w - P.w;
+            vals[0] += dx; vals[1] += dy; vals[2] += dz; vals[3] += dw;
+            vals[4] = fmaf(dx, dx, vals[4]); vals[5] = fmaf(dy, dy, vals[5]);
+            vals[6] = fmaf(dz, dz, vals[6]); vals[7] = fmaf(dw, dw, vals[7]);
+        }
         // lanes of one channel group are CGS apart inside a wave: xor-shuffle them together, then the 4 waves through LDS
-        float vals[8] = {t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w};
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int off = CGS; off < 64; off <<= 1) vals[i] += __shfl_xor(vals[i], off, 64);
-        __syncthreads();                               // the patch is dead: reuse it
         const int wl = threadIdx.x & 63, wave = threadIdx.x >> 6;
         if (wl < CGS) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                tile[(wave * 2 + 0) * DT_CB + wl * 4 + i] = vals[i];
-                tile[(wave * 2 + 1) * DT_CB + wl * 4 + i] = vals[4 + i];
+                wred[(wave * 2 + 0) * DT_CB + wl * 4 + i] = vals[i];
+                wred[(wave * 2 + 1) * DT_CB + wl * 4 + i] = vals[4 + i];
             }
         }
         __syncthreads();
-        if (threadIdx.x < 2 * DT_CB) {
-            const int which = threadIdx.x / DT_CB, ch = threadIdx.x % DT_CB;
-            if (c0 + ch < g.c) {
-                const float sum = (tile[(0 * 2 + which) * DT_CB + ch] + tile[(1 * 2 + which) * DT_CB + ch]) +
-                                  (tile[(2 * 2 + which) * DT_CB + ch] + tile[(3 * 2 + which) * DT_CB + ch]);
-                const int64_t prow = (n * tiles_y + ty0) * tiles_x + tx0;      // one partial row per spatial tile
-                stats[(prow * 2 + which) * g.c + c0 + ch] = sum;
-            }
+        if (threadIdx.x < DT_CB && c0 + (int)threadIdx.x < g.c) {
+            const int ch = threadIdx.x;
+            const float s1 = (wred[(0 * 2 + 0) * DT_CB + ch] + wred[(1 * 2 + 0) * DT_CB + ch]) +
+                             (wred[(2 * 2 + 0) * DT_CB + ch] + wred[(3 * 2 + 0) * DT_CB + ch]);
+            const float s2 = (wred[(0 * 2 + 1) * DT_CB + ch] + wred[(1 * 2 + 1) * DT_CB + ch]) +
+                             (wred[(2 * 2 + 1) * DT_CB + ch] + wred[(3 * 2 + 1) * DT_CB + ch]);
+            const int vh = g.hout - oy0 < DT_TH ? g.hout - oy0 : DT_TH, vw = g.wout - ox0 < DT_TW ? g.wout - ox0 : DT_TW;
+            const int64_t prow = (n * tiles_y + ty0) * tiles_x + tx0;      // one partial row per spatial tile
+            float* sp = stats + prow * 4 * g.c + c0 + ch;
+            sp[0] = (float)(vh * vw);
+            sp[g.c] = pv[ch];
+            sp[2 * (int64_t)g.c] = s1;
+            sp[3 * (int64_t)g.c] = s2;
         }
     }
 }

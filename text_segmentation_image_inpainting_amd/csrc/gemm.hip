@@ -29,7 +29,8 @@ struct Epilogue {
     const float* bias;   // [N]
     RowScale cs;         // output scale per (row, col)
     int vec_store;       // C rows are 16-byte aligned (ldc % 4 == 0, base aligned)
-    float* stats;        // [row blocks][2][N] BatchNorm partial sums of the stored values about the bias (or NULL)
+    float* stats;        // [row blocks][4][N] BatchNorm partials of the stored values: (count, pivot, sum(y-pivot),
+                         // sum((y-pivot)^2)), pivot = a value of the block itself (robust for near-constant channels); or NULL
 };
 
 // BatchNorm(+activation) of the producer folded into the A-operand load (K6b): a = act(sc[k]*v + sh[k])
@@ -360,7 +361,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
             if (col + e < N) bv[e] = ep.bias[col + e];
     }
     const bool has_cs = ep.cs.r0 != nullptr;
-    float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};   // BatchNorm partial sums about the bias
+    float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};   // BatchNorm partial sums about the block pivot
+    float pvt[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
         // side loads of this band (clamped rows: no divergent branches, nothing is used until the tile is staged)
@@ -395,6 +397,14 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
             for (int r = 0; r < 16; ++r)
                 Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * CS + (wn * TN + u) * 32 + li] = acc[t][u][r];
         __syncthreads();
+        if (t == 0 && ep.stats != nullptr) {
+            // block pivot: (roughly) the value of the block's first row -- any number typical of the column does,
+            // it only has to be the same for every thread of the column group
+            const float4 q0 = *reinterpret_cast<const float4*>(Cs + c4 * 4);
+            const float rd0 = ep.denom != nullptr ? 1.0f / ep.denom[m0] : 1.0f;
+            pvt[0] = fmaf(q0.x, rd0, bv[0]); pvt[1] = fmaf(q0.y, rd0, bv[1]);
+            pvt[2] = fmaf(q0.z, rd0, bv[2]); pvt[3] = fmaf(q0.w, rd0, bv[3]);
+        }
 #pragma unroll
         for (int i = 0; i < F4_PER_THREAD; ++i) {
             const int rr = rr0 + ROW_STEP * i;
@@ -416,7 +426,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
             if (ep.stats != nullptr) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float d = v[e] - bv[e];
+                    const float d = v[e] - pvt[e];
                     st1[e] += d;
                     st2[e] = fmaf(d, d, st2[e]);
                 }
@@ -433,21 +443,28 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
     }
     if (ep.stats != nullptr) {
         // ROW_STEP threads share a column group: combine through LDS, one partial row per row block
-        static_assert(ROW_STEP * BN * 2 <= (BM + BN) * GEMM_LDS, "stat reduction must fit the operand LDS");
+        static_assert(ROW_STEP * BN * 2 + BN <= (BM + BN) * GEMM_LDS, "stat reduction must fit the operand LDS");
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             Cs[(rr0 * BN + c4 * 4 + e) * 2 + 0] = st1[e];
             Cs[(rr0 * BN + c4 * 4 + e) * 2 + 1] = st2[e];
         }
+        if (rr0 == 0) {   // pivots: one writer per column group, region after the sums
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Cs[ROW_STEP * BN * 2 + c4 * 4 + e] = pvt[e];
+        }
         __syncthreads();
         if (tid < BN && n0 + tid < N) {
             float a1 = 0.f, a2 = 0.f;
 #pragma unroll 4
             for (int j = 0; j < ROW_STEP; ++j) { a1 += Cs[(j * BN + tid) * 2 + 0]; a2 += Cs[(j * BN + tid) * 2 + 1]; }
-            float* sp = ep.stats + (int64_t)(bid / ntn) * 2 * N;
-            sp[n0 + tid] = a1;
-            sp[N + n0 + tid] = a2;
+            float* sp = ep.stats + (int64_t)(bid / ntn) * 4 * N;
+            const int64_t left = M - m0;
+            sp[n0 + tid] = (float)(left < BM ? left : BM);
+            sp[N + n0 + tid] = Cs[ROW_STEP * BN * 2 + tid];
+            sp[2 * N + n0 + tid] = a1;
+            sp[3 * N + n0 + tid] = a2;
         }
     }
 }

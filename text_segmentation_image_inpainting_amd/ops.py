@@ -108,7 +108,7 @@ class _Pointwise(torch.autograd.Function):
         else:
             if want_stats:
                 rows = _lib.lib().tsii_pw_stat_rows(m)
-                part = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+                part = torch.empty((rows, 4, cout), dtype=torch.float32, device=x.device)
             call("tsii_pw_fwd_bn", ptr(x), m, k, ptr(w), cout, ptr(bias), ptr(r0), int(split), ptr(r1),
                  ptr(denom), ptr(keep), ptr(in_scale), ptr(in_shift), int(in_act), float(in_slope), ptr(part), ptr(y),
                  _lib.stream())
@@ -186,7 +186,7 @@ class _Depthwise(torch.autograd.Function):
                  ho, wo, ptr(y), ptr(ws), _lib.stream())
         else:
             if want_stats:
-                part = torch.empty((dw_stat_rows(x.shape, g), 2, c), dtype=torch.float32, device=x.device)
+                part = torch.empty((dw_stat_rows(x.shape, g), 4, c), dtype=torch.float32, device=x.device)
             call("tsii_dw_fwd_bn", ptr(x), ptr(rmask), ptr(w), ptr(bias), ptr(denom), ptr(keep), n, h, wd, c, *g,
                  ho, wo, ptr(in_scale), ptr(in_shift), int(in_act), float(in_slope), ptr(part), ptr(y), ptr(ws),
                  _lib.stream())
@@ -369,7 +369,7 @@ class _BNLazy(torch.autograd.Function):
     backward receives the gradient w.r.t. the normalised activation and is the full BatchNorm(+act) backward."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, part, pivot, training, momentum, eps, act, slope):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, part, training, momentum, eps, act, slope):
         _lib.check_device(y)
         y = y.contiguous()
         c = y.shape[-1]
@@ -385,7 +385,7 @@ class _BNLazy(torch.autograd.Function):
                 rows = part.shape[0]
                 nbytes = _lib.lib().tsii_bn_finalize_ws_bytes(rows, c)
                 ws = _ws(nbytes, y)
-                call("tsii_bn_finalize", ptr(part), rows, c, m, ptr(pivot), ptr(mean), ptr(var), ptr(running_mean),
+                call("tsii_bn_finalize", ptr(part), rows, c, m, ptr(mean), ptr(var), ptr(running_mean),
                      ptr(running_var), float(momentum), ptr(gamma), ptr(beta), float(eps), ptr(scale), ptr(shift),
                      ptr(ws), nbytes, st)
             else:
@@ -418,7 +418,7 @@ class _BNLazy(torch.autograd.Function):
         ws = _ws(nbytes, y)
         call("tsii_bn_act_bwd", ptr(ga), ptr(y), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), eps, act,
              slope, int(training), ptr(dy), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _lib.stream())
-        return (dy, dgamma, dbeta) + (None,) * 9
+        return (dy, dgamma, dbeta) + (None,) * 8
 
 
 class _LazyApply(torch.autograd.Function):
@@ -442,9 +442,9 @@ class _LazyApply(torch.autograd.Function):
 
 
 def bn_lazy(y, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, act=ACT_NONE, slope=0.0,
-            part=None, pivot=None) -> LazyBN:
-    """BatchNorm(+act) of a conv output as a LazyBN; ``part``/``pivot``: the conv's partial sums and its bias."""
-    token, scale, shift, mean, var = _BNLazy.apply(y, gamma, beta, running_mean, running_var, part, pivot, training,
+            part=None) -> LazyBN:
+    """BatchNorm(+act) of a conv output as a LazyBN; ``part``: the statistics partials the conv left behind."""
+    token, scale, shift, mean, var = _BNLazy.apply(y, gamma, beta, running_mean, running_var, part, training,
                                                    momentum, eps, act, slope)
     return LazyBN(token, scale, shift, act, slope, mean, var, gamma.detach(), beta.detach(), eps)
 

@@ -17,6 +17,12 @@ from . import ops
 from .BaseModels import BaseModule, act_code, to_nchw, to_nhwc
 from .masks import MaskParts, as_parts
 
+import os
+
+# A/B knob for the K6b BatchNorm folding: "1" (default) statistics in the conv epilogue + apply on load,
+# "stats" statistics only, "0" the separate-kernel path
+FUSE_BN = os.environ.get("TSII_FUSE_BN", "1")
+
 inplace_batch_norm = False  # reference: optional un-vendored InPlaceABN (:12-17); never available
 
 
@@ -172,14 +178,14 @@ class PartialActivatedBN(BaseModule):
                        momentum, bn.eps, act, slope, residual)
         return y, mp
 
-    def forward_lazy(self, y, mp, part=None, pivot=None):
-        """K6b: statistics from the producing conv's partial sums (``part``, taken about its bias ``pivot``); the
-        normalised activation stays virtual (ops.LazyBN) until a consumer loads it or ``materialize()`` writes it."""
+    def forward_lazy(self, y, mp, part=None):
+        """K6b: statistics from the partials the producing conv left behind (``part``); the normalised activation
+        stays virtual (ops.LazyBN) until a consumer loads it or ``materialize()`` writes it."""
         bn, act, slope, training, momentum = self._cfg()
         if bn.weight is None:
             raise NotImplementedError("BatchNorm2d(affine=False) is not used by the reference networks")
         lazy = ops.bn_lazy(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, act, slope,
-                           part if training else None, pivot)
+                           part if training else None)
         return lazy, mp
 
     def forward(self, args):
@@ -227,11 +233,11 @@ def run_block(block, x, mp, allow_lazy=False, residual=None):
     trailing BatchNorm is written (MobileNetV2.py:186-187)."""
     mods = list(block)
     conv_types = (PartialConv, PartialConv1x1)
-    if len(mods) == 2 and isinstance(mods[0], conv_types) and isinstance(mods[1], PartialActivatedBN):
+    if FUSE_BN != "0" and len(mods) == 2 and isinstance(mods[0], conv_types) and isinstance(mods[1], PartialActivatedBN):
         conv, bn = mods
         y, m, part = conv.forward_nhwc(x, mp, want_stats=True)
-        lazy, m = bn.forward_lazy(y, m, part, conv.feature_conv.bias)
-        if allow_lazy and residual is None:
+        lazy, m = bn.forward_lazy(y, m, part)
+        if allow_lazy and residual is None and FUSE_BN == "1":
             return lazy, m
         return lazy.materialize(residual), m
     for mod in mods:
