@@ -132,7 +132,7 @@ def main():
     for _ in range(args.warmup):
         loss = trainer.step(corrupted, mask, clean_nhwc)
     sync()
-    _lib.start_timing(["tsii_pw_fwd", "tsii_pw_bwd_dx"])
+    _lib.start_timing(["tsii_pw_fwd", "tsii_pw_fwd_bn", "tsii_pw_bwd_dx"])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.step(corrupted, mask, clean_nhwc)
@@ -152,9 +152,8 @@ def main():
         agg = {}
         for name, recs in timed.items():
             for ms, a in recs:
-                m, p, q = a[0], a[1], a[2]       # (M, K, N) for pw_fwd ; (M, N, K) for pw_bwd_dx
-                out_cols = q if name == "tsii_pw_fwd" else q
-                v = nt_variant(out_cols)
+                m, p, q = a[0], a[1], a[2]       # (M, K, N) for pw_fwd[_bn] ; (M, N, K) for pw_bwd_dx
+                v = nt_variant(q)
                 d = agg.setdefault(v, {"ms": 0.0, "flop": 0.0, "launches": 0, "alg_bytes": 0.0})
                 d["ms"] += ms
                 d["flop"] += 2.0 * m * p * q

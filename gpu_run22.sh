@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu22.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu22.log
+timeout 600 python tools/profile_step.py > gpurun_out/profile_step22.log 2>&1; grep -E "^  tsii_|total" gpurun_out/profile_step22.log | cut -c1-120 | head -30
+timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-700

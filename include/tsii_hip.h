@@ -154,7 +154,8 @@ int tsii_bn_act_bwd(const float* dout, const float* y, int64_t m, int c,
  *   scale = gamma/sqrt(var+eps), shift = beta - mean*scale -- no separate pass over y.
  * Consumer side ("in_scale/in_shift"): the next conv applies a = act(in_scale[c]*v + in_shift[c]) to every
  *   element it loads (before the x*mask multiply; zero padding pads a), so the normalised activation is never
- *   written to HBM.  in_scale == NULL: plain input.  The *_bwd_dw_bn forms recompute a the same way;
+ *   written to HBM.  in_scale == NULL: plain input; in_act is NONE, RELU, LEAKY (slope in [0,1]) or RELU6 (the
+ *   load-time form is min(max(z, neg*z), hi); anything else is an error).  The *_bwd_dw_bn forms recompute a the same way;
  *   dX is unchanged (it is the gradient w.r.t. a) and feeds tsii_bn_act_bwd together with the raw y. */
 int64_t tsii_pw_stat_rows(int64_t m);
 int tsii_pw_fwd_bn(const float* x, int64_t m, int k, const float* w, int n, const float* bias,

@@ -231,6 +231,8 @@ CONV_GEMM_CASES = [
     (40, 136, 3, 1, 1, 1, True, False, True, 9),     # > 128 output channels, K = 360 (tile tails)
     (67, 3, 3, 1, 1, 1, True, False, True, 9),       # ImageFillOrigin final layer: LDS-tiled Cout<=4 path, 16-wide tile
     (35, 3, 3, 1, 1, 1, True, False, True, 40),      # ImageFill final layer: 32-wide tile, several tiles
+    (24, 4, 3, 1, 1, 1, False, False, False, 21),    # head kernels: 4 output channels, zero-padded channel groups, one plane
+    (64, 2, 3, 1, 1, 1, True, True, False, 19),      # head kernels: 16-wide tile, same_holes
 ]
 
 

@@ -399,6 +399,335 @@ static int small_dw_blocks(const ConvGeom& g, int tw, int* tiles_per_block) {
     return cdiv(total, *tiles_per_block);
 }
 
+// ---- head path: 3x3 / stride 1 / dilation 1, Cout <= 4, plane masks --------------------------------------------
+// ImageFill's 35->3 output layer (and the 67->3 heads of ImageFillOrigin / V2) at full resolution: 8.4 M pixels x
+// 945 MACs -- 0.3 ms of HBM traffic, but the generic few-output-channel kernels above spend ~10 ms on it per
+// step: their element-wise staging waits on every load and the odd pixel stride (35 floats) forces scalar LDS
+// reads.  Here the patch is staged with 8 independent loads in flight per thread into pixels padded to CP = 4*CG
+// floats (36-float stride: the conflict-free ds_read_b128 pattern of the GEMM tiles), the x*mask multiply rides in
+// the staging (mask planes staged first), weights are wave-uniform (scalar loads), and all loops are unrolled.
+template <int CG>
+struct Head {
+    static constexpr int CP = CG * 4;
+    static constexpr int TH = 8;
+    static constexpr int TW = (10 * 34 * CP <= 12288) ? 32 : 16;
+    static constexpr int NPX = TH * TW;
+    static constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW;
+    static constexpr int TILE = NPIX * CP;
+    static constexpr int SIDE = (2 * NPIX > NPX * 4) ? 2 * NPIX : NPX * 4;   // mask planes of the patch, later dy*inv
+    static_assert(TILE <= 12288, "patch must fit 48 KB");
+};
+
+// exact e / d for 0 <= e < 2^24 without an integer division
+__device__ __forceinline__ int fdiv_small(int e, int d, float inv_d) {
+    int q = (int)((float)e * inv_d);
+    if (q * d > e) --q;
+    else if ((q + 1) * d <= e) ++q;
+    return q;
+}
+
+template <int CG>
+__device__ __forceinline__ void head_stage(float* __restrict__ tile, float* __restrict__ side, const float* __restrict__ x,
+                                           const RowScale& rs, const ConvGeom& g, int64_t n, int iy0, int ix0) {
+    using H = Head<CG>;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    // 1. the two mask planes of the patch; pad channels of every pixel are zero
+    for (int p = tid; p < H::NPIX; p += nt) {
+        const int py = p / H::PW, px = p - py * H::PW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        float m0 = 0.f, m1 = 0.f;
+        if (iy >= 0 && iy < g.h && ix >= 0 && ix < g.w) {
+            const int64_t ipix = (n * g.h + iy) * g.w + ix;
+            m0 = rs.r0 != nullptr ? rs.r0[ipix] : 1.f;
+            m1 = (rs.r0 != nullptr && rs.r1 != nullptr) ? rs.r1[ipix] : 1.f;
+        }
+        side[p] = m0;
+        side[H::NPIX + p] = m1;
+        for (int c = g.cin; c < H::CP; ++c) tile[p * H::CP + c] = 0.f;
+    }
+    __syncthreads();
+    // 2. x * mask: element e = (patch pixel p, channel ci); a patch row is one contiguous run of the NHWC tensor
+    const int total = H::NPIX * g.cin;
+    const float inv_cin = 1.0f / (float)g.cin;
+    const int split = rs.r0 != nullptr ? rs.split : 0x7fffffff;
+    for (int e0 = tid; e0 < total; e0 += nt * 8) {
+        float v[8];
+        int dst[8], msk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * nt;
+            const int p = fdiv_small(e, g.cin, inv_cin);
+            const int ci = e - p * g.cin;
+            const int py = p / H::PW, px = p - py * H::PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            v[u] = 0.f;
+            dst[u] = p * H::CP + ci;
+            msk[u] = (ci < split ? 0 : H::NPIX) + p;
+            if (e < total && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w)
+                v[u] = x[((n * g.h + iy) * g.w + ix) * g.cin + ci];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + u * nt < total) tile[dst[u]] = v[u] * side[msk[u]];
+    }
+}
+
+// w[co][ci][t] -> w4[((t*CG + cg)*4 + j)*4 + co], ci = cg*4 + j, zero padded
+__global__ void head_prep_fwd_kernel(const float* __restrict__ w, int cin, int cout, int CG, float* __restrict__ w4) {
+    const int total = 9 * CG * 16;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i & 3, j = (i >> 2) & 3;
+        const int cg = (i >> 4) % CG, t = (i >> 4) / CG;
+        const int ci = cg * 4 + j;
+        w4[i] = (co < cout && ci < cin) ? w[((int64_t)co * cin + ci) * 9 + t] : 0.f;
+    }
+}
+// w[co][ci][t] -> wd[(t*4 + co)*CP + ci], zero padded
+__global__ void head_prep_dx_kernel(const float* __restrict__ w, int cin, int cout, int CP, float* __restrict__ wd) {
+    const int total = 9 * 4 * CP;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ci = i % CP, co = (i / CP) & 3, t = i / (4 * CP);
+        wd[i] = (co < cout && ci < cin) ? w[((int64_t)co * cin + ci) * 9 + t] : 0.f;
+    }
+}
+
+template <int CG, int NCO>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, RowScale rs, const float* __restrict__ w4,
+                                                       const float* __restrict__ bias, const float* __restrict__ denom,
+                                                       const float* __restrict__ keep, ConvGeom g, float* __restrict__ y) {
+    using H = Head<CG>;
+    __shared__ __attribute__((aligned(16))) float tile[H::TILE];
+    __shared__ __attribute__((aligned(16))) float side[H::SIDE];
+    const int64_t n = blockIdx.z;
+    const int oy0 = blockIdx.y * H::TH, ox0 = blockIdx.x * H::TW;
+    head_stage<CG>(tile, side, x, rs, g, n, oy0 - g.ph, ox0 - g.pw);
+    __syncthreads();
+    constexpr int SPLIT = 256 / H::NPX;             // waves sharing a pixel (TW 16): each takes every SPLIT-th group
+    const int pixl = threadIdx.x % H::NPX;
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x / H::NPX);
+    const int tx = pixl % H::TW, ty = pixl / H::TW;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float* tp = tile + ((ty + t / 3) * H::PW + tx + t % 3) * H::CP;
+#pragma unroll
+        for (int j = 0; j < (CG + SPLIT - 1) / SPLIT; ++j) {
+            const int cg = j * SPLIT + part;
+            if (cg >= CG) break;
+            const float4 xv = *reinterpret_cast<const float4*>(tp + cg * 4);
+            const float* __restrict__ wp = w4 + (t * CG + cg) * 16;
+#pragma unroll
+            for (int e = 0; e < NCO; ++e) {
+                a[e] = fmaf(xv.x, wp[e], a[e]); a[e] = fmaf(xv.y, wp[4 + e], a[e]);
+                a[e] = fmaf(xv.z, wp[8 + e], a[e]); a[e] = fmaf(xv.w, wp[12 + e], a[e]);
+            }
+        }
+    }
+    if constexpr (SPLIT > 1) {
+        __syncthreads();
+        if (part != 0) *reinterpret_cast<float4*>(tile + ((part - 1) * H::NPX + pixl) * 4) = make_float4(a[0], a[1], a[2], a[3]);
+        __syncthreads();
+        if (part == 0) {
+#pragma unroll
+            for (int q = 1; q < SPLIT; ++q) {
+                const float4 o = *reinterpret_cast<const float4*>(tile + ((q - 1) * H::NPX + pixl) * 4);
+                a[0] += o.x; a[1] += o.y; a[2] += o.z; a[3] += o.w;
+            }
+        }
+    }
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (part != 0 || oy >= g.ho || ox >= g.wo) return;
+    const int64_t pix = (n * g.ho + oy) * g.wo + ox;
+    const bool kp = keep != nullptr ? (keep[pix] != 0.f) : true;
+    const float dn = denom != nullptr ? denom[pix] : 1.f;
+#pragma unroll
+    for (int e = 0; e < NCO; ++e) {
+        if (e >= g.cout) break;
+        float v = a[e];
+        if (kp) {
+            if (denom != nullptr) v = v / dn;
+            if (bias != nullptr) v += bias[e];
+        } else {
+            v = 0.f;
+        }
+        y[pix * g.cout + e] = v;
+    }
+}
+
+// dW partials: persistent block of 320 threads; thread k owns im2col column(s) k, k + 320 (= (tap, ci)) x NCO
+// output channels in registers and walks the pixels of each tile (x from LDS, dy*inv broadcast from LDS)
+template <int CG, int NCO>
+__global__ __launch_bounds__(320) void head_dw_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
+                                                      const float* __restrict__ x, RowScale rs, ConvGeom g,
+                                                      int tiles_per_block, float* __restrict__ part) {
+    using H = Head<CG>;
+    __shared__ __attribute__((aligned(16))) float tile[H::TILE];
+    __shared__ __attribute__((aligned(16))) float side[H::SIDE];
+    constexpr int NP = (9 * H::CP + 319) / 320;
+    const int KK = 9 * g.cin;
+    const int nq = (KK + 319) / 320;
+    const int ntx = (g.wo + H::TW - 1) / H::TW, nty = (g.ho + H::TH - 1) / H::TH;
+    const int total_tiles = g.n * nty * ntx;
+    int toff[NP], tci[NP], tt[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int k = threadIdx.x + 320 * q;
+        tt[q] = k < KK ? k / g.cin : 0;
+        tci[q] = k < KK ? k % g.cin : 0;
+        toff[q] = ((tt[q] / 3) * H::PW + tt[q] % 3) * H::CP + tci[q];
+    }
+    float acc[NP][NCO];
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int e = 0; e < NCO; ++e) acc[q][e] = 0.f;
+    const int t_beg = blockIdx.x * tiles_per_block;
+    const int t_end = t_beg + tiles_per_block < total_tiles ? t_beg + tiles_per_block : total_tiles;
+    for (int tl = t_beg; tl < t_end; ++tl) {
+        const int bx = tl % ntx, by = (tl / ntx) % nty;
+        const int64_t n = tl / (ntx * nty);
+        const int oy0 = by * H::TH, ox0 = bx * H::TW;
+        float gv[4] = {0.f, 0.f, 0.f, 0.f};           // this thread's dy*inv pixel, in flight during the staging
+        if (threadIdx.x < H::NPX) {
+            const int oy = oy0 + threadIdx.x / H::TW, ox = ox0 + threadIdx.x % H::TW;
+            if (oy < g.ho && ox < g.wo) {
+                const int64_t pix = (n * g.ho + oy) * g.wo + ox;
+                const float sc = inv != nullptr ? inv[pix] : 1.f;
+#pragma unroll
+                for (int e = 0; e < NCO; ++e)
+                    if (e < g.cout) gv[e] = dy[pix * g.cout + e] * sc;
+            }
+        }
+        __syncthreads();                               // previous tile fully consumed
+        head_stage<CG>(tile, side, x, rs, g, n, oy0 - g.ph, ox0 - g.pw);
+        __syncthreads();                               // patch ready, mask planes dead
+        if (threadIdx.x < H::NPX) *reinterpret_cast<float4*>(side + threadIdx.x * 4) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        __syncthreads();
+        for (int py = 0; py < H::TH; ++py) {
+#pragma unroll 8
+            for (int px = 0; px < H::TW; ++px) {
+                const float4 gq = *reinterpret_cast<const float4*>(side + (py * H::TW + px) * 4);
+                const float gg[4] = {gq.x, gq.y, gq.z, gq.w};
+                const int base = (py * H::PW + px) * H::CP;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    if (q >= nq) break;
+                    const float xv = tile[base + toff[q]];
+#pragma unroll
+                    for (int e = 0; e < NCO; ++e) acc[q][e] = fmaf(xv, gg[e], acc[q][e]);
+                }
+            }
+        }
+    }
+    float* pz = part + (int64_t)blockIdx.x * g.cout * g.cin * 9;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int k = threadIdx.x + 320 * q;
+        if (k >= KK) break;
+#pragma unroll
+        for (int e = 0; e < NCO; ++e)
+            if (e < g.cout) pz[((int64_t)e * g.cin + tci[q]) * 9 + tt[q]] = acc[q][e];
+    }
+}
+
+// dX: thread = one input pixel x up to 9 channel groups (36 accumulators); dy*inv patch in LDS, weights wave-uniform;
+// the 35-float pixels leave through an LDS transpose so that the global stores are contiguous runs
+template <int CG, int NCO>
+__global__ __launch_bounds__(256) void head_dx_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
+                                                      const float* __restrict__ wd, RowScale rs, ConvGeom g,
+                                                      float* __restrict__ dx) {
+    using H = Head<CG>;
+    constexpr int SPLIT = 256 / H::NPX;
+    constexpr int CGT = (CG + SPLIT - 1) / SPLIT;     // channel groups per thread
+    __shared__ __attribute__((aligned(16))) float outt[H::NPX * H::CP];
+    __shared__ __attribute__((aligned(16))) float gp[H::NPIX * 4];
+    __shared__ float mk[2 * H::NPX];
+    const int64_t n = blockIdx.z;
+    const int iy0 = blockIdx.y * H::TH, ix0 = blockIdx.x * H::TW;
+    // dy*inv patch: patch pixel r,c <-> output pixel (iy0 + ph - 2 + r, ix0 + pw - 2 + c)
+    for (int p = threadIdx.x; p < H::NPIX; p += 256) {
+        const int r = p / H::PW, c = p - r * H::PW;
+        const int oy = iy0 + g.ph - 2 + r, ox = ix0 + g.pw - 2 + c;
+        float gv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (oy >= 0 && oy < g.ho && ox >= 0 && ox < g.wo) {
+            const int64_t pix = (n * g.ho + oy) * g.wo + ox;
+            const float sc = inv != nullptr ? inv[pix] : 1.f;
+#pragma unroll
+            for (int e = 0; e < NCO; ++e)
+                if (e < g.cout) gv[e] = dy[pix * g.cout + e] * sc;
+        }
+        *reinterpret_cast<float4*>(gp + p * 4) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+    }
+    for (int p = threadIdx.x; p < H::NPX; p += 256) {   // x*mask multiplied back in (partial_convolution.py:51)
+        const int iy = iy0 + p / H::TW, ix = ix0 + p % H::TW;
+        float m0 = 0.f, m1 = 0.f;
+        if (iy < g.h && ix < g.w) {
+            const int64_t ipix = (n * g.h + iy) * g.w + ix;
+            m0 = rs.r0 != nullptr ? rs.r0[ipix] : 1.f;
+            m1 = (rs.r0 != nullptr && rs.r1 != nullptr) ? rs.r1[ipix] : 1.f;
+        }
+        mk[p] = m0; mk[H::NPX + p] = m1;
+    }
+    __syncthreads();
+    const int pixl = threadIdx.x % H::NPX;
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x / H::NPX);
+    const int tx = pixl % H::TW, ty = pixl / H::TW;
+    const int cg0 = part * CGT;
+    float acc[CGT][4];
+#pragma unroll
+    for (int j = 0; j < CGT; ++j) { acc[j][0] = 0.f; acc[j][1] = 0.f; acc[j][2] = 0.f; acc[j][3] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float4 gq = *reinterpret_cast<const float4*>(gp + ((ty + 2 - t / 3) * H::PW + tx + 2 - t % 3) * 4);
+        const float gg[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+        for (int j = 0; j < CGT; ++j) {
+            if (cg0 + j >= CG) break;
+#pragma unroll
+            for (int e = 0; e < NCO; ++e) {
+                const float* __restrict__ wp = wd + (t * 4 + e) * H::CP + (cg0 + j) * 4;
+                acc[j][0] = fmaf(gg[e], wp[0], acc[j][0]); acc[j][1] = fmaf(gg[e], wp[1], acc[j][1]);
+                acc[j][2] = fmaf(gg[e], wp[2], acc[j][2]); acc[j][3] = fmaf(gg[e], wp[3], acc[j][3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CGT; ++j)
+        if (cg0 + j < CG)
+            *reinterpret_cast<float4*>(outt + pixl * H::CP + (cg0 + j) * 4) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+    __syncthreads();
+    // write-out: tile row ty = one contiguous run of min(TW, w - ix0) * cin floats
+    const int vw = g.w - ix0 < H::TW ? g.w - ix0 : H::TW;
+    const int run = vw * g.cin;
+    const float inv_cin = 1.0f / (float)g.cin;
+    const int split = rs.r0 != nullptr ? rs.split : 0x7fffffff;
+    for (int r = 0; r < H::TH; ++r) {
+        const int iy = iy0 + r;
+        if (iy >= g.h) break;
+        float* drow = dx + ((n * g.h + iy) * g.w + ix0) * g.cin;
+        for (int e = threadIdx.x; e < run; e += 256) {
+            const int px = fdiv_small(e, g.cin, inv_cin);
+            const int ci = e - px * g.cin;
+            const int p = r * H::TW + px;
+            drow[e] = outt[p * H::CP + ci] * mk[(ci < split ? 0 : H::NPX) + p];
+        }
+    }
+}
+
+static int head_cg(const ConvGeom& g, const float* mfull) {   // channel groups of the head instantiation, 0 = not applicable
+    if (!(g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.dh == 1 && g.dw == 1 && g.cout <= 4 && mfull == nullptr)) return 0;
+    if (cdiv(g.ho, 8) > 65535 || cdiv(g.h, 8) > 65535 || g.n > 65535) return 0;
+    if (g.cin > 20 && g.cin <= 36) return 9;
+    if (g.cin > 36 && g.cin <= 68) return 17;
+    return 0;
+}
+static int head_dw_blocks(const ConvGeom& g, int tw, int* tiles_per_block) {
+    const int total = g.n * cdiv(g.ho, 8) * cdiv(g.wo, tw);
+    const int blocks = total < 768 ? total : 768;     // 3 resident blocks per CU
+    *tiles_per_block = cdiv(total, blocks);
+    return cdiv(total, *tiles_per_block);
+}
+
 // weight re-layouts for the implicit-GEMM path: w[co][ci][t] -> wr[co][t*cin + ci]  /  wd[ci][t*cout + co]
 __global__ void conv_w_layout_kernel(const float* __restrict__ w, int cin, int cout, int T, int dx_layout, float* __restrict__ out) {
     const int64_t total = (int64_t)cout * cin * T;
@@ -462,9 +791,12 @@ using namespace tsii;
 
 extern "C" size_t tsii_dense_ws_bytes(int cin, int cout, int kh, int kw) {
     if (cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0) return 0;
-    const size_t a = (size_t)kh * kw * cin * (pad4(cout) < 4 ? 4 : pad4(cout));
-    const size_t b = (size_t)kh * kw * cout * pad4(cin);
-    return (a > b ? a : b) * sizeof(float);
+    size_t fl = (size_t)kh * kw * pad4(cin) * (pad4(cout) < 4 ? 4 : pad4(cout));
+    if (kh == 3 && kw == 3 && cout <= 4 && cin <= 68) {   // head kernels pad the channels to their instantiation (36 / 68)
+        const size_t head = (size_t)9 * (cin <= 36 ? 36 : 68) * 4;
+        if (head > fl) fl = head;
+    }
+    return fl * sizeof(float);
 }
 
 extern "C" int tsii_dense_fwd(const float* x, const float* mfull, const float* r0, int split, const float* r1,
@@ -479,6 +811,18 @@ extern "C" int tsii_dense_fwd(const float* x, const float* mfull, const float* r
     hipStream_t st = (hipStream_t)stream;
     const int coutp = pad4(cout), T = kh * kw;
     float* wf = (float*)ws;
+    if (const int hcg = head_cg(g, mfull)) {       // 3x3 few-output-channel head
+        hipLaunchKernelGGL(head_prep_fwd_kernel, dim3(cdiv(9 * hcg * 16, 256)), dim3(256), 0, st, w, cin, cout, hcg, wf);
+        int rch = check_launch("head_prep_fwd");
+        if (rch) return rch;
+        const RowScale rsh = {r0, r1, split};
+        const dim3 grid(cdiv(wo, hcg == 9 ? 32 : 16), cdiv(ho, 8), n);
+        if (hcg == 9 && cout <= 3) hipLaunchKernelGGL((head_fwd_kernel<9, 3>), grid, dim3(256), 0, st, x, rsh, wf, bias, denom, keep, g, y);
+        else if (hcg == 9) hipLaunchKernelGGL((head_fwd_kernel<9, 4>), grid, dim3(256), 0, st, x, rsh, wf, bias, denom, keep, g, y);
+        else if (cout <= 3) hipLaunchKernelGGL((head_fwd_kernel<17, 3>), grid, dim3(256), 0, st, x, rsh, wf, bias, denom, keep, g, y);
+        else hipLaunchKernelGGL((head_fwd_kernel<17, 4>), grid, dim3(256), 0, st, x, rsh, wf, bias, denom, keep, g, y);
+        return check_launch("head_fwd");
+    }
     const SmallPlan sp = plan_small(g);
     if (sp.ok && cdiv(ho, DS_TH) <= 65535 && n <= 65535) {
         hipLaunchKernelGGL(dense_prep_small_kernel, dim3(cdiv(T * cin * 4, 256)), dim3(256), 0, st, w, cin, cout, T, wf);
@@ -522,6 +866,18 @@ extern "C" int tsii_dense_bwd_dx(const float* dy, const float* inv, const float*
     hipStream_t st = (hipStream_t)stream;
     const int cinp = pad4(cin), T = kh * kw;
     float* wb = (float*)ws;
+    if (const int hcg = head_cg(g, mfull)) {       // 3x3 few-output-channel head
+        hipLaunchKernelGGL(head_prep_dx_kernel, dim3(cdiv(9 * 4 * hcg * 4, 256)), dim3(256), 0, st, w, cin, cout, hcg * 4, wb);
+        int rch = check_launch("head_prep_dx");
+        if (rch) return rch;
+        const RowScale rsh = {r0, r1, split};
+        const dim3 grid(cdiv(wd, hcg == 9 ? 32 : 16), cdiv(h, 8), n);
+        if (hcg == 9 && cout <= 3) hipLaunchKernelGGL((head_dx_kernel<9, 3>), grid, dim3(256), 0, st, dy, inv, wb, rsh, g, dx);
+        else if (hcg == 9) hipLaunchKernelGGL((head_dx_kernel<9, 4>), grid, dim3(256), 0, st, dy, inv, wb, rsh, g, dx);
+        else if (cout <= 3) hipLaunchKernelGGL((head_dx_kernel<17, 3>), grid, dim3(256), 0, st, dy, inv, wb, rsh, g, dx);
+        else hipLaunchKernelGGL((head_dx_kernel<17, 4>), grid, dim3(256), 0, st, dy, inv, wb, rsh, g, dx);
+        return check_launch("head_dx");
+    }
     if (use_conv_gemm_dx(g, mfull, dy, dx, ws)) {
         hipLaunchKernelGGL(conv_w_layout_kernel, dim3(stream_grid((int64_t)T * cin * cout, 256)), dim3(256), 0, st, w, cin, cout, T, 1, wb);
         int rcg = check_launch("conv_w_layout");
@@ -566,6 +922,22 @@ extern "C" int tsii_dense_bwd_dw(const float* dy, const float* inv, const float*
     DdPlan p = plan_dd(g);
     RowScale rs = {r0, r1, split};
     float* part = (float*)ws;
+    if (const int hcg = head_cg(g, mfull)) {       // 3x3 few-output-channel head
+        int tpb = 0;
+        const int blocks = head_dw_blocks(g, hcg == 9 ? 32 : 16, &tpb);
+        if (hcg == 9 && cout <= 3) hipLaunchKernelGGL((head_dw_kernel<9, 3>), dim3(blocks), dim3(320), 0, st, dy, inv, x, rs, g, tpb, part);
+        else if (hcg == 9) hipLaunchKernelGGL((head_dw_kernel<9, 4>), dim3(blocks), dim3(320), 0, st, dy, inv, x, rs, g, tpb, part);
+        else if (cout <= 3) hipLaunchKernelGGL((head_dw_kernel<17, 3>), dim3(blocks), dim3(320), 0, st, dy, inv, x, rs, g, tpb, part);
+        else hipLaunchKernelGGL((head_dw_kernel<17, 4>), dim3(blocks), dim3(320), 0, st, dy, inv, x, rs, g, tpb, part);
+        int rch = check_launch("head_dw");
+        if (rch) return rch;
+        const int64_t lenh = (int64_t)cout * cin * 9;
+        rch = launch_reduce_rows(part, blocks, lenh, dwgt, st);
+        if (rch) return rch;
+        if (dbias != nullptr)
+            rch = launch_colsum_scaled(dy, keep, (int64_t)n * ho * wo, cout, dbias, part + (size_t)blocks * lenh, st);
+        return rch;
+    }
     if (use_conv_gemm(g, mfull, dy, x, ws)) {
         const ConvGemmGeom cgg = {n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo};
         int rcg = launch_conv_gemm_dw(dy, inv, x, mfull, rs, cgg, dwgt, part, st);

@@ -235,14 +235,8 @@ struct DtGeom {
     int n, hin, win, c, s, d, pad_h, pad_w, hout, wout, flip;
 };
 
-// BatchNorm(+activation) of the producer applied to the staged input (K6b): a = act(sc[c]*v + sh[c]); zero padding
-// stays zero (it pads the activated tensor).  sc == nullptr: none.
-struct DwBN {
-    const float* sc;
-    const float* sh;
-    int act;
-    float slope;
-};
+// InBN (K6b) on the staged input: zero padding stays zero (it pads the activated tensor).
+typedef InBN DwBN;
 
 template <int DT_TH, int DT_TW, int DT_CB, int DT_LDS_FLOATS>
 __global__ __launch_bounds__(256) void dw_tile_kernel(const float* __restrict__ in, const float* __restrict__ pre,
@@ -278,8 +272,8 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const float* __restrict__ 
             const int64_t ipix = (n * g.hin + iy) * g.win + ix;
             v = *reinterpret_cast<const float4*>(in + ipix * g.c + c);
             if (bn_in) {
-                v.x = apply_act(fmaf(v.x, isc.x, ish.x), ib.act, ib.slope); v.y = apply_act(fmaf(v.y, isc.y, ish.y), ib.act, ib.slope);
-                v.z = apply_act(fmaf(v.z, isc.z, ish.z), ib.act, ib.slope); v.w = apply_act(fmaf(v.w, isc.w, ish.w), ib.act, ib.slope);
+                v.x = bn_act_load(v.x, isc.x, ish.x, ib.neg, ib.hi); v.y = bn_act_load(v.y, isc.y, ish.y, ib.neg, ib.hi);
+                v.z = bn_act_load(v.z, isc.z, ish.z, ib.neg, ib.hi); v.w = bn_act_load(v.w, isc.w, ish.w, ib.neg, ib.hi);
             }
             if (pre != nullptr) { const float m = pre[ipix]; v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
         }
@@ -387,7 +381,7 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const float* __restrict__ 
 }
 
 // -> 0 launched, 1 not applicable (caller falls back to the direct kernel), <0 error
-static const DwBN kNoDwBN = {nullptr, nullptr, 0, 0.f};
+static const DwBN kNoDwBN = {nullptr, nullptr, 1.f, 0.f};
 static constexpr int DT_TH0 = 8, DT_TW0 = 16;     // output tile of every variant (also the BatchNorm partial-row grain)
 
 template <int TH, int TW, int CB, int LDSF>
@@ -461,8 +455,8 @@ __global__ __launch_bounds__(256) void dw_tile_dw_kernel(const float* __restrict
                 const int64_t ipix = (n * g.hin + iy) * g.win + ix;
                 v = *reinterpret_cast<const float4*>(x + ipix * g.c + c);
                 if (bn_in) {
-                    v.x = apply_act(fmaf(v.x, isc.x, ish.x), ib.act, ib.slope); v.y = apply_act(fmaf(v.y, isc.y, ish.y), ib.act, ib.slope);
-                    v.z = apply_act(fmaf(v.z, isc.z, ish.z), ib.act, ib.slope); v.w = apply_act(fmaf(v.w, isc.w, ish.w), ib.act, ib.slope);
+                    v.x = bn_act_load(v.x, isc.x, ish.x, ib.neg, ib.hi); v.y = bn_act_load(v.y, isc.y, ish.y, ib.neg, ib.hi);
+                    v.z = bn_act_load(v.z, isc.z, ish.z, ib.neg, ib.hi); v.w = bn_act_load(v.w, isc.w, ish.w, ib.neg, ib.hi);
                 }
                 if (rmask != nullptr) { const float m = rmask[ipix]; v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
             }
@@ -656,8 +650,8 @@ extern "C" int tsii_dw_fwd_bn(const float* x, const float* rmask, const float* w
                               const float* in_scale, const float* in_shift, int in_act, float in_slope,
                               float* stat_part, float* y, float* ws, void* stream) {
     TSII_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dw_fwd_bn: in_scale / in_shift go together");
-    TSII_REQUIRE(in_act >= 0 && in_act <= 4, "dw_fwd_bn: unknown activation %d", in_act);
-    const DwBN ib = {in_scale, in_shift, in_act, in_slope};
+    DwBN ib;
+    TSII_REQUIRE(make_in_bn(in_scale, in_shift, in_act, in_slope, &ib) == 0, "dw_fwd_bn: activation %d has no load-time form", in_act);
     return dw_fwd_impl(x, rmask, w, bias, denom, keep, n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo, ib, stat_part, y, ws,
                        stream);
 }
@@ -752,7 +746,8 @@ extern "C" int tsii_dw_bwd_dw_bn(const float* dy, const float* inv, const float*
                                  const float* in_scale, const float* in_shift, int in_act, float in_slope,
                                  float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream) {
     TSII_REQUIRE(in_scale && in_shift, "dw_bwd_dw_bn: null scale / shift");
-    const DwBN ib = {in_scale, in_shift, in_act, in_slope};
+    DwBN ib;
+    TSII_REQUIRE(make_in_bn(in_scale, in_shift, in_act, in_slope, &ib) == 0, "dw_bwd_dw_bn: activation %d has no load-time form", in_act);
     return dw_bwd_dw_impl(dy, inv, keep, x, rmask, n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo, ib, dwgt, dbias, ws,
                           ws_bytes, stream);
 }

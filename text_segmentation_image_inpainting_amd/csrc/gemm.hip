@@ -33,13 +33,6 @@ struct Epilogue {
                          // sum((y-pivot)^2)), pivot = a value of the block itself (robust for near-constant channels); or NULL
 };
 
-// BatchNorm(+activation) of the producer folded into the A-operand load (K6b): a = act(sc[k]*v + sh[k])
-struct InBN {
-    const float* sc;
-    const float* sh;
-    int act;
-    float slope;
-};
 
 // ---- tile loaders ----------------------------------------------------------------------
 // NT: tile of ROWS x 32 floats from a row-major matrix (K contiguous); 8 float4 per row.  A thread
@@ -110,7 +103,7 @@ __device__ __forceinline__ void nt_store(float* __restrict__ S, const float4 (&r
 template <int ROWS>
 __device__ __forceinline__ void nt_store_bn(float* __restrict__ S, const float4 (&regs)[ROWS / 32], int k0, int split,
                                             const float (&s0)[ROWS / 32], const float (&s1)[ROWS / 32], const float4 psc,
-                                            const float4 psh, int act, float slope) {
+                                            const float4 psh, float neg, float hi) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i) {
@@ -118,10 +111,10 @@ __device__ __forceinline__ void nt_store_bn(float* __restrict__ S, const float4 
         const int r = f >> 3, c4 = f & 7;
         const int k = k0 + c4 * 4;
         float4 v = regs[i];
-        v.x = apply_act(fmaf(v.x, psc.x, psh.x), act, slope) * ((k + 0 < split) ? s0[i] : s1[i]);
-        v.y = apply_act(fmaf(v.y, psc.y, psh.y), act, slope) * ((k + 1 < split) ? s0[i] : s1[i]);
-        v.z = apply_act(fmaf(v.z, psc.z, psh.z), act, slope) * ((k + 2 < split) ? s0[i] : s1[i]);
-        v.w = apply_act(fmaf(v.w, psc.w, psh.w), act, slope) * ((k + 3 < split) ? s0[i] : s1[i]);
+        v.x = bn_act_load(v.x, psc.x, psh.x, neg, hi) * ((k + 0 < split) ? s0[i] : s1[i]);
+        v.y = bn_act_load(v.y, psc.y, psh.y, neg, hi) * ((k + 1 < split) ? s0[i] : s1[i]);
+        v.z = bn_act_load(v.z, psc.z, psh.z, neg, hi) * ((k + 2 < split) ? s0[i] : s1[i]);
+        v.w = bn_act_load(v.w, psc.w, psh.w, neg, hi) * ((k + 3 < split) ? s0[i] : s1[i]);
         *reinterpret_cast<float4*>(S + r * GEMM_LDS + c4 * 4) = v;
     }
 }
@@ -287,7 +280,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
     const int pk = (tid & 7) * 4;
     if constexpr (BNIN) {
         if (pk < K) { psc = *reinterpret_cast<const float4*>(ib.sc + pk); psh = *reinterpret_cast<const float4*>(ib.sh + pk); }
-        nt_store_bn<BM>(As, ra, 0, as.split, sa0, sa1, psc, psh, ib.act, ib.slope);
+        nt_store_bn<BM>(As, ra, 0, as.split, sa0, sa1, psc, psh, ib.neg, ib.hi);
     } else if constexpr (AMODE == 0) nt_store<BM, true>(As, ra, 0, as.split, sa0, sa1);
     else conv_store<BM>(As, ra, cg, 0, sa0, sa1);
     nt_store<BN, false>(Bs, rb, 0, 0, sb0, sb1);
@@ -329,7 +322,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
         }
         __syncthreads();
         if (more) {
-            if constexpr (BNIN) nt_store_bn<BM>(As, ra, (kt + 1) * GEMM_BK, as.split, sa0, sa1, psc, psh, ib.act, ib.slope);
+            if constexpr (BNIN) nt_store_bn<BM>(As, ra, (kt + 1) * GEMM_BK, as.split, sa0, sa1, psc, psh, ib.neg, ib.hi);
             else if constexpr (AMODE == 0) nt_store<BM, true>(As, ra, (kt + 1) * GEMM_BK, as.split, sa0, sa1);
             else conv_store<BM>(As, ra, cg, (kt + 1) * GEMM_BK, sa0, sa1);
             nt_store<BN, false>(Bs, rb, 0, 0, sb0, sb1);
@@ -537,8 +530,8 @@ __device__ __forceinline__ void tn_store(float* __restrict__ S, const float4 (&r
 // tn_store with the producer's BatchNorm + activation applied first; tab = [sc[COLS] | sh[COLS]] of this block's columns
 template <int COLS>
 __device__ __forceinline__ void tn_store_bn(float* __restrict__ S, const float4 (&regs)[COLS / 32], int c0, int split,
-                                            bool split_active, float f0, float f1, const float* __restrict__ tab, int act,
-                                            float slope) {
+                                            bool split_active, float f0, float f1, const float* __restrict__ tab, float neg,
+                                            float hi) {
     const int r = threadIdx.x >> 3, j = threadIdx.x & 7;
 #pragma unroll
     for (int i = 0; i < COLS / 32; ++i) {
@@ -547,10 +540,10 @@ __device__ __forceinline__ void tn_store_bn(float* __restrict__ S, const float4 
         const float4 sc = *reinterpret_cast<const float4*>(tab + c4 * 4);
         const float4 sh = *reinterpret_cast<const float4*>(tab + COLS + c4 * 4);
         float4 v = regs[i];
-        v.x = apply_act(fmaf(v.x, sc.x, sh.x), act, slope) * ((!split_active || c + 0 < split) ? f0 : f1);
-        v.y = apply_act(fmaf(v.y, sc.y, sh.y), act, slope) * ((!split_active || c + 1 < split) ? f0 : f1);
-        v.z = apply_act(fmaf(v.z, sc.z, sh.z), act, slope) * ((!split_active || c + 2 < split) ? f0 : f1);
-        v.w = apply_act(fmaf(v.w, sc.w, sh.w), act, slope) * ((!split_active || c + 3 < split) ? f0 : f1);
+        v.x = bn_act_load(v.x, sc.x, sh.x, neg, hi) * ((!split_active || c + 0 < split) ? f0 : f1);
+        v.y = bn_act_load(v.y, sc.y, sh.y, neg, hi) * ((!split_active || c + 1 < split) ? f0 : f1);
+        v.z = bn_act_load(v.z, sc.z, sh.z, neg, hi) * ((!split_active || c + 2 < split) ? f0 : f1);
+        v.w = bn_act_load(v.w, sc.w, sh.w, neg, hi) * ((!split_active || c + 3 < split) ? f0 : f1);
         *reinterpret_cast<float4*>(S + r * TnLd<COLS>::value + c4 * 4) = v;
     }
 }
@@ -665,7 +658,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
     else tn_load<BN, VEC>(B, ldb, mbeg, mend, q0, Q, nullptr, sb, rb, fb0, fb1);
     tn_store<BM>(As, ra, p0, 0, false, fa0, fa1);
     if constexpr (BCONV != 0) conv_tn_store<BN>(Bs, rb, cg, q0, gb0, gb1);
-    else if constexpr (BNIN) tn_store_bn<BN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1, bnt, ib.act, ib.slope);
+    else if constexpr (BNIN) tn_store_bn<BN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1, bnt, ib.neg, ib.hi);
     else tn_store<BN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1);
     __syncthreads();
 
@@ -693,7 +686,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
         if (more) {
             tn_store<BM>(As, ra, p0, 0, false, fa0, fa1);
             if constexpr (BCONV != 0) conv_tn_store<BN>(Bs, rb, cg, q0, gb0, gb1);
-            else if constexpr (BNIN) tn_store_bn<BN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1, bnt, ib.act, ib.slope);
+            else if constexpr (BNIN) tn_store_bn<BN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1, bnt, ib.neg, ib.hi);
             else tn_store<BN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1);
             __syncthreads();
         }
@@ -716,7 +709,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
 
 // ---- host-side dispatch ----------------------------------------------------------------
 static const ConvGather kNoConv = {0, 0, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, nullptr, nullptr, 0, nullptr};
-static const InBN kNoBN = {nullptr, nullptr, 0, 0.f};
+static const InBN kNoBN = {nullptr, nullptr, 1.f, 0.f};
 
 template <int WM, int WN, int TM, int TN, int AMODE>
 static int launch_nt_conv_cfg(const float* A, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
@@ -891,8 +884,8 @@ extern "C" int tsii_pw_fwd_bn(const float* x, int64_t m, int k, const float* w, 
                               const float* in_scale, const float* in_shift, int in_act, float in_slope,
                               float* stat_part, float* y, void* stream) {
     TSII_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "pw_fwd_bn: in_scale / in_shift go together");
-    TSII_REQUIRE(in_act >= 0 && in_act <= 4, "pw_fwd_bn: unknown activation %d", in_act);
-    const InBN ib = {in_scale, in_shift, in_act, in_slope};
+    InBN ib;
+    TSII_REQUIRE(make_in_bn(in_scale, in_shift, in_act, in_slope, &ib) == 0, "pw_fwd_bn: activation %d has no load-time form", in_act);
     return pw_fwd_impl(x, m, k, w, n, bias, r0, split, r1, denom, keep, ib, stat_part, y, stream);
 }
 
@@ -959,6 +952,7 @@ extern "C" int tsii_pw_bwd_dw_bn(const float* dy, const float* x, int64_t m, int
                                  const float* in_scale, const float* in_shift, int in_act, float in_slope,
                                  float* dw, float* dbias, void* ws, size_t ws_bytes, void* stream) {
     TSII_REQUIRE(in_scale && in_shift, "pw_bwd_dw_bn: null scale / shift");
-    const InBN ib = {in_scale, in_shift, in_act, in_slope};
+    InBN ib;
+    TSII_REQUIRE(make_in_bn(in_scale, in_shift, in_act, in_slope, &ib) == 0, "pw_bwd_dw_bn: activation %d has no load-time form", in_act);
     return pw_bwd_dw_impl(dy, x, m, n, k, inv, keep, r0, split, r1, ib, dw, dbias, ws, ws_bytes, stream);
 }

@@ -42,6 +42,29 @@ __device__ __forceinline__ float act_grad(float v, int act, float slope) {
     return 1.f;
 }
 
+// K6b: BatchNorm(+ReLU-family activation) of the producer applied to an operand while it is loaded:
+//   z = sc[c]*v + sh[c];  a = min(max(z, neg*z), hi)      (4 VALU ops, branch-free, NaN propagates)
+//   NONE: neg 1, hi inf | RELU: 0, inf | LEAKY: slope in [0,1], inf | RELU6: 0, 6.   sc == nullptr: no transform.
+struct InBN {
+    const float* sc;
+    const float* sh;
+    float neg;
+    float hi;
+};
+__device__ __forceinline__ float bn_act_load(float v, float sc, float sh, float neg, float hi) {
+    const float z = fmaf(v, sc, sh);
+    return fminf(fmaxf(z, neg * z), hi);
+}
+static inline int make_in_bn(const float* sc, const float* sh, int act, float slope, InBN* out) {
+    out->sc = sc; out->sh = sh; out->hi = __builtin_huge_valf();
+    if (act == TSII_ACT_NONE) out->neg = 1.f;
+    else if (act == TSII_ACT_RELU) out->neg = 0.f;
+    else if (act == TSII_ACT_LEAKY && slope >= 0.f && slope <= 1.f) out->neg = slope;
+    else if (act == TSII_ACT_RELU6) { out->neg = 0.f; out->hi = 6.f; }
+    else return -1;   // sigmoid, leaky slope outside [0,1]: no load-time form
+    return 0;
+}
+
 // row scale (include/tsii_hip.h): r0 == nullptr -> 1
 struct RowScale {
     const float* r0;

@@ -344,6 +344,11 @@ def bn_act(y, gamma, beta, running_mean, running_var, training, momentum=0.1, ep
     return _BNAct.apply(y, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, slope)
 
 
+def load_time_act(act, slope) -> bool:
+    """Activations the conv kernels can apply while loading (include/tsii_hip.h, K6b)."""
+    return act in (ACT_NONE, ACT_RELU, ACT_RELU6) or (act == ACT_LEAKY and 0.0 <= slope <= 1.0)
+
+
 class LazyBN:
     """BatchNorm(+activation) output that has not been written to memory (K6b): ``token`` aliases the RAW conv
     output y and carries the autograd edge of the normalised activation a = act(scale*y + shift); consumers that

@@ -237,7 +237,7 @@ def run_block(block, x, mp, allow_lazy=False, residual=None):
         conv, bn = mods
         y, m, part = conv.forward_nhwc(x, mp, want_stats=True)
         lazy, m = bn.forward_lazy(y, m, part)
-        if allow_lazy and residual is None and FUSE_BN == "1":
+        if allow_lazy and residual is None and FUSE_BN == "1" and ops.load_time_act(lazy.act, lazy.slope):
             return lazy, m
         return lazy.materialize(residual), m
     for mod in mods:
