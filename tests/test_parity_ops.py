@@ -318,3 +318,34 @@ def test_stem_conv_elementwise_gather_vs_oracle(backend):
         assert_close(y, yo, TOL, "plain stem y")
         y.backward(gy.to(dev))
         assert_close(conv.weight.grad, w.grad, TOL, "plain stem dw")
+
+
+@pytest.mark.gpu
+def test_train_step_graph_replay_matches_eager_gpu():
+    """The HIP-graph replay of the training step (train_step.FlatSGDTrainer.capture) does exactly the work of the
+    Python-launched step: same loss and bit-identical parameters / BatchNorm buffers after two steps."""
+    from text_segmentation_image_inpainting_amd.BaseModels import to_nhwc
+    from text_segmentation_image_inpainting_amd.synthetic import make_batch
+    from text_segmentation_image_inpainting_amd.train_step import FlatSGDTrainer
+    with BACKENDS["gpu"]() as dev:
+        corrupted, mask, clean = make_batch(2, 64, seed0=5)
+        corrupted, mask = corrupted.to(dev), mask.to(dev)
+        clean_nhwc = to_nhwc(clean.to(dev))
+        results = []
+        for graphed in (False, True):
+            torch.manual_seed(0)
+            model = T.ImageFill()
+            fill_state_dict_(model.state_dict(), seed=11)
+            model = model.to(dev).train()
+            tr = FlatSGDTrainer(model, lr=1e-2, momentum=0.9, weight_decay=1e-4)
+            if graphed:
+                tr.capture(corrupted, mask, clean_nhwc)
+                losses = [float(tr.step_graph().item()) for _ in range(2)]
+            else:
+                losses = [float(tr.step(corrupted, mask, clean_nhwc).item()) for _ in range(2)]
+            results.append((losses, tr.flat_param.clone(), {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "tracked" in k}))
+        (l0, p0, b0), (l1, p1, b1) = results
+        assert l0 == l1, (l0, l1)
+        assert torch.equal(p0, p1)
+        for k in b0:
+            assert torch.equal(b0[k], b1[k]), k

@@ -56,10 +56,13 @@ class FlatSGDTrainer:
         loss = self.loss_fn(out, clean_nhwc)
         # mean over ranks folded into the backward seed: sum-all-reduce then yields the average
         loss.backward(torch.full((), 1.0 / self.world, dtype=torch.float32, device=loss.device))
-        return loss
+        return loss.detach()    # do not hand the autograd graph (and its AccumulateGrad nodes) to the caller
+
+    def _pack_gradients(self):
+        torch._foreach_copy_(self.grad_views, [p.grad for p in self.params])
 
     def reduce_gradients(self):
-        torch._foreach_copy_(self.grad_views, [p.grad for p in self.params])
+        self._pack_gradients()
         if self.distributed:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
         for p, v in zip(self.params, self.grad_views):
@@ -73,3 +76,55 @@ class FlatSGDTrainer:
         self.reduce_gradients()
         self.update()
         return loss
+
+    # ---- HIP-graph replay of the step --------------------------------------------------------------------------
+    # One step is ~900 kernel launches from Python; captured once into a HIP graph the whole chain is replayed
+    # with a single launch, which removes the host-side gaps between kernels (~2.5 % of the step on MI355X).
+    def capture(self, corrupted, mask, clean_nhwc, warmup=2):
+        """Capture forward + loss + backward + gradient packing (+ the SGD update when there is no all-reduce)
+        for batches of this shape.  The tensors passed here become the graph's static input buffers;
+        ``step_graph`` copies each new batch into them.  Parameters, optimizer state and BatchNorm buffers
+        are restored after the warm-up runs, so capturing does not advance training."""
+        dev = self.flat_param.device
+        self._static_in = (corrupted, mask, clean_nhwc)
+        buffers = [b for b in self.model.buffers()]
+        saved = [self.flat_param.clone(), self.flat_buf.clone()] + [b.clone() for b in buffers]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self.forward_backward(corrupted, mask, clean_nhwc)
+                self._pack_gradients()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+
+        def restore():
+            with torch.no_grad():
+                self.flat_param.copy_(saved[0])
+                self.flat_buf.copy_(saved[1])
+                for b, v in zip(buffers, saved[2:]):
+                    b.copy_(v)
+
+        restore()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._static_loss = self.forward_backward(corrupted, mask, clean_nhwc)
+            self._pack_gradients()
+            if not self.distributed:
+                self.update()
+        torch.cuda.synchronize(dev)
+        restore()                      # capture does not execute, but keep the contract explicit
+        for p, v in zip(self.params, self.grad_views):
+            p.grad = v
+        return self
+
+    def step_graph(self, corrupted=None, mask=None, clean_nhwc=None):
+        """Replay the captured step; new batches are copied into the static input buffers first."""
+        for new, static in zip((corrupted, mask, clean_nhwc), self._static_in):
+            if new is not None and new.data_ptr() != static.data_ptr():
+                static.copy_(new)
+        self._graph.replay()
+        if self.distributed:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
+            self.update()
+        return self._static_loss
