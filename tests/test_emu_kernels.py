@@ -22,7 +22,8 @@ def P(a):
 
 @pytest.mark.parametrize("M,K,N,bias,masked", [(300, 64, 128, True, True), (257, 96, 192, True, False),
                                                (130, 40, 32, False, True), (70, 6, 5, True, True),
-                                               (260, 128, 256, False, False), (200, 36, 136, True, True)])
+                                               (260, 128, 256, False, False), (200, 36, 136, True, True),
+                                               (300, 192, 128, True, True), (210, 132, 256, False, True)])
 def test_pointwise_gemms(emu, M, K, N, bias, masked):
     L = emu
     rng = np.random.default_rng(M + K + N)
@@ -70,3 +71,58 @@ def test_pointwise_gemms(emu, M, K, N, bias, masked):
     assert np.abs(dw - rdw).max() <= 1e-5 * np.abs(rdw).max()
     rdb = (dy.astype(np.float64) * (keep[:, None] if masked else 1.0)).sum(0)
     assert np.abs(db - rdb).max() <= 1e-5 * np.abs(rdb).max()
+
+
+@pytest.mark.parametrize("M,K,N,act,slope", [(300, 64, 128, 2, 0.3), (257, 192, 192, 1, 0.0), (140, 36, 40, 3, 0.0),
+                                             (260, 128, 256, 0, 0.0)])
+def test_pointwise_fused_batchnorm(emu, M, K, N, act, slope):
+    """K6b at kernel level: BatchNorm(+act) of the producer applied on operand load (forward and dW) and the
+    statistics partials of the output (-> tsii_bn_finalize) against float64 numpy."""
+    L = emu
+    rng = np.random.default_rng(7 * M + K + N)
+    xr = (rng.standard_normal((M, K)) * 2 + 0.5).astype(np.float32)      # raw conv output of the producer
+    sc = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    sh = rng.standard_normal(K).astype(np.float32)
+    w = rng.standard_normal((N, K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    r0 = (rng.uniform(size=M) > 0.3).astype(np.float32)
+    denom = rng.integers(1, 9, size=M).astype(np.float32)
+    keep = (rng.uniform(size=M) > 0.2).astype(np.float32)
+    z = xr.astype(np.float64) * sc + sh
+    a = {0: z, 1: np.maximum(z, 0), 2: np.where(z > 0, z, slope * z), 3: np.clip(z, 0, 6)}[act]
+    am = a * r0[:, None]
+    rows = L.tsii_pw_stat_rows(M)
+    part = np.zeros((rows, 4, N), np.float32)
+    y = np.zeros((M, N), np.float32)
+    assert L.tsii_pw_fwd_bn(P(xr), M, K, P(w), N, P(b), P(r0), K, None, P(denom), P(keep), P(sc), P(sh), act, slope,
+                            P(part), P(y), None) == 0, L.tsii_last_error()
+    ref = (am @ w.T.astype(np.float64) / denom[:, None] + b) * keep[:, None]
+    assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max()
+    # statistics of y from the partials
+    mean, var = np.zeros(N, np.float32), np.zeros(N, np.float32)
+    rm, rv = np.zeros(N, np.float32), np.ones(N, np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, N).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+    scale, shift = np.zeros(N, np.float32), np.zeros(N, np.float32)
+    nb = L.tsii_bn_finalize_ws_bytes(rows, N)
+    ws = np.zeros(nb // 4 + 4, np.float32)
+    assert L.tsii_bn_finalize(P(part), rows, N, M, P(mean), P(var), P(rm), P(rv), 0.1, P(gamma), P(beta), 1e-5,
+                              P(scale), P(shift), P(ws), nb, None) == 0, L.tsii_last_error()
+    y64 = y.astype(np.float64)
+    assert np.abs(mean - y64.mean(0)).max() <= 1e-6 * (np.abs(y64).max() + 1)
+    assert np.abs(var - y64.var(0)).max() <= 2e-6 * y64.var(0).max()
+    assert np.abs(rm - 0.1 * y64.mean(0)).max() <= 1e-6 * (np.abs(y64).max() + 1)
+    assert np.abs(rv - (0.9 + 0.1 * y64.var(0, ddof=1))).max() <= 2e-6 * (1 + y64.var(0).max())
+    rs = gamma / np.sqrt(y64.var(0) + 1e-5)
+    assert np.abs(scale - rs).max() <= 1e-5 * np.abs(rs).max()
+    assert np.abs(shift - (beta - y64.mean(0) * rs)).max() <= 1e-5 * (np.abs(beta).max() + np.abs(y64.mean(0) * rs).max())
+    # dW with the same load-time transform
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    inv = (keep / denom).astype(np.float32)
+    nbytes = L.tsii_pw_bwd_dw_ws_bytes(M, N, K)
+    ws2 = np.zeros(nbytes // 4 + 4, np.float32)
+    dw = np.zeros((N, K), np.float32)
+    db = np.zeros(N, np.float32)
+    assert L.tsii_pw_bwd_dw_bn(P(dy), P(xr), M, N, K, P(inv), P(keep), P(r0), K, None, P(sc), P(sh), act, slope,
+                               P(dw), P(db), P(ws2), nbytes, None) == 0, L.tsii_last_error()
+    rdw = (dy.astype(np.float64) * inv[:, None]).T @ am
+    assert np.abs(dw - rdw).max() <= 1e-5 * np.abs(rdw).max()

@@ -380,6 +380,230 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const float* __restrict__ 
     }
 }
 
+// ---- marching-strip 3x3 stencil, stride 1 (forward, and dX with flipped taps) ------------------------------
+// The tile kernel above re-reads a 2d-row halo above and below every 8-row tile (1.4x the input for d = 1) and
+// has nothing in flight while it computes.  Here a block owns a 16-pixel x 32-channel STRIP and marches down it
+// 8 output rows at a time through a ring of 8 + 2d input rows in LDS: every input row is read once (only the
+// 2d-pixel side halo remains, 1.125x), and the next 8 rows (and the per-pixel planes of the next step) are
+// already in flight (global -> registers) while the current ones are computed and stored; they are written into
+// the ring slots the step has just finished with.  BatchNorm partial sums (K6b) accumulate in registers over the
+// whole strip: one reduction / partial row per block.  D (dilation) is a template parameter so that the slab
+// geometry (pixel -> row, column) is compile-time arithmetic instead of per-thread index tables.
+static constexpr int ST_R = 8, ST_TW = 16, ST_CB = 32;
+#ifndef ST_UNROLL
+#define ST_UNROLL 2
+#endif
+static constexpr int ST_UNROLL_K = ST_UNROLL;   // pixels of a thread processed together (all 4: ~150 VGPRs of LDS data in flight)
+
+template <int D, bool FUSED>   // FUSED: BatchNorm on load and / or statistics partials (either may still be off at run time)
+__global__ __launch_bounds__(256, FUSED ? 2 : 3) void dw_strip_kernel(
+    const float* __restrict__ in, const float* __restrict__ pre, const float* __restrict__ wT, const float* __restrict__ bias,
+    const float* __restrict__ denom, const float* __restrict__ keep, const float* __restrict__ post_mul, DtGeom g, int chunk_rows,
+    unsigned strips_x, unsigned chunks_y, unsigned cblocks, DwBN ib, float* __restrict__ stats, float* __restrict__ out) {
+    constexpr int PW = ST_TW + 2 * D, NR = ST_R + 2 * D;
+    constexpr int CGS = ST_CB / 4, LANES = 256 / CGS, NP = ST_R * ST_TW / LANES;
+    constexpr int PF = (ST_R * PW + LANES - 1) / LANES;        // slab pixels per thread per step
+    constexpr int NPX = ST_R * ST_TW;
+    static_assert(2 * D <= ST_R, "the prologue fetch covers the 2d halo rows");
+    __shared__ __attribute__((aligned(16))) float ring[NR * PW * ST_CB];
+    __shared__ float planes[2][3][NPX];                        // keep / denom / post_mul of a step's pixels, double buffered
+    unsigned b = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned cb = b % cblocks; b /= cblocks;
+    const unsigned sx = b % strips_x; b /= strips_x;
+    const unsigned cy = b % chunks_y;
+    const int64_t n = b / chunks_y;
+    const int cg = threadIdx.x % CGS, lane = threadIdx.x / CGS;
+    const int c = (int)cb * ST_CB + cg * 4;
+    const bool cok = c < g.c;
+    const int oy_beg = (int)cy * chunk_rows;
+    const int oy_end = oy_beg + chunk_rows < g.hout ? oy_beg + chunk_rows : g.hout;
+    const int ox0 = (int)sx * ST_TW;
+    const int iy_base = oy_beg - g.pad_h, ix0 = ox0 - g.pad_w;   // input row of ring row 0 / input column of slab column 0
+    const int nsteps = (oy_end - oy_beg + ST_R - 1) / ST_R;
+
+    float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool bn_in = FUSED && ib.sc != nullptr;
+    if (bn_in && cok) { isc = *reinterpret_cast<const float4*>(ib.sc + c); ish = *reinterpret_cast<const float4*>(ib.sh + c); }
+    float4 w[9];
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cok) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const float4*>(wT + (g.flip ? 8 - t : t) * g.c + c);
+        if (bias != nullptr) bq = make_float4(bias[c], bias[c + 1], bias[c + 2], bias[c + 3]);
+    }
+
+    float4 pf[PF];
+    float pm[PF];
+    // global -> registers for ring rows [rr0, rr0 + cnt): slab pixel p = lane + 32 i -> (row, px); wave-uniform 64-bit
+    // base + 32-bit offsets
+    auto fetch = [&](int rr0, int cnt) {
+        const int iyb = iy_base + rr0;
+        const int64_t pixbase = (n * g.hin + iyb) * (int64_t)g.win + ix0;
+        const float* __restrict__ src = in + pixbase * g.c + c;
+        const float* __restrict__ psrc = pre != nullptr ? pre + pixbase : nullptr;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int p = lane + LANES * i;
+            const int row = p / PW, px = p - row * PW;
+            const int iy = iyb + row, ix = ix0 + px;
+            pf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            pm[i] = 0.f;
+            if (row < cnt && cok && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win) {
+                const int off = row * g.win + px;
+                pf[i] = *reinterpret_cast<const float4*>(src + off * g.c);
+                pm[i] = psrc != nullptr ? psrc[off] : 1.f;
+            }
+        }
+    };
+    // registers -> ring (BatchNorm + activation of the producer, then the per-pixel plane; out-of-image stays 0)
+    auto commit = [&](int rr0, int cnt) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int p = lane + LANES * i;
+            const int row = p / PW, px = p - row * PW;
+            if (row >= cnt) continue;
+            float4 v = pf[i];
+            const float m = pm[i];
+            if (bn_in) {
+                v.x = bn_act_load(v.x, isc.x, ish.x, ib.neg, ib.hi); v.y = bn_act_load(v.y, isc.y, ish.y, ib.neg, ib.hi);
+                v.z = bn_act_load(v.z, isc.z, ish.z, ib.neg, ib.hi); v.w = bn_act_load(v.w, isc.w, ish.w, ib.neg, ib.hi);
+            }
+            v.x *= m; v.y *= m; v.z *= m; v.w *= m;          // m == 0 outside the image: zero padding of the activated tensor
+            *reinterpret_cast<float4*>(ring + (((rr0 + row) % NR) * PW + px) * ST_CB + cg * 4) = v;
+        }
+    };
+    // per-pixel planes of step s (threads 0..127: one pixel each): global -> registers -> LDS, one step ahead
+    float pl0 = 1.f, pl1 = 1.f, pl2 = 1.f;
+    auto fetch_planes = [&](int s) {
+        if (threadIdx.x < NPX) {
+            const int oy = oy_beg + ST_R * s + (int)threadIdx.x / ST_TW, ox = ox0 + (int)threadIdx.x % ST_TW;
+            const bool ok = oy < oy_end && ox < g.wout;
+            const int64_t q = (n * g.hout + (ok ? oy : oy_beg)) * (int64_t)g.wout + (ok ? ox : ox0);
+            pl0 = keep != nullptr ? keep[q] : 1.f;
+            pl1 = denom != nullptr ? denom[q] : 1.f;
+            pl2 = post_mul != nullptr ? post_mul[q] : 1.f;
+        }
+    };
+    auto commit_planes = [&](int s) {
+        if (threadIdx.x < NPX) {
+            planes[s & 1][0][threadIdx.x] = pl0; planes[s & 1][1][threadIdx.x] = pl1; planes[s & 1][2][threadIdx.x] = pl2;
+        }
+    };
+
+    fetch_planes(0);
+    fetch(0, 2 * D);
+    commit(0, 2 * D);
+    fetch(2 * D, ST_R);
+    commit(2 * D, ST_R);
+    commit_planes(0);
+    __syncthreads();
+
+    // this thread's output pixels p = lane + 32 k: column tx = lane % 16 for every k, row ty = lane / 16 + 2 k
+    const int tx = lane % ST_TW, ty0 = lane / ST_TW;
+    const bool xok = cok && ox0 + tx < g.wout;
+    // BatchNorm partials: thread-local pivot (its first output), merged to a common pivot once at the end
+    float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
+    float vals[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int cnt = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        const bool more = s + 1 < nsteps;
+        if (more) { fetch(2 * D + ST_R * (s + 1), ST_R); fetch_planes(s + 1); }   // in flight during the compute below
+        const int oyb = oy_beg + ST_R * s;
+        float* __restrict__ out_b = out + ((n * g.hout + oyb) * (int64_t)g.wout + ox0) * g.c + c;
+        const float* __restrict__ pls = &planes[s & 1][0][0];
+#pragma unroll ST_UNROLL_K
+        for (int k = 0; k < NP; ++k) {
+            const int ty = ty0 + 2 * k;
+            if (!(xok && oyb + ty < oy_end)) continue;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* rp = ring + (((ST_R * s + ty + ky * D) % NR) * PW + tx) * ST_CB + cg * 4;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float4 v = *reinterpret_cast<const float4*>(rp + kx * D * ST_CB);
+                    const float4 ww = w[ky * 3 + kx];
+                    a.x = fmaf(v.x, ww.x, a.x); a.y = fmaf(v.y, ww.y, a.y); a.z = fmaf(v.z, ww.z, a.z); a.w = fmaf(v.w, ww.w, a.w);
+                }
+            }
+            const int pp = ty * ST_TW + tx;
+            if (denom != nullptr) { const float dn = pls[NPX + pp]; a.x /= dn; a.y /= dn; a.z /= dn; a.w /= dn; }
+            a.x += bq.x; a.y += bq.y; a.z += bq.z; a.w += bq.w;
+            if (post_mul != nullptr) {
+                const float pmk = pls[2 * NPX + pp];
+                a.x = pmk != 0.f ? a.x * pmk : 0.f; a.y = pmk != 0.f ? a.y * pmk : 0.f;
+                a.z = pmk != 0.f ? a.z * pmk : 0.f; a.w = pmk != 0.f ? a.w * pmk : 0.f;
+            }
+            if (keep != nullptr && pls[pp] == 0.f) a = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(out_b + (ty * g.wout + tx) * g.c) = a;
+            if (FUSED && stats != nullptr) {
+                if (cnt == 0) P = a;
+                ++cnt;
+                const float dx = a.x - P.x, dy = a.y - P.y, dz = a.z - P.z, dw = a.w - P.w;
+                vals[0] += dx; vals[1] += dy; vals[2] += dz; vals[3] += dw;
+                vals[4] = fmaf(dx, dx, vals[4]); vals[5] = fmaf(dy, dy, vals[5]);
+                vals[6] = fmaf(dz, dz, vals[6]); vals[7] = fmaf(dw, dw, vals[7]);
+            }
+        }
+        __syncthreads();                                    // every read of this step's rows is done
+        if (more) { commit(2 * D + ST_R * (s + 1), ST_R); commit_planes(s + 1); }   // into the slots this step no longer needs
+        __syncthreads();
+    }
+    if (FUSED && stats != nullptr) {
+        // merge the 32 pixel lanes of every channel: (count, pivot, s1, s2) per thread through the (now free) ring,
+        // re-based to the pivot of the first lane that saw a pixel:  s1' = s1 + n dp,  s2' = s2 + 2 dp s1 + n dp^2
+        float* mrg = ring;                                   // [256][13]
+        static_assert(256 * 13 <= NR * PW * ST_CB, "merge buffer fits the ring");
+        float* mt = mrg + threadIdx.x * 13;
+        mt[0] = (float)cnt;
+        mt[1] = P.x; mt[2] = P.y; mt[3] = P.z; mt[4] = P.w;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mt[5 + i] = vals[i];
+        __syncthreads();
+        if (threadIdx.x < ST_CB && (int)cb * ST_CB + (int)threadIdx.x < g.c) {
+            const int ch = threadIdx.x, mcg = ch / 4, mi = ch % 4;
+            float nn = 0.f, pv = 0.f, s1 = 0.f, s2 = 0.f;
+            for (int l = 0; l < LANES; ++l) {
+                const float* q = mrg + (l * CGS + mcg) * 13;
+                const float n_t = q[0];
+                if (n_t == 0.f) continue;
+                if (nn == 0.f) pv = q[1 + mi];
+                const float dp = q[1 + mi] - pv, a1 = q[5 + mi], a2 = q[9 + mi];
+                s1 += fmaf(n_t, dp, a1);
+                s2 += a2 + dp * (2.f * a1 + n_t * dp);
+                nn += n_t;
+            }
+            const int64_t prow = (n * chunks_y + cy) * strips_x + sx;       // one partial row per strip chunk
+            float* sp = stats + prow * 4 * g.c + (int)cb * ST_CB + ch;
+            sp[0] = nn;
+            sp[g.c] = pv;
+            sp[2 * (int64_t)g.c] = s1;
+            sp[3 * (int64_t)g.c] = s2;
+        }
+    }
+}
+
+struct StripPlan {
+    bool ok;
+    int chunk_rows;
+    unsigned strips_x, chunks_y, cblocks;
+};
+static StripPlan plan_strip(int n, int hout, int wout, int c, int s, int d) {
+    StripPlan p;
+    p.ok = (s == 1 && d >= 1 && d <= 2 && c % 4 == 0);
+    p.strips_x = cdiv(wout, ST_TW);
+    p.cblocks = cdiv(c, ST_CB);
+    const int64_t per_chunk = (int64_t)p.strips_x * p.cblocks * n;
+    int64_t want = cdiv64(1536, per_chunk);                  // ~6 blocks per CU
+    const int max_chunks = cdiv(hout, ST_R);
+    if (want > max_chunks) want = max_chunks;
+    if (want < 1) want = 1;
+    p.chunk_rows = cdiv(cdiv(hout, (int)want), ST_R) * ST_R;
+    p.chunks_y = cdiv(hout, p.chunk_rows);
+    if (per_chunk * p.chunks_y >= (1ll << 31)) p.ok = false;
+    return p;
+}
+
 // -> 0 launched, 1 not applicable (caller falls back to the direct kernel), <0 error
 static const DwBN kNoDwBN = {nullptr, nullptr, 1.f, 0.f};
 static constexpr int DT_TH0 = 8, DT_TW0 = 16;     // output tile of every variant (also the BatchNorm partial-row grain)
@@ -408,6 +632,20 @@ static int try_launch_dw_tile(const float* in, const float* pre, const float* wT
                               DwBN ib = kNoDwBN, float* stats = nullptr) {
     if (g.c % 4 != 0 || !aligned16(in) || !aligned16(out) || !aligned16(wT)) return 1;
     if (ib.sc != nullptr && (!aligned16(ib.sc) || !aligned16(ib.sh))) return 1;
+    const StripPlan sp = plan_strip(g.n, g.hout, g.wout, g.c, g.s, g.d);
+    if (sp.ok) {
+        const int64_t nblk = (int64_t)sp.strips_x * sp.chunks_y * sp.cblocks * g.n;
+        const dim3 grid((unsigned)nblk);
+        const bool fused = ib.sc != nullptr || stats != nullptr;
+        if (g.d == 1 && fused) hipLaunchKernelGGL((dw_strip_kernel<1, true>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                                  sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, out);
+        else if (g.d == 1) hipLaunchKernelGGL((dw_strip_kernel<1, false>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                              sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, out);
+        else if (g.d == 2 && !fused) hipLaunchKernelGGL((dw_strip_kernel<2, false>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                                        sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, out);
+        else return 1;
+        return check_launch("dw_strip");
+    }
     int rc = launch_dw_tile_variant<DT_TH0, DT_TW0, 32, 6144>(in, pre, wT, bias, denom, keep, post_mul, g, ib, stats, out, st);
     if (rc == 1) rc = launch_dw_tile_variant<DT_TH0, DT_TW0, 32, 10240>(in, pre, wT, bias, denom, keep, post_mul, g, ib, stats, out, st);
     return rc;
@@ -641,6 +879,8 @@ extern "C" int tsii_dw_fwd(const float* x, const float* rmask, const float* w, c
 extern "C" int64_t tsii_dw_stat_rows(int n, int ho, int wo, int c, int kh, int kw, int sh, int sw, int dh, int dw) {
     if (n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || c % 4 != 0) return 0;
     if (!(kh == 3 && kw == 3 && sh == sw && dh == dw) || !dw_tile_fits(sh, dh)) return 0;
+    const StripPlan sp = plan_strip(n, ho, wo, c, sh, dh);
+    if (sp.ok) return (int64_t)n * sp.chunks_y * sp.strips_x;          // marching-strip kernel: one row per strip chunk
     return (int64_t)n * cdiv(ho, DT_TH0) * cdiv(wo, DT_TW0);
 }
 

@@ -763,14 +763,17 @@ static int launch_nt(const float* A, int64_t lda, RowScale as, const float* B, i
 
 struct TnPlan {
     bool big;
+    bool narrow;   // 128 x 64 tiles: Q leaves at most half of its last 128-wide tile (e.g. 384 x 192)
     int bm, bn;
     int splits;
     int64_t chunk;
 };
-static TnPlan plan_tn(int64_t M, int P, int Q) {
+static TnPlan plan_tn(int64_t M, int P, int Q, bool allow_narrow = false) {
     TnPlan pl;
     pl.big = (P >= 128 && Q >= 128);
     pl.bm = pl.bn = pl.big ? 128 : 64;
+    pl.narrow = allow_narrow && pl.big && (Q % 128) >= 1 && (Q % 128) <= 64;
+    if (pl.narrow) pl.bn = 64;
     const int tiles = cdiv(P, pl.bm) * cdiv(Q, pl.bn);
     int64_t want = 1024 / tiles;
     if (want < 1) want = 1;
@@ -903,8 +906,9 @@ extern "C" int tsii_pw_bwd_dx(const float* dy, int64_t m, int n, const float* w,
 
 extern "C" size_t tsii_pw_bwd_dw_ws_bytes(int64_t m, int n, int k) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    TnPlan pl = plan_tn(m, n, k);
-    return ((size_t)pl.splits * n * k + colsum_ws_floats(m, n)) * sizeof(float);
+    const TnPlan a = plan_tn(m, n, k, true), b = plan_tn(m, n, k, false);   // the call picks one by operand alignment
+    const int splits = a.splits > b.splits ? a.splits : b.splits;
+    return ((size_t)splits * n * k + colsum_ws_floats(m, n)) * sizeof(float);
 }
 
 static int pw_bwd_dw_impl(const float* dy, const float* x, int64_t m, int n, int k, const float* inv, const float* keep,
@@ -914,15 +918,18 @@ static int pw_bwd_dw_impl(const float* dy, const float* x, int64_t m, int n, int
     TSII_REQUIRE(m > 0 && k > 0 && n > 0, "pw_bwd_dw: bad shape");
     TSII_REQUIRE(ws_bytes >= tsii_pw_bwd_dw_ws_bytes(m, n, k), "pw_bwd_dw: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    TnPlan pl = plan_tn(m, n, k);
+    const bool vec = (n % 4 == 0) && (k % 4 == 0) && aligned16(dy) && aligned16(x);
+    TnPlan pl = plan_tn(m, n, k, vec);
     float* part = (float*)ws;
     RowScale sb = {r0, r1, split};
-    const bool vec = (n % 4 == 0) && (k % 4 == 0) && aligned16(dy) && aligned16(x);
     dim3 grid(cdiv(k, pl.bn), cdiv(n, pl.bm), pl.splits);
     if (ib.sc != nullptr) {
         TSII_REQUIRE(vec, "pw_bwd_dw: input BatchNorm needs n, k %% 4 == 0 and 16-byte aligned operands");
-        if (pl.big) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 0, true>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv, ib);
+        if (pl.narrow) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 1, true, 0, true>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv, ib);
+        else if (pl.big) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 0, true>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv, ib);
         else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, 0, true>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv, ib);
+    } else if (pl.narrow) {
+        hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 1, true, 0>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv, kNoBN);
     } else if (pl.big) {
         if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 0>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv, kNoBN);
         else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, false, 0>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv, kNoBN);
