@@ -35,16 +35,22 @@ def nt_variant(n_cols: int) -> str:
     return "gemm_nt<128x64>" if n_cols > 32 else "gemm_nt<128x32>"
 
 
+PMC_SUMMARY = "r01_f_pmc_hbm_traffic_bs32.json"   # tools/collect_profiles.sh -> tools/pmc_summary.py
+
+
 def pmc_traffic(kernel_label: str):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, x2 read correction; see the file's `_how`)."""
-    path = os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic_bs32.json")
-    names = {"gemm_nt<128x128>": "tsii::gemm_nt_kernel<2, 2, 2, 2, true, 0>",
-             "gemm_nt<128x64>": "tsii::gemm_nt_kernel<2, 2, 2, 1, true, 0>",
-             "gemm_nt<128x32>": "tsii::gemm_nt_kernel<4, 1, 1, 1, true, 0>"}
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes, x2 read correction; see the file's `_how`), launch-weighted over the template
+    instances of the tile variant (plain and BatchNorm-on-load loaders)."""
+    path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
+    prefixes = {"gemm_nt<128x128>": "tsii::gemm_nt_kernel<2, 2, 2, 2, true, 0",
+                "gemm_nt<128x64>": "tsii::gemm_nt_kernel<2, 2, 2, 1, true, 0",
+                "gemm_nt<128x32>": "tsii::gemm_nt_kernel<4, 1, 1, 1, true, 0"}
     try:
-        rec = json.load(open(path))["kernels"][names[kernel_label]]
-        return rec["bytes_per_launch"]
+        kernels = json.load(open(path))["kernels"]
+        recs = [r for k, r in kernels.items() if k.startswith(prefixes[kernel_label])]
+        launches = sum(r["launches"] for r in recs)
+        return sum(r["bytes_per_launch"] * r["launches"] for r in recs) / launches
     except Exception:  # noqa: BLE001 - no summary committed for this kernel/config
         return None
 
@@ -189,7 +195,7 @@ def main():
             roofline = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
                         "traffic": (pmc_traffic(k) if (args.batch == 32 and args.size == 512 and args.model == "ImageFill") else None),
-                        "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_c_pmc_hbm_traffic_bs32.json)",
+                        "traffic_unit": "HBM bytes per launch (PMC, profiles/" + PMC_SUMMARY + ")",
                         "alg_bytes_per_launch": round(d["alg_bytes"] / d["launches"]),
                         "alg_flop_per_launch": round(d["flop"] / d["launches"]),
                         "launches_per_step": d["launches"] // args.steps,

@@ -754,6 +754,173 @@ __global__ __launch_bounds__(256) void dw_tile_dw_kernel(const float* __restrict
     }
 }
 
+// ---- marching-strip dW (stride 1): same ring of x rows as dw_strip_kernel, the 9 taps x 4 channels (+ bias)
+// accumulate in registers over the whole strip; the next step's x rows AND dy pixels are in flight during the
+// multiply-accumulate of the current one.  One partial row per block, combined by dw_reduce_kernel.
+template <int D>
+__global__ __launch_bounds__(256, 2) void dw_strip_dw_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
+                                                             const float* __restrict__ keep, const float* __restrict__ x,
+                                                             const float* __restrict__ rmask, DtGeom g, int chunk_rows,
+                                                             unsigned strips_x, unsigned chunks_y, unsigned cblocks, DwBN ib,
+                                                             float* __restrict__ part) {
+    constexpr int PW = ST_TW + 2 * D, NR = ST_R + 2 * D;
+    constexpr int CGS = ST_CB / 4, LANES = 256 / CGS, NP = ST_R * ST_TW / LANES;
+    constexpr int PF = (ST_R * PW + LANES - 1) / LANES;
+    constexpr int NPX = ST_R * ST_TW;
+    __shared__ __attribute__((aligned(16))) float ring[NR * PW * ST_CB];
+    __shared__ float planes[2][2][NPX];                        // keep / inv of a step's pixels, double buffered
+    const unsigned cb = blockIdx.x % cblocks;
+    unsigned b = blockIdx.x / cblocks;                         // partial row index
+    const unsigned prow_idx = b;
+    const unsigned sx = b % strips_x; b /= strips_x;
+    const unsigned cy = b % chunks_y;
+    const int64_t n = b / chunks_y;
+    const int cg = threadIdx.x % CGS, lane = threadIdx.x / CGS;
+    const int c = (int)cb * ST_CB + cg * 4;
+    const bool cok = c < g.c;
+    const int oy_beg = (int)cy * chunk_rows;
+    const int oy_end = oy_beg + chunk_rows < g.hout ? oy_beg + chunk_rows : g.hout;
+    const int ox0 = (int)sx * ST_TW;
+    const int iy_base = oy_beg - g.pad_h, ix0 = ox0 - g.pad_w;
+    const int nsteps = (oy_end - oy_beg + ST_R - 1) / ST_R;
+
+    float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool bn_in = ib.sc != nullptr;
+    if (bn_in && cok) { isc = *reinterpret_cast<const float4*>(ib.sc + c); ish = *reinterpret_cast<const float4*>(ib.sh + c); }
+
+    float4 pf[PF];
+    float pm[PF];
+    auto fetch = [&](int rr0, int cnt) {
+        const int iyb = iy_base + rr0;
+        const int64_t pixbase = (n * g.hin + iyb) * (int64_t)g.win + ix0;
+        const float* __restrict__ src = x + pixbase * g.c + c;
+        const float* __restrict__ psrc = rmask != nullptr ? rmask + pixbase : nullptr;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int p = lane + LANES * i;
+            const int row = p / PW, px = p - row * PW;
+            const int iy = iyb + row, ix = ix0 + px;
+            pf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            pm[i] = 0.f;
+            if (row < cnt && cok && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win) {
+                const int off = row * g.win + px;
+                pf[i] = *reinterpret_cast<const float4*>(src + off * g.c);
+                pm[i] = psrc != nullptr ? psrc[off] : 1.f;
+            }
+        }
+    };
+    auto commit = [&](int rr0, int cnt) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int p = lane + LANES * i;
+            const int row = p / PW, px = p - row * PW;
+            if (row >= cnt) continue;
+            float4 v = pf[i];
+            const float m = pm[i];
+            if (bn_in) {
+                v.x = bn_act_load(v.x, isc.x, ish.x, ib.neg, ib.hi); v.y = bn_act_load(v.y, isc.y, ish.y, ib.neg, ib.hi);
+                v.z = bn_act_load(v.z, isc.z, ish.z, ib.neg, ib.hi); v.w = bn_act_load(v.w, isc.w, ish.w, ib.neg, ib.hi);
+            }
+            v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+            *reinterpret_cast<float4*>(ring + (((rr0 + row) % NR) * PW + px) * ST_CB + cg * 4) = v;
+        }
+    };
+    const int tx = lane % ST_TW, ty0 = lane / ST_TW;
+    const bool xok = cok && ox0 + tx < g.wout;
+    // dy of this thread's 4 pixels for step s, and the keep / inv planes (threads 0..127: one pixel each)
+    float4 gn[NP];
+    float pl0 = 0.f, pl1 = 0.f;
+    auto fetch_dy = [&](int s) {
+        const int oyb = oy_beg + ST_R * s;
+        const float* __restrict__ src = dy + ((n * g.hout + oyb) * (int64_t)g.wout + ox0) * g.c + c;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int ty = ty0 + 2 * k;
+            gn[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xok && oyb + ty < oy_end) gn[k] = *reinterpret_cast<const float4*>(src + (ty * g.wout + tx) * g.c);
+        }
+        if (threadIdx.x < NPX) {
+            const int oy = oyb + (int)threadIdx.x / ST_TW, ox = ox0 + (int)threadIdx.x % ST_TW;
+            pl0 = 0.f; pl1 = 0.f;                              // out of range: no gradient
+            if (oy < oy_end && ox < g.wout) {
+                const int64_t q = (n * g.hout + oy) * (int64_t)g.wout + ox;
+                pl0 = keep != nullptr ? keep[q] : 1.f;
+                pl1 = inv != nullptr ? inv[q] : 1.f;
+            }
+        }
+    };
+    auto commit_planes = [&](int s) {
+        if (threadIdx.x < NPX) { planes[s & 1][0][threadIdx.x] = pl0; planes[s & 1][1][threadIdx.x] = pl1; }
+    };
+
+    float4 acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    fetch_dy(0);
+    fetch(0, 2 * D);
+    commit(0, 2 * D);
+    fetch(2 * D, ST_R);
+    commit(2 * D, ST_R);
+    commit_planes(0);
+    __syncthreads();
+
+    for (int s = 0; s < nsteps; ++s) {
+        const bool more = s + 1 < nsteps;
+        float4 gv[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) gv[k] = gn[k];
+        if (more) { fetch(2 * D + ST_R * (s + 1), ST_R); fetch_dy(s + 1); }
+        const float* __restrict__ pls = &planes[s & 1][0][0];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            __builtin_amdgcn_sched_barrier(0);             // one pixel's 9 LDS reads in flight at a time (VGPR budget)
+            const int ty = ty0 + 2 * k;
+            const int pp = ty * ST_TW + tx;
+            if (pls[pp] == 0.f) continue;                  // hole / out of range: no gradient (partial_convolution.py:72)
+            float4 gq = gv[k];
+            acc[9].x += gq.x; acc[9].y += gq.y; acc[9].z += gq.z; acc[9].w += gq.w;   // bias: added after the division
+            const float sc = pls[NPX + pp];
+            gq.x *= sc; gq.y *= sc; gq.z *= sc; gq.w *= sc;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* rp = ring + (((ST_R * s + ty + ky * D) % NR) * PW + tx) * ST_CB + cg * 4;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float4 v = *reinterpret_cast<const float4*>(rp + kx * D * ST_CB);
+                    float4& a = acc[ky * 3 + kx];
+                    a.x = fmaf(gq.x, v.x, a.x); a.y = fmaf(gq.y, v.y, a.y); a.z = fmaf(gq.z, v.z, a.z); a.w = fmaf(gq.w, v.w, a.w);
+                }
+            }
+        }
+        __syncthreads();
+        if (more) { commit(2 * D + ST_R * (s + 1), ST_R); commit_planes(s + 1); }
+        __syncthreads();
+    }
+    // combine the 32 pixel lanes through the (free) ring: [10 taps][256 threads] float4, then 80 threads per ... sum
+    float4* red4 = reinterpret_cast<float4*>(ring);
+    static_assert(10 * 256 * 4 <= 2 * NR * PW * ST_CB, "two passes of 5 taps fit the ring");
+    float* prow = part + (int64_t)prow_idx * 10 * g.c;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 5; ++t) red4[t * 256 + threadIdx.x] = acc[half * 5 + t];
+        __syncthreads();
+        // 5 taps x 32 channels = 160 sums of 32 lanes each
+        if (threadIdx.x < 160) {
+            const int t = threadIdx.x / ST_CB, ch = threadIdx.x % ST_CB;
+            if ((int)cb * ST_CB + ch < g.c) {
+                const float* col = ring + (t * 256) * 4 + (ch / 4) * 4 + (ch % 4);
+                float sum = 0.f;
+#pragma unroll 8
+                for (int l = 0; l < LANES; ++l) sum += col[l * CGS * 4];
+                prow[(int64_t)(half * 5 + t) * g.c + (int)cb * ST_CB + ch] = sum;
+            }
+        }
+    }
+}
+
 struct DtDwPlan {
     bool ok;
     int PH, PW;
@@ -928,9 +1095,12 @@ extern "C" size_t tsii_dw_bwd_dw_ws_bytes(int n, int ho, int wo, int c, int kh, 
     // the scalar plan (taken when c % 4 != 0 or a pointer is unaligned) never needs more rows
     const DwPlan a = plan_dw(n, ho, c, c % 4 == 0), b = plan_dw(n, ho, c, false);
     int R = a.R > b.R ? a.R : b.R;
-    if (kh == 3 && kw == 3) {   // LDS-tiled plan (any stride/dilation: upper bound over both)
+    if (kh == 3 && kw == 3) {   // LDS-tiled plan (any stride/dilation: upper bound over both) and the strip plan
         const int g1 = (int)plan_dt_dw(n, ho, wo, c, 1, 1).groups;
         if (g1 > R) R = g1;
+        const StripPlan sp = plan_strip(n, ho, wo, c, 1, 1);
+        const int64_t g2 = (int64_t)n * sp.chunks_y * sp.strips_x;
+        if (g2 > R) R = (int)g2;
     }
     return (size_t)R * (size_t)(kh * kw + 1) * c * sizeof(float);
 }
@@ -946,6 +1116,22 @@ static int dw_bwd_dw_impl(const float* dy, const float* inv, const float* keep, 
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (c % 4 == 0) && aligned16(dy) && aligned16(x) && (ib.sc == nullptr || (aligned16(ib.sc) && aligned16(ib.sh)));
     float* part = (float*)ws;
+    if (vec && kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == dw && (dh == 1 || (dh == 2 && ib.sc == nullptr))) {
+        const StripPlan sp = plan_strip(n, ho, wo, c, 1, dh);   // marching strips
+        if (sp.ok) {
+            DtGeom tg = {n, h, wd, c, 1, dh, ph, pw, ho, wo, 0};
+            const unsigned rows = (unsigned)n * sp.chunks_y * sp.strips_x;
+            const dim3 grid(rows * sp.cblocks);
+            if (dh == 1) hipLaunchKernelGGL((dw_strip_dw_kernel<1>), grid, dim3(256), 0, st, dy, inv, keep, x, rmask, tg, sp.chunk_rows,
+                                            sp.strips_x, sp.chunks_y, sp.cblocks, ib, part);
+            else hipLaunchKernelGGL((dw_strip_dw_kernel<2>), grid, dim3(256), 0, st, dy, inv, keep, x, rmask, tg, sp.chunk_rows,
+                                    sp.strips_x, sp.chunks_y, sp.cblocks, ib, part);
+            int rc0 = check_launch("dw_strip_dw");
+            if (rc0) return rc0;
+            hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)cdiv64((int64_t)10 * c, 32)), dim3(256), 0, st, part, (int)rows, 9, c, dwgt, dbias);
+            return check_launch("dw_reduce");
+        }
+    }
     if (vec && kh == 3 && kw == 3 && sh == sw && dh == dw) {
         const DtDwPlan tp = plan_dt_dw(n, ho, wo, c, sh, dh);
         if (tp.ok) {
