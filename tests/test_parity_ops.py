@@ -349,3 +349,33 @@ def test_train_step_graph_replay_matches_eager_gpu():
         assert torch.equal(p0, p1)
         for k in b0:
             assert torch.equal(b0[k], b1[k]), k
+
+
+@both_backends
+def test_depthwise_strip_kernels_vs_oracle(backend):
+    """K2 marching-strip stencils (stride 1 d 1/2, stride 2) incl. tile tails, several strip chunks and channel tails:
+    forward, new_mask, dX, dW, db of the depth-wise PartialConv vs the oracle."""
+    with BACKENDS[backend]() as dev:
+        for idx, (c, s, d, H, W) in enumerate([(40, 1, 1, 21, 37), (36, 1, 2, 19, 18), (40, 2, 1, 22, 37), (64, 2, 1, 33, 16)]):
+            m = T.PartialConv(c, c, 3, s, d, d, c, True, True)
+            fill_state_dict_(m.state_dict(), seed=900 + idx)
+            rng = np.random.default_rng(900 + idx)
+            x = torch.from_numpy(rng.standard_normal((2, c, H, W)).astype(np.float32))
+            pa = (torch.from_numpy(rng.uniform(size=(2, 1, H, W))) > 0.3).float()
+            pa[:, :, 3:9, 2:8] = 0
+            mask = pa.expand(-1, c, -1, -1).contiguous()
+            w = m.feature_conv.weight.detach().clone().requires_grad_(True)
+            b = m.feature_conv.bias.detach().clone().requires_grad_(True)
+            xo = x.clone().requires_grad_(True)
+            yo, nmo = O.partial_conv(xo, mask, w, b, s, d, d, c, True)
+            gy = torch.from_numpy(rng.standard_normal(tuple(yo.shape)).astype(np.float32))
+            yo.backward(gy)
+            m = m.to(dev)
+            xd = x.to(dev).requires_grad_(True)
+            y, nm = m((xd, pa.expand(-1, c, -1, -1).to(dev)))
+            assert_close(y, yo, TOL, f"dw strip case {idx} y")
+            assert np.array_equal(nm.detach().cpu().numpy(), nmo.detach().numpy()), f"case {idx} new_mask"
+            y.backward(gy.to(dev))
+            assert_close(xd.grad, xo.grad, TOL, f"dw strip case {idx} dx")
+            assert_close(m.feature_conv.weight.grad, w.grad, TOL, f"dw strip case {idx} dw")
+            assert_close(m.feature_conv.bias.grad, b.grad, TOL, f"dw strip case {idx} db")

@@ -395,16 +395,19 @@ static constexpr int ST_R = 8, ST_TW = 16, ST_CB = 32;
 #endif
 static constexpr int ST_UNROLL_K = ST_UNROLL;   // pixels of a thread processed together (all 4: ~150 VGPRs of LDS data in flight)
 
-template <int D, bool FUSED>   // FUSED: BatchNorm on load and / or statistics partials (either may still be off at run time)
+template <int S, int D, bool FUSED>   // stride, dilation; FUSED: BatchNorm on load and / or statistics partials (either may be off at run time)
 __global__ __launch_bounds__(256, FUSED ? 2 : 3) void dw_strip_kernel(
     const float* __restrict__ in, const float* __restrict__ pre, const float* __restrict__ wT, const float* __restrict__ bias,
     const float* __restrict__ denom, const float* __restrict__ keep, const float* __restrict__ post_mul, DtGeom g, int chunk_rows,
     unsigned strips_x, unsigned chunks_y, unsigned cblocks, DwBN ib, float* __restrict__ stats, float* __restrict__ out) {
-    constexpr int PW = ST_TW + 2 * D, NR = ST_R + 2 * D;
-    constexpr int CGS = ST_CB / 4, LANES = 256 / CGS, NP = ST_R * ST_TW / LANES;
-    constexpr int PF = (ST_R * PW + LANES - 1) / LANES;        // slab pixels per thread per step
-    constexpr int NPX = ST_R * ST_TW;
-    static_assert(2 * D <= ST_R, "the prologue fetch covers the 2d halo rows");
+    constexpr int R = ST_R / S, TW = ST_TW / S;                 // output rows x columns per step: 8 x 16 at stride 1, 4 x 8 at stride 2
+    constexpr int PW = (TW - 1) * S + 2 * D + 1, NR = (R - 1) * S + 2 * D + 1;
+    constexpr int NEW = R * S, PRO = NR - NEW;                 // input rows a step brings in / rows the prologue adds first
+    constexpr int CGS = ST_CB / 4, LANES = 256 / CGS, NP = R * TW / LANES;
+    constexpr int PF = (NEW * PW + LANES - 1) / LANES;         // slab pixels per thread per step
+    constexpr int NPX = R * TW;
+    constexpr int TYS = LANES / TW;                            // row stride between a thread's pixels
+    static_assert(PRO >= 0 && PRO <= NEW, "the prologue fetch covers the halo rows");
     __shared__ __attribute__((aligned(16))) float ring[NR * PW * ST_CB];
     __shared__ float planes[2][3][NPX];                        // keep / denom / post_mul of a step's pixels, double buffered
     unsigned b = xcd_remap(blockIdx.x, gridDim.x);
@@ -417,9 +420,9 @@ __global__ __launch_bounds__(256, FUSED ? 2 : 3) void dw_strip_kernel(
     const bool cok = c < g.c;
     const int oy_beg = (int)cy * chunk_rows;
     const int oy_end = oy_beg + chunk_rows < g.hout ? oy_beg + chunk_rows : g.hout;
-    const int ox0 = (int)sx * ST_TW;
-    const int iy_base = oy_beg - g.pad_h, ix0 = ox0 - g.pad_w;   // input row of ring row 0 / input column of slab column 0
-    const int nsteps = (oy_end - oy_beg + ST_R - 1) / ST_R;
+    const int ox0 = (int)sx * TW;
+    const int iy_base = oy_beg * S - g.pad_h, ix0 = ox0 * S - g.pad_w;   // input row of ring row 0 / input column of slab column 0
+    const int nsteps = (oy_end - oy_beg + R - 1) / R;
 
     float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool bn_in = FUSED && ib.sc != nullptr;
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(256, FUSED ? 2 : 3) void dw_strip_kernel(
     float pl0 = 1.f, pl1 = 1.f, pl2 = 1.f;
     auto fetch_planes = [&](int s) {
         if (threadIdx.x < NPX) {
-            const int oy = oy_beg + ST_R * s + (int)threadIdx.x / ST_TW, ox = ox0 + (int)threadIdx.x % ST_TW;
+            const int oy = oy_beg + R * s + (int)threadIdx.x / TW, ox = ox0 + (int)threadIdx.x % TW;
             const bool ok = oy < oy_end && ox < g.wout;
             const int64_t q = (n * g.hout + (ok ? oy : oy_beg)) * (int64_t)g.wout + (ok ? ox : ox0);
             pl0 = keep != nullptr ? keep[q] : 1.f;
@@ -491,15 +494,15 @@ __global__ __launch_bounds__(256, FUSED ? 2 : 3) void dw_strip_kernel(
     };
 
     fetch_planes(0);
-    fetch(0, 2 * D);
-    commit(0, 2 * D);
-    fetch(2 * D, ST_R);
-    commit(2 * D, ST_R);
+    fetch(0, PRO);
+    commit(0, PRO);
+    fetch(PRO, NEW);
+    commit(PRO, NEW);
     commit_planes(0);
     __syncthreads();
 
-    // this thread's output pixels p = lane + 32 k: column tx = lane % 16 for every k, row ty = lane / 16 + 2 k
-    const int tx = lane % ST_TW, ty0 = lane / ST_TW;
+    // this thread's output pixels p = lane + 32 k: column tx = lane % TW for every k, row ty = lane / TW + (32 / TW) k
+    const int tx = lane % TW, ty0 = lane / TW;
     const bool xok = cok && ox0 + tx < g.wout;
     // BatchNorm partials: thread-local pivot (its first output), merged to a common pivot once at the end
     float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -507,18 +510,18 @@ __global__ __launch_bounds__(256, FUSED ? 2 : 3) void dw_strip_kernel(
     int cnt = 0;
     for (int s = 0; s < nsteps; ++s) {
         const bool more = s + 1 < nsteps;
-        if (more) { fetch(2 * D + ST_R * (s + 1), ST_R); fetch_planes(s + 1); }   // in flight during the compute below
-        const int oyb = oy_beg + ST_R * s;
+        if (more) { fetch(PRO + NEW * (s + 1), NEW); fetch_planes(s + 1); }   // in flight during the compute below
+        const int oyb = oy_beg + R * s;
         float* __restrict__ out_b = out + ((n * g.hout + oyb) * (int64_t)g.wout + ox0) * g.c + c;
         const float* __restrict__ pls = &planes[s & 1][0][0];
 #pragma unroll ST_UNROLL_K
         for (int k = 0; k < NP; ++k) {
-            const int ty = ty0 + 2 * k;
+            const int ty = ty0 + TYS * k;
             if (!(xok && oyb + ty < oy_end)) continue;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const float* rp = ring + (((ST_R * s + ty + ky * D) % NR) * PW + tx) * ST_CB + cg * 4;
+                const float* rp = ring + ((((R * s + ty) * S + ky * D) % NR) * PW + tx * S) * ST_CB + cg * 4;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const float4 v = *reinterpret_cast<const float4*>(rp + kx * D * ST_CB);
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(256, FUSED ? 2 : 3) void dw_strip_kernel(
                     a.x = fmaf(v.x, ww.x, a.x); a.y = fmaf(v.y, ww.y, a.y); a.z = fmaf(v.z, ww.z, a.z); a.w = fmaf(v.w, ww.w, a.w);
                 }
             }
-            const int pp = ty * ST_TW + tx;
+            const int pp = ty * TW + tx;
             if (denom != nullptr) { const float dn = pls[NPX + pp]; a.x /= dn; a.y /= dn; a.z /= dn; a.w /= dn; }
             a.x += bq.x; a.y += bq.y; a.z += bq.z; a.w += bq.w;
             if (post_mul != nullptr) {
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(256, FUSED ? 2 : 3) void dw_strip_kernel(
             }
         }
         __syncthreads();                                    // every read of this step's rows is done
-        if (more) { commit(2 * D + ST_R * (s + 1), ST_R); commit_planes(s + 1); }   // into the slots this step no longer needs
+        if (more) { commit(PRO + NEW * (s + 1), NEW); commit_planes(s + 1); }   // into the slots this step no longer needs
         __syncthreads();
     }
     if (FUSED && stats != nullptr) {
@@ -583,6 +586,135 @@ __global__ __launch_bounds__(256, FUSED ? 2 : 3) void dw_strip_kernel(
     }
 }
 
+// ---- marching-strip dX for 3x3 / stride 2 / pad 1 / dilation 1 --------------------------------------------------
+//   dx[iy, ix] = rmask[iy, ix] * sum_{ky,kx : (iy+1-ky), (ix+1-kx) even}  w[ky,kx] * (dy*inv)[(iy+1-ky)/2, (ix+1-kx)/2]
+// A block owns a 16-pixel x 32-channel strip of the INPUT grid and marches down it 8 rows at a time; the ring holds the
+// 5 x 9 dy*inv pixels a step needs (4 new dy rows per step: dy is a quarter of dx, the kernel is write-bound).  A
+// thread's pixels all have the same (row, column) parity -- rows ty0 + 2k, one column -- so its tap set is fixed: two
+// candidate taps per axis, the second one zero-weighted where the parity admits a single tap.
+__global__ __launch_bounds__(256, 3) void dw_strip_dx2_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
+                                                              const float* __restrict__ wT, const float* __restrict__ rmask,
+                                                              int n_img, int h, int w_in, int c_all, int ho, int wo, int chunk_rows,
+                                                              unsigned strips_x, unsigned chunks_y, unsigned cblocks,
+                                                              float* __restrict__ dx) {
+    constexpr int R = 8, TW = 16, NEW = 4, PRO = 1, NR = 5, PW = 9;
+    constexpr int CGS = ST_CB / 4, LANES = 256 / CGS, NP = R * TW / LANES, PF = (NEW * PW + LANES - 1) / LANES;
+    constexpr int NPX = R * TW;
+    __shared__ __attribute__((aligned(16))) float ring[NR * PW * ST_CB];
+    __shared__ float planes[2][NPX];                             // rmask of a step's pixels, double buffered
+    unsigned b = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned cb = b % cblocks; b /= cblocks;
+    const unsigned sx = b % strips_x; b /= strips_x;
+    const unsigned cy = b % chunks_y;
+    const int64_t n = b / chunks_y;
+    (void)n_img;
+    const int cg = threadIdx.x % CGS, lane = threadIdx.x / CGS;
+    const int c = (int)cb * ST_CB + cg * 4;
+    const bool cok = c < c_all;
+    const int iy_beg = (int)cy * chunk_rows;                    // multiple of 8
+    const int iy_end = iy_beg + chunk_rows < h ? iy_beg + chunk_rows : h;
+    const int ix0 = (int)sx * TW;
+    const int oy_base = iy_beg / 2, ox_base = ix0 / 2;          // dy pixel of ring row 0 / slab column 0
+    const int nsteps = (iy_end - iy_beg + R - 1) / R;
+
+    float4 pf[PF];
+    float pm[PF];
+    auto fetch = [&](int rr0, int cnt) {
+        const int oyb = oy_base + rr0;
+        const int64_t pixbase = (n * ho + oyb) * (int64_t)wo + ox_base;
+        const float* __restrict__ src = dy + pixbase * c_all + c;
+        const float* __restrict__ psrc = inv != nullptr ? inv + pixbase : nullptr;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int p = lane + LANES * i;
+            const int row = p / PW, px = p - row * PW;
+            const int oy = oyb + row, ox = ox_base + px;
+            pf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            pm[i] = 0.f;
+            if (row < cnt && cok && oy < ho && ox < wo) {
+                const int off = row * wo + px;
+                pf[i] = *reinterpret_cast<const float4*>(src + off * c_all);
+                pm[i] = psrc != nullptr ? psrc[off] : 1.f;
+            }
+        }
+    };
+    auto commit = [&](int rr0, int cnt) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int p = lane + LANES * i;
+            const int row = p / PW, px = p - row * PW;
+            if (row >= cnt) continue;
+            float4 v = pf[i];
+            const float m = pm[i];
+            v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+            *reinterpret_cast<float4*>(ring + (((rr0 + row) % NR) * PW + px) * ST_CB + cg * 4) = v;
+        }
+    };
+    float pl0 = 1.f;
+    auto fetch_planes = [&](int s) {
+        if (threadIdx.x < NPX) {
+            const int iy = iy_beg + R * s + (int)threadIdx.x / TW, ix = ix0 + (int)threadIdx.x % TW;
+            const bool ok = iy < iy_end && ix < w_in;
+            pl0 = (rmask != nullptr && ok) ? rmask[(n * h + iy) * (int64_t)w_in + ix] : 1.f;
+        }
+    };
+    auto commit_planes = [&](int s) {
+        if (threadIdx.x < NPX) planes[s & 1][threadIdx.x] = pl0;
+    };
+
+    // this thread's pixels: column tx, rows ty0 + 2k -> fixed parity; candidate taps (A, B) per axis
+    const int tx = lane % TW, ty0 = lane / TW;
+    const bool xok = cok && ix0 + tx < w_in;
+    const bool ey = ((ty0 + 1) & 1) == 0, ex = ((tx + 1) & 1) == 0;   // (i + pad) even: taps 0 and 2, else tap 1 only
+    const int kyA = ey ? 0 : 1, kyB = ey ? 2 : 1, kxA = ex ? 0 : 1, kxB = ex ? 2 : 1;
+    float4 wAA = make_float4(0.f, 0.f, 0.f, 0.f), wAB = wAA, wBA = wAA, wBB = wAA;
+    if (cok) {
+        wAA = *reinterpret_cast<const float4*>(wT + (kyA * 3 + kxA) * c_all + c);
+        if (ex) wAB = *reinterpret_cast<const float4*>(wT + (kyA * 3 + kxB) * c_all + c);
+        if (ey) wBA = *reinterpret_cast<const float4*>(wT + (kyB * 3 + kxA) * c_all + c);
+        if (ey && ex) wBB = *reinterpret_cast<const float4*>(wT + (kyB * 3 + kxB) * c_all + c);
+    }
+    const int cxA = (tx + 1 - kxA) / 2, cxB = (tx + 1 - kxB) / 2;     // slab columns of the two candidates
+
+    fetch_planes(0);
+    fetch(0, PRO);
+    commit(0, PRO);
+    fetch(PRO, NEW);
+    commit(PRO, NEW);
+    commit_planes(0);
+    __syncthreads();
+
+    for (int s = 0; s < nsteps; ++s) {
+        const bool more = s + 1 < nsteps;
+        if (more) { fetch(PRO + NEW * (s + 1), NEW); fetch_planes(s + 1); }
+        const int iyb = iy_beg + R * s;
+        float* __restrict__ out_b = dx + ((n * h + iyb) * (int64_t)w_in + ix0) * c_all + c;
+        const float* __restrict__ pls = &planes[s & 1][0];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int ty = ty0 + 2 * k;
+            if (!(xok && iyb + ty < iy_end)) continue;
+            const int rA = (4 * s + (ty + 1 - kyA) / 2) % NR, rB = (4 * s + (ty + 1 - kyB) / 2) % NR;
+            const float4 vAA = *reinterpret_cast<const float4*>(ring + (rA * PW + cxA) * ST_CB + cg * 4);
+            const float4 vAB = *reinterpret_cast<const float4*>(ring + (rA * PW + cxB) * ST_CB + cg * 4);
+            const float4 vBA = *reinterpret_cast<const float4*>(ring + (rB * PW + cxA) * ST_CB + cg * 4);
+            const float4 vBB = *reinterpret_cast<const float4*>(ring + (rB * PW + cxB) * ST_CB + cg * 4);
+            float4 a;
+            a.x = fmaf(vAA.x, wAA.x, fmaf(vAB.x, wAB.x, fmaf(vBA.x, wBA.x, vBB.x * wBB.x)));
+            a.y = fmaf(vAA.y, wAA.y, fmaf(vAB.y, wAB.y, fmaf(vBA.y, wBA.y, vBB.y * wBB.y)));
+            a.z = fmaf(vAA.z, wAA.z, fmaf(vAB.z, wAB.z, fmaf(vBA.z, wBA.z, vBB.z * wBB.z)));
+            a.w = fmaf(vAA.w, wAA.w, fmaf(vAB.w, wAB.w, fmaf(vBA.w, wBA.w, vBB.w * wBB.w)));
+            const float pmk = pls[ty * TW + tx];
+            a.x = pmk != 0.f ? a.x * pmk : 0.f; a.y = pmk != 0.f ? a.y * pmk : 0.f;
+            a.z = pmk != 0.f ? a.z * pmk : 0.f; a.w = pmk != 0.f ? a.w * pmk : 0.f;
+            *reinterpret_cast<float4*>(out_b + (ty * w_in + tx) * c_all) = a;
+        }
+        __syncthreads();
+        if (more) { commit(PRO + NEW * (s + 1), NEW); commit_planes(s + 1); }
+        __syncthreads();
+    }
+}
+
 struct StripPlan {
     bool ok;
     int chunk_rows;
@@ -590,8 +722,8 @@ struct StripPlan {
 };
 static StripPlan plan_strip(int n, int hout, int wout, int c, int s, int d) {
     StripPlan p;
-    p.ok = (s == 1 && d >= 1 && d <= 2 && c % 4 == 0);
-    p.strips_x = cdiv(wout, ST_TW);
+    p.ok = ((s == 1 && d >= 1 && d <= 2) || (s == 2 && d == 1)) && c % 4 == 0;
+    p.strips_x = cdiv(wout, ST_TW / (s == 2 ? 2 : 1));
     p.cblocks = cdiv(c, ST_CB);
     const int64_t per_chunk = (int64_t)p.strips_x * p.cblocks * n;
     int64_t want = cdiv64(1536, per_chunk);                  // ~6 blocks per CU
@@ -637,11 +769,14 @@ static int try_launch_dw_tile(const float* in, const float* pre, const float* wT
         const int64_t nblk = (int64_t)sp.strips_x * sp.chunks_y * sp.cblocks * g.n;
         const dim3 grid((unsigned)nblk);
         const bool fused = ib.sc != nullptr || stats != nullptr;
-        if (g.d == 1 && fused) hipLaunchKernelGGL((dw_strip_kernel<1, true>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+        if (g.s == 2 && !fused) hipLaunchKernelGGL((dw_strip_kernel<2, 1, false>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                                    sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, out);
+        else if (g.s == 2) return 1;
+        else if (g.d == 1 && fused) hipLaunchKernelGGL((dw_strip_kernel<1, 1, true>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
                                                   sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, out);
-        else if (g.d == 1) hipLaunchKernelGGL((dw_strip_kernel<1, false>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+        else if (g.d == 1) hipLaunchKernelGGL((dw_strip_kernel<1, 1, false>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
                                               sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, out);
-        else if (g.d == 2 && !fused) hipLaunchKernelGGL((dw_strip_kernel<2, false>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+        else if (g.d == 2 && !fused) hipLaunchKernelGGL((dw_strip_kernel<1, 2, false>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
                                                         sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, out);
         else return 1;
         return check_launch("dw_strip");
@@ -757,17 +892,22 @@ __global__ __launch_bounds__(256) void dw_tile_dw_kernel(const float* __restrict
 // ---- marching-strip dW (stride 1): same ring of x rows as dw_strip_kernel, the 9 taps x 4 channels (+ bias)
 // accumulate in registers over the whole strip; the next step's x rows AND dy pixels are in flight during the
 // multiply-accumulate of the current one.  One partial row per block, combined by dw_reduce_kernel.
-template <int D>
+template <int S, int D>
 __global__ __launch_bounds__(256, 2) void dw_strip_dw_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
                                                              const float* __restrict__ keep, const float* __restrict__ x,
                                                              const float* __restrict__ rmask, DtGeom g, int chunk_rows,
                                                              unsigned strips_x, unsigned chunks_y, unsigned cblocks, DwBN ib,
                                                              float* __restrict__ part) {
-    constexpr int PW = ST_TW + 2 * D, NR = ST_R + 2 * D;
-    constexpr int CGS = ST_CB / 4, LANES = 256 / CGS, NP = ST_R * ST_TW / LANES;
-    constexpr int PF = (ST_R * PW + LANES - 1) / LANES;
-    constexpr int NPX = ST_R * ST_TW;
-    __shared__ __attribute__((aligned(16))) float ring[NR * PW * ST_CB];
+    constexpr int R = ST_R / S, TW = ST_TW / S;
+    constexpr int PW = (TW - 1) * S + 2 * D + 1, NR = (R - 1) * S + 2 * D + 1;
+    constexpr int NEW = R * S, PRO = NR - NEW;
+    constexpr int CGS = ST_CB / 4, LANES = 256 / CGS, NP = R * TW / LANES;
+    constexpr int PF = (NEW * PW + LANES - 1) / LANES;
+    constexpr int NPX = R * TW;
+    constexpr int TYS = LANES / TW;
+    static_assert(PRO >= 0 && PRO <= NEW, "the prologue fetch covers the halo rows");
+    constexpr int RING = NR * PW * ST_CB > 5 * 256 * 4 ? NR * PW * ST_CB : 5 * 256 * 4;   // also the final lane-combine buffer
+    __shared__ __attribute__((aligned(16))) float ring[RING];
     __shared__ float planes[2][2][NPX];                        // keep / inv of a step's pixels, double buffered
     const unsigned cb = blockIdx.x % cblocks;
     unsigned b = blockIdx.x / cblocks;                         // partial row index
@@ -780,9 +920,9 @@ __global__ __launch_bounds__(256, 2) void dw_strip_dw_kernel(const float* __rest
     const bool cok = c < g.c;
     const int oy_beg = (int)cy * chunk_rows;
     const int oy_end = oy_beg + chunk_rows < g.hout ? oy_beg + chunk_rows : g.hout;
-    const int ox0 = (int)sx * ST_TW;
-    const int iy_base = oy_beg - g.pad_h, ix0 = ox0 - g.pad_w;
-    const int nsteps = (oy_end - oy_beg + ST_R - 1) / ST_R;
+    const int ox0 = (int)sx * TW;
+    const int iy_base = oy_beg * S - g.pad_h, ix0 = ox0 * S - g.pad_w;
+    const int nsteps = (oy_end - oy_beg + R - 1) / R;
 
     float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool bn_in = ib.sc != nullptr;
@@ -825,22 +965,22 @@ __global__ __launch_bounds__(256, 2) void dw_strip_dw_kernel(const float* __rest
             *reinterpret_cast<float4*>(ring + (((rr0 + row) % NR) * PW + px) * ST_CB + cg * 4) = v;
         }
     };
-    const int tx = lane % ST_TW, ty0 = lane / ST_TW;
+    const int tx = lane % TW, ty0 = lane / TW;
     const bool xok = cok && ox0 + tx < g.wout;
     // dy of this thread's 4 pixels for step s, and the keep / inv planes (threads 0..127: one pixel each)
     float4 gn[NP];
     float pl0 = 0.f, pl1 = 0.f;
     auto fetch_dy = [&](int s) {
-        const int oyb = oy_beg + ST_R * s;
+        const int oyb = oy_beg + R * s;
         const float* __restrict__ src = dy + ((n * g.hout + oyb) * (int64_t)g.wout + ox0) * g.c + c;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const int ty = ty0 + 2 * k;
+            const int ty = ty0 + TYS * k;
             gn[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (xok && oyb + ty < oy_end) gn[k] = *reinterpret_cast<const float4*>(src + (ty * g.wout + tx) * g.c);
         }
         if (threadIdx.x < NPX) {
-            const int oy = oyb + (int)threadIdx.x / ST_TW, ox = ox0 + (int)threadIdx.x % ST_TW;
+            const int oy = oyb + (int)threadIdx.x / TW, ox = ox0 + (int)threadIdx.x % TW;
             pl0 = 0.f; pl1 = 0.f;                              // out of range: no gradient
             if (oy < oy_end && ox < g.wout) {
                 const int64_t q = (n * g.hout + oy) * (int64_t)g.wout + ox;
@@ -858,10 +998,10 @@ __global__ __launch_bounds__(256, 2) void dw_strip_dw_kernel(const float* __rest
     for (int t = 0; t < 10; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     fetch_dy(0);
-    fetch(0, 2 * D);
-    commit(0, 2 * D);
-    fetch(2 * D, ST_R);
-    commit(2 * D, ST_R);
+    fetch(0, PRO);
+    commit(0, PRO);
+    fetch(PRO, NEW);
+    commit(PRO, NEW);
     commit_planes(0);
     __syncthreads();
 
@@ -870,13 +1010,13 @@ __global__ __launch_bounds__(256, 2) void dw_strip_dw_kernel(const float* __rest
         float4 gv[NP];
 #pragma unroll
         for (int k = 0; k < NP; ++k) gv[k] = gn[k];
-        if (more) { fetch(2 * D + ST_R * (s + 1), ST_R); fetch_dy(s + 1); }
+        if (more) { fetch(PRO + NEW * (s + 1), NEW); fetch_dy(s + 1); }
         const float* __restrict__ pls = &planes[s & 1][0][0];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             __builtin_amdgcn_sched_barrier(0);             // one pixel's 9 LDS reads in flight at a time (VGPR budget)
-            const int ty = ty0 + 2 * k;
-            const int pp = ty * ST_TW + tx;
+            const int ty = ty0 + TYS * k;
+            const int pp = ty * TW + tx;
             if (pls[pp] == 0.f) continue;                  // hole / out of range: no gradient (partial_convolution.py:72)
             float4 gq = gv[k];
             acc[9].x += gq.x; acc[9].y += gq.y; acc[9].z += gq.z; acc[9].w += gq.w;   // bias: added after the division
@@ -884,7 +1024,7 @@ __global__ __launch_bounds__(256, 2) void dw_strip_dw_kernel(const float* __rest
             gq.x *= sc; gq.y *= sc; gq.z *= sc; gq.w *= sc;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const float* rp = ring + (((ST_R * s + ty + ky * D) % NR) * PW + tx) * ST_CB + cg * 4;
+                const float* rp = ring + ((((R * s + ty) * S + ky * D) % NR) * PW + tx * S) * ST_CB + cg * 4;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const float4 v = *reinterpret_cast<const float4*>(rp + kx * D * ST_CB);
@@ -894,12 +1034,11 @@ __global__ __launch_bounds__(256, 2) void dw_strip_dw_kernel(const float* __rest
             }
         }
         __syncthreads();
-        if (more) { commit(2 * D + ST_R * (s + 1), ST_R); commit_planes(s + 1); }
+        if (more) { commit(PRO + NEW * (s + 1), NEW); commit_planes(s + 1); }
         __syncthreads();
     }
     // combine the 32 pixel lanes through the (free) ring: [10 taps][256 threads] float4, then 80 threads per ... sum
     float4* red4 = reinterpret_cast<float4*>(ring);
-    static_assert(10 * 256 * 4 <= 2 * NR * PW * ST_CB, "two passes of 5 taps fit the ring");
     float* prow = part + (int64_t)prow_idx * 10 * g.c;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -1079,6 +1218,15 @@ extern "C" int tsii_dw_bwd_dx(const float* dy, const float* inv, const float* w,
         rc = try_launch_dw_tile(dy, inv, ws, nullptr, nullptr, nullptr, rmask, tg, dx, st);
         if (rc <= 0) return rc;
     }
+    if (vec && kh == 3 && kw == 3 && sh == 2 && sw == 2 && dh == 1 && dw == 1 && ph == 1 && pw == 1) {   // marching strips
+        const StripPlan sp = plan_strip(n, h, wd, c, 1, 1);     // strips of the input grid
+        if (sp.ok) {
+            const int64_t nblk2 = (int64_t)sp.strips_x * sp.chunks_y * sp.cblocks * n;
+            hipLaunchKernelGGL(dw_strip_dx2_kernel, dim3((unsigned)nblk2), dim3(256), 0, st, dy, inv, ws, rmask, n, h, wd, c, ho, wo,
+                               sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, dx);
+            return check_launch("dw_strip_dx2");
+        }
+    }
     const bool k3 = false;  // see dw_fwd
     const int px = (vec && k3) ? DwPx<true>::value : DwPx<false>::value;
     const int64_t nblk = (int64_t)cdiv(cdiv(wd, px) * (vec ? c / 4 : c), 256) * h * n;
@@ -1098,9 +1246,11 @@ extern "C" size_t tsii_dw_bwd_dw_ws_bytes(int n, int ho, int wo, int c, int kh, 
     if (kh == 3 && kw == 3) {   // LDS-tiled plan (any stride/dilation: upper bound over both) and the strip plan
         const int g1 = (int)plan_dt_dw(n, ho, wo, c, 1, 1).groups;
         if (g1 > R) R = g1;
-        const StripPlan sp = plan_strip(n, ho, wo, c, 1, 1);
-        const int64_t g2 = (int64_t)n * sp.chunks_y * sp.strips_x;
-        if (g2 > R) R = (int)g2;
+        for (int ss = 1; ss <= 2; ++ss) {       // strip plans of both strides (the stride is not part of this signature)
+            const StripPlan sp = plan_strip(n, ho, wo, c, ss, 1);
+            const int64_t g2 = (int64_t)n * sp.chunks_y * sp.strips_x;
+            if (g2 > R) R = (int)g2;
+        }
     }
     return (size_t)R * (size_t)(kh * kw + 1) * c * sizeof(float);
 }
@@ -1116,15 +1266,18 @@ static int dw_bwd_dw_impl(const float* dy, const float* inv, const float* keep, 
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (c % 4 == 0) && aligned16(dy) && aligned16(x) && (ib.sc == nullptr || (aligned16(ib.sc) && aligned16(ib.sh)));
     float* part = (float*)ws;
-    if (vec && kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == dw && (dh == 1 || (dh == 2 && ib.sc == nullptr))) {
-        const StripPlan sp = plan_strip(n, ho, wo, c, 1, dh);   // marching strips
+    if (vec && kh == 3 && kw == 3 && sh == sw && dh == dw &&
+        ((sh == 1 && (dh == 1 || (dh == 2 && ib.sc == nullptr))) || (sh == 2 && dh == 1 && ib.sc == nullptr))) {
+        const StripPlan sp = plan_strip(n, ho, wo, c, sh, dh);   // marching strips
         if (sp.ok) {
-            DtGeom tg = {n, h, wd, c, 1, dh, ph, pw, ho, wo, 0};
+            DtGeom tg = {n, h, wd, c, sh, dh, ph, pw, ho, wo, 0};
             const unsigned rows = (unsigned)n * sp.chunks_y * sp.strips_x;
             const dim3 grid(rows * sp.cblocks);
-            if (dh == 1) hipLaunchKernelGGL((dw_strip_dw_kernel<1>), grid, dim3(256), 0, st, dy, inv, keep, x, rmask, tg, sp.chunk_rows,
+            if (sh == 2) hipLaunchKernelGGL((dw_strip_dw_kernel<2, 1>), grid, dim3(256), 0, st, dy, inv, keep, x, rmask, tg, sp.chunk_rows,
                                             sp.strips_x, sp.chunks_y, sp.cblocks, ib, part);
-            else hipLaunchKernelGGL((dw_strip_dw_kernel<2>), grid, dim3(256), 0, st, dy, inv, keep, x, rmask, tg, sp.chunk_rows,
+            else if (dh == 1) hipLaunchKernelGGL((dw_strip_dw_kernel<1, 1>), grid, dim3(256), 0, st, dy, inv, keep, x, rmask, tg, sp.chunk_rows,
+                                                 sp.strips_x, sp.chunks_y, sp.cblocks, ib, part);
+            else hipLaunchKernelGGL((dw_strip_dw_kernel<1, 2>), grid, dim3(256), 0, st, dy, inv, keep, x, rmask, tg, sp.chunk_rows,
                                     sp.strips_x, sp.chunks_y, sp.cblocks, ib, part);
             int rc0 = check_launch("dw_strip_dw");
             if (rc0) return rc0;

@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
                 if (k < K) { psc = *reinterpret_cast<const float4*>(ib.sc + k); psh = *reinterpret_cast<const float4*>(ib.sh + k); }
             }
         }
+        __builtin_amdgcn_s_setprio(2);   // MFMA phase first: the other waves' load / store phases fill the gaps
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             float a[TM][4], b[TN][4];
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
                     for (int u = 0; u < TN; ++u)
                         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[u][j], acc[t][u], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         if (more) {
             if constexpr (BNIN) nt_store_bn<BM>(As, ra, (kt + 1) * GEMM_BK, as.split, sa0, sa1, psc, psh, ib.neg, ib.hi);
@@ -669,6 +671,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
             if constexpr (BCONV != 0) conv_tn_load<BN, BCONV == 2>(B, cg, mt + GEMM_BK, mend, q0, Q, rb, gb0, gb1);
             else tn_load<BN, VEC>(B, ldb, mt + GEMM_BK, mend, q0, Q, nullptr, sb, rb, fb0, fb1);
         }
+        __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int kk = 0; kk < GEMM_BK / 2; ++kk) {
             float a[TM], b[TN];
@@ -682,6 +685,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
                 for (int u = 0; u < TN; ++u)
                     acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[u], acc[t][u], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         if (more) {
             tn_store<BM>(As, ra, p0, 0, false, fa0, fa1);
