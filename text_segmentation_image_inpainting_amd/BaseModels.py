@@ -106,10 +106,17 @@ def act_code(act):
 # forward() to the HIP kernels.  Tensors between modules are NCHW-shaped with channels_last memory,
 # so the NHWC views the kernels want are free.
 class Conv2d(nn.Conv2d):
+    bn_follows = False    # set by Conv_block: the conv also emits the BatchNorm statistics partials of its output (K6b)
+
     def forward(self, x):
         if self.padding_mode != "zeros":
             raise NotImplementedError("only zero padding has a HIP kernel")
         g = ops.make_geom(self.kernel_size, self.stride, self.padding, self.dilation)
+        if self.bn_follows and self.training:
+            y, part = ops.conv2d(to_nhwc(x), self.weight, self.bias, g, self.groups, want_stats=True)
+            out = to_nchw(y)
+            out._tsii_stat_part = part     # picked up by the BNAct that nn.Sequential calls next with this very object
+            return out
         return to_nchw(ops.conv2d(to_nhwc(x), self.weight, self.bias, g, self.groups))
 
 
@@ -124,8 +131,9 @@ class BNAct(nn.Sequential):
             bn.num_batches_tracked.add_(1)
         momentum = 0.1 if bn.momentum is None else bn.momentum
         res = None if residual is None else to_nhwc(residual)
+        part = getattr(x, "_tsii_stat_part", None) if training else None
         y = ops.bn_act(to_nhwc(x), bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps,
-                       act, slope, res)
+                       act, slope, res, part)
         return to_nchw(y)
 
 
@@ -176,6 +184,7 @@ def cat_channels(xs):
 def Conv_block(in_channels, out_channels, kernel_size, stride=1, padding=0,
                dilation=1, groups=1, bias=True, BN=False, activation=None):
     m = [Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)]
+    m[0].bn_follows = bool(BN)
     if BN:
         if activation:
             m += [BNAct(nn.BatchNorm2d(out_channels), activation)]

@@ -299,7 +299,7 @@ def pconv_dense(x, w, bias, mfull, r0, split, r1, denom, keep, inv, g: Geom):
 # ---------------------------------------------------------------------------------------
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, slope):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, slope, part=None):
         _lib.check_device(y)
         y = y.contiguous()
         c = y.shape[-1]
@@ -308,10 +308,17 @@ class _BNAct(torch.autograd.Function):
         if training:
             mean = torch.empty(c, dtype=torch.float32, device=y.device)
             var = torch.empty(c, dtype=torch.float32, device=y.device)
-            nbytes = _lib.lib().tsii_bn_ws_bytes(m, c)
-            ws = _ws(nbytes, y)
-            call("tsii_bn_stats", ptr(y), m, c, ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
-                 float(momentum), ptr(ws), nbytes, st)
+            if part is not None:      # statistics from the partials the producing conv left behind (K6b)
+                rows = part.shape[0]
+                nbytes = _lib.lib().tsii_bn_finalize_ws_bytes(rows, c)
+                ws = _ws(nbytes, y)
+                call("tsii_bn_finalize", ptr(part), rows, c, m, ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
+                     float(momentum), None, None, float(eps), None, None, ptr(ws), nbytes, st)
+            else:
+                nbytes = _lib.lib().tsii_bn_ws_bytes(m, c)
+                ws = _ws(nbytes, y)
+                call("tsii_bn_stats", ptr(y), m, c, ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
+                     float(momentum), ptr(ws), nbytes, st)
         else:
             mean, var = running_mean, running_var
         residual = _c(residual)
@@ -336,12 +343,12 @@ class _BNAct(torch.autograd.Function):
         ws = _ws(nbytes, y)
         call("tsii_bn_act_bwd", ptr(gout), ptr(y), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), eps, act,
              slope, int(training), ptr(dy), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _lib.stream())
-        return dy, dgamma, dbeta, None, None, (gout if has_res else None), None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, (gout if has_res else None), None, None, None, None, None, None
 
 
 def bn_act(y, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5,
-           act=ACT_NONE, slope=0.0, residual=None):
-    return _BNAct.apply(y, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, slope)
+           act=ACT_NONE, slope=0.0, residual=None, part=None):
+    return _BNAct.apply(y, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, slope, part)
 
 
 def load_time_act(act, slope) -> bool:
@@ -598,15 +605,17 @@ def sgd_nesterov_(p, grad, buf, lr, momentum, weight_decay):
 # ---------------------------------------------------------------------------------------
 # segmentation path (models/common.py, models/text_segmentation.py, loss.py:58-83)
 # ---------------------------------------------------------------------------------------
-def conv2d(x, w, b, g: Geom, groups: int):
-    """Plain nn.Conv2d on NHWC data through the partial-conv kernels with no mask planes."""
+def conv2d(x, w, b, g: Geom, groups: int, want_stats=False):
+    """Plain nn.Conv2d on NHWC data through the partial-conv kernels with no mask planes.  With ``want_stats``
+    returns (y, stat_part or None): the BatchNorm partials of y when the kernel taken can emit them (K6b)."""
     cin, cout = x.shape[-1], w.shape[0]
     if groups == 1:
         if tuple(g)[:6] == (1, 1, 1, 1, 0, 0):
-            return pconv_pointwise(x, w, b)
-        return pconv_dense(x, w, b, None, None, 0, None, None, None, None, g)
+            return pconv_pointwise(x, w, b, want_stats=want_stats)
+        y = pconv_dense(x, w, b, None, None, 0, None, None, None, None, g)
+        return (y, None) if want_stats else y
     if groups == cin == cout:
-        return pconv_depthwise(x, w, b, None, None, None, None, g)
+        return pconv_depthwise(x, w, b, None, None, None, None, g, want_stats=want_stats)
     raise NotImplementedError(f"conv2d groups={groups} (neither 1 nor depth-wise) has no HIP kernel")
 
 
