@@ -168,6 +168,16 @@ def main():
             print(f"[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); reporting the eager loop", file=sys.stderr)
             sync()
     final_loss = float(loss.item())
+    # forward-only rate (SURVEY.md 8(d) asks for both): train-mode BatchNorm forward + loss, no autograd tape
+    fwd_steps = max(2, args.steps // 2)
+    with torch.no_grad():
+        trainer.loss_fn(model((corrupted, mask)), clean_nhwc)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(fwd_steps):
+            trainer.loss_fn(model((corrupted, mask)), clean_nhwc)
+        sync()
+        fwd_elapsed = time.perf_counter() - t1
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -222,6 +232,8 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
             "roofline": roofline, "whole_step_roofline": whole, "final_loss": final_loss,
             "launch": "hip_graph_replay" if graphed else "eager", "eager_ms_per_step": round(eager_ms, 3),
+            "forward_only": {"value": round(world * args.batch * fwd_steps / fwd_elapsed, 2), "unit": "imgs/s (rank 0 clock)",
+                             "ms_per_step": round(fwd_elapsed / fwd_steps * 1e3, 3), "steps": fwd_steps},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.size, args.cpu_threads or min(os.cpu_count() or 1, 32))
