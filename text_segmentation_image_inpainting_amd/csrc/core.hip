@@ -25,16 +25,32 @@ int check_launch(const char* what) {
 }
 
 // ---- out[j] = sum_r ws[r][j] -------------------------------------------------
-__global__ void reduce_rows_kernel(const float* __restrict__ ws, int rows, int64_t len, float* __restrict__ out) {
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < len; j += (int64_t)gridDim.x * blockDim.x) {
-        double acc = 0.0;
-        for (int r = 0; r < rows; ++r) acc += (double)ws[(int64_t)r * len + j];
-        out[j] = (float)acc;
+// block = 64 columns x 4 row lanes, 4 independent loads in flight per lane (one thread per column walking up to 1024
+// rows serially measured 52 us per call, 1.7 ms per step)
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ ws, int rows, int64_t len, float* __restrict__ out) {
+    __shared__ double sh[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int64_t j0 = (int64_t)blockIdx.x * 64; j0 < len; j0 += (int64_t)gridDim.x * 64) {
+        const int64_t j = j0 + tx;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        if (j < len) {
+            for (int r = ty; r < rows; r += 16) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int rr = r + 4 * u;
+                    if (rr < rows) a[u] += (double)ws[(int64_t)rr * len + j];
+                }
+            }
+        }
+        __syncthreads();
+        sh[ty][tx] = (a[0] + a[1]) + (a[2] + a[3]);
+        __syncthreads();
+        if (ty == 0 && j < len) out[j] = (float)((sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]));
     }
 }
 
 int launch_reduce_rows(const float* ws, int rows, int64_t len, float* out, hipStream_t stream) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(stream_grid(len, 256)), dim3(256), 0, stream, ws, rows, len, out);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(stream_grid(cdiv64(len, 64) * 256, 256)), dim3(256), 0, stream, ws, rows, len, out);
     return check_launch("reduce_rows");
 }
 

@@ -114,6 +114,7 @@ class _Pointwise(torch.autograd.Function):
                  _lib.stream())
         ctx.save_for_backward(x, w, r0, r1, inv, keep, in_scale, in_shift)
         ctx.split, ctx.has_bias, ctx.in_cfg = int(split), bias is not None, (int(in_act), float(in_slope))
+        ctx.set_materialize_grads(False)   # no zero tensors for the statistics output (one tiny fill kernel each otherwise)
         if want_stats:
             ctx.mark_non_differentiable(part)
             return y, part
@@ -121,6 +122,8 @@ class _Pointwise(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, *_):
+        if gy is None:
+            return (None,) * 14
         x, w, r0, r1, inv, keep, in_scale, in_shift = ctx.saved_tensors
         gy = gy.contiguous()
         n, h, wd, k = x.shape
@@ -192,6 +195,7 @@ class _Depthwise(torch.autograd.Function):
                  _lib.stream())
         ctx.save_for_backward(x, w, rmask, inv, keep, in_scale, in_shift)
         ctx.g, ctx.has_bias, ctx.in_cfg = g, bias is not None, (int(in_act), float(in_slope))
+        ctx.set_materialize_grads(False)
         if want_stats:
             ctx.mark_non_differentiable(part)
             return y, part
@@ -199,6 +203,8 @@ class _Depthwise(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, *_):
+        if gy is None:
+            return (None,) * 13
         x, w, rmask, inv, keep, in_scale, in_shift = ctx.saved_tensors
         g = ctx.g
         gy = gy.contiguous()
@@ -414,10 +420,13 @@ class _BNLazy(torch.autograd.Function):
         ctx.cfg = (bool(training), float(eps), int(act), float(slope))
         token = y.detach()          # same storage, fresh autograd identity
         ctx.mark_non_differentiable(scale, shift, mean, var)
+        ctx.set_materialize_grads(False)
         return token, scale, shift, mean, var
 
     @staticmethod
     def backward(ctx, ga, *_):
+        if ga is None:
+            return (None,) * 11
         y, mean, var, gamma, beta = ctx.saved_tensors
         training, eps, act, slope = ctx.cfg
         ga = ga.contiguous()
