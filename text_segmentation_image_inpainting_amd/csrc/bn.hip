@@ -475,6 +475,36 @@ extern "C" int tsii_bn_act_bwd(const float* dout, const float* y, int64_t m, int
     return check_launch("bn_bwd_apply");
 }
 
+extern "C" int tsii_bn_act_bwd_pre(const float* dout, const float* y, int64_t m, int c, const float* mean,
+                                   const float* var, const float* gamma, const float* beta, float eps, int act,
+                                   float slope, int training, const float* bwd_part, int64_t rows, float* dy,
+                                   float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(dout && y && mean && var && gamma && beta && dy && dgamma && dbeta && bwd_part && ws, "bn_act_bwd_pre: null pointer");
+    TSII_REQUIRE(m > 0 && c > 0 && rows > 0 && rows < (1ll << 31), "bn_act_bwd_pre: bad shape");
+    TSII_REQUIRE(ws_bytes >= (size_t)cdiv64(rows, BN_L1_ROWS) * 2 * c * sizeof(double) + 16, "bn_act_bwd_pre: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int R = (int)rows;
+    int rc;
+    if (R > BN_L1_ROWS) {
+        double* l1 = (double*)(((uintptr_t)ws + 7) & ~(uintptr_t)7);
+        const int chunks = cdiv(R, BN_L1_ROWS);
+        hipLaunchKernelGGL(part2_l1_kernel, dim3(cdiv(c, 32), chunks), dim3(256), 0, st, bwd_part, R, c, l1);
+        rc = check_launch("bn_part_l1");
+        if (rc) return rc;
+        hipLaunchKernelGGL((bn_bwd_final_kernel<double>), dim3(cdiv(c, 32)), dim3(256), 0, st, (const double*)l1, chunks, c, dgamma, dbeta);
+    } else {
+        hipLaunchKernelGGL((bn_bwd_final_kernel<float>), dim3(cdiv(c, 32)), dim3(256), 0, st, bwd_part, R, c, dgamma, dbeta);
+    }
+    rc = check_launch("bn_bwd_final");
+    if (rc) return rc;
+    const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(dout) && aligned16(dy);
+    const int64_t total = m * (vec ? c / 4 : c);
+    const unsigned grid = chan_grid(total, vec ? c / 4 : c, 256);
+    if (vec) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(grid), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta, eps, act, slope, training, dgamma, dbeta, dy);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(grid), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta, eps, act, slope, training, dgamma, dbeta, dy);
+    return check_launch("bn_bwd_apply");
+}
+
 extern "C" int tsii_act_fwd(const float* x, int64_t numel, int act, float slope, float* out, void* stream) {
     TSII_REQUIRE(x && out && numel > 0, "act_fwd: bad arguments");
     TSII_REQUIRE(act >= 0 && act <= 4, "act_fwd: unknown activation %d", act);

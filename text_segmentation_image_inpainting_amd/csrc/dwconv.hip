@@ -238,6 +238,20 @@ struct DtGeom {
 // InBN (K6b) on the staged input: zero padding stays zero (it pads the activated tensor).
 typedef InBN DwBN;
 
+// dX mode of the strip kernel feeding a BatchNorm backward (K6c): the kernel's output IS the gradient w.r.t. the
+// normalised activation a = act(gamma*xhat+beta) of the raw tensor `y` (same grid as the output), so the two
+// reductions of the BatchNorm backward, sum(dz) and sum(dz*xhat) with dz = out*act'(z), are taken here per strip
+// instead of in a separate pass over (out, y).  part: [strip blocks][2][C].
+struct DwBnBwd {
+    const float* y;
+    const float* mean;
+    const float* var;
+    const float* gamma;
+    const float* beta;
+    float eps, neg, hi;
+    float* part;
+};
+
 template <int DT_TH, int DT_TW, int DT_CB, int DT_LDS_FLOATS>
 __global__ __launch_bounds__(256) void dw_tile_kernel(const float* __restrict__ in, const float* __restrict__ pre,
                                                       const float* __restrict__ wT, const float* __restrict__ bias,
@@ -395,11 +409,15 @@ static constexpr int ST_R = 8, ST_TW = 16, ST_CB = 32;
 #endif
 static constexpr int ST_UNROLL_K = ST_UNROLL;   // pixels of a thread processed together (all 4: ~150 VGPRs of LDS data in flight)
 
-template <int S, int D, bool FUSED>   // stride, dilation; FUSED: BatchNorm on load and / or statistics partials (either may be off at run time)
-__global__ __launch_bounds__(256, FUSED ? 2 : 3) void dw_strip_kernel(
+// MODE 0: plain; 1: forward with BatchNorm on load and / or statistics partials (K6b; either may be off at run time);
+// 2: dX feeding a BatchNorm backward (K6c)
+template <int S, int D, int MODE>
+__global__ __launch_bounds__(256, MODE != 0 ? 2 : 3) void dw_strip_kernel(
     const float* __restrict__ in, const float* __restrict__ pre, const float* __restrict__ wT, const float* __restrict__ bias,
     const float* __restrict__ denom, const float* __restrict__ keep, const float* __restrict__ post_mul, DtGeom g, int chunk_rows,
-    unsigned strips_x, unsigned chunks_y, unsigned cblocks, DwBN ib, float* __restrict__ stats, float* __restrict__ out) {
+    unsigned strips_x, unsigned chunks_y, unsigned cblocks, DwBN ib, float* __restrict__ stats, DwBnBwd bb,
+    float* __restrict__ out) {
+    constexpr bool FUSED = (MODE == 1), BNB = (MODE == 2);
     constexpr int R = ST_R / S, TW = ST_TW / S;                 // output rows x columns per step: 8 x 16 at stride 1, 4 x 8 at stride 2
     constexpr int PW = (TW - 1) * S + 2 * D + 1, NR = (R - 1) * S + 2 * D + 1;
     constexpr int NEW = R * S, PRO = NR - NEW;                 // input rows a step brings in / rows the prologue adds first
@@ -435,6 +453,15 @@ __global__ __launch_bounds__(256, FUSED ? 2 : 3) void dw_strip_kernel(
         if (bias != nullptr) bq = make_float4(bias[c], bias[c + 1], bias[c + 2], bias[c + 3]);
     }
 
+    const bool bnb = BNB && bb.y != nullptr;
+    float4 bmu = make_float4(0.f, 0.f, 0.f, 0.f), bis = bmu, bga = bmu, bbe = bmu;
+    if (bnb && cok) {
+        bmu = *reinterpret_cast<const float4*>(bb.mean + c);
+        const float4 vv = *reinterpret_cast<const float4*>(bb.var + c);
+        bis = make_float4(1.0f / sqrtf(vv.x + bb.eps), 1.0f / sqrtf(vv.y + bb.eps), 1.0f / sqrtf(vv.z + bb.eps), 1.0f / sqrtf(vv.w + bb.eps));
+        bga = *reinterpret_cast<const float4*>(bb.gamma + c);
+        bbe = *reinterpret_cast<const float4*>(bb.beta + c);
+    }
     float4 pf[PF];
     float pm[PF];
     // global -> registers for ring rows [rr0, rr0 + cnt): slab pixel p = lane + 32 i -> (row, px); wave-uniform 64-bit
@@ -514,8 +541,20 @@ __global__ __launch_bounds__(256, FUSED ? 2 : 3) void dw_strip_kernel(
         const int oyb = oy_beg + R * s;
         float* __restrict__ out_b = out + ((n * g.hout + oyb) * (int64_t)g.wout + ox0) * g.c + c;
         const float* __restrict__ pls = &planes[s & 1][0][0];
-#pragma unroll ST_UNROLL_K
+        float4 yv[NP];                                       // K6c: raw BatchNorm input at this thread's output pixels
+        if (bnb) {
+            const float* __restrict__ y_b = bb.y + ((n * g.hout + oyb) * (int64_t)g.wout + ox0) * g.c + c;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int ty = ty0 + TYS * k;
+                yv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (xok && oyb + ty < oy_end) yv[k] = *reinterpret_cast<const float4*>(y_b + (ty * g.wout + tx) * g.c);
+            }
+        }
+        // two pixels' LDS reads in flight; K6c: fully unrolled (static yv[k]), one pixel at a time
+#pragma unroll (BNB ? NP : ST_UNROLL_K)
         for (int k = 0; k < NP; ++k) {
+            if (BNB) __builtin_amdgcn_sched_barrier(0);
             const int ty = ty0 + TYS * k;
             if (!(xok && oyb + ty < oy_end)) continue;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -539,6 +578,18 @@ __global__ __launch_bounds__(256, FUSED ? 2 : 3) void dw_strip_kernel(
             }
             if (keep != nullptr && pls[pp] == 0.f) a = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(out_b + (ty * g.wout + tx) * g.c) = a;
+            if (bnb) {
+                const float4 yq = yv[k];
+                const float hx = (yq.x - bmu.x) * bis.x, hy = (yq.y - bmu.y) * bis.y, hz = (yq.z - bmu.z) * bis.z, hw = (yq.w - bmu.w) * bis.w;
+                const float zx = fmaf(hx, bga.x, bbe.x), zy = fmaf(hy, bga.y, bbe.y), zz = fmaf(hz, bga.z, bbe.z), zw = fmaf(hw, bga.w, bbe.w);
+                const float dx = a.x * ((zx > 0.f && zx < bb.hi) ? 1.f : (zx > 0.f ? 0.f : bb.neg));
+                const float dy = a.y * ((zy > 0.f && zy < bb.hi) ? 1.f : (zy > 0.f ? 0.f : bb.neg));
+                const float dz = a.z * ((zz > 0.f && zz < bb.hi) ? 1.f : (zz > 0.f ? 0.f : bb.neg));
+                const float dw = a.w * ((zw > 0.f && zw < bb.hi) ? 1.f : (zw > 0.f ? 0.f : bb.neg));
+                vals[0] += dx; vals[1] += dy; vals[2] += dz; vals[3] += dw;
+                vals[4] = fmaf(dx, hx, vals[4]); vals[5] = fmaf(dy, hy, vals[5]);
+                vals[6] = fmaf(dz, hz, vals[6]); vals[7] = fmaf(dw, hw, vals[7]);
+            }
             if (FUSED && stats != nullptr) {
                 if (cnt == 0) P = a;
                 ++cnt;
@@ -552,7 +603,22 @@ __global__ __launch_bounds__(256, FUSED ? 2 : 3) void dw_strip_kernel(
         if (more) { commit(PRO + NEW * (s + 1), NEW); commit_planes(s + 1); }   // into the slots this step no longer needs
         __syncthreads();
     }
-    if (FUSED && stats != nullptr) {
+    if (bnb) {
+        float* mrg = ring;                                   // [256][8]
+        float* mt = mrg + threadIdx.x * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mt[i] = vals[i];
+        __syncthreads();
+        if (threadIdx.x < 2 * ST_CB) {
+            const int which = threadIdx.x / ST_CB, ch = threadIdx.x % ST_CB;
+            if ((int)cb * ST_CB + ch < g.c) {
+                float sum = 0.f;
+                for (int l = 0; l < LANES; ++l) sum += mrg[(l * CGS + ch / 4) * 8 + which * 4 + ch % 4];
+                const int64_t prow = (n * chunks_y + cy) * strips_x + sx;
+                bb.part[(prow * 2 + which) * g.c + (int)cb * ST_CB + ch] = sum;
+            }
+        }
+    } else if (FUSED && stats != nullptr) {
         // merge the 32 pixel lanes of every channel: (count, pivot, s1, s2) per thread through the (now free) ring,
         // re-based to the pivot of the first lane that saw a pixel:  s1' = s1 + n dp,  s2' = s2 + 2 dp s1 + n dp^2
         float* mrg = ring;                                   // [256][13]
@@ -738,6 +804,7 @@ static StripPlan plan_strip(int n, int hout, int wout, int c, int s, int d) {
 
 // -> 0 launched, 1 not applicable (caller falls back to the direct kernel), <0 error
 static const DwBN kNoDwBN = {nullptr, nullptr, 1.f, 0.f};
+static const DwBnBwd kNoBnBwd = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
 static constexpr int DT_TH0 = 8, DT_TW0 = 16;     // output tile of every variant (also the BatchNorm partial-row grain)
 
 template <int TH, int TW, int CB, int LDSF>
@@ -761,26 +828,29 @@ static bool dw_tile_fits(int s, int d) {   // patch fits the forward AND the dW 
 
 static int try_launch_dw_tile(const float* in, const float* pre, const float* wT, const float* bias, const float* denom,
                               const float* keep, const float* post_mul, DtGeom g, float* out, hipStream_t st,
-                              DwBN ib = kNoDwBN, float* stats = nullptr) {
+                              DwBN ib = kNoDwBN, float* stats = nullptr, DwBnBwd bb = kNoBnBwd) {
     if (g.c % 4 != 0 || !aligned16(in) || !aligned16(out) || !aligned16(wT)) return 1;
     if (ib.sc != nullptr && (!aligned16(ib.sc) || !aligned16(ib.sh))) return 1;
     const StripPlan sp = plan_strip(g.n, g.hout, g.wout, g.c, g.s, g.d);
     if (sp.ok) {
         const int64_t nblk = (int64_t)sp.strips_x * sp.chunks_y * sp.cblocks * g.n;
         const dim3 grid((unsigned)nblk);
-        const bool fused = ib.sc != nullptr || stats != nullptr;
-        if (g.s == 2 && !fused) hipLaunchKernelGGL((dw_strip_kernel<2, 1, false>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
-                                                    sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, out);
+        const bool fused = ib.sc != nullptr || stats != nullptr || bb.y != nullptr;
+        if (g.s == 2 && !fused) hipLaunchKernelGGL((dw_strip_kernel<2, 1, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                                    sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
         else if (g.s == 2) return 1;
-        else if (g.d == 1 && fused) hipLaunchKernelGGL((dw_strip_kernel<1, 1, true>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
-                                                  sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, out);
-        else if (g.d == 1) hipLaunchKernelGGL((dw_strip_kernel<1, 1, false>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
-                                              sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, out);
-        else if (g.d == 2 && !fused) hipLaunchKernelGGL((dw_strip_kernel<1, 2, false>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
-                                                        sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, out);
+        else if (g.d == 1 && bb.y != nullptr) hipLaunchKernelGGL((dw_strip_kernel<1, 1, 2>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                                                  sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
+        else if (g.d == 1 && fused) hipLaunchKernelGGL((dw_strip_kernel<1, 1, 1>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                                  sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
+        else if (g.d == 1) hipLaunchKernelGGL((dw_strip_kernel<1, 1, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                              sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
+        else if (g.d == 2 && !fused) hipLaunchKernelGGL((dw_strip_kernel<1, 2, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                                        sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
         else return 1;
         return check_launch("dw_strip");
     }
+    if (bb.y != nullptr) return 1;       // K6c only exists on the strip path
     int rc = launch_dw_tile_variant<DT_TH0, DT_TW0, 32, 6144>(in, pre, wT, bias, denom, keep, post_mul, g, ib, stats, out, st);
     if (rc == 1) rc = launch_dw_tile_variant<DT_TH0, DT_TW0, 32, 10240>(in, pre, wT, bias, denom, keep, post_mul, g, ib, stats, out, st);
     return rc;
@@ -1202,9 +1272,9 @@ extern "C" int tsii_dw_fwd_bn(const float* x, const float* rmask, const float* w
                        stream);
 }
 
-extern "C" int tsii_dw_bwd_dx(const float* dy, const float* inv, const float* w, const float* rmask,
-                              int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw,
-                              int dh, int dw, int ho, int wo, float* dx, float* ws, void* stream) {
+static int dw_bwd_dx_impl(const float* dy, const float* inv, const float* w, const float* rmask,
+                          int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw,
+                          int dh, int dw, int ho, int wo, DwBnBwd bb, float* dx, float* ws, void* stream) {
     TSII_REQUIRE(dy && w && dx && ws, "dw_bwd_dx: null pointer");
     DW_GEOM();
     if (check_geom(g, "dw_bwd_dx")) return -1;
@@ -1215,9 +1285,10 @@ extern "C" int tsii_dw_bwd_dx(const float* dy, const float* inv, const float* w,
     if (kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == dw) {
         // stride 1: dx[i] = rmask[i] * sum_t w[t] * (dy*inv)[i + pad - t*d] -- the forward stencil with flipped taps
         DtGeom tg = {n, ho, wo, c, 1, dh, 2 * dh - ph, 2 * dw - pw, h, wd, 1};
-        rc = try_launch_dw_tile(dy, inv, ws, nullptr, nullptr, nullptr, rmask, tg, dx, st);
+        rc = try_launch_dw_tile(dy, inv, ws, nullptr, nullptr, nullptr, rmask, tg, dx, st, kNoDwBN, nullptr, bb);
         if (rc <= 0) return rc;
     }
+    TSII_REQUIRE(bb.y == nullptr, "dw_bwd_dx_bn: the BatchNorm-backward form needs the marching-strip path (tsii_dw_stat_rows() > 0)");
     if (vec && kh == 3 && kw == 3 && sh == 2 && sw == 2 && dh == 1 && dw == 1 && ph == 1 && pw == 1) {   // marching strips
         const StripPlan sp = plan_strip(n, h, wd, c, 1, 1);     // strips of the input grid
         if (sp.ok) {
@@ -1236,6 +1307,27 @@ extern "C" int tsii_dw_bwd_dx(const float* dy, const float* inv, const float* w,
     else if (vec) hipLaunchKernelGGL((dw_bwd_dx_kernel<4, false>), grid, dim3(256), 0, st, dy, inv, ws, rmask, g, dx);
     else hipLaunchKernelGGL((dw_bwd_dx_kernel<1, false>), grid, dim3(256), 0, st, dy, inv, ws, rmask, g, dx);
     return check_launch("dw_bwd_dx");
+}
+
+extern "C" int tsii_dw_bwd_dx(const float* dy, const float* inv, const float* w, const float* rmask,
+                              int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw,
+                              int dh, int dw, int ho, int wo, float* dx, float* ws, void* stream) {
+    return dw_bwd_dx_impl(dy, inv, w, rmask, n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo, kNoBnBwd, dx, ws, stream);
+}
+
+extern "C" int tsii_dw_bwd_dx_bn(const float* dy, const float* inv, const float* w, const float* rmask,
+                                 int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw,
+                                 int dh, int dw, int ho, int wo,
+                                 const float* bn_y, const float* bn_mean, const float* bn_var, const float* bn_gamma,
+                                 const float* bn_beta, float bn_eps, int bn_act, float bn_slope,
+                                 float* dx, float* bwd_part, float* ws, void* stream) {
+    TSII_REQUIRE(bn_y && bn_mean && bn_var && bn_gamma && bn_beta && bwd_part, "dw_bwd_dx_bn: null pointer");
+    TSII_REQUIRE(aligned16(bn_y) && aligned16(bn_mean) && aligned16(bn_var) && aligned16(bn_gamma) && aligned16(bn_beta),
+                 "dw_bwd_dx_bn: BatchNorm operands must be 16-byte aligned");
+    InBN tmp;
+    TSII_REQUIRE(make_in_bn(bn_mean, bn_var, bn_act, bn_slope, &tmp) == 0, "dw_bwd_dx_bn: activation %d has no load-time form", bn_act);
+    const DwBnBwd bb = {bn_y, bn_mean, bn_var, bn_gamma, bn_beta, bn_eps, tmp.neg, tmp.hi, bwd_part};
+    return dw_bwd_dx_impl(dy, inv, w, rmask, n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo, bb, dx, ws, stream);
 }
 
 extern "C" size_t tsii_dw_bwd_dw_ws_bytes(int n, int ho, int wo, int c, int kh, int kw) {

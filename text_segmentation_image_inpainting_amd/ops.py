@@ -15,6 +15,11 @@ from ._lib import call, ptr
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3, 4
 
+import os as _os
+
+# A/B knob for K6c (BatchNorm-backward reductions taken by the kernel that produces the incoming gradient)
+FUSE_BN_BWD = _os.environ.get("TSII_FUSE_BN_BWD", "1") != "0"
+
 
 class Geom(NamedTuple):
     kh: int
@@ -155,6 +160,7 @@ def pconv_pointwise(x, w, bias=None, r0=None, split=0, r1=None, denom=None, keep
     with ``want_stats`` returns (y, stat_part)."""
     if isinstance(x, LazyBN):
         if x.token.shape[-1] % 4 == 0:
+            x.consumed()
             return _Pointwise.apply(x.token, w, bias, r0, r1, denom, keep, inv, split, x.scale, x.shift, x.act, x.slope,
                                     want_stats)
         x = x.materialize()
@@ -175,8 +181,9 @@ class _Depthwise(torch.autograd.Function):
     """See _Pointwise for in_scale / in_shift / want_stats (K6b)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, rmask, denom, keep, inv, g, in_scale, in_shift, in_act, in_slope, want_stats):
+    def forward(ctx, x, w, bias, rmask, denom, keep, inv, g, in_scale, in_shift, in_act, in_slope, want_stats, bn=None):
         _lib.check_device(x)
+        ctx.bn = bn     # (mean, var, gamma, beta, eps, slot) of the lazily applied producer BatchNorm (K6c) or None
         x, w = x.contiguous(), w.contiguous()
         n, h, wd, c = x.shape
         assert w.shape[0] == c and w.shape[1] == 1, "depth-wise weight must be [C,1,kh,kw]"
@@ -204,7 +211,7 @@ class _Depthwise(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, *_):
         if gy is None:
-            return (None,) * 13
+            return (None,) * 14
         x, w, rmask, inv, keep, in_scale, in_shift = ctx.saved_tensors
         g = ctx.g
         gy = gy.contiguous()
@@ -215,8 +222,19 @@ class _Depthwise(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             ws = _ws(4 * c * g.kh * g.kw, x)
-            call("tsii_dw_bwd_dx", ptr(gy), ptr(inv), ptr(w), ptr(rmask), n, h, wd, c, *g, ho, wo,
-                 ptr(dx), ptr(ws), st)
+            rows = 0
+            if ctx.bn is not None and FUSE_BN_BWD and load_time_act(*ctx.in_cfg):
+                rows = int(_lib.lib().tsii_dw_stat_rows(n, h, wd, c, g.kh, g.kw, g.sh, g.sw, g.dh, g.dw))   # strips of the dX grid
+            if rows > 0:
+                mean, var, gamma, beta, eps, slot = ctx.bn
+                part = torch.empty((rows, 2, c), dtype=torch.float32, device=x.device)
+                call("tsii_dw_bwd_dx_bn", ptr(gy), ptr(inv), ptr(w), ptr(rmask), n, h, wd, c, *g, ho, wo,
+                     ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ctx.in_cfg[0], ctx.in_cfg[1],
+                     ptr(dx), ptr(part), ptr(ws), st)
+                slot.part = part
+            else:
+                call("tsii_dw_bwd_dx", ptr(gy), ptr(inv), ptr(w), ptr(rmask), n, h, wd, c, *g, ho, wo,
+                     ptr(dx), ptr(ws), st)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(w)
             db = torch.empty(c, dtype=torch.float32, device=x.device) if ctx.has_bias else None
@@ -228,7 +246,7 @@ class _Depthwise(torch.autograd.Function):
             else:
                 call("tsii_dw_bwd_dw_bn", ptr(gy), ptr(inv), ptr(keep), ptr(x), ptr(rmask), n, h, wd, c, *g, ho, wo,
                      ptr(in_scale), ptr(in_shift), ctx.in_cfg[0], ctx.in_cfg[1], ptr(dw), ptr(db), ptr(ws), nbytes, st)
-        return (dx, dw, db) + (None,) * 10
+        return (dx, dw, db) + (None,) * 11
 
 
 def pconv_depthwise(x, w, bias, rmask, denom, keep, inv, g: Geom, want_stats=False):
@@ -240,7 +258,9 @@ def pconv_depthwise(x, w, bias, rmask, denom, keep, inv, g: Geom, want_stats=Fal
         x, lazy = x.materialize(), False
     stats = want_stats and fusable
     if lazy:
-        out = _Depthwise.apply(x.token, w, bias, rmask, denom, keep, inv, g, x.scale, x.shift, x.act, x.slope, stats)
+        x.consumed()
+        bn = (x.mean, x.var, x.gamma, x.beta, x.eps, x.slot) if x.slot is not None else None
+        out = _Depthwise.apply(x.token, w, bias, rmask, denom, keep, inv, g, x.scale, x.shift, x.act, x.slope, stats, bn)
     else:
         out = _Depthwise.apply(x, w, bias, rmask, denom, keep, inv, g, None, None, 0, 0.0, stats)
     if want_stats and not stats:
@@ -362,22 +382,38 @@ def load_time_act(act, slope) -> bool:
     return act in (ACT_NONE, ACT_RELU, ACT_RELU6) or (act == ACT_LEAKY and 0.0 <= slope <= 1.0)
 
 
+class _BwdSlot:
+    """Hand-over between the backward of a LazyBN's consumer and _BNLazy.backward (K6c): a consumer whose dX kernel
+    also took the BatchNorm-backward reductions leaves them here; they are used only if it was the sole consumer."""
+
+    __slots__ = ("consumers", "part")
+
+    def __init__(self):
+        self.consumers, self.part = 0, None
+
+
 class LazyBN:
     """BatchNorm(+activation) output that has not been written to memory (K6b): ``token`` aliases the RAW conv
     output y and carries the autograd edge of the normalised activation a = act(scale*y + shift); consumers that
     can apply (scale, shift, act) while loading take it as is, everything else calls ``materialize()``."""
 
-    __slots__ = ("token", "scale", "shift", "act", "slope", "mean", "var", "gamma", "beta", "eps")
+    __slots__ = ("token", "scale", "shift", "act", "slope", "mean", "var", "gamma", "beta", "eps", "slot")
 
-    def __init__(self, token, scale, shift, act, slope, mean, var, gamma, beta, eps):
+    def __init__(self, token, scale, shift, act, slope, mean, var, gamma, beta, eps, slot=None):
         self.token, self.scale, self.shift, self.act, self.slope = token, scale, shift, int(act), float(slope)
         self.mean, self.var, self.gamma, self.beta, self.eps = mean, var, gamma, beta, float(eps)
+        self.slot = slot
 
     @property
     def shape(self):
         return self.token.shape
 
+    def consumed(self):
+        if self.slot is not None:
+            self.slot.consumers += 1
+
     def materialize(self, residual=None):
+        self.consumed()
         return _LazyApply.apply(self.token, self.mean, self.var, self.gamma, self.beta, self.eps, self.act, self.slope,
                                 residual)
 
@@ -387,13 +423,14 @@ class _BNLazy(torch.autograd.Function):
     backward receives the gradient w.r.t. the normalised activation and is the full BatchNorm(+act) backward."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, part, training, momentum, eps, act, slope):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, part, training, momentum, eps, act, slope, slot):
         _lib.check_device(y)
         y = y.contiguous()
         c = y.shape[-1]
         m = y.numel() // c
         st = _lib.stream()
         dev = y.device
+        ctx.slot = slot
         scale = torch.empty(c, dtype=torch.float32, device=dev)
         shift = torch.empty(c, dtype=torch.float32, device=dev)
         if training:
@@ -426,7 +463,7 @@ class _BNLazy(torch.autograd.Function):
     @staticmethod
     def backward(ctx, ga, *_):
         if ga is None:
-            return (None,) * 11
+            return (None,) * 12
         y, mean, var, gamma, beta = ctx.saved_tensors
         training, eps, act, slope = ctx.cfg
         ga = ga.contiguous()
@@ -437,9 +474,18 @@ class _BNLazy(torch.autograd.Function):
         dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
         nbytes = _lib.lib().tsii_bn_ws_bytes(m, c)
         ws = _ws(nbytes, y)
-        call("tsii_bn_act_bwd", ptr(ga), ptr(y), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), eps, act,
-             slope, int(training), ptr(dy), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _lib.stream())
-        return (dy, dgamma, dbeta) + (None,) * 8
+        slot = ctx.slot
+        part = slot.part if (slot is not None and slot.consumers == 1) else None
+        if slot is not None:
+            slot.part = None
+        if part is not None:       # K6c: the sole consumer's dX kernel already took sum(dz), sum(dz*xhat)
+            call("tsii_bn_act_bwd_pre", ptr(ga), ptr(y), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), eps, act,
+                 slope, int(training), ptr(part), part.shape[0], ptr(dy), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes,
+                 _lib.stream())
+        else:
+            call("tsii_bn_act_bwd", ptr(ga), ptr(y), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), eps, act,
+                 slope, int(training), ptr(dy), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _lib.stream())
+        return (dy, dgamma, dbeta) + (None,) * 9
 
 
 class _LazyApply(torch.autograd.Function):
@@ -465,9 +511,10 @@ class _LazyApply(torch.autograd.Function):
 def bn_lazy(y, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, act=ACT_NONE, slope=0.0,
             part=None) -> LazyBN:
     """BatchNorm(+act) of a conv output as a LazyBN; ``part``: the statistics partials the conv left behind."""
+    slot = _BwdSlot()
     token, scale, shift, mean, var = _BNLazy.apply(y, gamma, beta, running_mean, running_var, part, training,
-                                                   momentum, eps, act, slope)
-    return LazyBN(token, scale, shift, act, slope, mean, var, gamma.detach(), beta.detach(), eps)
+                                                   momentum, eps, act, slope, slot)
+    return LazyBN(token, scale, shift, act, slope, mean, var, gamma.detach(), beta.detach(), eps, slot)
 
 
 class _Act(torch.autograd.Function):
