@@ -193,6 +193,13 @@ int tsii_dw_bwd_dx_bn(const float* dy, const float* inv, const float* w, const f
                       int ho, int wo, const float* bn_y, const float* bn_mean, const float* bn_var,
                       const float* bn_gamma, const float* bn_beta, float bn_eps, int bn_act, float bn_slope,
                       float* dx, float* bwd_part, float* ws, void* stream);
+/* same for the point-wise dX (N = k % 4 == 0): dx is the gradient w.r.t. a = act(BN(bn_y)), bn_y raw [m,k];
+ * bwd_part[tsii_pw_stat_rows(m)][2][k] */
+int tsii_pw_bwd_dx_bn(const float* dy, int64_t m, int n, const float* w, int k, const float* inv,
+                      const float* r0, int split, const float* r1,
+                      const float* bn_y, const float* bn_mean, const float* bn_var, const float* bn_gamma,
+                      const float* bn_beta, float bn_eps, int bn_act, float bn_slope,
+                      float* dx, float* bwd_part, float* wt_ws, void* stream);
 int tsii_bn_act_bwd_pre(const float* dout, const float* y, int64_t m, int c,
                         const float* mean, const float* var, const float* gamma, const float* beta,
                         float eps, int act, float slope, int training, const float* bwd_part, int64_t rows,

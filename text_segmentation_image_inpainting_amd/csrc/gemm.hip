@@ -31,6 +31,15 @@ struct Epilogue {
     int vec_store;       // C rows are 16-byte aligned (ldc % 4 == 0, base aligned)
     float* stats;        // [row blocks][4][N] BatchNorm partials of the stored values: (count, pivot, sum(y-pivot),
                          // sum((y-pivot)^2)), pivot = a value of the block itself (robust for near-constant channels); or NULL
+    // K6c (dX feeding a BatchNorm backward; BNB instantiations only): the stored values are the gradient w.r.t.
+    // a = act(gamma*xhat+beta) of the raw [M,N] tensor bn_y; the epilogue also leaves per row block (sum dz, sum dz*xhat)
+    const float* bn_y;
+    const float* bn_mean;
+    const float* bn_var;
+    const float* bn_gamma;
+    const float* bn_beta;
+    float bn_eps, bn_neg, bn_hi;
+    float* bn_part;      // [row blocks][2][N]
 };
 
 
@@ -234,13 +243,14 @@ __device__ __forceinline__ void conv_store(float* __restrict__ S, const float4 (
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC, int AMODE, bool BNIN = false>
-__global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda, RowScale as,
+template <int WM, int WN, int TM, int TN, bool VEC, int AMODE, bool BNIN = false, bool BNB = false>
+__global__ __launch_bounds__(256, BNB ? 2 : 3) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda, RowScale as,
                                                       const float* __restrict__ B, int64_t ldb,
                                                       float* __restrict__ C, int64_t ldc,
                                                       int64_t M, int N, int K, Epilogue ep, unsigned ntn,
                                                       ConvGather cg, InBN ib) {
     static_assert(!BNIN || (VEC && AMODE == 0), "input BatchNorm rides the plain vector loader");
+    static_assert(!BNB || (VEC && AMODE == 0 && !BNIN), "K6c rides the plain dX form");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per block");
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * GEMM_LDS];
@@ -358,6 +368,15 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
     const bool has_cs = ep.cs.r0 != nullptr;
     float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};   // BatchNorm partial sums about the block pivot
     float pvt[4] = {0.f, 0.f, 0.f, 0.f};
+    float bmu[4] = {0.f, 0.f, 0.f, 0.f}, bis[4] = {0.f, 0.f, 0.f, 0.f}, bga[4] = {0.f, 0.f, 0.f, 0.f}, bbe[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BNB) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (col + e < N) {
+                bmu[e] = ep.bn_mean[col + e]; bis[e] = 1.0f / sqrtf(ep.bn_var[col + e] + ep.bn_eps);
+                bga[e] = ep.bn_gamma[col + e]; bbe[e] = ep.bn_beta[col + e];
+            }
+    }
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
         // side loads of this band (clamped rows: no divergent branches, nothing is used until the tile is staged)
@@ -383,6 +402,14 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
             if (ep.cs.r1 != nullptr) {
 #pragma unroll
                 for (int i = 0; i < F4_PER_THREAD; ++i) c1v[i] = ep.cs.r1[rowv[i] < M ? rowv[i] : M - 1];
+            }
+        }
+        float4 yq[BNB ? F4_PER_THREAD : 1];
+        if constexpr (BNB) {     // the raw BatchNorm input at the positions this thread stores (N % 4 == 0, 16-byte rows)
+#pragma unroll
+            for (int i = 0; i < F4_PER_THREAD; ++i) {
+                yq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rowv[i] < M && col_ok) yq[i] = *reinterpret_cast<const float4*>(ep.bn_y + rowv[i] * (int64_t)N + col);
             }
         }
         __syncthreads();
@@ -426,6 +453,17 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
                     st2[e] = fmaf(d, d, st2[e]);
                 }
             }
+            if constexpr (BNB) {
+                const float ye[4] = {yq[i].x, yq[i].y, yq[i].z, yq[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (ye[e] - bmu[e]) * bis[e];
+                    const float z = fmaf(xh, bga[e], bbe[e]);
+                    const float dz = v[e] * ((z > 0.f && z < ep.bn_hi) ? 1.f : (z > 0.f ? 0.f : ep.bn_neg));
+                    st1[e] += dz;
+                    st2[e] = fmaf(dz, xh, st2[e]);
+                }
+            }
             float* cp = C + row * ldc + col;
             if (ep.vec_store && col + 3 < N) {
                 *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -435,6 +473,24 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const float* __restrict
                     if (col + e < N) cp[e] = v[e];
             }
         }
+    }
+    if constexpr (BNB) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Cs[(rr0 * BN + c4 * 4 + e) * 2 + 0] = st1[e];
+            Cs[(rr0 * BN + c4 * 4 + e) * 2 + 1] = st2[e];
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < N) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll 4
+            for (int j = 0; j < ROW_STEP; ++j) { a1 += Cs[(j * BN + tid) * 2 + 0]; a2 += Cs[(j * BN + tid) * 2 + 1]; }
+            float* sp = ep.bn_part + (int64_t)(bid / ntn) * 2 * N;
+            sp[n0 + tid] = a1;
+            sp[N + n0 + tid] = a2;
+        }
+        return;
     }
     if (ep.stats != nullptr) {
         // ROW_STEP threads share a column group: combine through LDS, one partial row per row block
@@ -743,7 +799,12 @@ static int launch_nt_cfg(const float* A, int64_t lda, RowScale as, const float* 
     const unsigned ntn = (unsigned)cdiv(N, BN);
     const int64_t nblocks = cdiv64(M, BM) * ntn;
     TSII_REQUIRE(nblocks < (1ll << 31), "gemm_nt: grid too large");
-    if (ib.sc != nullptr) {
+    if (ep.bn_y != nullptr) {
+        TSII_REQUIRE(vec && ib.sc == nullptr && N % 4 == 0 && ldc == N && aligned16(ep.bn_y) && ep.vec_store,
+                     "gemm_nt: the BatchNorm-backward epilogue needs N %% 4 == 0 and 16-byte aligned operands");
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, true, 0, false, true>), dim3((unsigned)nblocks), dim3(256), 0, stream,
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, kNoConv, kNoBN);
+    } else if (ib.sc != nullptr) {
         TSII_REQUIRE(vec && aligned16(ib.sc) && aligned16(ib.sh), "gemm_nt: input BatchNorm needs K %% 4 == 0 and 16-byte aligned operands");
         hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, true, 0, true>), dim3((unsigned)nblocks), dim3(256), 0, stream,
                            A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, kNoConv, ib);
@@ -896,16 +957,36 @@ extern "C" int tsii_pw_fwd_bn(const float* x, int64_t m, int k, const float* w, 
     return pw_fwd_impl(x, m, k, w, n, bias, r0, split, r1, denom, keep, ib, stat_part, y, stream);
 }
 
-extern "C" int tsii_pw_bwd_dx(const float* dy, int64_t m, int n, const float* w, int k, const float* inv,
-                              const float* r0, int split, const float* r1, float* dx, float* wt_ws, void* stream) {
+static int pw_bwd_dx_impl(const float* dy, int64_t m, int n, const float* w, int k, const float* inv,
+                          const float* r0, int split, const float* r1, Epilogue ep, float* dx, float* wt_ws, void* stream) {
     TSII_REQUIRE(dy && w && dx && wt_ws, "pw_bwd_dx: null pointer");
     TSII_REQUIRE(m > 0 && k > 0 && n > 0, "pw_bwd_dx: bad shape");
     // W [n,k] -> Wt [k,n] so both GEMM operands are contraction-contiguous
     int rc = launch_transpose(w, n, k, wt_ws, (hipStream_t)stream);
     if (rc) return rc;
     RowScale as = {inv, nullptr, n};  // g = dy * inv[m]
-    Epilogue ep = {nullptr, nullptr, nullptr, {r0, r1, split}, 0};
+    ep.cs = {r0, r1, split};
     return launch_nt(dy, n, as, wt_ws, n, dx, k, m, k, n, ep, (hipStream_t)stream);
+}
+
+extern "C" int tsii_pw_bwd_dx(const float* dy, int64_t m, int n, const float* w, int k, const float* inv,
+                              const float* r0, int split, const float* r1, float* dx, float* wt_ws, void* stream) {
+    Epilogue ep = {};
+    return pw_bwd_dx_impl(dy, m, n, w, k, inv, r0, split, r1, ep, dx, wt_ws, stream);
+}
+
+extern "C" int tsii_pw_bwd_dx_bn(const float* dy, int64_t m, int n, const float* w, int k, const float* inv,
+                                 const float* r0, int split, const float* r1,
+                                 const float* bn_y, const float* bn_mean, const float* bn_var, const float* bn_gamma,
+                                 const float* bn_beta, float bn_eps, int bn_act, float bn_slope,
+                                 float* dx, float* bwd_part, float* wt_ws, void* stream) {
+    TSII_REQUIRE(bn_y && bn_mean && bn_var && bn_gamma && bn_beta && bwd_part, "pw_bwd_dx_bn: null pointer");
+    InBN tmp;
+    TSII_REQUIRE(make_in_bn(bn_mean, bn_var, bn_act, bn_slope, &tmp) == 0, "pw_bwd_dx_bn: activation %d has no load-time form", bn_act);
+    Epilogue ep = {};
+    ep.bn_y = bn_y; ep.bn_mean = bn_mean; ep.bn_var = bn_var; ep.bn_gamma = bn_gamma; ep.bn_beta = bn_beta;
+    ep.bn_eps = bn_eps; ep.bn_neg = tmp.neg; ep.bn_hi = tmp.hi; ep.bn_part = bwd_part;
+    return pw_bwd_dx_impl(dy, m, n, w, k, inv, r0, split, r1, ep, dx, wt_ws, stream);
 }
 
 extern "C" size_t tsii_pw_bwd_dw_ws_bytes(int64_t m, int n, int k) {

@@ -98,8 +98,9 @@ class _Pointwise(torch.autograd.Function):
     of y as a second, non-differentiable output."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, r0, r1, denom, keep, inv, split, in_scale, in_shift, in_act, in_slope, want_stats):
+    def forward(ctx, x, w, bias, r0, r1, denom, keep, inv, split, in_scale, in_shift, in_act, in_slope, want_stats, bn=None):
         _lib.check_device(x)
+        ctx.bn = bn     # (mean, var, gamma, beta, eps, slot) of the lazily applied producer BatchNorm (K6c) or None
         x, w = x.contiguous(), w.contiguous()
         n, h, wd, k = x.shape
         cout = w.shape[0]
@@ -128,7 +129,7 @@ class _Pointwise(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, *_):
         if gy is None:
-            return (None,) * 14
+            return (None,) * 15
         x, w, r0, r1, inv, keep, in_scale, in_shift = ctx.saved_tensors
         gy = gy.contiguous()
         n, h, wd, k = x.shape
@@ -139,8 +140,16 @@ class _Pointwise(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)   # gradient w.r.t. the (virtual) normalised input when in_scale is set
             wt = _ws(4 * k * cout, x)
-            call("tsii_pw_bwd_dx", ptr(gy), m, cout, ptr(w), k, ptr(inv), ptr(r0), ctx.split, ptr(r1),
-                 ptr(dx), ptr(wt), st)
+            if ctx.bn is not None and FUSE_BN_BWD and k % 4 == 0 and cout % 4 == 0 and load_time_act(*ctx.in_cfg):
+                mean, var, gamma, beta, eps, slot = ctx.bn
+                part = torch.empty((int(_lib.lib().tsii_pw_stat_rows(m)), 2, k), dtype=torch.float32, device=x.device)
+                call("tsii_pw_bwd_dx_bn", ptr(gy), m, cout, ptr(w), k, ptr(inv), ptr(r0), ctx.split, ptr(r1),
+                     ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ctx.in_cfg[0], ctx.in_cfg[1],
+                     ptr(dx), ptr(part), ptr(wt), st)
+                slot.part = part
+            else:
+                call("tsii_pw_bwd_dx", ptr(gy), m, cout, ptr(w), k, ptr(inv), ptr(r0), ctx.split, ptr(r1),
+                     ptr(dx), ptr(wt), st)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(w)
             db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
@@ -152,7 +161,7 @@ class _Pointwise(torch.autograd.Function):
             else:
                 call("tsii_pw_bwd_dw_bn", ptr(gy), ptr(x), m, cout, k, ptr(inv), ptr(keep), ptr(r0), ctx.split, ptr(r1),
                      ptr(in_scale), ptr(in_shift), ctx.in_cfg[0], ctx.in_cfg[1], ptr(dw), ptr(db), ptr(ws), nbytes, st)
-        return (dx, dw, db) + (None,) * 11
+        return (dx, dw, db) + (None,) * 12
 
 
 def pconv_pointwise(x, w, bias=None, r0=None, split=0, r1=None, denom=None, keep=None, inv=None, want_stats=False):
@@ -161,8 +170,9 @@ def pconv_pointwise(x, w, bias=None, r0=None, split=0, r1=None, denom=None, keep
     if isinstance(x, LazyBN):
         if x.token.shape[-1] % 4 == 0:
             x.consumed()
+            bn = (x.mean, x.var, x.gamma, x.beta, x.eps, x.slot) if x.slot is not None else None
             return _Pointwise.apply(x.token, w, bias, r0, r1, denom, keep, inv, split, x.scale, x.shift, x.act, x.slope,
-                                    want_stats)
+                                    want_stats, bn)
         x = x.materialize()
     return _Pointwise.apply(x, w, bias, r0, r1, denom, keep, inv, split, None, None, 0, 0.0, want_stats)
 
