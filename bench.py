@@ -143,7 +143,7 @@ def main():
     for _ in range(args.warmup):
         loss = trainer.step(corrupted, mask, clean_nhwc)
     sync()
-    _lib.start_timing(["tsii_pw_fwd", "tsii_pw_fwd_bn", "tsii_pw_bwd_dx"])
+    _lib.start_timing(["tsii_pw_fwd", "tsii_pw_fwd_bn", "tsii_pw_bwd_dx", "tsii_pw_bwd_dx_bn"])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.step(corrupted, mask, clean_nhwc)
@@ -190,7 +190,7 @@ def main():
         agg = {}
         for name, recs in timed.items():
             for ms, a in recs:
-                m, p, q = a[0], a[1], a[2]       # (M, K, N) for pw_fwd[_bn] ; (M, N, K) for pw_bwd_dx
+                m, p, q = a[0], a[1], a[2]       # (M, K, N) for pw_fwd[_bn] ; (M, N, K) for pw_bwd_dx[_bn]
                 v = nt_variant(q)
                 d = agg.setdefault(v, {"ms": 0.0, "flop": 0.0, "launches": 0, "alg_bytes": 0.0})
                 d["ms"] += ms
