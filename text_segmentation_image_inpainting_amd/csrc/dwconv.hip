@@ -222,15 +222,11 @@ __global__ __launch_bounds__(256) void dw_bwd_dw_kernel(const float* __restrict_
     }
 }
 
-// ---- LDS-tiled 3x3 stencil (forward, and dX for stride 1 with flipped taps) --------------------------
-// The direct kernels above issue ~20 vector-memory instructions per output pixel and are bound by VMEM
-// issue (measured ~2.5 TB/s).  Here a block stages the (TH*s+2d) x (TW*s+2d) x 32-channel input patch ONCE
-// (pre-multiplied by its per-pixel plane: the mask for forward, 1/count for dX) with coalesced 16-byte loads,
-// then every thread walks its taps out of LDS (pixel stride 128 B: x-adjacent pixels of a 16-lane group sit in
-// the two halves of the 256-byte bank row, conflict-free) with the 9 weights in registers.
+// ---- 3x3 stencils through LDS ------------------------------------------------------------------------------------
+// The direct kernels above issue ~20 vector-memory instructions per output pixel and are bound by VMEM issue (measured
+// ~1.9 TB/s); the marching-strip kernels below stage the input once in LDS (pre-multiplied by its per-pixel plane: the
+// mask for forward, 1/count for dX) and walk the taps out of it with the 9 weights in registers:
 //   y[o] = post[o] ? (sum_t w[t] * pre[i_t] * in[i_t]) / denom[o] + bias : 0,   i_t = o*s - pad + t*d
-// tile variants (TH x TW output pixels, CB channels, LDS floats); chosen per call, see try_launch_dw_tile
-
 struct DtGeom {
     int n, hin, win, c, s, d, pad_h, pad_w, hout, wout, flip;
 };
@@ -252,152 +248,10 @@ struct DwBnBwd {
     float* part;
 };
 
-template <int DT_TH, int DT_TW, int DT_CB, int DT_LDS_FLOATS>
-__global__ __launch_bounds__(256) void dw_tile_kernel(const float* __restrict__ in, const float* __restrict__ pre,
-                                                      const float* __restrict__ wT, const float* __restrict__ bias,
-                                                      const float* __restrict__ denom, const float* __restrict__ keep,
-                                                      const float* __restrict__ post_mul, DtGeom g, int PH, int PW,
-                                                      unsigned tiles_x, unsigned tiles_y, unsigned cblocks,
-                                                      DwBN ib, float* __restrict__ stats, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float tile[DT_LDS_FLOATS];
-    unsigned b = xcd_remap(blockIdx.x, gridDim.x);
-    const unsigned cb = b % cblocks; b /= cblocks;
-    const unsigned tx0 = b % tiles_x; b /= tiles_x;
-    const unsigned ty0 = b % tiles_y;
-    const int64_t n = b / tiles_y;
-    const int c0 = (int)cb * DT_CB;
-    const int oy0 = (int)ty0 * DT_TH, ox0 = (int)tx0 * DT_TW;
-    const int iy0 = oy0 * g.s - g.pad_h, ix0 = ox0 * g.s - g.pad_w;
-    // stage the patch: element = (pixel, 4-channel group); 8 groups per pixel
-    const int npix = PH * PW;
-    constexpr int CGS = DT_CB / 4;                 // channel groups per pixel
-    constexpr int LANES = 256 / CGS;               // pixel lanes
-    const int cg = threadIdx.x % CGS, lane = threadIdx.x / CGS;   // 256 % CGS == 0: the staging loop keeps this thread's cg
-    const int c = c0 + cg * 4;
-    float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool bn_in = ib.sc != nullptr;
-    if (bn_in && c < g.c) { isc = *reinterpret_cast<const float4*>(ib.sc + c); ish = *reinterpret_cast<const float4*>(ib.sh + c); }
-    for (int e = threadIdx.x; e < npix * CGS; e += 256) {
-        const int p = e / CGS;
-        const int py = p / PW, px = p - py * PW;
-        const int iy = iy0 + py, ix = ix0 + px;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win && c < g.c) {
-            const int64_t ipix = (n * g.hin + iy) * g.win + ix;
-            v = *reinterpret_cast<const float4*>(in + ipix * g.c + c);
-            if (bn_in) {
-                v.x = bn_act_load(v.x, isc.x, ish.x, ib.neg, ib.hi); v.y = bn_act_load(v.y, isc.y, ish.y, ib.neg, ib.hi);
-                v.z = bn_act_load(v.z, isc.z, ish.z, ib.neg, ib.hi); v.w = bn_act_load(v.w, isc.w, ish.w, ib.neg, ib.hi);
-            }
-            if (pre != nullptr) { const float m = pre[ipix]; v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
-        }
-        *reinterpret_cast<float4*>(tile + p * DT_CB + cg * 4) = v;
-    }
-    float4 w[9];
-    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < g.c) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const float4*>(wT + (g.flip ? 8 - t : t) * g.c + c);
-        if (bias != nullptr) bq = make_float4(bias[c], bias[c + 1], bias[c + 2], bias[c + 3]);   // bias may be 4-byte aligned only
-    }
-    // per-pixel side values of this thread's pixels, issued before the barrier (their latency hides behind the
-    // staging; loading them next to their use serialised ~4 L2 round trips per pixel)
-    constexpr int NP = DT_TH * DT_TW / LANES;
-    float kpv[NP], dnv[NP], pmv[NP];
-    int64_t opv[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const int p = lane + LANES * k;
-        const int oy = oy0 + p / DT_TW, ox = ox0 + p % DT_TW;
-        const bool ok = oy < g.hout && ox < g.wout;
-        opv[k] = ok ? (n * g.hout + oy) * g.wout + ox : -1;
-        const int64_t q = ok ? opv[k] : (n * g.hout + oy0) * g.wout + ox0;   // clamp: the tile origin is always valid
-        kpv[k] = keep != nullptr ? keep[q] : 1.f;
-        dnv[k] = denom != nullptr ? denom[q] : 1.f;
-        pmv[k] = post_mul != nullptr ? post_mul[q] : 1.f;
-    }
-    __syncthreads();
-    const bool cok = c < g.c;
-    float4 res[NP];                                  // outputs stay in registers for the BatchNorm partial sums
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        res[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int p = lane + LANES * k;              // x-adjacent lanes -> conflict-free LDS reads
-        const int ty = p / DT_TW, tx = p % DT_TW;
-        if (opv[k] < 0 || !cok) continue;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const float4 v = *reinterpret_cast<const float4*>(tile + ((ty * g.s + ky * g.d) * PW + tx * g.s + kx * g.d) * DT_CB + cg * 4);
-                const float4 ww = w[ky * 3 + kx];
-                a.x = fmaf(v.x, ww.x, a.x); a.y = fmaf(v.y, ww.y, a.y); a.z = fmaf(v.z, ww.z, a.z); a.w = fmaf(v.w, ww.w, a.w);
-            }
-        if (denom != nullptr) { const float dn = dnv[k]; a.x /= dn; a.y /= dn; a.z /= dn; a.w /= dn; }
-        a.x += bq.x; a.y += bq.y; a.z += bq.z; a.w += bq.w;
-        if (post_mul != nullptr) {
-            const float pm = pmv[k];
-            a.x = pm != 0.f ? a.x * pm : 0.f; a.y = pm != 0.f ? a.y * pm : 0.f;
-            a.z = pm != 0.f ? a.z * pm : 0.f; a.w = pm != 0.f ? a.w * pm : 0.f;
-        }
-        if (kpv[k] == 0.f) a = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(out + opv[k] * g.c + c) = a;
-        res[k] = a;
-    }
-    if (stats != nullptr) {
-        // (count, pivot, sum(y-pivot), sum((y-pivot)^2)) per channel for this tile; pivot = the tile's first output
-        // pixel (always valid), broadcast through the dead patch so every lane subtracts the same number
-        __syncthreads();
-        float* pv = tile;                              // [DT_CB]
-        float* wred = tile + DT_CB;                    // [4 waves][2][DT_CB]
-        if (lane == 0) *reinterpret_cast<float4*>(pv + cg * 4) = res[0];
-        __syncthreads();
-        const float4 P = *reinterpret_cast<const float4*>(pv + cg * 4);
-        float vals[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            if (opv[k] < 0 || !cok) continue;
-            const float dx = res[k].x - P.x, dy = res[k].y - P.y, dz = res[k].z - P.z, dw = res[k].w - P.w;
-            vals[0] += dx; vals[1] += dy; vals[2] += dz; vals[3] += dw;
-            vals[4] = fmaf(dx, dx, vals[4]); vals[5] = fmaf(dy, dy, vals[5]);
-            vals[6] = fmaf(dz, dz, vals[6]); vals[7] = fmaf(dw, dw, vals[7]);
-        }
-        // lanes of one channel group are CGS apart inside a wave: xor-shuffle them together, then the 4 waves through LDS
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int off = CGS; off < 64; off <<= 1) vals[i] += __shfl_xor(vals[i], off, 64);
-        const int wl = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (wl < CGS) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                wred[(wave * 2 + 0) * DT_CB + wl * 4 + i] = vals[i];
-                wred[(wave * 2 + 1) * DT_CB + wl * 4 + i] = vals[4 + i];
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < DT_CB && c0 + (int)threadIdx.x < g.c) {
-            const int ch = threadIdx.x;
-            const float s1 = (wred[(0 * 2 + 0) * DT_CB + ch] + wred[(1 * 2 + 0) * DT_CB + ch]) +
-                             (wred[(2 * 2 + 0) * DT_CB + ch] + wred[(3 * 2 + 0) * DT_CB + ch]);
-            const float s2 = (wred[(0 * 2 + 1) * DT_CB + ch] + wred[(1 * 2 + 1) * DT_CB + ch]) +
-                             (wred[(2 * 2 + 1) * DT_CB + ch] + wred[(3 * 2 + 1) * DT_CB + ch]);
-            const int vh = g.hout - oy0 < DT_TH ? g.hout - oy0 : DT_TH, vw = g.wout - ox0 < DT_TW ? g.wout - ox0 : DT_TW;
-            const int64_t prow = (n * tiles_y + ty0) * tiles_x + tx0;      // one partial row per spatial tile
-            float* sp = stats + prow * 4 * g.c + c0 + ch;
-            sp[0] = (float)(vh * vw);
-            sp[g.c] = pv[ch];
-            sp[2 * (int64_t)g.c] = s1;
-            sp[3 * (int64_t)g.c] = s2;
-        }
-    }
-}
-
 // ---- marching-strip 3x3 stencil, stride 1 (forward, and dX with flipped taps) ------------------------------
-// The tile kernel above re-reads a 2d-row halo above and below every 8-row tile (1.4x the input for d = 1) and
-// has nothing in flight while it computes.  Here a block owns a 16-pixel x 32-channel STRIP and marches down it
-// 8 output rows at a time through a ring of 8 + 2d input rows in LDS: every input row is read once (only the
+// (An 8x16-pixel LDS-tile kernel came first: it re-read a 2d-row halo above and below every tile, 1.4x the input for
+// d = 1, and had nothing in flight while it computed -- 1.84 ms where this kernel takes 1.24 ms.)
+// A block owns a 16-pixel x 32-channel STRIP and marches down it 8 output rows at a time through a ring of 8 + 2d input rows in LDS: every input row is read once (only the
 // 2d-pixel side halo remains, 1.125x), and the next 8 rows (and the per-pixel planes of the next step) are
 // already in flight (global -> registers) while the current ones are computed and stored; they are written into
 // the ring slots the step has just finished with.  BatchNorm partial sums (K6b) accumulate in registers over the
@@ -805,158 +659,31 @@ static StripPlan plan_strip(int n, int hout, int wout, int c, int s, int d) {
 // -> 0 launched, 1 not applicable (caller falls back to the direct kernel), <0 error
 static const DwBN kNoDwBN = {nullptr, nullptr, 1.f, 0.f};
 static const DwBnBwd kNoBnBwd = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
-static constexpr int DT_TH0 = 8, DT_TW0 = 16;     // output tile of every variant (also the BatchNorm partial-row grain)
 
-template <int TH, int TW, int CB, int LDSF>
-static int launch_dw_tile_variant(const float* in, const float* pre, const float* wT, const float* bias, const float* denom,
-                                  const float* keep, const float* post_mul, DtGeom g, DwBN ib, float* stats, float* out,
-                                  hipStream_t st) {
-    const int PH = (TH - 1) * g.s + 2 * g.d + 1, PW = (TW - 1) * g.s + 2 * g.d + 1;
-    if (PH * PW * CB > LDSF) return 1;
-    const unsigned tiles_x = cdiv(g.wout, TW), tiles_y = cdiv(g.hout, TH), cblocks = cdiv(g.c, CB);
-    const int64_t nblk = (int64_t)tiles_x * tiles_y * cblocks * g.n;
-    if (nblk >= (1ll << 31)) return 1;
-    hipLaunchKernelGGL((dw_tile_kernel<TH, TW, CB, LDSF>), dim3((unsigned)nblk), dim3(256), 0, st, in, pre, wT, bias, denom, keep,
-                       post_mul, g, PH, PW, tiles_x, tiles_y, cblocks, ib, stats, out);
-    return check_launch("dw_tile");
-}
+static bool dw_fused_ok(int s, int d) { return s == 1 && d == 1; }   // geometries with the K6b / K6c strip variants
 
-static bool dw_tile_fits(int s, int d) {   // patch fits the forward AND the dW tile kernels (6144 floats)
-    const int PH = (DT_TH0 - 1) * s + 2 * d + 1, PW = (DT_TW0 - 1) * s + 2 * d + 1;
-    return PH * PW * 32 <= 6144;
-}
-
-static int try_launch_dw_tile(const float* in, const float* pre, const float* wT, const float* bias, const float* denom,
-                              const float* keep, const float* post_mul, DtGeom g, float* out, hipStream_t st,
-                              DwBN ib = kNoDwBN, float* stats = nullptr, DwBnBwd bb = kNoBnBwd) {
+static int try_launch_dw_strip(const float* in, const float* pre, const float* wT, const float* bias, const float* denom,
+                               const float* keep, const float* post_mul, DtGeom g, float* out, hipStream_t st,
+                               DwBN ib = kNoDwBN, float* stats = nullptr, DwBnBwd bb = kNoBnBwd) {
     if (g.c % 4 != 0 || !aligned16(in) || !aligned16(out) || !aligned16(wT)) return 1;
     if (ib.sc != nullptr && (!aligned16(ib.sc) || !aligned16(ib.sh))) return 1;
     const StripPlan sp = plan_strip(g.n, g.hout, g.wout, g.c, g.s, g.d);
-    if (sp.ok) {
-        const int64_t nblk = (int64_t)sp.strips_x * sp.chunks_y * sp.cblocks * g.n;
-        const dim3 grid((unsigned)nblk);
-        const bool fused = ib.sc != nullptr || stats != nullptr || bb.y != nullptr;
-        if (g.s == 2 && !fused) hipLaunchKernelGGL((dw_strip_kernel<2, 1, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
-                                                    sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
-        else if (g.s == 2) return 1;
-        else if (g.d == 1 && bb.y != nullptr) hipLaunchKernelGGL((dw_strip_kernel<1, 1, 2>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
-                                                                  sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
-        else if (g.d == 1 && fused) hipLaunchKernelGGL((dw_strip_kernel<1, 1, 1>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
-                                                  sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
-        else if (g.d == 1) hipLaunchKernelGGL((dw_strip_kernel<1, 1, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
-                                              sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
-        else if (g.d == 2 && !fused) hipLaunchKernelGGL((dw_strip_kernel<1, 2, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
-                                                        sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
-        else return 1;
-        return check_launch("dw_strip");
-    }
-    if (bb.y != nullptr) return 1;       // K6c only exists on the strip path
-    int rc = launch_dw_tile_variant<DT_TH0, DT_TW0, 32, 6144>(in, pre, wT, bias, denom, keep, post_mul, g, ib, stats, out, st);
-    if (rc == 1) rc = launch_dw_tile_variant<DT_TH0, DT_TW0, 32, 10240>(in, pre, wT, bias, denom, keep, post_mul, g, ib, stats, out, st);
-    return rc;
-}
-
-// ---- LDS-tiled dW for 3x3 kernels -----------------------------------------------------------------
-// Persistent block (g, cb): walks spatial tiles of ONE 32-channel block, stages the masked input patch in LDS,
-// reads its own dy pixels straight from HBM, keeps 9 taps x 4 channels (+ bias) in registers across all its
-// tiles, combines the 32 pixel lanes through LDS at the end and writes its 32-channel slice of partial row g.
-__global__ __launch_bounds__(256) void dw_tile_dw_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
-                                                         const float* __restrict__ keep, const float* __restrict__ x,
-                                                         const float* __restrict__ rmask, DtGeom g, int PH, int PW,
-                                                         unsigned tiles_x, unsigned tiles_y, unsigned cblocks,
-                                                         unsigned tiles_per_block, DwBN ib, float* __restrict__ part) {
-    constexpr int TH = 8, TW = 16, CB = 32, CGS = 8, LANES = 32;
-    __shared__ __attribute__((aligned(16))) float tile[6144];
-    __shared__ float red[256];
-    const unsigned cb = blockIdx.x % cblocks, gi = blockIdx.x / cblocks;
-    const int c0 = (int)cb * CB;
-    const int cg = threadIdx.x % CGS, lane = threadIdx.x / CGS;
-    const int c = c0 + cg * 4;
-    const bool cok = c < g.c;
-    float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool bn_in = ib.sc != nullptr;
-    if (bn_in && cok) { isc = *reinterpret_cast<const float4*>(ib.sc + c); ish = *reinterpret_cast<const float4*>(ib.sh + c); }
-    const unsigned total_tiles = tiles_x * tiles_y * (unsigned)g.n;
-    const unsigned t_beg = gi * tiles_per_block;
-    const unsigned t_end = t_beg + tiles_per_block < total_tiles ? t_beg + tiles_per_block : total_tiles;
-    float4 acc[10];
-#pragma unroll
-    for (int t = 0; t < 10; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int npix = PH * PW;
-    for (unsigned tl = t_beg; tl < t_end; ++tl) {
-        const unsigned tx0 = tl % tiles_x, ty0 = (tl / tiles_x) % tiles_y;
-        const int64_t n = tl / (tiles_x * tiles_y);
-        const int oy0 = (int)ty0 * TH, ox0 = (int)tx0 * TW;
-        const int iy0 = oy0 * g.s - g.pad_h, ix0 = ox0 * g.s - g.pad_w;
-        __syncthreads();
-        for (int e = threadIdx.x; e < npix * CGS; e += 256) {   // 256 % CGS == 0: e % CGS == cg
-            const int p = e / CGS;
-            const int py = p / PW, px = p - py * PW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win && cok) {
-                const int64_t ipix = (n * g.hin + iy) * g.win + ix;
-                v = *reinterpret_cast<const float4*>(x + ipix * g.c + c);
-                if (bn_in) {
-                    v.x = bn_act_load(v.x, isc.x, ish.x, ib.neg, ib.hi); v.y = bn_act_load(v.y, isc.y, ish.y, ib.neg, ib.hi);
-                    v.z = bn_act_load(v.z, isc.z, ish.z, ib.neg, ib.hi); v.w = bn_act_load(v.w, isc.w, ish.w, ib.neg, ib.hi);
-                }
-                if (rmask != nullptr) { const float m = rmask[ipix]; v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
-            }
-            *reinterpret_cast<float4*>(tile + p * CB + cg * 4) = v;
-        }
-        // this thread's dy pixels (registers), issued before the barrier so they overlap the staging
-        float4 gv[TH * TW / LANES];
-        float gs[TH * TW / LANES];
-        bool gk[TH * TW / LANES];
-#pragma unroll
-        for (int k = 0; k < TH * TW / LANES; ++k) {
-            const int p = lane + LANES * k;
-            const int oy = oy0 + p / TW, ox = ox0 + p % TW;
-            gv[k] = make_float4(0.f, 0.f, 0.f, 0.f); gs[k] = 0.f; gk[k] = false;
-            if (cok && oy < g.hout && ox < g.wout) {
-                const int64_t opix = (n * g.hout + oy) * g.wout + ox;
-                gk[k] = keep != nullptr ? (keep[opix] != 0.f) : true;
-                gs[k] = inv != nullptr ? inv[opix] : 1.f;
-                gv[k] = *reinterpret_cast<const float4*>(dy + opix * g.c + c);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < TH * TW / LANES; ++k) {
-            if (!gk[k]) continue;                     // hole / out of range: no gradient (partial_convolution.py:72)
-            const int p = lane + LANES * k;
-            const int ty = p / TW, tx = p % TW;
-            float4 gq = gv[k];
-            acc[9].x += gq.x; acc[9].y += gq.y; acc[9].z += gq.z; acc[9].w += gq.w;   // bias: added after the division
-            gq.x *= gs[k]; gq.y *= gs[k]; gq.z *= gs[k]; gq.w *= gs[k];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float4 v = *reinterpret_cast<const float4*>(tile + ((ty * g.s + ky * g.d) * PW + tx * g.s + kx * g.d) * CB + cg * 4);
-                    float4& a = acc[ky * 3 + kx];
-                    a.x = fmaf(gq.x, v.x, a.x); a.y = fmaf(gq.y, v.y, a.y); a.z = fmaf(gq.z, v.z, a.z); a.w = fmaf(gq.w, v.w, a.w);
-                }
-        }
-    }
-    // combine the 32 pixel lanes; partial row gi, columns [t][c0 .. c0+31]
-    float* prow = part + (int64_t)gi * 10 * g.c;
-#pragma unroll
-    for (int t = 0; t < 10; ++t) {
-        const float vals[4] = {acc[t].x, acc[t].y, acc[t].z, acc[t].w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __syncthreads();
-            red[threadIdx.x] = vals[i];
-            __syncthreads();
-            if (lane == 0 && cok) {
-                float sum = 0.f;
-                for (int l = 0; l < LANES; ++l) sum += red[l * CGS + cg];
-                prow[(int64_t)t * g.c + c + i] = sum;
-            }
-        }
-    }
+    if (!sp.ok) return 1;
+    const int64_t nblk = (int64_t)sp.strips_x * sp.chunks_y * sp.cblocks * g.n;
+    const dim3 grid((unsigned)nblk);
+    const bool fused = ib.sc != nullptr || stats != nullptr || bb.y != nullptr;
+    if (fused && !dw_fused_ok(g.s, g.d)) return 1;
+    if (g.s == 2) hipLaunchKernelGGL((dw_strip_kernel<2, 1, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                     sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
+    else if (g.d == 2) hipLaunchKernelGGL((dw_strip_kernel<1, 2, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                          sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
+    else if (bb.y != nullptr) hipLaunchKernelGGL((dw_strip_kernel<1, 1, 2>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                                 sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
+    else if (fused) hipLaunchKernelGGL((dw_strip_kernel<1, 1, 1>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                       sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
+    else hipLaunchKernelGGL((dw_strip_kernel<1, 1, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                            sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
+    return check_launch("dw_strip");
 }
 
 // ---- marching-strip dW (stride 1): same ring of x rows as dw_strip_kernel, the 9 taps x 4 channels (+ bias)
@@ -1130,25 +857,6 @@ __global__ __launch_bounds__(256, 2) void dw_strip_dw_kernel(const float* __rest
     }
 }
 
-struct DtDwPlan {
-    bool ok;
-    int PH, PW;
-    unsigned tiles_x, tiles_y, cblocks, groups, tiles_per_block;
-};
-static DtDwPlan plan_dt_dw(int n, int ho, int wo, int c, int s, int d) {
-    DtDwPlan p;
-    p.PH = 7 * s + 2 * d + 1; p.PW = 15 * s + 2 * d + 1;
-    p.ok = (c % 4 == 0) && p.PH * p.PW * 32 <= 6144;
-    p.tiles_x = cdiv(wo, 16); p.tiles_y = cdiv(ho, 8); p.cblocks = cdiv(c, 32);
-    const unsigned total = p.tiles_x * p.tiles_y * (unsigned)n;
-    unsigned groups = 4096 / p.cblocks;
-    if (groups < 1) groups = 1;
-    if (groups > total) groups = total;
-    p.tiles_per_block = cdiv((int)total, (int)groups);
-    p.groups = cdiv((int)total, (int)p.tiles_per_block);
-    return p;
-}
-
 // sum the R partial rows (block = 32 columns x 8 row lanes, 4 loads in flight) and scatter back to the
 // reference layout dw[c][t], db[c]
 __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ part, int R, int T, int C,
@@ -1224,13 +932,13 @@ static int dw_fwd_impl(const float* x, const float* rmask, const float* w, const
     int rc = launch_transpose(w, c, kh * kw, ws, st);  // [C][T] -> [T][C]
     if (rc) return rc;
     const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(ws);
-    if (kh == 3 && kw == 3 && sh == sw && dh == dw) {   // LDS-tiled 3x3 stencil
+    if (kh == 3 && kw == 3 && sh == sw && dh == dw) {   // marching-strip 3x3 stencil
         DtGeom tg = {n, h, wd, c, sh, dh, ph, pw, ho, wo, 0};
-        rc = try_launch_dw_tile(x, rmask, ws, bias, denom, keep, nullptr, tg, y, st, ib, stats);
+        rc = try_launch_dw_strip(x, rmask, ws, bias, denom, keep, nullptr, tg, y, st, ib, stats);
         if (rc <= 0) return rc;
     }
     TSII_REQUIRE(ib.sc == nullptr && stats == nullptr,
-                 "dw_fwd_bn: the fused BatchNorm forms need the LDS-tiled 3x3 path (tsii_dw_stat_rows() > 0, 16-byte aligned operands)");
+                 "dw_fwd_bn: the fused BatchNorm forms need the marching-strip path (tsii_dw_stat_rows() > 0, 16-byte aligned operands)");
     // measured on MI355X: the fully unrolled 3x3 form (more loads in flight) is SLOWER here -- these
     // stencils are bound by vector-memory instruction issue, not latency -- so it stays disabled
     const bool k3 = false;
@@ -1254,10 +962,9 @@ extern "C" int tsii_dw_fwd(const float* x, const float* rmask, const float* w, c
 
 extern "C" int64_t tsii_dw_stat_rows(int n, int ho, int wo, int c, int kh, int kw, int sh, int sw, int dh, int dw) {
     if (n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || c % 4 != 0) return 0;
-    if (!(kh == 3 && kw == 3 && sh == sw && dh == dw) || !dw_tile_fits(sh, dh)) return 0;
+    if (!(kh == 3 && kw == 3 && sh == sw && dh == dw) || !dw_fused_ok(sh, dh)) return 0;
     const StripPlan sp = plan_strip(n, ho, wo, c, sh, dh);
-    if (sp.ok) return (int64_t)n * sp.chunks_y * sp.strips_x;          // marching-strip kernel: one row per strip chunk
-    return (int64_t)n * cdiv(ho, DT_TH0) * cdiv(wo, DT_TW0);
+    return sp.ok ? (int64_t)n * sp.chunks_y * sp.strips_x : 0;          // one partial row per strip chunk
 }
 
 extern "C" int tsii_dw_fwd_bn(const float* x, const float* rmask, const float* w, const float* bias,
@@ -1285,7 +992,7 @@ static int dw_bwd_dx_impl(const float* dy, const float* inv, const float* w, con
     if (kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == dw) {
         // stride 1: dx[i] = rmask[i] * sum_t w[t] * (dy*inv)[i + pad - t*d] -- the forward stencil with flipped taps
         DtGeom tg = {n, ho, wo, c, 1, dh, 2 * dh - ph, 2 * dw - pw, h, wd, 1};
-        rc = try_launch_dw_tile(dy, inv, ws, nullptr, nullptr, nullptr, rmask, tg, dx, st, kNoDwBN, nullptr, bb);
+        rc = try_launch_dw_strip(dy, inv, ws, nullptr, nullptr, nullptr, rmask, tg, dx, st, kNoDwBN, nullptr, bb);
         if (rc <= 0) return rc;
     }
     TSII_REQUIRE(bb.y == nullptr, "dw_bwd_dx_bn: the BatchNorm-backward form needs the marching-strip path (tsii_dw_stat_rows() > 0)");
@@ -1335,9 +1042,7 @@ extern "C" size_t tsii_dw_bwd_dw_ws_bytes(int n, int ho, int wo, int c, int kh, 
     // the scalar plan (taken when c % 4 != 0 or a pointer is unaligned) never needs more rows
     const DwPlan a = plan_dw(n, ho, c, c % 4 == 0), b = plan_dw(n, ho, c, false);
     int R = a.R > b.R ? a.R : b.R;
-    if (kh == 3 && kw == 3) {   // LDS-tiled plan (any stride/dilation: upper bound over both) and the strip plan
-        const int g1 = (int)plan_dt_dw(n, ho, wo, c, 1, 1).groups;
-        if (g1 > R) R = g1;
+    if (kh == 3 && kw == 3) {
         for (int ss = 1; ss <= 2; ++ss) {       // strip plans of both strides (the stride is not part of this signature)
             const StripPlan sp = plan_strip(n, ho, wo, c, ss, 1);
             const int64_t g2 = (int64_t)n * sp.chunks_y * sp.strips_x;
@@ -1377,19 +1082,7 @@ static int dw_bwd_dw_impl(const float* dy, const float* inv, const float* keep, 
             return check_launch("dw_reduce");
         }
     }
-    if (vec && kh == 3 && kw == 3 && sh == sw && dh == dw) {
-        const DtDwPlan tp = plan_dt_dw(n, ho, wo, c, sh, dh);
-        if (tp.ok) {
-            DtGeom tg = {n, h, wd, c, sh, dh, ph, pw, ho, wo, 0};
-            hipLaunchKernelGGL(dw_tile_dw_kernel, dim3(tp.groups * tp.cblocks), dim3(256), 0, st, dy, inv, keep, x, rmask, tg,
-                               tp.PH, tp.PW, tp.tiles_x, tp.tiles_y, tp.cblocks, tp.tiles_per_block, ib, part);
-            int rc0 = check_launch("dw_tile_dw");
-            if (rc0) return rc0;
-            hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)cdiv64((int64_t)10 * c, 32)), dim3(256), 0, st, part, (int)tp.groups, 9, c, dwgt, dbias);
-            return check_launch("dw_reduce");
-        }
-    }
-    TSII_REQUIRE(ib.sc == nullptr, "dw_bwd_dw_bn: the fused BatchNorm form needs the LDS-tiled 3x3 path");
+    TSII_REQUIRE(ib.sc == nullptr, "dw_bwd_dw_bn: the fused BatchNorm form needs the marching-strip path (tsii_dw_stat_rows() > 0)");
     const DwPlan p = plan_dw(n, ho, c, vec);
     const dim3 grid((unsigned)(p.gx * p.gy));
     const bool k3 = (kh == 3 && kw == 3);
