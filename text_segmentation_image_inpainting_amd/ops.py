@@ -17,8 +17,13 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3, 4
 
 import os as _os
 
-# A/B knob for K6c (BatchNorm-backward reductions taken by the kernel that produces the incoming gradient)
+# A/B knobs for K6c (BatchNorm-backward reductions taken by the kernel that produces the incoming gradient):
+# TSII_FUSE_BN_BWD = 0 off | 1 (default) in the depth-wise dX strip kernel | 2 also in the point-wise dX GEMM epilogue.
+# Measured on MI355X (ImageFill 512^2 bs 32): 107.8 -> 106.0 ms with 1, 105.6 ms with 2 -- the GEMM form saves 3.3 ms of
+# BatchNorm backward for 2.4 ms of extra epilogue (it runs at 2 blocks/CU) and drags the dominant kernel's MFMA
+# fraction down 3 points for 0.4 ms, so it stays opt-in.
 FUSE_BN_BWD = _os.environ.get("TSII_FUSE_BN_BWD", "1") != "0"
+FUSE_BN_BWD_PW = _os.environ.get("TSII_FUSE_BN_BWD", "1") == "2"
 
 
 class Geom(NamedTuple):
@@ -140,7 +145,7 @@ class _Pointwise(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)   # gradient w.r.t. the (virtual) normalised input when in_scale is set
             wt = _ws(4 * k * cout, x)
-            if ctx.bn is not None and FUSE_BN_BWD and k % 4 == 0 and cout % 4 == 0 and load_time_act(*ctx.in_cfg):
+            if ctx.bn is not None and FUSE_BN_BWD_PW and k % 4 == 0 and cout % 4 == 0 and load_time_act(*ctx.in_cfg):
                 mean, var, gamma, beta, eps, slot = ctx.bn
                 part = torch.empty((int(_lib.lib().tsii_pw_stat_rows(m)), 2, k), dtype=torch.float32, device=x.device)
                 call("tsii_pw_bwd_dx_bn", ptr(gy), m, cout, ptr(w), k, ptr(inv), ptr(r0), ctx.split, ptr(r1),
