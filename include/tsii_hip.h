@@ -177,6 +177,15 @@ int tsii_dw_bwd_dw_bn(const float* dy, const float* inv, const float* keep, cons
                       int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
                       int ho, int wo, const float* in_scale, const float* in_shift, int in_act, float in_slope,
                       float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream);
+/* dense k x k forward with the statistics partials ([rows][4][cout]); rows == 0: this geometry is not on the
+ * implicit-GEMM path (few-output-channel / generic kernels), use tsii_dense_fwd + tsii_bn_stats */
+int64_t tsii_dense_stat_rows(int has_mfull, int n, int h, int wd, int cin, int cout, int kh, int kw, int sh, int sw,
+                             int ph, int pw, int dh, int dw, int ho, int wo);
+int tsii_dense_fwd_bn(const float* x, const float* mfull, const float* r0, int split, const float* r1,
+                      const float* w, const float* bias, const float* denom, const float* keep,
+                      int n, int h, int wd, int cin, int cout,
+                      int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo,
+                      float* stat_part, float* y, void* ws, size_t ws_bytes, void* stream);
 size_t tsii_bn_finalize_ws_bytes(int64_t rows, int c);
 /* scale/shift may be NULL (then gamma/beta may be too) */
 int tsii_bn_finalize(const float* stat_part, int64_t rows, int c, int64_t m,

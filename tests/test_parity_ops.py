@@ -388,3 +388,29 @@ def test_depthwise_strip_kernels_vs_oracle(backend):
             assert_close(xd.grad, xo.grad, TOL, f"dw strip case {idx} dx")
             assert_close(m.feature_conv.weight.grad, w.grad, TOL, f"dw strip case {idx} dw")
             assert_close(m.feature_conv.bias.grad, b.grad, TOL, f"dw strip case {idx} db")
+
+
+@both_backends
+def test_dense_block_statistics_from_gemm_epilogue(backend, monkeypatch):
+    """conv(3x3 dense, implicit GEMM) + BatchNorm block: the statistics taken from the GEMM epilogue partials (K6b) give the
+    same outputs, running statistics and gradients as the separate statistics pass."""
+    from text_segmentation_image_inpainting_amd import partial_convolution as pc
+    with BACKENDS[backend]() as dev:
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setattr(pc, "FUSE_BN", mode)
+            torch.manual_seed(0)
+            blk = pc.partial_convolution_block(24, 40, 3, 1, 1, 1, BN=True, activation=torch.nn.LeakyReLU(0.3), same_holes=True)
+            fill_state_dict_(blk.state_dict(), seed=31)
+            blk = blk.to(dev).train()
+            rng = np.random.default_rng(31)
+            x = torch.from_numpy(rng.standard_normal((2, 24, 19, 23)).astype(np.float32)).to(dev).requires_grad_(True)
+            m = (torch.from_numpy(rng.uniform(size=(2, 1, 19, 23))) > 0.3).float().expand(-1, 24, -1, -1).to(dev)
+            from text_segmentation_image_inpainting_amd.BaseModels import run_nhwc, to_nhwc
+            from text_segmentation_image_inpainting_amd.masks import as_parts
+            y, mp = run_nhwc(blk, to_nhwc(x), as_parts(m))
+            y.square().sum().backward()
+            res[mode] = (y.detach().cpu(), x.grad.cpu(), blk[0].feature_conv.weight.grad.cpu(), blk[1].bn_act[0].weight.grad.cpu(),
+                         blk[1].bn_act[0].running_var.cpu().clone())
+        for a, b, what in zip(res["1"], res["0"], ("y", "dx", "dw", "dgamma", "running_var")):
+            assert_close(a, b, 2e-5, "dense block " + what, floor=1e-6)

@@ -45,6 +45,8 @@ SIGNATURES = {
     "tsii_dw_stat_rows": (_l, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "tsii_dw_fwd_bn": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _i, _f, _p, _p, _p, _p]),
     "tsii_dw_bwd_dw_bn": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _i, _f, _p, _p, _p, _z, _p]),
+    "tsii_dense_stat_rows": (_l, [_i, _i, _i, _i, _i, _i] + _GEOM + [_i, _i]),
+    "tsii_dense_fwd_bn": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _p, _z, _p]),
     "tsii_bn_finalize_ws_bytes": (_z, [_l, _i]),
     "tsii_bn_finalize": (_i, [_p, _l, _i, _l, _p, _p, _p, _p, _f, _p, _p, _f, _p, _p, _p, _z, _p]),
     "tsii_dw_bwd_dx_bn": (_i, [_p, _p, _p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p]),

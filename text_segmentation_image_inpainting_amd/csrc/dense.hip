@@ -799,10 +799,10 @@ extern "C" size_t tsii_dense_ws_bytes(int cin, int cout, int kh, int kw) {
     return fl * sizeof(float);
 }
 
-extern "C" int tsii_dense_fwd(const float* x, const float* mfull, const float* r0, int split, const float* r1,
-                              const float* w, const float* bias, const float* denom, const float* keep,
-                              int n, int h, int wd, int cin, int cout, int kh, int kw, int sh, int sw, int ph, int pw,
-                              int dh, int dw, int ho, int wo, float* y, void* ws, size_t ws_bytes, void* stream) {
+static int dense_fwd_impl(const float* x, const float* mfull, const float* r0, int split, const float* r1,
+                          const float* w, const float* bias, const float* denom, const float* keep,
+                          int n, int h, int wd, int cin, int cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                          int dh, int dw, int ho, int wo, float* stats, float* y, void* ws, size_t ws_bytes, void* stream) {
     TSII_REQUIRE(x && w && y && ws, "dense_fwd: null pointer");
     CONV_GEOM();
     if (check_conv_geom(g, "dense_fwd")) return -1;
@@ -811,6 +811,8 @@ extern "C" int tsii_dense_fwd(const float* x, const float* mfull, const float* r
     hipStream_t st = (hipStream_t)stream;
     const int coutp = pad4(cout), T = kh * kw;
     float* wf = (float*)ws;
+    TSII_REQUIRE(stats == nullptr || (head_cg(g, mfull) == 0 && !plan_small(g).ok && use_conv_gemm(g, mfull, x, y, ws)),
+                 "dense_fwd_bn: statistics partials need the implicit-GEMM path (tsii_dense_stat_rows() > 0, aligned operands)");
     if (const int hcg = head_cg(g, mfull)) {       // 3x3 few-output-channel head
         hipLaunchKernelGGL(head_prep_fwd_kernel, dim3(cdiv(9 * hcg * 16, 256)), dim3(256), 0, st, w, cin, cout, hcg, wf);
         int rch = check_launch("head_prep_fwd");
@@ -841,7 +843,7 @@ extern "C" int tsii_dense_fwd(const float* x, const float* mfull, const float* r
         if (rcg) return rcg;
         const ConvGemmGeom cgg = {n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo};
         RowScale rsg = {r0, r1, split};
-        return launch_conv_gemm_fwd(x, mfull, rsg, wf, bias, denom, keep, cgg, y, st);
+        return launch_conv_gemm_fwd(x, mfull, rsg, wf, bias, denom, keep, cgg, y, st, stats);
     }
     hipLaunchKernelGGL(dense_prep_fwd_kernel, dim3(stream_grid((int64_t)T * cin * coutp, 256)), dim3(256), 0, st,
                        w, cin, cout, T, coutp, wf);
@@ -852,6 +854,34 @@ extern "C" int tsii_dense_fwd(const float* x, const float* mfull, const float* r
     hipLaunchKernelGGL(dense_fwd_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, x, mfull, rs, wf, bias,
                        denom, keep, g, coutp, y);
     return check_launch("dense_fwd");
+}
+
+extern "C" int tsii_dense_fwd(const float* x, const float* mfull, const float* r0, int split, const float* r1,
+                              const float* w, const float* bias, const float* denom, const float* keep,
+                              int n, int h, int wd, int cin, int cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                              int dh, int dw, int ho, int wo, float* y, void* ws, size_t ws_bytes, void* stream) {
+    return dense_fwd_impl(x, mfull, r0, split, r1, w, bias, denom, keep, n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo,
+                          nullptr, y, ws, ws_bytes, stream);
+}
+
+extern "C" int64_t tsii_dense_stat_rows(int has_mfull, int n, int h, int wd, int cin, int cout, int kh, int kw, int sh, int sw,
+                                        int ph, int pw, int dh, int dw, int ho, int wo) {
+    if (n <= 0 || ho <= 0 || wo <= 0) return 0;
+    const ConvGeom g = {n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo};
+    const ConvGemmGeom cg = {n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo};
+    if (head_cg(g, has_mfull ? (const float*)1 : nullptr) != 0 || plan_small(g).ok) return 0;
+    if (!((has_mfull == 0 && conv_gemm_ok(cg)) || conv_gemm_elem_ok(cg))) return 0;
+    return cdiv64((int64_t)n * ho * wo, 128);
+}
+
+extern "C" int tsii_dense_fwd_bn(const float* x, const float* mfull, const float* r0, int split, const float* r1,
+                                 const float* w, const float* bias, const float* denom, const float* keep,
+                                 int n, int h, int wd, int cin, int cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                                 int dh, int dw, int ho, int wo, float* stat_part, float* y, void* ws, size_t ws_bytes,
+                                 void* stream) {
+    TSII_REQUIRE(stat_part != nullptr, "dense_fwd_bn: null stat_part");
+    return dense_fwd_impl(x, mfull, r0, split, r1, w, bias, denom, keep, n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo,
+                          stat_part, y, ws, ws_bytes, stream);
 }
 
 extern "C" int tsii_dense_bwd_dx(const float* dy, const float* inv, const float* w, const float* mfull,

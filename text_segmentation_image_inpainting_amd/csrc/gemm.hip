@@ -872,10 +872,10 @@ bool conv_gemm_elem_ok(const ConvGemmGeom& g) {   // element-wise gather: few in
 }
 
 int launch_conv_gemm_fwd(const float* x, const float* mfull, RowScale rs, const float* wr, const float* bias,
-                         const float* denom, const float* keep, const ConvGemmGeom& g, float* y, hipStream_t st) {
+                         const float* denom, const float* keep, const ConvGemmGeom& g, float* y, hipStream_t st, float* stats) {
     const int K = g.kh * g.kw * g.cin;
     const int64_t M = (int64_t)g.n * g.ho * g.wo;
-    Epilogue ep = {denom, keep, bias, {nullptr, nullptr, 0}, 0};
+    Epilogue ep = {denom, keep, bias, {nullptr, nullptr, 0}, 0, stats};
     const ConvGather cg = make_gather(g, false, rs.r0, rs.r1, rs.r0 != nullptr ? rs.split : 0, mfull);
     if (mfull != nullptr || g.cin % 4 != 0) return launch_nt_conv<3>(x, wr, K, y, g.cout, M, g.cout, K, ep, cg, st);
     return launch_nt_conv<1>(x, wr, K, y, g.cout, M, g.cout, K, ep, cg, st);

@@ -95,7 +95,7 @@ struct ConvGemmGeom {
 bool conv_gemm_ok(const ConvGemmGeom& g);        // vector gather: cin % 4 == 0, no per-channel mask
 bool conv_gemm_elem_ok(const ConvGemmGeom& g);   // element-wise gather: few input channels / per-channel mask
 int launch_conv_gemm_fwd(const float* x, const float* mfull, RowScale rs, const float* wr, const float* bias,
-                         const float* denom, const float* keep, const ConvGemmGeom& g, float* y, hipStream_t st);
+                         const float* denom, const float* keep, const ConvGemmGeom& g, float* y, hipStream_t st, float* stats = nullptr);
 int launch_conv_gemm_dx(const float* dy, const float* inv, const float* wd, RowScale rs_out, const ConvGemmGeom& g,
                         float* dx, hipStream_t st);
 size_t conv_gemm_dw_ws_floats(const ConvGemmGeom& g);

@@ -288,7 +288,7 @@ def pconv_depthwise(x, w, bias, rmask, denom, keep, inv, g: Geom, want_stats=Fal
 # ---------------------------------------------------------------------------------------
 class _Dense(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, mfull, r0, r1, denom, keep, inv, split, g):
+    def forward(ctx, x, w, bias, mfull, r0, r1, denom, keep, inv, split, g, want_stats=False):
         _lib.check_device(x)
         x, w = x.contiguous(), w.contiguous()
         n, h, wd, cin = x.shape
@@ -299,14 +299,27 @@ class _Dense(torch.autograd.Function):
         L = _lib.lib()
         nbytes = L.tsii_dense_ws_bytes(cin, cout, g.kh, g.kw)
         ws = _ws(nbytes, x)
-        call("tsii_dense_fwd", ptr(x), ptr(mfull), ptr(r0), int(split), ptr(r1), ptr(w), ptr(bias),
-             ptr(denom), ptr(keep), n, h, wd, cin, cout, *g, ho, wo, ptr(y), ptr(ws), nbytes, _lib.stream())
+        rows = int(L.tsii_dense_stat_rows(int(mfull is not None), n, h, wd, cin, cout, *g, ho, wo)) if want_stats else 0
+        part = None
+        if rows > 0:     # implicit-GEMM path: the BatchNorm statistics partials come out of the epilogue (K6b)
+            part = torch.empty((rows, 4, cout), dtype=torch.float32, device=x.device)
+            call("tsii_dense_fwd_bn", ptr(x), ptr(mfull), ptr(r0), int(split), ptr(r1), ptr(w), ptr(bias),
+                 ptr(denom), ptr(keep), n, h, wd, cin, cout, *g, ho, wo, ptr(part), ptr(y), ptr(ws), nbytes, _lib.stream())
+        else:
+            call("tsii_dense_fwd", ptr(x), ptr(mfull), ptr(r0), int(split), ptr(r1), ptr(w), ptr(bias),
+                 ptr(denom), ptr(keep), n, h, wd, cin, cout, *g, ho, wo, ptr(y), ptr(ws), nbytes, _lib.stream())
         ctx.save_for_backward(x, w, mfull, r0, r1, inv, keep)
         ctx.g, ctx.split, ctx.has_bias = g, int(split), bias is not None
+        ctx.set_materialize_grads(False)
+        if part is not None:
+            ctx.mark_non_differentiable(part)
+            return y, part
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, *_):
+        if gy is None:
+            return (None,) * 12
         x, w, mfull, r0, r1, inv, keep = ctx.saved_tensors
         g = ctx.g
         gy = gy.contiguous()
@@ -328,11 +341,15 @@ class _Dense(torch.autograd.Function):
             ws = _ws(nbytes, x)
             call("tsii_dense_bwd_dw", ptr(gy), ptr(inv), ptr(keep), ptr(x), ptr(mfull), ptr(r0), ctx.split, ptr(r1),
                  n, h, wd, cin, cout, *g, ho, wo, ptr(dw), ptr(db), ptr(ws), nbytes, st)
-        return dx, dw, db, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
-def pconv_dense(x, w, bias, mfull, r0, split, r1, denom, keep, inv, g: Geom):
-    return _Dense.apply(x, w, bias, mfull, r0, r1, denom, keep, inv, split, g)
+def pconv_dense(x, w, bias, mfull, r0, split, r1, denom, keep, inv, g: Geom, want_stats=False):
+    """With ``want_stats`` returns (y, stat_part or None) -- None when the geometry is not on the implicit-GEMM path."""
+    out = _Dense.apply(x, w, bias, mfull, r0, r1, denom, keep, inv, split, g, want_stats)
+    if want_stats and not isinstance(out, tuple):
+        return out, None
+    return out
 
 
 # ---------------------------------------------------------------------------------------
@@ -683,8 +700,7 @@ def conv2d(x, w, b, g: Geom, groups: int, want_stats=False):
     if groups == 1:
         if tuple(g)[:6] == (1, 1, 1, 1, 0, 0):
             return pconv_pointwise(x, w, b, want_stats=want_stats)
-        y = pconv_dense(x, w, b, None, None, 0, None, None, None, None, g)
-        return (y, None) if want_stats else y
+        return pconv_dense(x, w, b, None, None, 0, None, None, None, None, g, want_stats=want_stats)
     if groups == cin == cout:
         return pconv_depthwise(x, w, b, None, None, None, None, g, want_stats=want_stats)
     raise NotImplementedError(f"conv2d groups={groups} (neither 1 nor depth-wise) has no HIP kernel")

@@ -88,7 +88,9 @@ class PartialConv(BaseModule):
                     if want_stats:
                         y, part = y
                 else:
-                    y = ops.pconv_dense(real(x), w, b, None, r0, split, r1, denom, keep, inv, g)
+                    y = ops.pconv_dense(real(x), w, b, None, r0, split, r1, denom, keep, inv, g, want_stats=want_stats)
+                    if want_stats:
+                        y, part = y
             else:
                 mfull = mp.full_nhwc()
                 if pointwise:
@@ -97,7 +99,9 @@ class PartialConv(BaseModule):
                     if want_stats:
                         y, part = y
                 else:
-                    y = ops.pconv_dense(real(x), w, b, mfull, None, 0, None, denom, keep, inv, g)
+                    y = ops.pconv_dense(real(x), w, b, mfull, None, 0, None, denom, keep, inv, g, want_stats=want_stats)
+                    if want_stats:
+                        y, part = y
         elif groups == cin == cout:
             if mp.fusable and len(mp.parts) == 1:
                 y = ops.pconv_depthwise(x, w, b, mp.parts[0].plane, denom, keep, inv, g, want_stats=want_stats)
