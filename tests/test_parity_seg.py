@@ -101,11 +101,13 @@ def test_golden_seg_nets_64_gpu(name):
         for k in G.files:
             if k.startswith("grad."):
                 # tolerance: 3e-3, or 4x the reference's own fp32-vs-fp64 discrepancy for this tensor when that is
-                # larger (train-mode BN chains amplify rounding noise)
+                # larger (train-mode BN chains amplify rounding noise) -- measured against the reference's
+                # fp64 gradient; against its fp32 gradient the two noises add (triangle inequality: one more unit)
                 ref64 = G["grad64." + k[5:]]
                 scale = max(float(np.abs(G[k]).max()), 1e-3 * gmax)
                 noise = float(np.abs(G[k] - ref64).max()) / scale
-                assert_close(params[k[5:]].grad, G[k], max(3e-3, 4 * noise), k, floor=1e-3 * gmax)
+                assert_close(params[k[5:]].grad, ref64.astype(np.float32), max(3e-3, 4 * noise), k + " vs fp64", floor=1e-3 * gmax)
+                assert_close(params[k[5:]].grad, G[k], max(3e-3, 5 * noise), k, floor=1e-3 * gmax)
                 n += 1
         assert n >= 12
 
