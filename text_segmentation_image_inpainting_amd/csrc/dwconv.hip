@@ -486,11 +486,17 @@ __global__ __launch_bounds__(256, MODE != 0 ? 2 : 3) void dw_strip_kernel(
         if (threadIdx.x < ST_CB && (int)cb * ST_CB + (int)threadIdx.x < g.c) {
             const int ch = threadIdx.x, mcg = ch / 4, mi = ch % 4;
             float nn = 0.f, pv = 0.f, s1 = 0.f, s2 = 0.f;
+            bool have = false;
+            {   // common pivot: an interior lane's (lane 17 = row 1, column 1 of the step) when it saw pixels -- the strip's
+                // first pixel is an image-border pixel, the typical outlier of a channel
+                const float* qi = mrg + ((LANES / 2 + 1) * CGS + mcg) * 13;
+                if (qi[0] != 0.f) { pv = qi[1 + mi]; have = true; }
+            }
             for (int l = 0; l < LANES; ++l) {
                 const float* q = mrg + (l * CGS + mcg) * 13;
                 const float n_t = q[0];
                 if (n_t == 0.f) continue;
-                if (nn == 0.f) pv = q[1 + mi];
+                if (!have) { pv = q[1 + mi]; have = true; }
                 const float dp = q[1 + mi] - pv, a1 = q[5 + mi], a2 = q[9 + mi];
                 s1 += fmaf(n_t, dp, a1);
                 s2 += a2 + dp * (2.f * a1 + n_t * dp);

@@ -422,10 +422,12 @@ __global__ __launch_bounds__(256, BNB ? 2 : 3) void gemm_nt_kernel(const float* 
                 Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * CS + (wn * TN + u) * 32 + li] = acc[t][u][r];
         __syncthreads();
         if (t == 0 && ep.stats != nullptr) {
-            // block pivot: (roughly) the value of the block's first row -- any number typical of the column does,
-            // it only has to be the same for every thread of the column group
-            const float4 q0 = *reinterpret_cast<const float4*>(Cs + c4 * 4);
-            const float rd0 = ep.denom != nullptr ? 1.0f / ep.denom[m0] : 1.0f;
+            // block pivot: (roughly) the value of the block's middle row (row 64; image-border pixels, where the first
+            // row of a block often sits, are the outliers of a channel) -- any number typical of the column does, it
+            // only has to be the same for every thread of the column group
+            const bool mid = m0 + 64 < M;
+            const float4 q0 = *reinterpret_cast<const float4*>(Cs + (mid ? (2 / TM) * 32 * CS : 0) + c4 * 4);
+            const float rd0 = ep.denom != nullptr ? 1.0f / ep.denom[mid ? m0 + 64 : m0] : 1.0f;
             pvt[0] = fmaf(q0.x, rd0, bv[0]); pvt[1] = fmaf(q0.y, rd0, bv[1]);
             pvt[2] = fmaf(q0.z, rd0, bv[2]); pvt[3] = fmaf(q0.w, rd0, bv[3]);
         }
