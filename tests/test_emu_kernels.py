@@ -109,9 +109,9 @@ def test_pointwise_fused_batchnorm(emu, M, K, N, act, slope):
                               P(scale), P(shift), P(ws), nb, None) == 0, L.tsii_last_error()
     y64 = y.astype(np.float64)
     assert np.abs(mean - y64.mean(0)).max() <= 1e-6 * (np.abs(y64).max() + 1)
-    assert np.abs(var - y64.var(0)).max() <= 2e-6 * y64.var(0).max()
+    assert np.abs(var - y64.var(0)).max() <= 4e-6 * y64.var(0).max()
     assert np.abs(rm - 0.1 * y64.mean(0)).max() <= 1e-6 * (np.abs(y64).max() + 1)
-    assert np.abs(rv - (0.9 + 0.1 * y64.var(0, ddof=1))).max() <= 2e-6 * (1 + y64.var(0).max())
+    assert np.abs(rv - (0.9 + 0.1 * y64.var(0, ddof=1))).max() <= 4e-6 * (1 + y64.var(0).max())
     rs = gamma / np.sqrt(y64.var(0) + 1e-5)
     assert np.abs(scale - rs).max() <= 1e-5 * np.abs(rs).max()
     assert np.abs(shift - (beta - y64.mean(0) * rs)).max() <= 1e-5 * (np.abs(beta).max() + np.abs(y64.mean(0) * rs).max())
