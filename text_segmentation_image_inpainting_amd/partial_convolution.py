@@ -239,7 +239,11 @@ def run_block(block, x, mp, allow_lazy=False, residual=None):
     conv_types = (PartialConv, PartialConv1x1)
     if FUSE_BN != "0" and len(mods) == 2 and isinstance(mods[0], conv_types) and isinstance(mods[1], PartialActivatedBN):
         conv, bn = mods
-        y, m, part = conv.forward_nhwc(x, mp, want_stats=True)
+        bn0 = bn.bn_act[0]
+        if bn0.training or bn0.running_mean is None:
+            y, m, part = conv.forward_nhwc(x, mp, want_stats=True)
+        else:                                        # eval: running statistics, nothing to collect
+            (y, m), part = conv.forward_nhwc(x, mp), None
         lazy, m = bn.forward_lazy(y, m, part)
         if allow_lazy and residual is None and FUSE_BN == "1" and ops.load_time_act(lazy.act, lazy.slope):
             return lazy, m
