@@ -1,0 +1,47 @@
+"""n3: CyclicLR (host-side schedule, mirror of the reference's models/utils/cls.py interface) -- closed-form values and
+stock torch.optim.lr_scheduler.CyclicLR as the oracle for the three built-in policies."""
+import pytest
+import torch
+
+from text_segmentation_image_inpainting_amd.utils.cls import CyclicLR
+
+
+class _Trainer:           # stands in for train_step.FlatSGDTrainer (single lr attribute)
+    lr = 0.0
+
+
+@pytest.mark.parametrize("mode,gamma", [("triangular", 1.0), ("triangular2", 1.0), ("exp_range", 0.999)])
+def test_cyclic_lr_matches_torch(mode, gamma):
+    w = torch.nn.Parameter(torch.zeros(1))
+    ours_opt = torch.optim.SGD([w], lr=0.1)
+    ref_opt = torch.optim.SGD([w], lr=0.1)
+    ours = CyclicLR(ours_opt, base_lr=1e-3, max_lr=6e-3, step_size=7, mode=mode, gamma=gamma)
+    ref = torch.optim.lr_scheduler.CyclicLR(ref_opt, base_lr=1e-3, max_lr=6e-3, step_size_up=7, mode=mode, gamma=gamma,
+                                            cycle_momentum=False)
+    tr = _Trainer()
+    flat = CyclicLR(tr, base_lr=1e-3, max_lr=6e-3, step_size=7, mode=mode, gamma=gamma)
+    # the reference's usage (cls.py docstring): scheduler.batch_step() BEFORE each batch -- the constructor applies
+    # iteration 0 and then rewinds, so the first call applies iteration 0 again (same quirk here)
+    for it in range(60):
+        ours.batch_step(); flat.batch_step()
+        assert ours.last_batch_iteration == it
+        assert ours_opt.param_groups[0]["lr"] == pytest.approx(ref_opt.param_groups[0]["lr"], rel=1e-9, abs=1e-15), it
+        assert tr.lr == pytest.approx(ours_opt.param_groups[0]["lr"], rel=1e-12)
+        ref_opt.step(); ref.step()
+
+
+def test_cyclic_lr_closed_form_and_resume():
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1)
+    s = CyclicLR(opt, base_lr=0.0, max_lr=1.0, step_size=4)
+    seen = []
+    for _ in range(9):
+        s.batch_step()
+        seen.append(opt.param_groups[0]["lr"])
+    assert seen == pytest.approx([0.0, 0.25, 0.5, 0.75, 1.0, 0.75, 0.5, 0.25, 0.0])
+    opt2 = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1)
+    CyclicLR(opt2, base_lr=0.0, max_lr=1.0, step_size=4, last_batch_iteration=5)
+    assert opt2.param_groups[0]["lr"] == pytest.approx(0.5)
+    with pytest.raises(ValueError):
+        CyclicLR(opt, mode="nope")
+    with pytest.raises(ValueError):
+        CyclicLR(opt, base_lr=[1e-3, 2e-3])
