@@ -195,6 +195,43 @@ def Conv_block(in_channels, out_channels, kernel_size, stride=1, padding=0,
     return m
 
 
+def run_chain(mods, x):
+    """Run a list of modules built from Conv_block pieces on an NCHW-shaped tensor with every ``Conv2d -> BNAct`` pair
+    folded (K6b): the conv emits the BatchNorm statistics partials and, when another Conv2d follows, the normalised
+    activation stays virtual (ops.LazyBN) and is applied by that conv while loading (models/MobileNetV2.py:127-140,
+    models/BaseModels.py:105-127 chains).  Anything else in the list runs through its own forward()."""
+    h, lazy, i, n = to_nhwc(x), None, 0, len(mods)
+    while i < n:
+        m = mods[i]
+        if isinstance(m, Conv2d) and i + 1 < n and isinstance(mods[i + 1], BNAct) and m.padding_mode == "zeros":
+            bn = mods[i + 1][0]
+            act, slope = act_code(mods[i + 1][1] if len(mods[i + 1]) > 1 else None)
+            training = bn.training or bn.running_mean is None
+            if training and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            momentum = 0.1 if bn.momentum is None else bn.momentum
+            g = ops.make_geom(m.kernel_size, m.stride, m.padding, m.dilation)
+            src = lazy if lazy is not None else h
+            if training:
+                y, part = ops.conv2d(src, m.weight, m.bias, g, m.groups, want_stats=True)
+            else:
+                y, part = ops.conv2d(src, m.weight, m.bias, g, m.groups), None
+            lz = ops.bn_lazy(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, act, slope, part)
+            if i + 2 < n and isinstance(mods[i + 2], Conv2d) and ops.load_time_act(act, slope):
+                h, lazy = None, lz
+            else:
+                h, lazy = lz.materialize(), None
+            i += 2
+            continue
+        if lazy is not None:
+            h, lazy = lazy.materialize(), None
+        h = to_nhwc(m(to_nchw(h)))
+        i += 1
+    if lazy is not None:
+        h = lazy.materialize()
+    return to_nchw(h)
+
+
 class DSConvBlock(BaseModule):
     """depth-wise separable convolution (models/BaseModels.py:105-127)"""
 
@@ -209,7 +246,7 @@ class DSConvBlock(BaseModule):
                         dilation=1, bias=bias, BN=BN, activation=activation_point))
 
     def forward(self, x):
-        return self.point_wise_conv(self.depth_wise_conv(x))
+        return run_chain(list(self.depth_wise_conv) + list(self.point_wise_conv), x)
 
 
 def run_nhwc(layer, x, mp):

@@ -6,7 +6,7 @@ from torch import nn
 from torch.utils.checkpoint import checkpoint
 
 from . import ops
-from .BaseModels import BaseModule, Conv_block, run_nhwc, to_nchw, to_nhwc  # noqa: F401
+from .BaseModels import BaseModule, Conv_block, run_chain, run_nhwc, to_nchw, to_nhwc  # noqa: F401
 from .common import SpatialChannelSqueezeExcitation
 from .masks import MaskParts, as_parts
 from .partial_convolution import PartialActivatedBN, partial_convolution_block, run_block  # noqa: F401
@@ -111,9 +111,10 @@ class InvertedResidual(BaseModule):
         return nn.Sequential(*m)
 
     def forward(self, x):
+        y = run_chain(list(self.conv), x)       # expand -> depth-wise -> project with the BatchNorms folded (K6b)
         if self.res_connect:
-            return to_nchw(ops.add_act(to_nhwc(x), to_nhwc(self.conv(x))))          # x + conv(x) (:146-147)
-        return self.conv(x)
+            return to_nchw(ops.add_act(to_nhwc(x), to_nhwc(y)))          # x + conv(x) (:146-147)
+        return y
 
 
 

@@ -700,6 +700,8 @@ def conv2d(x, w, b, g: Geom, groups: int, want_stats=False):
     if groups == 1:
         if tuple(g)[:6] == (1, 1, 1, 1, 0, 0):
             return pconv_pointwise(x, w, b, want_stats=want_stats)
+        if isinstance(x, LazyBN):
+            x = x.materialize()       # the gather loaders have no load-time BatchNorm
         return pconv_dense(x, w, b, None, None, 0, None, None, None, None, g, want_stats=want_stats)
     if groups == cin == cout:
         return pconv_depthwise(x, w, b, None, None, None, None, g, want_stats=want_stats)
