@@ -365,7 +365,8 @@ def test_depthwise_strip_kernels_vs_oracle(backend):
     """K2 marching-strip stencils (stride 1 d 1/2, stride 2) incl. tile tails, several strip chunks and channel tails:
     forward, new_mask, dX, dW, db of the depth-wise PartialConv vs the oracle."""
     with BACKENDS[backend]() as dev:
-        for idx, (c, s, d, H, W) in enumerate([(40, 1, 1, 21, 37), (36, 1, 2, 19, 18), (40, 2, 1, 22, 37), (64, 2, 1, 33, 16)]):
+        for idx, (c, s, d, H, W) in enumerate([(40, 1, 1, 21, 37), (36, 1, 2, 19, 18), (40, 2, 1, 22, 37), (64, 2, 1, 33, 16),
+                                               (36, 1, 4, 20, 23), (32, 1, 8, 33, 18)]):
             m = T.PartialConv(c, c, 3, s, d, d, c, True, True)
             fill_state_dict_(m.state_dict(), seed=900 + idx)
             rng = np.random.default_rng(900 + idx)

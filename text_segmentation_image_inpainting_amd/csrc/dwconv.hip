@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, MODE != 0 ? 2 : 3) void dw_strip_kernel(
     constexpr int PF = (NEW * PW + LANES - 1) / LANES;         // slab pixels per thread per step
     constexpr int NPX = R * TW;
     constexpr int TYS = LANES / TW;                            // row stride between a thread's pixels
-    static_assert(PRO >= 0 && PRO <= NEW, "the prologue fetch covers the halo rows");
+    static_assert(PRO >= 0, "ring rows");
     __shared__ __attribute__((aligned(16))) float ring[NR * PW * ST_CB];
     __shared__ float planes[2][3][NPX];                        // keep / denom / post_mul of a step's pixels, double buffered
     unsigned b = xcd_remap(blockIdx.x, gridDim.x);
@@ -375,8 +375,11 @@ __global__ __launch_bounds__(256, MODE != 0 ? 2 : 3) void dw_strip_kernel(
     };
 
     fetch_planes(0);
-    fetch(0, PRO);
-    commit(0, PRO);
+#pragma unroll
+    for (int r = 0; r < PRO; r += NEW) {               // halo rows first (more than one round for large dilations)
+        fetch(r, PRO - r < NEW ? PRO - r : NEW);
+        commit(r, PRO - r < NEW ? PRO - r : NEW);
+    }
     fetch(PRO, NEW);
     commit(PRO, NEW);
     commit_planes(0);
@@ -648,7 +651,7 @@ struct StripPlan {
 };
 static StripPlan plan_strip(int n, int hout, int wout, int c, int s, int d) {
     StripPlan p;
-    p.ok = ((s == 1 && d >= 1 && d <= 2) || (s == 2 && d == 1)) && c % 4 == 0;
+    p.ok = ((s == 1 && (d == 1 || d == 2 || d == 4 || d == 8)) || (s == 2 && d == 1)) && c % 4 == 0;
     p.strips_x = cdiv(wout, ST_TW / (s == 2 ? 2 : 1));
     p.cblocks = cdiv(c, ST_CB);
     const int64_t per_chunk = (int64_t)p.strips_x * p.cblocks * n;
@@ -683,6 +686,10 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
                                      sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
     else if (g.d == 2) hipLaunchKernelGGL((dw_strip_kernel<1, 2, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
                                           sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
+    else if (g.d == 4) hipLaunchKernelGGL((dw_strip_kernel<1, 4, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                          sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
+    else if (g.d == 8) hipLaunchKernelGGL((dw_strip_kernel<1, 8, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                          sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
     else if (bb.y != nullptr) hipLaunchKernelGGL((dw_strip_kernel<1, 1, 2>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
                                                  sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
     else if (fused) hipLaunchKernelGGL((dw_strip_kernel<1, 1, 1>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
@@ -708,7 +715,7 @@ __global__ __launch_bounds__(256, 2) void dw_strip_dw_kernel(const float* __rest
     constexpr int PF = (NEW * PW + LANES - 1) / LANES;
     constexpr int NPX = R * TW;
     constexpr int TYS = LANES / TW;
-    static_assert(PRO >= 0 && PRO <= NEW, "the prologue fetch covers the halo rows");
+    static_assert(PRO >= 0, "ring rows");
     constexpr int RING = NR * PW * ST_CB > 5 * 256 * 4 ? NR * PW * ST_CB : 5 * 256 * 4;   // also the final lane-combine buffer
     __shared__ __attribute__((aligned(16))) float ring[RING];
     __shared__ float planes[2][2][NPX];                        // keep / inv of a step's pixels, double buffered
@@ -801,8 +808,11 @@ __global__ __launch_bounds__(256, 2) void dw_strip_dw_kernel(const float* __rest
     for (int t = 0; t < 10; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     fetch_dy(0);
-    fetch(0, PRO);
-    commit(0, PRO);
+#pragma unroll
+    for (int r = 0; r < PRO; r += NEW) {
+        fetch(r, PRO - r < NEW ? PRO - r : NEW);
+        commit(r, PRO - r < NEW ? PRO - r : NEW);
+    }
     fetch(PRO, NEW);
     commit(PRO, NEW);
     commit_planes(0);
@@ -1070,7 +1080,7 @@ static int dw_bwd_dw_impl(const float* dy, const float* inv, const float* keep, 
     const bool vec = (c % 4 == 0) && aligned16(dy) && aligned16(x) && (ib.sc == nullptr || (aligned16(ib.sc) && aligned16(ib.sh)));
     float* part = (float*)ws;
     if (vec && kh == 3 && kw == 3 && sh == sw && dh == dw &&
-        ((sh == 1 && (dh == 1 || (dh == 2 && ib.sc == nullptr))) || (sh == 2 && dh == 1 && ib.sc == nullptr))) {
+        ((sh == 1 && (dh == 1 || ((dh == 2 || dh == 4 || dh == 8) && ib.sc == nullptr))) || (sh == 2 && dh == 1 && ib.sc == nullptr))) {
         const StripPlan sp = plan_strip(n, ho, wo, c, sh, dh);   // marching strips
         if (sp.ok) {
             DtGeom tg = {n, h, wd, c, sh, dh, ph, pw, ho, wo, 0};
@@ -1079,6 +1089,10 @@ static int dw_bwd_dw_impl(const float* dy, const float* inv, const float* keep, 
             if (sh == 2) hipLaunchKernelGGL((dw_strip_dw_kernel<2, 1>), grid, dim3(256), 0, st, dy, inv, keep, x, rmask, tg, sp.chunk_rows,
                                             sp.strips_x, sp.chunks_y, sp.cblocks, ib, part);
             else if (dh == 1) hipLaunchKernelGGL((dw_strip_dw_kernel<1, 1>), grid, dim3(256), 0, st, dy, inv, keep, x, rmask, tg, sp.chunk_rows,
+                                                 sp.strips_x, sp.chunks_y, sp.cblocks, ib, part);
+            else if (dh == 4) hipLaunchKernelGGL((dw_strip_dw_kernel<1, 4>), grid, dim3(256), 0, st, dy, inv, keep, x, rmask, tg, sp.chunk_rows,
+                                                 sp.strips_x, sp.chunks_y, sp.cblocks, ib, part);
+            else if (dh == 8) hipLaunchKernelGGL((dw_strip_dw_kernel<1, 8>), grid, dim3(256), 0, st, dy, inv, keep, x, rmask, tg, sp.chunk_rows,
                                                  sp.strips_x, sp.chunks_y, sp.cblocks, ib, part);
             else hipLaunchKernelGGL((dw_strip_dw_kernel<1, 2>), grid, dim3(256), 0, st, dy, inv, keep, x, rmask, tg, sp.chunk_rows,
                                     sp.strips_x, sp.chunks_y, sp.cblocks, ib, part);
