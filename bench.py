@@ -35,7 +35,7 @@ def nt_variant(n_cols: int) -> str:
     return "gemm_nt<128x64>" if n_cols > 32 else "gemm_nt<128x32>"
 
 
-PMC_SUMMARY = "r01_g_pmc_hbm_traffic_bs32.json"   # tools/collect_profiles.sh -> tools/pmc_summary.py
+PMC_SUMMARY = "r01_h_pmc_hbm_traffic_bs32.json"   # tools/collect_profiles.sh -> tools/pmc_summary.py
 
 
 def pmc_traffic(kernel_label: str):
