@@ -415,3 +415,47 @@ def test_dense_block_statistics_from_gemm_epilogue(backend, monkeypatch):
                          blk[1].bn_act[0].running_var.cpu().clone())
         for a, b, what in zip(res["1"], res["0"], ("y", "dx", "dw", "dgamma", "running_var")):
             assert_close(a, b, 2e-5, "dense block " + what, floor=1e-6)
+
+
+@pytest.mark.gpu
+def test_imagefill_full_size_properties_gpu():
+    """BASELINE size (512x512) checks that need no oracle run: the forward is deterministic (bit-identical repeats), an
+    image's eval-mode output does not depend on its batch mates, new_mask planes stay binary and nested (holes only
+    shrink layer by layer), and two identical training steps produce bit-identical gradients."""
+    from text_segmentation_image_inpainting_amd.BaseModels import to_nhwc
+    from text_segmentation_image_inpainting_amd.synthetic import make_batch
+    from text_segmentation_image_inpainting_amd.train_step import FlatSGDTrainer
+    with BACKENDS["gpu"]() as dev:
+        torch.manual_seed(0)
+        model = T.ImageFill()
+        fill_state_dict_(model.state_dict(), seed=3)
+        model = model.to(dev)
+        corrupted, mask, clean = make_batch(4, 512, seed0=77)
+        corrupted, mask, clean = corrupted.to(dev), mask.to(dev), clean.to(dev)
+        model.eval()
+        with torch.no_grad():
+            y1 = model((corrupted, mask))
+            y2 = model((corrupted, mask))
+            assert torch.equal(y1, y2)
+            assert torch.isfinite(y1).all()
+            for i in (0, 3):
+                yi = model((corrupted[i:i + 1], mask[i:i + 1]))
+                assert_close(yi, y1[i:i + 1], 1e-6, f"batch independence, image {i}")
+            # mask path alone: a partial conv's new mask is binary and contains the old valid region
+            from text_segmentation_image_inpainting_amd.masks import as_parts
+            stem = model.encoder[0][0]
+            _, mp1 = stem.forward_nhwc(to_nhwc(corrupted), as_parts(mask))
+            nm = mp1.as_tensor()
+            assert set(torch.unique(nm).tolist()) <= {0.0, 1.0}
+            pooled = torch.nn.functional.max_pool2d(mask[:, :1], 2)     # valid at stride 2 wherever any input pixel was valid
+            assert bool((nm[:, :1] >= pooled).all())
+        grads = []
+        for _ in range(2):
+            torch.manual_seed(0)
+            m2 = T.ImageFill()
+            fill_state_dict_(m2.state_dict(), seed=3)
+            tr = FlatSGDTrainer(m2.to(dev).train(), lr=1e-3)
+            tr.forward_backward(corrupted, mask, to_nhwc(clean))
+            tr.reduce_gradients()
+            grads.append(tr.flat_grad.clone())
+        assert torch.equal(grads[0], grads[1])

@@ -209,3 +209,50 @@ class EvaluateSet(Dataset):
             x = interpolate(x.float(), size=tuple(reversed(origin_size)), mode="bilinear", align_corners=False)
             return x.expand(-1, 3, -1, -1) > 0
         return m
+
+
+class DevicePrefetcher:
+    """Feeds a training loop from a ``DataLoader`` of (corrupted, mask, clean) tuples: batch k+1 is
+    copied host -> HBM on a side HIP stream (from pinned memory, so the copy is asynchronous) while the kernels of batch k
+    run on the compute stream.  At ~310 img/s the three 3 MB/img tensors are 2.8 GB/s -- 4 % of PCIe Gen5 x16 -- so the
+    copy disappears behind the step.
+
+        for corrupted, mask, clean in DevicePrefetcher(loader, device):
+            trainer.step(corrupted, mask, to_nhwc(clean))
+    """
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def _upload(self, batch):
+        out = []
+        with torch.cuda.stream(self.stream):
+            for t in batch:
+                if torch.is_tensor(t):
+                    if not t.is_pinned():
+                        t = t.pin_memory()
+                    out.append(t.to(self.device, non_blocking=True))
+                else:
+                    out.append(t)
+        return tuple(out)
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._upload(next(it))
+        except StopIteration:
+            return
+        for batch in it:
+            cur = nxt
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)   # batch k has landed
+            for t in cur:
+                if torch.is_tensor(t):
+                    t.record_stream(torch.cuda.current_stream(self.device))
+            nxt = self._upload(batch)                                          # batch k+1 flies during step k
+            yield cur
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        for t in nxt:
+            if torch.is_tensor(t):
+                t.record_stream(torch.cuda.current_stream(self.device))
+        yield nxt
