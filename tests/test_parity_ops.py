@@ -242,6 +242,8 @@ CONV_GEMM_CASES = [
     (35, 3, 3, 1, 1, 1, True, False, True, 40),      # ImageFill final layer: 32-wide tile, several tiles
     (24, 4, 3, 1, 1, 1, False, False, False, 21),    # head kernels: 4 output channels, zero-padded channel groups, one plane
     (64, 2, 3, 1, 1, 1, True, True, False, 19),      # head kernels: 16-wide tile, same_holes
+    (16, 32, 5, 2, 2, 1, True, True, False, 14),     # strided dX as stride phases: 5x5 s2 (9/6/6/4 taps), even size
+    (24, 48, 3, 2, 1, 1, False, False, True, 15),    # 3x3 s2 (4/2/2/1 taps), odd size, two mask planes
 ]
 
 

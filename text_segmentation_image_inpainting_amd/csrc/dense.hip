@@ -909,6 +909,11 @@ extern "C" int tsii_dense_bwd_dx(const float* dy, const float* inv, const float*
         return check_launch("head_dx");
     }
     if (use_conv_gemm_dx(g, mfull, dy, dx, ws)) {
+        const ConvGemmGeom cgp = {n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo};
+        if (conv_gemm_dx_phases_ok(cgp)) {           // strided: one stride-1 problem per stride phase
+            RowScale rsp = {r0, r1, split};
+            return launch_conv_gemm_dx_phases(dy, inv, w, wb, rsp, cgp, dx, st);
+        }
         hipLaunchKernelGGL(conv_w_layout_kernel, dim3(stream_grid((int64_t)T * cin * cout, 256)), dim3(256), 0, st, w, cin, cout, T, 1, wb);
         int rcg = check_launch("conv_w_layout");
         if (rcg) return rcg;

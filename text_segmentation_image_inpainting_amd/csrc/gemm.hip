@@ -144,6 +144,9 @@ struct ConvGather {
     const float* p1;
     int split;       // channels < split use p0, the rest p1 (p1 == nullptr -> 1.0)
     const float* pfull;  // general per-channel mask with the source tensor's shape (element-wise gather only)
+    // dX of a strided conv, one launch per stride phase (AMODE 2): row (n, ry, rx) of the phase grid is the output pixel
+    // (n, ry*o_sy + o_y0, rx*o_sx + o_x0) of the [.., o_h, o_w] tensor; o_sy == 0: rows are output pixels as they come
+    int o_h, o_w, o_sy, o_sx, o_y0, o_x0;
 };
 
 template <int AMODE>
@@ -389,21 +392,34 @@ __global__ __launch_bounds__(256, BNB ? 2 : 3) void gemm_nt_kernel(const float* 
             const int rr = rr0 + ROW_STEP * i;
             rowv[i] = m0 + ((rr >> 5) * TM + t) * 32 + (rr & 31);
             kpv[i] = 1.f; dnv[i] = 1.f; c0v[i] = 1.f; c1v[i] = 1.f;
+            if constexpr (AMODE == 2) {
+                if (cg.o_sy != 0) {          // stride-phase launch: GEMM row -> pixel of the strided output (rows >= M stay >= M)
+                    const int64_t row = rowv[i];
+                    if (row < M) {
+                        const int rx = (int)(row % cg.rw), ry = (int)((row / cg.rw) % cg.rh);
+                        const int64_t n = row / ((int64_t)cg.rw * cg.rh);
+                        rowv[i] = (n * cg.o_h + ry * cg.o_sy + cg.o_y0) * (int64_t)cg.o_w + rx * cg.o_sx + cg.o_x0;
+                    } else {
+                        rowv[i] = INT64_MAX;
+                    }
+                }
+            }
         }
+        const int64_t Mout = (AMODE == 2 && cg.o_sy != 0) ? (int64_t)INT64_MAX : M;   // remapped rows are already range-checked
         if (ep.keep != nullptr) {
 #pragma unroll
-            for (int i = 0; i < F4_PER_THREAD; ++i) kpv[i] = ep.keep[rowv[i] < M ? rowv[i] : M - 1];
+            for (int i = 0; i < F4_PER_THREAD; ++i) kpv[i] = ep.keep[rowv[i] < Mout ? rowv[i] : 0];
         }
         if (ep.denom != nullptr) {
 #pragma unroll
-            for (int i = 0; i < F4_PER_THREAD; ++i) dnv[i] = ep.denom[rowv[i] < M ? rowv[i] : M - 1];
+            for (int i = 0; i < F4_PER_THREAD; ++i) dnv[i] = ep.denom[rowv[i] < Mout ? rowv[i] : 0];
         }
         if (has_cs) {
 #pragma unroll
-            for (int i = 0; i < F4_PER_THREAD; ++i) c0v[i] = ep.cs.r0[rowv[i] < M ? rowv[i] : M - 1];
+            for (int i = 0; i < F4_PER_THREAD; ++i) c0v[i] = ep.cs.r0[rowv[i] < Mout ? rowv[i] : 0];
             if (ep.cs.r1 != nullptr) {
 #pragma unroll
-                for (int i = 0; i < F4_PER_THREAD; ++i) c1v[i] = ep.cs.r1[rowv[i] < M ? rowv[i] : M - 1];
+                for (int i = 0; i < F4_PER_THREAD; ++i) c1v[i] = ep.cs.r1[rowv[i] < Mout ? rowv[i] : 0];
             }
         }
         float4 yq[BNB ? F4_PER_THREAD : 1];
@@ -411,7 +427,7 @@ __global__ __launch_bounds__(256, BNB ? 2 : 3) void gemm_nt_kernel(const float* 
 #pragma unroll
             for (int i = 0; i < F4_PER_THREAD; ++i) {
                 yq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rowv[i] < M && col_ok) yq[i] = *reinterpret_cast<const float4*>(ep.bn_y + rowv[i] * (int64_t)N + col);
+                if (rowv[i] < Mout && col_ok) yq[i] = *reinterpret_cast<const float4*>(ep.bn_y + rowv[i] * (int64_t)N + col);
             }
         }
         __syncthreads();
@@ -435,7 +451,7 @@ __global__ __launch_bounds__(256, BNB ? 2 : 3) void gemm_nt_kernel(const float* 
         for (int i = 0; i < F4_PER_THREAD; ++i) {
             const int rr = rr0 + ROW_STEP * i;
             const int64_t row = rowv[i];
-            if (row >= M || !col_ok) continue;
+            if (row >= Mout || !col_ok) continue;
             const float4 q = *reinterpret_cast<const float4*>(Cs + rr * CS + c4 * 4);
             float v[4] = {q.x, q.y, q.z, q.w};
             if (ep.denom != nullptr) {
@@ -772,7 +788,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const float* __restrict
 }
 
 // ---- host-side dispatch ----------------------------------------------------------------
-static const ConvGather kNoConv = {0, 0, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, nullptr, nullptr, 0, nullptr};
+static const ConvGather kNoConv = {0, 0, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, nullptr, nullptr, 0, nullptr, 0, 0, 0, 0, 0, 0};
 static const InBN kNoBN = {nullptr, nullptr, 1.f, 0.f};
 
 template <int WM, int WN, int TM, int TN, int AMODE>
@@ -863,6 +879,7 @@ static ConvGather make_gather(const ConvGemmGeom& g, bool dx_mode, const float* 
     else { cg.h = g.ho; cg.w = g.wo; cg.c = g.cout; cg.rh = g.h; cg.rw = g.w; }
     cg.kw = g.kw; cg.sh = g.sh; cg.sw = g.sw; cg.ph = g.ph; cg.pw = g.pw; cg.dh = g.dh; cg.dw = g.dw;
     cg.p0 = p0; cg.p1 = p1; cg.split = split;
+    cg.o_h = cg.o_w = cg.o_sy = cg.o_sx = cg.o_y0 = cg.o_x0 = 0;
     return cg;
 }
 
@@ -890,6 +907,62 @@ int launch_conv_gemm_dx(const float* dy, const float* inv, const float* wd, RowS
     Epilogue ep = {nullptr, nullptr, nullptr, rs_out, 0};
     const ConvGather cg = make_gather(g, true, inv, nullptr, 0x7fffffff);
     return launch_nt_conv<2>(dy, wd, K, dx, g.cin, M, g.cin, K, ep, cg, st);
+}
+
+// ---- dX of a strided conv (dilation 1) as sh*sw stride-1 problems --------------------------------------------
+// Gathering all kh*kw taps for every input pixel and masking the non-divisible ones wastes (sh*sw - 1)/(sh*sw) of the
+// MFMA work (measured: the 5x5 stride-2 dX of ImageFillOrigin took 9.4 ms against 2.5 ms for its forward).  Input pixels
+// of phase (py, px) = (iy % sh, ix % sw) only ever see the taps ky = ky0 + sh*a, kx = kx0 + sw*b with
+// ky0 = (py + ph) % sh: a stride-1 dX with the sub-sampled kernel, "padding" (py + ph - ky0) / sh, and its rows
+// scattered back to the strided positions by the epilogue (ConvGather::o_*).
+// w[co][ci][ky][kx] -> out[ci][((a*nb + b)*cout + co)]
+__global__ void conv_w_layout_phase_kernel(const float* __restrict__ w, int cin, int cout, int kh, int kw, int ky0, int kx0,
+                                           int sh, int sw, int na, int nb, float* __restrict__ out) {
+    const int64_t total = (int64_t)cin * na * nb * cout;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % cout);
+        const int t = (int)((i / cout) % (na * nb));
+        const int64_t ci = i / ((int64_t)cout * na * nb);
+        const int ky = ky0 + sh * (t / nb), kx = kx0 + sw * (t % nb);
+        out[i] = w[(((int64_t)co * cin + ci) * kh + ky) * kw + kx];
+    }
+}
+
+bool conv_gemm_dx_phases_ok(const ConvGemmGeom& g) {
+    if (!(g.sh > 1 || g.sw > 1) || g.dh != 1 || g.dw != 1 || g.kh < g.sh || g.kw < g.sw) return false;
+    const int min_taps = (g.kh / g.sh) * (g.kw / g.sw);          // fewest taps any phase sees
+    return min_taps >= 1 && min_taps * g.cout >= 32;
+}
+
+// wd_ws: cin*cout*kh*kw floats (the phase layouts partition the taps)
+int launch_conv_gemm_dx_phases(const float* dy, const float* inv, const float* w, float* wd_ws, RowScale rs_out,
+                               const ConvGemmGeom& g, float* dx, hipStream_t st) {
+    float* wp = wd_ws;
+    for (int py = 0; py < g.sh; ++py)
+        for (int px = 0; px < g.sw; ++px) {
+            const int rh = (g.h - py + g.sh - 1) / g.sh, rw = (g.w - px + g.sw - 1) / g.sw;
+            if (rh <= 0 || rw <= 0) continue;
+            const int ky0 = (py + g.ph) % g.sh, kx0 = (px + g.pw) % g.sw;
+            const int na = (g.kh - ky0 + g.sh - 1) / g.sh, nb = (g.kw - kx0 + g.sw - 1) / g.sw;
+            const int K = na * nb * g.cout;
+            hipLaunchKernelGGL(conv_w_layout_phase_kernel, dim3(stream_grid((int64_t)g.cin * K, 256)), dim3(256), 0, st, w, g.cin, g.cout,
+                               g.kh, g.kw, ky0, kx0, g.sh, g.sw, na, nb, wp);
+            int rc = check_launch("conv_w_layout_phase");
+            if (rc) return rc;
+            ConvGather cg;
+            cg.pfull = nullptr;
+            cg.h = g.ho; cg.w = g.wo; cg.c = g.cout; cg.rh = rh; cg.rw = rw;
+            cg.kw = nb; cg.sh = 1; cg.sw = 1; cg.dh = 1; cg.dw = 1;
+            cg.ph = (py + g.ph - ky0) / g.sh; cg.pw = (px + g.pw - kx0) / g.sw;
+            cg.p0 = inv; cg.p1 = nullptr; cg.split = 0x7fffffff;
+            cg.o_h = g.h; cg.o_w = g.w; cg.o_sy = g.sh; cg.o_sx = g.sw; cg.o_y0 = py; cg.o_x0 = px;
+            Epilogue ep = {nullptr, nullptr, nullptr, rs_out, 0};
+            const int64_t M = (int64_t)g.n * rh * rw;
+            rc = launch_nt_conv<2>(dy, wp, K, dx, g.cin, M, g.cin, K, ep, cg, st);
+            if (rc) return rc;
+            wp += (size_t)g.cin * K;
+        }
+    return 0;
 }
 
 __global__ void conv_dw_reduce_kernel(const float* __restrict__ part, int S, int cout, int cin, int T, float* __restrict__ dw) {

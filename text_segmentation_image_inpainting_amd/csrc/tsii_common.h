@@ -98,6 +98,9 @@ int launch_conv_gemm_fwd(const float* x, const float* mfull, RowScale rs, const 
                          const float* denom, const float* keep, const ConvGemmGeom& g, float* y, hipStream_t st, float* stats = nullptr);
 int launch_conv_gemm_dx(const float* dy, const float* inv, const float* wd, RowScale rs_out, const ConvGemmGeom& g,
                         float* dx, hipStream_t st);
+bool conv_gemm_dx_phases_ok(const ConvGemmGeom& g);
+int launch_conv_gemm_dx_phases(const float* dy, const float* inv, const float* w, float* wd_ws, RowScale rs_out,
+                               const ConvGemmGeom& g, float* dx, hipStream_t st);
 size_t conv_gemm_dw_ws_floats(const ConvGemmGeom& g);
 int launch_conv_gemm_dw(const float* dy, const float* inv, const float* x, const float* mfull, RowScale rs,
                         const ConvGemmGeom& g, float* dwgt, float* ws, hipStream_t st);
