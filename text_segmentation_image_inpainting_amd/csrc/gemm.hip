@@ -849,19 +849,16 @@ static int launch_nt(const float* A, int64_t lda, RowScale as, const float* B, i
 struct TnPlan {
     bool big;
     bool narrow;   // 128 x 64 tiles: Q leaves at most half of its last 128-wide tile (e.g. 384 x 192)
-    bool wide;     // 64 x 128 tiles: few output channels (P <= 64) against a long Q (dense-conv dW, Q = taps * Cin)
     int bm, bn;
     int splits;
     int64_t chunk;
 };
-static TnPlan plan_tn(int64_t M, int P, int Q, bool allow_narrow = false, bool allow_wide = false) {
+static TnPlan plan_tn(int64_t M, int P, int Q, bool allow_narrow = false) {
     TnPlan pl;
     pl.big = (P >= 128 && Q >= 128);
     pl.bm = pl.bn = pl.big ? 128 : 64;
     pl.narrow = allow_narrow && pl.big && (Q % 128) >= 1 && (Q % 128) <= 64;
     if (pl.narrow) pl.bn = 64;
-    pl.wide = allow_wide && !pl.big && P <= 64 && Q >= 256;
-    if (pl.wide) pl.bn = 128;
     const int tiles = cdiv(P, pl.bm) * cdiv(Q, pl.bn);
     int64_t want = 1024 / tiles;
     if (want < 1) want = 1;
@@ -983,21 +980,20 @@ __global__ void conv_dw_reduce_kernel(const float* __restrict__ part, int S, int
 
 size_t conv_gemm_dw_ws_floats(const ConvGemmGeom& g) {
     const int K = g.kh * g.kw * g.cin;
-    const TnPlan a = plan_tn((int64_t)g.n * g.ho * g.wo, g.cout, K), b = plan_tn((int64_t)g.n * g.ho * g.wo, g.cout, K, false, true);
-    return (size_t)(a.splits > b.splits ? a.splits : b.splits) * g.cout * K;
+    const TnPlan pl = plan_tn((int64_t)g.n * g.ho * g.wo, g.cout, K);
+    return (size_t)pl.splits * g.cout * K;
 }
 
 int launch_conv_gemm_dw(const float* dy, const float* inv, const float* x, const float* mfull, RowScale rs,
                         const ConvGemmGeom& g, float* dwgt, float* ws, hipStream_t st) {
     const int K = g.kh * g.kw * g.cin, T = g.kh * g.kw;
     const int64_t M = (int64_t)g.n * g.ho * g.wo;
-    const bool elem = (mfull != nullptr || g.cin % 4 != 0);
-    const TnPlan pl = plan_tn(M, g.cout, K, false, !elem);
+    const TnPlan pl = plan_tn(M, g.cout, K);
     const ConvGather cg = make_gather(g, false, rs.r0, rs.r1, rs.r0 != nullptr ? rs.split : 0, mfull);
     const RowScale none = {nullptr, nullptr, 0};
     dim3 grid(cdiv(K, pl.bn), cdiv(g.cout, pl.bm), pl.splits);
-    if (pl.wide) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 2, true, 1>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg, kNoBN);
-    else if (pl.big && !elem) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 1>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg, kNoBN);
+    const bool elem = (mfull != nullptr || g.cin % 4 != 0);
+    if (pl.big && !elem) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 1>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg, kNoBN);
     else if (!elem) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, 1>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg, kNoBN);
     else if (pl.big) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 2>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg, kNoBN);
     else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, 2>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg, kNoBN);
