@@ -244,6 +244,7 @@ CONV_GEMM_CASES = [
     (64, 2, 3, 1, 1, 1, True, True, False, 19),      # head kernels: 16-wide tile, same_holes
     (16, 32, 5, 2, 2, 1, True, True, False, 14),     # strided dX as stride phases: 5x5 s2 (9/6/6/4 taps), even size
     (24, 48, 3, 2, 1, 1, False, False, True, 15),    # 3x3 s2 (4/2/2/1 taps), odd size, two mask planes
+    (128, 1, 3, 1, 1, 1, True, True, False, 11),     # 128 -> 1 logits conv: forward on the GEMM path (Cout below the gather minimum)
 ]
 
 

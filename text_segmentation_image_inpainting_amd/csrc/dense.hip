@@ -837,7 +837,12 @@ static int dense_fwd_impl(const float* x, const float* mfull, const float* r0, i
                                 rs0, wf, bias, denom, keep, g, sp.PH, sp.PW, y);
         return check_launch("dense_small_fwd");
     }
-    if (use_conv_gemm(g, mfull, x, y, ws)) {   // MFMA implicit GEMM
+    // Forward only: the gather needs Cin % 4 == 0 but nothing of Cout, so convs with very few output channels over many
+    // input channels (the 128 -> 1 logits conv of the segmentation nets: 8.5 ms per step on the generic kernel) take the
+    // 128x32 GEMM tile too -- 31/32 of its MFMA columns idle, still several times faster.
+    const bool few_out_gemm = stats == nullptr && mfull == nullptr && cin % 4 == 0 && cout < 16 && T * cin >= 128 &&
+                              aligned16(x) && aligned16(ws);
+    if (use_conv_gemm(g, mfull, x, y, ws) || few_out_gemm) {   // MFMA implicit GEMM
         hipLaunchKernelGGL(conv_w_layout_kernel, dim3(stream_grid((int64_t)T * cin * cout, 256)), dim3(256), 0, st, w, cin, cout, T, 0, wf);
         int rcg = check_launch("conv_w_layout");
         if (rcg) return rcg;
