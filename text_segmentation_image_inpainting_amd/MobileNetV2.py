@@ -6,10 +6,10 @@ from torch import nn
 from torch.utils.checkpoint import checkpoint
 
 from . import ops
-from .BaseModels import BaseModule, Conv_block, run_chain, run_nhwc, to_nchw, to_nhwc  # noqa: F401
+from .BaseModels import BaseModule, Conv_block, run_chain, to_nchw, to_nhwc
 from .common import SpatialChannelSqueezeExcitation
 from .masks import MaskParts, as_parts
-from .partial_convolution import PartialActivatedBN, partial_convolution_block, run_block  # noqa: F401
+from .partial_convolution import partial_convolution_block, run_block
 
 
 class MobileNetV2(BaseModule):

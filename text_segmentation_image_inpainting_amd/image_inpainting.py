@@ -7,7 +7,6 @@ SURVEY.md F7 -- and is out of scope.)
 forward() keeps activations NHWC and masks as planes end to end: the nearest-upsample +
 concat of the decoder is one kernel (K7) and the concatenated *mask* is never materialised.
 """
-import torch
 from torch import nn
 
 from . import ops
