@@ -669,7 +669,7 @@ static StripPlan plan_strip(int n, int hout, int wout, int c, int s, int d) {
 static const DwBN kNoDwBN = {nullptr, nullptr, 1.f, 0.f};
 static const DwBnBwd kNoBnBwd = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
 
-static bool dw_fused_ok(int s, int d) { return s == 1 && d == 1; }   // geometries with the K6b / K6c strip variants
+static bool dw_fused_ok(int s, int d) { return (s == 1 || s == 2) && d == 1; }   // geometries with the K6b strip variants (K6c: stride 1 only)
 
 static int try_launch_dw_strip(const float* in, const float* pre, const float* wT, const float* bias, const float* denom,
                                const float* keep, const float* post_mul, DtGeom g, float* out, hipStream_t st,
@@ -682,7 +682,10 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
     const dim3 grid((unsigned)nblk);
     const bool fused = ib.sc != nullptr || stats != nullptr || bb.y != nullptr;
     if (fused && !dw_fused_ok(g.s, g.d)) return 1;
-    if (g.s == 2) hipLaunchKernelGGL((dw_strip_kernel<2, 1, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+    if (bb.y != nullptr && g.s != 1) return 1;
+    if (g.s == 2 && fused) hipLaunchKernelGGL((dw_strip_kernel<2, 1, 1>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                              sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
+    else if (g.s == 2) hipLaunchKernelGGL((dw_strip_kernel<2, 1, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
                                      sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
     else if (g.d == 2) hipLaunchKernelGGL((dw_strip_kernel<1, 2, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
                                           sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
@@ -1080,7 +1083,7 @@ static int dw_bwd_dw_impl(const float* dy, const float* inv, const float* keep, 
     const bool vec = (c % 4 == 0) && aligned16(dy) && aligned16(x) && (ib.sc == nullptr || (aligned16(ib.sc) && aligned16(ib.sh)));
     float* part = (float*)ws;
     if (vec && kh == 3 && kw == 3 && sh == sw && dh == dw &&
-        ((sh == 1 && (dh == 1 || ((dh == 2 || dh == 4 || dh == 8) && ib.sc == nullptr))) || (sh == 2 && dh == 1 && ib.sc == nullptr))) {
+        ((sh == 1 && (dh == 1 || ((dh == 2 || dh == 4 || dh == 8) && ib.sc == nullptr))) || (sh == 2 && dh == 1))) {
         const StripPlan sp = plan_strip(n, ho, wo, c, sh, dh);   // marching strips
         if (sp.ok) {
             DtGeom tg = {n, h, wd, c, sh, dh, ph, pw, ho, wo, 0};
