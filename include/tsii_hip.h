@@ -126,6 +126,18 @@ int tsii_dense_bwd_dw(const float* dy, const float* inv, const float* keep, cons
                       int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo,
                       float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- K4b: stems (odd k, stride 2, pad (k-1)/2, very few input channels; models/image_inpainting.py:23) as a stride-1
+ * valid convolution over the space-to-depth image, so they run on the vector-gather implicit GEMM:
+ *   tsii_stem_s2d:   x [n,h,w,c] * mask (mfull, or the r0/split/r1 planes, or none) zero-padded by `pad`
+ *                    -> out [n,(h+2pad)/2,(w+2pad)/2,4c], channel order (row phase, column phase, c)
+ *   tsii_stem_w_fwd: w [cout,cin,k,k] -> w2 [cout,4cin,ka,ka], ka = (k+1)/2 (reference layout of that conv)
+ *   tsii_stem_w_bwd: dw2 [cout,4cin,ka,ka] -> dw [cout,cin,k,k]
+ * then tsii_dense_fwd / tsii_dense_bwd_dw on (out, w2) with kernel ka, stride 1, padding 0. */
+int tsii_stem_s2d(const float* x, const float* mfull, const float* r0, int split, const float* r1,
+                  int n, int h, int w, int c, int pad, float* out, void* stream);
+int tsii_stem_w_fwd(const float* w, int cout, int cin, int k, float* w2, void* stream);
+int tsii_stem_w_bwd(const float* dw2, int cout, int cin, int k, float* dw, void* stream);
+
 /* ---- K6: BatchNorm2d (+activation, +residual)  (partial_convolution.py:193-197,
  *          residual add MobileNetV2.py:186-187, image_inpainting.py:216) ------------------
  * y is [M,C].  Training: batch mean / biased variance (and running-stat update with

@@ -35,6 +35,9 @@ SIGNATURES = {
     "tsii_dense_bwd_dx": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _z, _p]),
     "tsii_dense_bwd_dw_ws_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
     "tsii_dense_bwd_dw": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _p, _z, _p]),
+    "tsii_stem_s2d": (_i, [_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "tsii_stem_w_fwd": (_i, [_p, _i, _i, _i, _p, _p]),
+    "tsii_stem_w_bwd": (_i, [_p, _i, _i, _i, _p, _p]),
     "tsii_bn_ws_bytes": (_z, [_l, _i]),
     "tsii_bn_stats": (_i, [_p, _l, _i, _p, _p, _p, _p, _f, _p, _z, _p]),
     "tsii_bn_act_fwd": (_i, [_p, _l, _i, _p, _p, _p, _p, _f, _i, _f, _p, _p, _p]),

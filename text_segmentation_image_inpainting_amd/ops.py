@@ -24,6 +24,8 @@ import os as _os
 # fraction down 3 points for 0.4 ms, so it stays opt-in.
 FUSE_BN_BWD = _os.environ.get("TSII_FUSE_BN_BWD", "1") != "0"
 FUSE_BN_BWD_PW = _os.environ.get("TSII_FUSE_BN_BWD", "1") == "2"
+# A/B knob for K4b (stems as a space-to-depth stride-1 conv on the vector-gather GEMM)
+USE_STEM_S2D = _os.environ.get("TSII_STEM_S2D", "1") != "0"
 
 
 class Geom(NamedTuple):
@@ -344,9 +346,84 @@ class _Dense(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
+class _StemS2D(torch.autograd.Function):
+    """K4b: odd k, stride 2, pad (k-1)/2 conv over <= 4 input channels as a stride-1 valid conv over the space-to-depth
+    image (x*mask folded into the rearrangement), on the vector-gather implicit GEMM.  No input gradient (data layer)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, mfull, r0, r1, denom, keep, inv, split, g, want_stats):
+        _lib.check_device(x)
+        x, w = x.contiguous(), w.contiguous()
+        n, h, wd, cin = x.shape
+        cout, k, pad = w.shape[0], g.kh, g.ph
+        ka, c4 = (k + 1) // 2, 4 * cin
+        h2, w2 = (h + 2 * pad) // 2, (wd + 2 * pad) // 2
+        ho, wo = g.out_hw(h, wd)
+        st, L = _lib.stream(), _lib.lib()
+        x2 = torch.empty((n, h2, w2, c4), dtype=torch.float32, device=x.device)
+        call("tsii_stem_s2d", ptr(x), ptr(mfull), ptr(r0), int(split), ptr(r1), n, h, wd, cin, pad, ptr(x2), st)
+        wk = torch.empty((cout, c4, ka, ka), dtype=torch.float32, device=x.device)
+        call("tsii_stem_w_fwd", ptr(w), cout, cin, k, ptr(wk), st)
+        g2 = Geom(ka, ka, 1, 1, 0, 0, 1, 1)
+        assert g2.out_hw(h2, w2) == (ho, wo)
+        y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+        nbytes = L.tsii_dense_ws_bytes(c4, cout, ka, ka)
+        ws = _ws(nbytes, x)
+        rows = int(L.tsii_dense_stat_rows(0, n, h2, w2, c4, cout, *g2, ho, wo)) if want_stats else 0
+        part = None
+        if rows > 0:
+            part = torch.empty((rows, 4, cout), dtype=torch.float32, device=x.device)
+            call("tsii_dense_fwd_bn", ptr(x2), None, None, 0, None, ptr(wk), ptr(bias), ptr(denom), ptr(keep),
+                 n, h2, w2, c4, cout, *g2, ho, wo, ptr(part), ptr(y), ptr(ws), nbytes, st)
+        else:
+            call("tsii_dense_fwd", ptr(x2), None, None, 0, None, ptr(wk), ptr(bias), ptr(denom), ptr(keep),
+                 n, h2, w2, c4, cout, *g2, ho, wo, ptr(y), ptr(ws), nbytes, st)
+        ctx.save_for_backward(x2, inv, keep)
+        ctx.cfg = (tuple(w.shape), g2, (n, h2, w2, c4, ho, wo), bias is not None)
+        ctx.set_materialize_grads(False)
+        if part is not None:
+            ctx.mark_non_differentiable(part)
+            return y, part
+        return y
+
+    @staticmethod
+    def backward(ctx, gy, *_):
+        if gy is None:
+            return (None,) * 12
+        x2, inv, keep = ctx.saved_tensors
+        wshape, g2, (n, h2, w2, c4, ho, wo), has_bias = ctx.cfg
+        cout, cin, k = wshape[0], wshape[1], wshape[2]
+        gy = gy.contiguous()
+        L, st = _lib.lib(), _lib.stream()
+        dw = db = None
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            ka = g2.kh
+            dwk = torch.empty((cout, c4, ka, ka), dtype=torch.float32, device=gy.device)
+            db = torch.empty(cout, dtype=torch.float32, device=gy.device) if has_bias else None
+            nbytes = L.tsii_dense_bwd_dw_ws_bytes(n, ho, wo, c4, cout, ka, ka)
+            ws = _ws(nbytes, gy)
+            call("tsii_dense_bwd_dw", ptr(gy), ptr(inv), ptr(keep), ptr(x2), None, None, 0, None,
+                 n, h2, w2, c4, cout, *g2, ho, wo, ptr(dwk), ptr(db), ptr(ws), nbytes, st)
+            dw = torch.empty(wshape, dtype=torch.float32, device=gy.device)
+            call("tsii_stem_w_bwd", ptr(dwk), cout, cin, k, ptr(dw), st)
+        return (None, dw, db) + (None,) * 9
+
+
+def _stem_form(x, w, g: Geom):
+    """Geometry of _StemS2D: odd square kernel, stride 2, "same" padding, no dilation, <= 4 input channels, GEMM-sized
+    Cout, even padded image, and no gradient wanted for the input."""
+    cin, cout = x.shape[-1], w.shape[0]
+    return (USE_STEM_S2D and not x.requires_grad and g.kh == g.kw and g.kh % 2 == 1 and g.kh >= 3 and g.sh == g.sw == 2 and
+            g.ph == g.pw == (g.kh - 1) // 2 and g.dh == g.dw == 1 and cin <= 4 and cout % 4 == 0 and cout >= 16 and
+            (x.shape[1] + 2 * g.ph) % 2 == 0 and (x.shape[2] + 2 * g.pw) % 2 == 0)
+
+
 def pconv_dense(x, w, bias, mfull, r0, split, r1, denom, keep, inv, g: Geom, want_stats=False):
     """With ``want_stats`` returns (y, stat_part or None) -- None when the geometry is not on the implicit-GEMM path."""
-    out = _Dense.apply(x, w, bias, mfull, r0, r1, denom, keep, inv, split, g, want_stats)
+    if _stem_form(x, w, g):
+        out = _StemS2D.apply(x, w, bias, mfull, r0, r1, denom, keep, inv, split, g, want_stats)
+    else:
+        out = _Dense.apply(x, w, bias, mfull, r0, r1, denom, keep, inv, split, g, want_stats)
     if want_stats and not isinstance(out, tuple):
         return out, None
     return out
