@@ -126,3 +126,45 @@ def test_pointwise_fused_batchnorm(emu, M, K, N, act, slope):
                                P(dw), P(db), P(ws2), nbytes, None) == 0, L.tsii_last_error()
     rdw = (dy.astype(np.float64) * inv[:, None]).T @ am
     assert np.abs(dw - rdw).max() <= 1e-5 * np.abs(rdw).max()
+
+
+@pytest.mark.parametrize("k,cin,h,w", [(7, 3, 10, 14), (5, 3, 8, 8), (3, 4, 6, 10)])
+def test_stem_space_to_depth_entry_points(emu, k, cin, h, w):
+    """K4b at kernel level: tsii_stem_s2d / tsii_stem_w_fwd / tsii_stem_w_bwd against numpy, and the identity
+    conv_s2(x*m, w) == conv_valid_s1(s2d(x*m), w2) they are built on."""
+    L = emu
+    rng = np.random.default_rng(k * 100 + cin)
+    n, cout, pad = 2, 5, (k - 1) // 2
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    m = (rng.uniform(size=(n, h, w, cin)) > 0.3).astype(np.float32)
+    wt = rng.standard_normal((cout, cin, k, k)).astype(np.float32)
+    h2, w2, ka = (h + 2 * pad) // 2, (w + 2 * pad) // 2, (k + 1) // 2
+    x2 = np.zeros((n, h2, w2, 4 * cin), np.float32)
+    assert L.tsii_stem_s2d(P(x), P(m), None, 0, None, n, h, w, cin, pad, P(x2), None) == 0, L.tsii_last_error()
+    xp = np.pad(x * m, ((0, 0), (pad, pad), (pad, pad), (0, 0)))
+    ref = np.zeros_like(x2)
+    for py in range(2):
+        for px in range(2):
+            ref[..., (py * 2 + px) * cin:(py * 2 + px + 1) * cin] = xp[:, py::2, px::2, :]
+    assert np.array_equal(x2, ref)
+    wk = np.zeros((cout, 4 * cin, ka, ka), np.float32)
+    assert L.tsii_stem_w_fwd(P(wt), cout, cin, k, P(wk), None) == 0, L.tsii_last_error()
+    # direct stride-2 conv vs valid stride-1 conv of the rearranged operands (float64)
+    ho, wo = (h + 2 * pad - k) // 2 + 1, (w + 2 * pad - k) // 2 + 1
+    y_ref = np.zeros((n, ho, wo, cout))
+    y_s2d = np.zeros((n, ho, wo, cout))
+    for oy in range(ho):
+        for ox in range(wo):
+            patch = xp[:, 2 * oy:2 * oy + k, 2 * ox:2 * ox + k, :].astype(np.float64)           # [n,k,k,cin]
+            y_ref[:, oy, ox, :] = np.einsum("nyxc,ocyx->no", patch, wt.astype(np.float64))
+            p2 = ref[:, oy:oy + ka, ox:ox + ka, :].astype(np.float64)                             # [n,ka,ka,4cin]
+            y_s2d[:, oy, ox, :] = np.einsum("nyxe,oeyx->no", p2, wk.astype(np.float64))
+    assert np.abs(y_ref - y_s2d).max() <= 1e-12 * max(1.0, np.abs(y_ref).max())
+    # the weight-gradient map is the adjoint selection
+    dwk = rng.standard_normal(wk.shape).astype(np.float32)
+    dw = np.zeros_like(wt)
+    assert L.tsii_stem_w_bwd(P(dwk), cout, cin, k, P(dw), None) == 0, L.tsii_last_error()
+    for ky in range(k):
+        for kx in range(k):
+            e0 = ((ky & 1) * 2 + (kx & 1)) * cin
+            assert np.array_equal(dw[:, :, ky, kx], dwk[:, e0:e0 + cin, ky // 2, kx // 2])
