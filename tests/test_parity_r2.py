@@ -1,0 +1,288 @@
+"""Round-2 parity holes (VERDICT r1 "What's weak" 1-5):
+
+* large-dilation depth-wise convolutions (d = 8 / 16 / 17 / 29: MobileNetV2 stage 6/7, RFB branches,
+  models/MobileNetV2.py:203-215, models/common.py:102) on maps where every off-centre tap is IN range;
+* RFB on a 32x32 map and TextSegament / XceptionTextSegment at 256x256 (32x32 map at 1/8) vs the CPU oracle;
+* the fused SGD-Nesterov kernel vs ``torch.optim.SGD(momentum, nesterov=True, weight_decay)`` (checkpoints/ReadME.md:4);
+* ``DoubleUpSample`` / up-sample + concat as exact copies (models/partial_convolution.py:229-231);
+* BASELINE config 3 at full size (TextSegament 512x512): determinism, batch independence, finite gradients.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import text_segmentation_image_inpainting_amd as T
+from oracle import pconv_oracle as O
+from oracle import seg_oracle as S
+from oracle.filler import fill_state_dict_, make_state_dict
+from tests.backends import BACKENDS, both_backends
+from tests.util import assert_close
+
+TOL = 1e-3
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@both_backends
+def test_depthwise_large_dilation_taps_in_range(backend):
+    """d = 8/16/17/29 with H, W > 2d: all nine taps land inside the map for the interior pixels (the 64x64-input
+    fixtures only ever exercised the centre tap).  Plain depth-wise conv (BaseModels.Conv2d, the segmentation path) and
+    the depth-wise PartialConv with a hole mask; forward, dX, dW (db) vs stock torch / the oracle on CPU."""
+    from text_segmentation_image_inpainting_amd.BaseModels import Conv2d
+    cases = [(8, 8, 33, 40), (8, 16, 64, 64), (12, 17, 40, 64), (8, 29, 64, 61), (8, 29, 64, 64)]
+    with BACKENDS[backend]() as dev:
+        for idx, (c, d, H, W) in enumerate(cases):
+            rng = np.random.default_rng(1200 + idx)
+            conv = Conv2d(c, c, 3, 1, d, d, groups=c, bias=True)
+            fill_state_dict_(conv.state_dict(), seed=1200 + idx)
+            x = torch.from_numpy(rng.standard_normal((2, c, H, W)).astype(np.float32))
+            w = conv.weight.detach().clone().requires_grad_(True)
+            b = conv.bias.detach().clone().requires_grad_(True)
+            xo = x.clone().requires_grad_(True)
+            yo = F.conv2d(xo, w, b, 1, d, d, c)
+            gy = torch.from_numpy(rng.standard_normal(tuple(yo.shape)).astype(np.float32))
+            yo.backward(gy)
+            conv = conv.to(dev)
+            xd = x.to(dev).requires_grad_(True)
+            y = conv(xd)
+            assert_close(y, yo, TOL, f"dw d={d} y")
+            y.backward(gy.to(dev))
+            assert_close(xd.grad, xo.grad, TOL, f"dw d={d} dx")
+            assert_close(conv.weight.grad, w.grad, TOL, f"dw d={d} dw")
+            assert_close(conv.bias.grad, b.grad, TOL, f"dw d={d} db")
+        for idx, (c, d, H, W) in enumerate([(8, 16, 48, 56), (8, 8, 40, 33)]):
+            rng = np.random.default_rng(1300 + idx)
+            m = T.PartialConv(c, c, 3, 1, d, d, c, True, True)
+            fill_state_dict_(m.state_dict(), seed=1300 + idx)
+            x = torch.from_numpy(rng.standard_normal((2, c, H, W)).astype(np.float32))
+            pa = (torch.from_numpy(rng.uniform(size=(2, 1, H, W))) > 0.3).float()
+            pa[:, :, 5:30, 7:29] = 0        # a hole wider than the dilation: some windows are all-hole
+            mask = pa.expand(-1, c, -1, -1).contiguous()
+            w = m.feature_conv.weight.detach().clone().requires_grad_(True)
+            b = m.feature_conv.bias.detach().clone().requires_grad_(True)
+            xo = x.clone().requires_grad_(True)
+            yo, nmo = O.partial_conv(xo, mask, w, b, 1, d, d, c, True)
+            gy = torch.from_numpy(rng.standard_normal(tuple(yo.shape)).astype(np.float32))
+            yo.backward(gy)
+            m = m.to(dev)
+            xd = x.to(dev).requires_grad_(True)
+            y, nm = m((xd, pa.expand(-1, c, -1, -1).to(dev)))
+            assert_close(y, yo, TOL, f"pconv dw d={d} y")
+            assert np.array_equal(nm.detach().cpu().numpy(), nmo.detach().numpy()), f"pconv dw d={d} new_mask"
+            y.backward(gy.to(dev))
+            assert_close(xd.grad, xo.grad, TOL, f"pconv dw d={d} dx")
+            assert_close(m.feature_conv.weight.grad, w.grad, TOL, f"pconv dw d={d} dw")
+
+
+def _rfb_case(dev, hw, cin, cout, seed):
+    act = torch.nn.LeakyReLU(0.3)
+    m = T.RFB(cin, cout, activation=act, add_sece=True)
+    fill_state_dict_(m.state_dict(), seed=seed)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.standard_normal((2, cin, hw, hw)).astype(np.float32))
+    xo = x.clone().requires_grad_(True)
+    yo = S.rfb(sd, "", xo, cout, O.leaky(0.3), True)
+    gy = torch.from_numpy(rng.standard_normal(tuple(yo.shape)).astype(np.float32))
+    yo.backward(gy)
+    m = m.to(dev).train()
+    xd = x.to(dev).requires_grad_(True)
+    y = m(xd)
+    assert_close(y, yo, TOL, f"RFB {hw}x{hw} y")
+    y.backward(gy.to(dev))
+    assert_close(xd.grad, xo.grad, 2e-3, f"RFB {hw}x{hw} dx")
+    params = dict(m.named_parameters())
+    gmax = max(float(v.grad.abs().max()) for k, v in sd.items() if v.grad is not None)
+    n = 0
+    for k, v in sd.items():
+        if v.grad is not None:
+            assert_close(params[k].grad, v.grad, 3e-3, f"RFB {hw}x{hw} grad {k}", floor=1e-3 * gmax)
+            n += 1
+    assert n >= 20
+
+
+def test_rfb_32x32_emu():
+    """RFB with the d = 5 / 17 taps in range (32x32 map = cfg 1's 1/8 map), small channel counts, through the emulator."""
+    with BACKENDS["emu"]() as dev:
+        _rfb_case(dev, 32, 16, 8, seed=1400)
+
+
+@pytest.mark.gpu
+def test_rfb_64x64_gpu():
+    """RFB at cfg 3's 64x64 map: every branch dilation (5 / 17 / 29) has live off-centre taps."""
+    with BACKENDS["gpu"]() as dev:
+        _rfb_case(dev, 64, 64, 32, seed=1401)
+        _rfb_case(dev, 32, 48, 16, seed=1402)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["TextSegament", "XceptionTextSegment"])
+def test_seg_nets_256_vs_oracle_gpu(name):
+    """cfg 1 size (256x256 -> 32x32 map at 1/8): eval and train forward, focal loss and every trainable gradient vs
+    the CPU oracle (itself pinned to the reference at 64x64 by tests/test_oracle_seg_golden.py).  Gradient tolerance
+    as in test_golden_seg_nets_64_gpu: noise-aware against an fp64 run of the oracle."""
+    keys = json.load(open(os.path.join(GOLD, "seg_state_dict_keys.json")))[name]
+    fn = S.SEG_MODELS[name]
+    rng = np.random.default_rng(1500)
+    x = torch.from_numpy(rng.standard_normal((2, 3, 256, 256)).astype(np.float32))
+    t = (torch.from_numpy(rng.uniform(size=(2, 1, 256, 256))) > 0.8).float()
+
+    def oracle(dtype):
+        sd = make_state_dict([(k, s) for k, s in keys], seed=43, gain=1.0, dtype=dtype)
+        with torch.no_grad():
+            ye = fn(sd, x.to(dtype), training=False)
+        for k, v in sd.items():
+            if v.dtype.is_floating_point and "running" not in k:
+                v.requires_grad_(True)
+        y = fn(sd, x.to(dtype), training=True)
+        loss = S.binary_focal_loss(y, t.to(dtype), 0.0, 1.0, 2.0)
+        loss.backward()
+        return ye, y.detach(), float(loss), {k: v.grad for k, v in sd.items() if v.grad is not None}
+
+    ye32, y32, l32, g32 = oracle(torch.float32)
+    ye64, y64, l64, g64 = oracle(torch.float64)
+    with BACKENDS["gpu"]() as dev:
+        m = getattr(T, name)()
+        fill_state_dict_(m.state_dict(), seed=43, gain=1.0)
+        m = m.to(dev)
+        m.eval()
+        with torch.no_grad():
+            ye = m(x.to(dev))
+        assert_close(ye, ye64, TOL, name + " 256 eval vs fp64 oracle")
+        m.train()
+        y = m(x.to(dev))
+        noise_y = float((y32.double() - y64).abs().max() / y64.abs().max())
+        assert_close(y, y64, max(TOL, 4 * noise_y), name + " 256 train vs fp64 oracle")
+        loss = T.BinaryFocalLoss(0, 1, 2)(y, t.to(dev))
+        assert abs(loss.item() - l64) < 1e-4 * max(1.0, abs(l64))
+        loss.backward()
+        params = dict(m.named_parameters())
+        gmax = max(float(v.abs().max()) for v in g64.values())
+        n = 0
+        for k, ref64 in g64.items():
+            scale = max(float(ref64.abs().max()), 1e-3 * gmax)
+            noise = float((g32[k].double() - ref64).abs().max()) / scale
+            assert_close(params[k].grad, ref64.float(), max(3e-3, 4 * noise), f"{name} 256 grad {k}", floor=1e-3 * gmax)
+            n += 1
+        assert n >= 100
+
+
+@pytest.mark.gpu
+def test_sgd_nesterov_vs_torch_gpu():
+    """tsii_sgd_nesterov over a flat buffer == torch.optim.SGD(lr, momentum, nesterov=True, weight_decay) on CPU,
+    three steps with fresh gradients (first step: buf = grad; torch/optim/sgd.py semantics)."""
+    from text_segmentation_image_inpainting_amd import ops
+    rng = np.random.default_rng(1600)
+    for lr, mom, wd, n in ((0.01, 0.9, 1e-4, 100003), (0.1, 0.8, 0.0, 4096), (0.05, 0.95, 1e-2, 777)):
+        p0 = rng.standard_normal(n).astype(np.float32)
+        grads = [rng.standard_normal(n).astype(np.float32) for _ in range(3)]
+        pt = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+        opt = torch.optim.SGD([pt], lr=lr, momentum=mom, nesterov=True, weight_decay=wd)
+        with BACKENDS["gpu"]() as dev:
+            p = torch.from_numpy(p0.copy()).to(dev)
+            buf = torch.zeros_like(p)
+            for g in grads:
+                pt.grad = torch.from_numpy(g.copy())
+                opt.step()
+                ops.sgd_nesterov_(p, torch.from_numpy(g.copy()).to(dev), buf, lr, mom, wd)
+                assert_close(p, pt.detach(), 1e-6, f"sgd-nesterov lr={lr} mom={mom} wd={wd} params")
+                assert_close(buf, opt.state[pt]["momentum_buffer"], 1e-6, "momentum buffer")
+
+
+def test_sgd_nesterov_vs_torch_emu():
+    from text_segmentation_image_inpainting_amd import ops
+    rng = np.random.default_rng(1601)
+    n, lr, mom, wd = 1000, 0.01, 0.9, 1e-3
+    p0 = rng.standard_normal(n).astype(np.float32)
+    pt = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.SGD([pt], lr=lr, momentum=mom, nesterov=True, weight_decay=wd)
+    with BACKENDS["emu"]():
+        p = torch.from_numpy(p0.copy())
+        buf = torch.zeros_like(p)
+        for _ in range(3):
+            g = rng.standard_normal(n).astype(np.float32)
+            pt.grad = torch.from_numpy(g.copy())
+            opt.step()
+            ops.sgd_nesterov_(p, torch.from_numpy(g.copy()), buf, lr, mom, wd)
+            assert_close(p, pt.detach(), 1e-6, "sgd-nesterov params")
+            assert_close(buf, opt.state[pt]["momentum_buffer"], 1e-6, "momentum buffer")
+
+
+@both_backends
+def test_upsample_concat_exact(backend):
+    """a6: DoubleUpSample (nearest x2) and the fused up-sample + channel concat are exact copies (forward and backward:
+    the backward of nearest x2 is the 2x2 block sum, exact up to fp32 summation order of 4 terms)."""
+    from text_segmentation_image_inpainting_amd import ops
+    from text_segmentation_image_inpainting_amd.BaseModels import to_nchw, to_nhwc
+    with BACKENDS[backend]() as dev:
+        for idx, (c1, c2, h, w) in enumerate([(8, 4, 5, 7), (32, 3, 6, 6), (5, 0, 4, 9), (12, 35, 3, 8)]):
+            rng = np.random.default_rng(1700 + idx)
+            low = torch.from_numpy(rng.standard_normal((2, c1, h, w)).astype(np.float32))
+            lo = low.clone().requires_grad_(True)
+            up = F.interpolate(lo, scale_factor=2, mode="nearest")
+            if c2:
+                skip = torch.from_numpy(rng.standard_normal((2, c2, 2 * h, 2 * w)).astype(np.float32))
+                so = skip.clone().requires_grad_(True)
+                ref = torch.cat([up, so], 1)
+            else:
+                ref = up
+            gy = torch.from_numpy(rng.standard_normal(tuple(ref.shape)).astype(np.float32))
+            ref.backward(gy)
+            ld = low.to(dev).requires_grad_(True)
+            if c2:
+                sdv = skip.to(dev).requires_grad_(True)
+                out = to_nchw(ops.upcat(to_nhwc(ld), to_nhwc(sdv)))
+            else:
+                out = to_nchw(ops.upsample2x(to_nhwc(ld)))
+            assert torch.equal(out.detach().cpu(), ref.detach()), f"upcat case {idx} forward not exact"
+            out.backward(gy.to(dev))
+            assert_close(ld.grad, lo.grad, 1e-6, f"upcat case {idx} dlow")
+            if c2:
+                assert torch.equal(sdv.grad.cpu(), so.grad), f"upcat case {idx} dskip not exact"
+        # the module: x and the mask tensor are both up-sampled (models/partial_convolution.py:229-231)
+        x = torch.from_numpy(np.random.default_rng(1710).standard_normal((2, 6, 4, 5)).astype(np.float32))
+        mk = (torch.from_numpy(np.random.default_rng(1711).uniform(size=(2, 1, 4, 5))) > 0.4).float().expand(-1, 6, -1, -1).contiguous()
+        y, m2 = T.DoubleUpSample(scale_factor=2, mode="nearest")((x.to(dev), mk.to(dev)))
+        m2 = m2.as_tensor() if hasattr(m2, "as_tensor") else m2
+        assert torch.equal(y.cpu(), F.interpolate(x, scale_factor=2, mode="nearest"))
+        assert torch.equal(m2.cpu(), F.interpolate(mk, scale_factor=2, mode="nearest"))
+
+
+@pytest.mark.gpu
+def test_textsegament_full_size_properties_gpu():
+    """BASELINE config 3 size (TextSegament, 512x512; batch 8 here -- batch 64 is the bench configuration): forward
+    is deterministic, an image's eval output does not depend on its batch mates, a training step gives finite
+    gradients for every trainable parameter and bit-identical gradients when repeated."""
+    with BACKENDS["gpu"]() as dev:
+        from text_segmentation_image_inpainting_amd.synthetic import make_seg_batch
+        x, t = make_seg_batch(8, 512, seed0=300)
+        x, t = x.to(dev), t.to(dev)
+        torch.manual_seed(0)
+        m = T.TextSegament()
+        fill_state_dict_(m.state_dict(), seed=47, gain=1.0)
+        m = m.to(dev).eval()
+        with torch.no_grad():
+            y1, y2 = m(x), m(x)
+            assert tuple(y1.shape) == (8, 1, 512, 512)
+            assert torch.equal(y1, y2) and bool(torch.isfinite(y1).all())
+            for i in (0, 5):
+                assert_close(m(x[i:i + 1]), y1[i:i + 1], 1e-5, f"batch independence, image {i}")
+        crit = T.BinaryFocalLoss(0, 1, 2)
+        grads = []
+        for _ in range(2):
+            m2 = T.TextSegament()
+            fill_state_dict_(m2.state_dict(), seed=47, gain=1.0)
+            m2 = m2.to(dev).train()
+            loss = crit(m2(x), t)
+            loss.backward()
+            assert bool(torch.isfinite(loss))
+            g = [p.grad for p in m2.parameters() if p.requires_grad]
+            assert all(v is not None and bool(torch.isfinite(v).all()) for v in g)
+            grads.append(torch.cat([v.reshape(-1) for v in g]))
+        assert torch.equal(grads[0], grads[1])

@@ -92,3 +92,33 @@ def make_batch(batch: int, size=512, seed0=0, bernoulli=False):
     """Collated batch (three float32 tensors [B,3,S,S]) -- what a DataLoader over the Dataset yields."""
     parts = [make_sample(seed0 + i, size, bernoulli) for i in range(batch)]
     return tuple(torch.from_numpy(np.stack([p[j] for p in parts])) for j in range(3))
+
+
+SEG_MEAN = (0.4935, 0.4563, 0.4544)   # Examples/demo_segmentation.py:59-60
+SEG_STD = (0.3769, 0.3615, 0.3566)
+
+
+def make_seg_sample(seed: int, size=512):
+    """(image, target) for the text-segmentation nets (SURVEY.md 8(d) cfg 1 / 3): a normalised manga tile
+    float32 [3,S,S] and the binary 'text' mask float32 [1,S,S] = its dark strokes dilated by 5 px."""
+    rng = np.random.default_rng(seed)
+    base = rng.uniform(0.7, 1.0)
+    img = Image.new("L", (size, size), int(255 * base))
+    tgt = Image.new("L", (size, size), 0)
+    di, dt = ImageDraw.Draw(img), ImageDraw.Draw(tgt)
+    for _ in range(int(rng.integers(20, 41))):
+        x0, y0 = (int(v) for v in rng.integers(0, size, size=2))
+        x1, y1 = (int(np.clip(v, 0, size - 1)) for v in (x0 + rng.integers(-120, 121), y0 + rng.integers(-120, 121)))
+        wd = int(rng.integers(1, 7))
+        di.line([x0, y0, x1, y1], width=wd, fill=int(rng.integers(0, 90)))
+        dt.line([x0, y0, x1, y1], width=wd + 10, fill=255)
+    arr = np.asarray(img, dtype=np.float32) / 255.0
+    arr = np.clip(arr + rng.normal(0, 0.01, arr.shape).astype(np.float32), 0.0, 1.0)
+    x = np.stack([(arr - m) / s for m, s in zip(SEG_MEAN, SEG_STD)]).astype(np.float32)
+    t = (np.asarray(tgt, dtype=np.uint8) > 0).astype(np.float32)[None]
+    return x, t
+
+
+def make_seg_batch(batch: int, size=512, seed0=0):
+    parts = [make_seg_sample(seed0 + i, size) for i in range(batch)]
+    return tuple(torch.from_numpy(np.stack([p[j] for p in parts])) for j in range(2))
