@@ -85,6 +85,14 @@ def to_nchw(y: torch.Tensor) -> torch.Tensor:
     return y.permute(0, 3, 1, 2)
 
 
+def bn_momentum(bn) -> float:
+    """BatchNorm2d.momentum; ``None`` (cumulative moving average) has no kernel -- fail loudly instead of
+    silently substituting torch's default."""
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) has no HIP kernel")
+    return float(bn.momentum)
+
+
 def act_code(act):
     """nn activation module -> (kernel activation id, slope)."""
     if act is None or act is False:
@@ -115,7 +123,8 @@ class Conv2d(nn.Conv2d):
         if self.bn_follows and self.training:
             y, part = ops.conv2d(to_nhwc(x), self.weight, self.bias, g, self.groups, want_stats=True)
             out = to_nchw(y)
-            out._tsii_stat_part = part     # picked up by the BNAct that nn.Sequential calls next with this very object
+            if part is not None:           # picked up by the BNAct that nn.Sequential calls next with this very object
+                out._tsii_stat_part = (part, out.data_ptr(), out._version)
             return out
         return to_nchw(ops.conv2d(to_nhwc(x), self.weight, self.bias, g, self.groups))
 
@@ -129,9 +138,14 @@ class BNAct(nn.Sequential):
         training = bn.training or bn.running_mean is None
         if training and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
-        momentum = 0.1 if bn.momentum is None else bn.momentum
+        momentum = bn_momentum(bn)
         res = None if residual is None else to_nhwc(residual)
-        part = getattr(x, "_tsii_stat_part", None) if training else None
+        # statistics partials the producing Conv2d left on this very tensor object (K6b); used only while the tensor
+        # still is that conv's untouched output (same storage, same version counter), otherwise the separate pass runs
+        part = None
+        tag = getattr(x, "_tsii_stat_part", None) if training else None
+        if tag is not None and tag[1] == x.data_ptr() and tag[2] == x._version and tag[0].shape[-1] == x.shape[1]:
+            part = tag[0]
         y = ops.bn_act(to_nhwc(x), bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps,
                        act, slope, res, part)
         return to_nchw(y)
@@ -209,7 +223,7 @@ def run_chain(mods, x):
             training = bn.training or bn.running_mean is None
             if training and bn.num_batches_tracked is not None:
                 bn.num_batches_tracked.add_(1)
-            momentum = 0.1 if bn.momentum is None else bn.momentum
+            momentum = bn_momentum(bn)
             g = ops.make_geom(m.kernel_size, m.stride, m.padding, m.dilation)
             src = lazy if lazy is not None else h
             if training:

@@ -61,6 +61,12 @@ def _c(t: Optional[torch.Tensor]):
     return None if t is None else t.contiguous()
 
 
+def _al16(*ts) -> bool:
+    """All given tensors start on a 16-byte boundary (the fused strip / vector kernels' requirement; torch
+    allocations always do, contiguous views at an odd element offset do not)."""
+    return all(t is None or t.data_ptr() % 16 == 0 for t in ts)
+
+
 # ---------------------------------------------------------------------------------------
 # K1 mask planes (no autograd)
 # ---------------------------------------------------------------------------------------
@@ -240,7 +246,8 @@ class _Depthwise(torch.autograd.Function):
             dx = torch.empty_like(x)
             ws = _ws(4 * c * g.kh * g.kw, x)
             rows = 0
-            if ctx.bn is not None and FUSE_BN_BWD and load_time_act(*ctx.in_cfg) and g.sh == 1 and g.sw == 1:   # K6c: stride-1 dX only
+            if (ctx.bn is not None and FUSE_BN_BWD and load_time_act(*ctx.in_cfg) and g.sh == 1 and g.sw == 1   # K6c: stride-1 dX only
+                    and _al16(gy, x)):
                 rows = int(_lib.lib().tsii_dw_stat_rows(n, h, wd, c, g.kh, g.kw, g.sh, g.sw, g.dh, g.dw))   # strips of the dX grid
             if rows > 0:
                 mean, var, gamma, beta, eps, slot = ctx.bn
@@ -270,7 +277,9 @@ def pconv_depthwise(x, w, bias, rmask, denom, keep, inv, g: Geom, want_stats=Fal
     """``x`` may be a LazyBN; with ``want_stats`` returns (y, stat_part or None) -- None when the geometry has no
     fused form (the caller then takes the statistics with the separate pass)."""
     lazy = isinstance(x, LazyBN)
-    fusable = (lazy or want_stats) and dw_stat_rows((x.token if lazy else x).shape, g) > 0
+    src = x.token if lazy else x
+    # the fused forms need the marching-strip kernel: supported geometry AND 16-byte aligned operands
+    fusable = (lazy or want_stats) and src.is_contiguous() and _al16(src) and dw_stat_rows(src.shape, g) > 0
     if lazy and not fusable:
         x, lazy = x.materialize(), False
     stats = want_stats and fusable

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .BaseModels import BaseModule, act_code, to_nchw, to_nhwc
+from .BaseModels import BaseModule, act_code, bn_momentum, to_nchw, to_nhwc
 from .masks import MaskParts, as_parts
 
 import os
@@ -171,7 +171,7 @@ class PartialActivatedBN(BaseModule):
         training = bn.training or bn.running_mean is None
         if training and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
-        momentum = 0.1 if bn.momentum is None else bn.momentum
+        momentum = bn_momentum(bn)
         return bn, act, slope, training, momentum
 
     def forward_nhwc(self, x, mp, residual=None):

@@ -46,8 +46,28 @@ class FlatSGDTrainer:
         self.loss_fn = loss_fn or (lambda out_nchw, clean_nhwc: ops.l1_mean(to_nhwc(out_nchw), clean_nhwc))
 
     def broadcast_parameters(self, src=0):
+        """Rank ``src``'s weights, optimizer state and module buffers (BatchNorm running statistics and batch
+        counters) become every rank's: after a checkpoint load on one rank or a restart all replicas agree."""
         if self.distributed:
             dist.broadcast(self.flat_param, src=src, group=self.pg)
+            dist.broadcast(self.flat_buf, src=src, group=self.pg)
+            self.broadcast_buffers(src)
+
+    def broadcast_buffers(self, src=0):
+        """BatchNorm statistics stay process-local during training (the reference has no SyncBN); call this before
+        saving a checkpoint if every rank must hold rank ``src``'s buffers."""
+        if not self.distributed:
+            return
+        bufs = [b for b in self.model.buffers()]
+        for dtype in {b.dtype for b in bufs}:
+            group = [b for b in bufs if b.dtype == dtype]
+            flat = torch.cat([b.detach().reshape(-1) for b in group])
+            dist.broadcast(flat, src=src, group=self.pg)
+            off = 0
+            with torch.no_grad():
+                for b in group:
+                    b.copy_(flat[off:off + b.numel()].view_as(b))
+                    off += b.numel()
 
     def forward_backward(self, corrupted, mask, clean_nhwc):
         for p in self.params:
@@ -59,7 +79,15 @@ class FlatSGDTrainer:
         return loss.detach()    # do not hand the autograd graph (and its AccumulateGrad nodes) to the caller
 
     def _pack_gradients(self):
-        torch._foreach_copy_(self.grad_views, [p.grad for p in self.params])
+        dst, src = [], []
+        for v, p in zip(self.grad_views, self.params):
+            if p.grad is None:          # parameter not reached by this step's graph (unused / frozen branch)
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def reduce_gradients(self):
         self._pack_gradients()
@@ -127,4 +155,4 @@ class FlatSGDTrainer:
         if self.distributed:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
             self.update()
-        return self._static_loss
+        return self._static_loss.clone()   # the static tensor is overwritten by the next replay
