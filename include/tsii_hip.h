@@ -43,6 +43,16 @@ extern "C" {
 int tsii_version(void);
 const char* tsii_last_error(void);
 
+/* Arithmetic of the point-wise / implicit-GEMM matrix products (process-wide switch, read by every later call):
+ *   6 (default) split-bf16: each fp32 operand is split exactly into 3 bf16 pieces while it is staged, the 6 partial
+ *               products of weight >= 2^-16 go through v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- dropped terms
+ *               <= 2^-23 |a*b|, i.e. fp32-class results at 2.7x the matrix-core rate of the f32-input MFMA;
+ *   3           2 pieces / 3 partial products (error <= 2^-15 |a*b|): inference-grade, opt-in;
+ *   0           v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chain).
+ * The environment variable TSII_GEMM_PRODUCTS sets the initial value.  inputs/outputs are fp32 in every mode. */
+int tsii_set_gemm_products(int products);
+int tsii_get_gemm_products(void);
+
 /* ---- K1: mask bookkeeping (partial_convolution.py:57-66,74-77,129-135) --------------- */
 
 /* plane[n,h,w] = sum_c mask[n,c,h,w]; mask given with element strides (any layout).

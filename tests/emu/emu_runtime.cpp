@@ -23,6 +23,7 @@ static ucontext_t sched_ctx;
 static int cur = -1;
 static const std::function<void()>* body = nullptr;
 static unsigned xbuf[16][64][2];
+static unsigned short bbuf[16][64][2][8];
 
 static void entry() {
     (*body)();
@@ -92,6 +93,24 @@ f32x4_emu mfma_16x16x4(float a, float b, f32x4_emu c) {
             std::memcpy(&bv, &xbuf[wave][col + 16 * k][1], 4);
             acc = fmaf(av, bv, acc);
         }
+        c[r] = acc;
+    }
+    wavesync();
+    return c;
+}
+
+f32x16_emu mfma_32x32x16_bf16(bf16x8_emu a, bf16x8_emu b, f32x16_emu c) {
+    const int lane = cur & 63, wave = cur >> 6;
+    std::memcpy(&bbuf[wave][lane][0][0], &a, 16);
+    std::memcpy(&bbuf[wave][lane][1][0], &b, 16);
+    wavesync();
+    const int hi = lane >> 5, col = lane & 31;
+    auto f = [](unsigned short h) { unsigned u = (unsigned)h << 16; float v; std::memcpy(&v, &u, 4); return v; };
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k)
+            acc = fmaf(f(bbuf[wave][row + 32 * (k >> 3)][0][k & 7]), f(bbuf[wave][col + 32 * (k >> 3)][1][k & 7]), acc);
         c[r] = acc;
     }
     wavesync();

@@ -10,7 +10,8 @@
 // one after another.  __syncthreads() and the wave collectives (__shfl_*, MFMA) are
 // cooperative yield points.  Wavefront = 64 lanes, MFMA 32x32x2 f32 fragment layout
 // as documented for gfx950 (A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
-// D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31]).
+// D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31]); MFMA 32x32x16 bf16: lane l holds A[i=l&31][k=8*(l>>5)+j] and
+// B[k=8*(l>>5)+j][col=l&31], j = 0..7, same D map, fp32 accumulation in k order.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -46,6 +47,7 @@ static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, 
 
 typedef float f32x16_emu __attribute__((ext_vector_type(16)));
 typedef float f32x4_emu __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_emu __attribute__((ext_vector_type(8)));
 
 namespace hipemu {
 extern dim3 tIdx, bIdx, bDim, gDim;
@@ -54,6 +56,7 @@ void syncthreads();
 unsigned exchange32(unsigned v, int src_lane_delta_mode, int arg, int width);
 f32x16_emu mfma_32x32x2(float a, float b, f32x16_emu c);
 f32x4_emu mfma_16x16x4(float a, float b, f32x4_emu c);
+f32x16_emu mfma_32x32x16_bf16(bf16x8_emu a, bf16x8_emu b, f32x16_emu c);
 int lane_id();
 }  // namespace hipemu
 
@@ -91,6 +94,10 @@ static inline f32x16_emu __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, 
 }
 static inline f32x4_emu __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4_emu c, int, int, int) {
     return hipemu::mfma_16x16x4(a, b, c);
+}
+
+static inline f32x16_emu __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf16x8_emu a, bf16x8_emu b, f32x16_emu c, int, int, int) {
+    return hipemu::mfma_32x32x16_bf16(a, b, c);
 }
 
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

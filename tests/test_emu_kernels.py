@@ -1,5 +1,6 @@
-"""Kernel-level checks through the C ABI on the TEST-ONLY emulator (tests/emu): the fp32-MFMA GEMMs
-(fragment layout, tile tails, row scales, LDS-staged epilogue) against float64 numpy."""
+"""Kernel-level checks through the C ABI on the TEST-ONLY emulator (tests/emu): the MFMA GEMMs in their three
+arithmetic modes (tsii_set_gemm_products: 0 = f32-input MFMA, 6 = split-bf16 fp32 class, 3 = split-bf16 2 planes)
+-- fragment layouts, LDS swizzle, tile tails, row scales, LDS-staged epilogue -- against float64 numpy."""
 import ctypes
 
 import numpy as np
@@ -20,12 +21,24 @@ def P(a):
     return None if a is None else ctypes.c_void_p(a.ctypes.data)
 
 
+# tolerance of a GEMM result relative to max|ref| per mode (K <= 192 here): fp32 class for 0 and 6
+MODE_TOL = {0: 1e-5, 6: 1e-5, 3: 2e-4}
+
+
+@pytest.fixture(params=[6, 0, 3])
+def mode(request, emu):
+    assert emu.tsii_set_gemm_products(request.param) == 0
+    yield request.param
+    emu.tsii_set_gemm_products(6)
+
+
 @pytest.mark.parametrize("M,K,N,bias,masked", [(300, 64, 128, True, True), (257, 96, 192, True, False),
                                                (130, 40, 32, False, True), (70, 6, 5, True, True),
                                                (260, 128, 256, False, False), (200, 36, 136, True, True),
                                                (300, 192, 128, True, True), (210, 132, 256, False, True)])
-def test_pointwise_gemms(emu, M, K, N, bias, masked):
+def test_pointwise_gemms(emu, mode, M, K, N, bias, masked):
     L = emu
+    tol = MODE_TOL[mode]
     rng = np.random.default_rng(M + K + N)
     x = rng.standard_normal((M, K)).astype(np.float32)
     w = rng.standard_normal((N, K)).astype(np.float32)
@@ -48,7 +61,7 @@ def test_pointwise_gemms(emu, M, K, N, bias, masked):
         ref = ref + b
     if masked:
         ref = ref * keep[:, None]
-    assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert np.abs(y - ref).max() <= tol * np.abs(ref).max()
 
     dy = rng.standard_normal((M, N)).astype(np.float32)
     inv = (keep / denom).astype(np.float32) if masked else None
@@ -60,7 +73,7 @@ def test_pointwise_gemms(emu, M, K, N, bias, masked):
     if masked:
         rdx[:, :split] *= r0[:, None]
         rdx[:, split:] *= r1[:, None]
-    assert np.abs(dx - rdx).max() <= 1e-5 * np.abs(rdx).max()
+    assert np.abs(dx - rdx).max() <= tol * np.abs(rdx).max()
 
     nbytes = L.tsii_pw_bwd_dw_ws_bytes(M, N, K)
     ws = np.zeros(nbytes // 4 + 4, np.float32)
@@ -68,17 +81,18 @@ def test_pointwise_gemms(emu, M, K, N, bias, masked):
     db = np.zeros(N, np.float32)
     assert L.tsii_pw_bwd_dw(P(dy), P(x), M, N, K, P(inv), P(keep), P(r0), split, P(r1), P(dw), P(db), P(ws), nbytes, None) == 0, L.tsii_last_error()
     rdw = g.T @ xm
-    assert np.abs(dw - rdw).max() <= 1e-5 * np.abs(rdw).max()
+    assert np.abs(dw - rdw).max() <= tol * np.abs(rdw).max()
     rdb = (dy.astype(np.float64) * (keep[:, None] if masked else 1.0)).sum(0)
     assert np.abs(db - rdb).max() <= 1e-5 * np.abs(rdb).max()
 
 
 @pytest.mark.parametrize("M,K,N,act,slope", [(300, 64, 128, 2, 0.3), (257, 192, 192, 1, 0.0), (140, 36, 40, 3, 0.0),
                                              (260, 128, 256, 0, 0.0)])
-def test_pointwise_fused_batchnorm(emu, M, K, N, act, slope):
+def test_pointwise_fused_batchnorm(emu, mode, M, K, N, act, slope):
     """K6b at kernel level: BatchNorm(+act) of the producer applied on operand load (forward and dW) and the
     statistics partials of the output (-> tsii_bn_finalize) against float64 numpy."""
     L = emu
+    tol = MODE_TOL[mode]
     rng = np.random.default_rng(7 * M + K + N)
     xr = (rng.standard_normal((M, K)) * 2 + 0.5).astype(np.float32)      # raw conv output of the producer
     sc = rng.uniform(0.5, 1.5, K).astype(np.float32)
@@ -97,7 +111,7 @@ def test_pointwise_fused_batchnorm(emu, M, K, N, act, slope):
     assert L.tsii_pw_fwd_bn(P(xr), M, K, P(w), N, P(b), P(r0), K, None, P(denom), P(keep), P(sc), P(sh), act, slope,
                             P(part), P(y), None) == 0, L.tsii_last_error()
     ref = (am @ w.T.astype(np.float64) / denom[:, None] + b) * keep[:, None]
-    assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert np.abs(y - ref).max() <= tol * np.abs(ref).max()
     # statistics of y from the partials
     mean, var = np.zeros(N, np.float32), np.zeros(N, np.float32)
     rm, rv = np.zeros(N, np.float32), np.ones(N, np.float32)
@@ -125,7 +139,7 @@ def test_pointwise_fused_batchnorm(emu, M, K, N, act, slope):
     assert L.tsii_pw_bwd_dw_bn(P(dy), P(xr), M, N, K, P(inv), P(keep), P(r0), K, None, P(sc), P(sh), act, slope,
                                P(dw), P(db), P(ws2), nbytes, None) == 0, L.tsii_last_error()
     rdw = (dy.astype(np.float64) * inv[:, None]).T @ am
-    assert np.abs(dw - rdw).max() <= 1e-5 * np.abs(rdw).max()
+    assert np.abs(dw - rdw).max() <= tol * np.abs(rdw).max()
 
 
 @pytest.mark.parametrize("k,cin,h,w", [(7, 3, 10, 14), (5, 3, 8, 8), (3, 4, 6, 10)])

@@ -18,6 +18,8 @@ _GEOM = [_i] * 8  # kh kw sh sw ph pw dh dw
 SIGNATURES = {
     "tsii_version": (_i, []),
     "tsii_last_error": (ctypes.c_char_p, []),
+    "tsii_set_gemm_products": (_i, [_i]),
+    "tsii_get_gemm_products": (_i, []),
     "tsii_mask_channel_sum": (_i, [_p, _i, _i, _i, _i, _l, _l, _l, _l, _p, _p]),
     "tsii_mask_update": (_i, [_p, _f, _p, _f, _i, _i, _i] + _GEOM + [_i, _i, _f, _i, _p, _p, _p, _p]),
     "tsii_plane_upsample2x": (_i, [_p, _i, _i, _i, _p, _p]),

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--shapes", default="")
+    ap.add_argument("--modes", default="", help="comma list of tsii_set_gemm_products values (0, 3, 6) to loop over")
     args = ap.parse_args()
     from text_segmentation_image_inpainting_amd import _lib
     from text_segmentation_image_inpainting_amd._lib import call, ptr
@@ -48,7 +49,9 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / args.iters
 
-    for (M, K, N, masked) in shapes:
+    modes = [int(v) for v in args.modes.split(",")] if args.modes else [L.tsii_get_gemm_products()]
+    for (M, K, N, masked), gm in [(sh, m) for sh in shapes for m in modes]:
+        L.tsii_set_gemm_products(gm)
         x = torch.randn(M, K, device=dev)
         w = torch.randn(N, K, device=dev) * 0.05
         dy = torch.randn(M, N, device=dev)
@@ -70,14 +73,15 @@ def main():
         res = []
         if args.only in ("", "fwd"):
             t = timeit(lambda: call("tsii_pw_fwd", ptr(x), M, K, ptr(w), N, None, ptr(r0), split, ptr(r1), ptr(denom), None, ptr(y), st))
-            res.append(f"fwd {t:7.3f} ms {fl / t / 1e9:6.1f} TF/s")
+            res.append(f"fwd {t:7.3f} ms {fl / t / 1e9:6.1f} TF/s {4.0 * M * (K + N) / t / 1e9:5.2f} TB/s")
         if args.only in ("", "dx"):
             t = timeit(lambda: call("tsii_pw_bwd_dx", ptr(dy), M, N, ptr(w), K, ptr(inv), ptr(r0), split, ptr(r1), ptr(dx), ptr(wt), st))
-            res.append(f"dx {t:7.3f} ms {fl / t / 1e9:6.1f} TF/s")
+            res.append(f"dx {t:7.3f} ms {fl / t / 1e9:6.1f} TF/s {4.0 * M * (K + N) / t / 1e9:5.2f} TB/s")
         if args.only in ("", "dw"):
             t = timeit(lambda: call("tsii_pw_bwd_dw", ptr(dy), ptr(x), M, N, K, ptr(inv), None, ptr(r0), split, ptr(r1), ptr(dw), None, ptr(ws), nb, st))
             res.append(f"dw {t:7.3f} ms {fl / t / 1e9:6.1f} TF/s")
-        print(f"M={M:8d} K={K:5d} N={N:5d} masked={int(masked)} | " + " | ".join(res), flush=True)
+        gb = 4.0 * M * (K + N) / 1e9
+        print(f"mode={gm} M={M:8d} K={K:5d} N={N:5d} masked={int(masked)} alg {gb:5.2f} GB | " + " | ".join(res), flush=True)
 
 
 if __name__ == "__main__":
