@@ -669,6 +669,14 @@ static int pw_bwd_dw_impl(const float* dy, const float* x, int64_t m, int n, int
     float* part = (float*)ws;
     RowScale sb = {r0, r1, split};
     dim3 grid(cdiv(k, pl.bn), cdiv(n, pl.bm), pl.splits);
+    if (tn_split_ok(dy, n, x, k, n, k)) {     // split-bf16 MFMA (gemm_split.hip): same partial-slab workspace + row reduce
+        int rc = launch_tn_split(dy, n, inv, x, k, sb, part, m, n, k, pl.chunk, pl.splits, pl.narrow ? 1 : (pl.big ? 0 : 2), ib, st);
+        if (rc) return rc;
+        rc = launch_reduce_rows(part, pl.splits, (int64_t)n * k, dw, st);
+        if (rc) return rc;
+        if (dbias != nullptr) rc = launch_colsum_scaled(dy, keep, m, n, dbias, part + (size_t)pl.splits * n * k, st);
+        return rc;
+    }
     if (ib.sc != nullptr) {
         TSII_REQUIRE(vec, "pw_bwd_dw: input BatchNorm needs n, k %% 4 == 0 and 16-byte aligned operands");
         if (pl.narrow) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 1, true, 0, true>), grid, dim3(256), 0, st, dy, (int64_t)n, inv, x, (int64_t)k, sb, part, m, n, k, pl.chunk, kNoConv, ib);

@@ -58,26 +58,26 @@ __device__ __forceinline__ int split_off(int row, int chunk) { return row * 64 +
 template <int ROWS>
 struct SplitChunks { static constexpr int value = (ROWS * 4 + 255) / 256; };
 
-// raw loads of this thread's chunks: 8 consecutive k of a row-major [rows, K] fp32 matrix as 2 float4
+// raw loads of this thread's chunks: 8 consecutive k of a row-major [rows, K] fp32 matrix as 2 float4.  BRANCH-FREE:
+// out-of-range rows / k are clamped to valid addresses and zeroed by the store pass (a branch around each load made
+// hipcc wait vmcnt(0) after every single load -- the loads must issue back to back and stay in flight over the MFMAs).
 template <int ROWS>
 __device__ __forceinline__ void split_load(const float* __restrict__ Pm, int64_t ld, int64_t row0, int64_t nrows, int k0, int K,
                                            float4 (&regs)[SplitChunks<ROWS>::value][2]) {
-    // wave-uniform 64-bit base (SGPRs) + 32-bit per-thread offsets: per-chunk 64-bit address VGPRs made the kernel spill
+    // wave-uniform 64-bit base (SGPRs) + 32-bit per-thread BYTE offsets (saddr + voffset addressing)
     const int tid = threadIdx.x;
-    const float* __restrict__ base = Pm + row0 * ld;
-    const int left = (int)((nrows - row0 < ROWS) ? (nrows - row0) : ROWS);
+    const char* __restrict__ base = reinterpret_cast<const char*>(Pm + row0 * ld);
+    const int last = (int)((nrows - row0 < ROWS) ? (nrows - row0) : ROWS) - 1;      // >= 0: the block has at least one row
 #pragma unroll
     for (int i = 0; i < SplitChunks<ROWS>::value; ++i) {
         const int f = tid + 256 * i;
-        const int r = f >> 2, c = f & 3;
-        const int k = k0 + c * 8;
-        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-        if (r < left && k < K) {     // K % 8 == 0: a chunk is all in or all out (r < ROWS whenever r < left)
-            const float* p = base + (unsigned)(r * (int)ld + k);
-            v0 = *reinterpret_cast<const float4*>(p);
-            v1 = *reinterpret_cast<const float4*>(p + 4);
-        }
-        regs[i][0] = v0; regs[i][1] = v1;      // not touched until the store pass: the loads stay in flight over the MFMAs
+        int r = f >> 2;
+        r = r < last ? r : last;
+        int k = k0 + (f & 3) * 8;
+        k = k < K - 8 ? k : K - 8;                                                 // K % 8 == 0, K >= 8
+        const float* p = reinterpret_cast<const float*>(base + (unsigned)((r * (int)ld + k) * 4));
+        regs[i][0] = *reinterpret_cast<const float4*>(p);
+        regs[i][1] = *reinterpret_cast<const float4*>(p + 4);
     }
 }
 
@@ -99,7 +99,7 @@ __device__ __forceinline__ void split_row_scales(const RowScale& rs, int64_t row
 template <int ROWS, int P, bool SCALED, bool BNIN>
 __device__ __forceinline__ void split_store(unsigned char* __restrict__ S, const float4 (&regs)[SplitChunks<ROWS>::value][2], int k0, int split,
                                             const float (&s0)[SplitChunks<ROWS>::value], const float (&s1)[SplitChunks<ROWS>::value],
-                                            const float4 (&psc)[2], const float4 (&psh)[2], float neg, float hi) {
+                                            const float4 (&psc)[2], const float4 (&psh)[2], float neg, float hi, int nvalid, int K) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < SplitChunks<ROWS>::value; ++i) {
@@ -107,6 +107,7 @@ __device__ __forceinline__ void split_store(unsigned char* __restrict__ S, const
         if (ROWS * 4 % 256 != 0 && f >= ROWS * 4) continue;
         const int r = f >> 2, c = f & 3;
         float v[8] = {regs[i][0].x, regs[i][0].y, regs[i][0].z, regs[i][0].w, regs[i][1].x, regs[i][1].y, regs[i][1].z, regs[i][1].w};
+        const bool valid = r < nvalid && k0 + c * 8 < K;      // clamped loads (split_load): rows / k outside the matrix are zeros
         if constexpr (BNIN) {
             const float sc[8] = {psc[0].x, psc[0].y, psc[0].z, psc[0].w, psc[1].x, psc[1].y, psc[1].z, psc[1].w};
             const float sh[8] = {psh[0].x, psh[0].y, psh[0].z, psh[0].w, psh[1].x, psh[1].y, psh[1].z, psh[1].w};
@@ -118,6 +119,8 @@ __device__ __forceinline__ void split_store(unsigned char* __restrict__ S, const
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= (k + e < split) ? s0[i] : s1[i];
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = valid ? v[e] : 0.f;
         u32x4 pl[P];
         split8<P>(v, pl);
         const int off = split_off(r, c);
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(256, BNB ? 2 : 3) void gemm_nt_split_kernel(const f
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
 
     constexpr int NA = SplitChunks<BM>::value, NB = SplitChunks<BN>::value;
+    const int mvalid = (int)((M - m0 < BM) ? (M - m0) : BM), nvalid = (N - n0 < BN) ? (N - n0) : BN;
     float4 ra[NA][2], rb[NB][2];
     float sa0[NA], sa1[NA], sb0[NB], sb1[NB];
 #pragma unroll
@@ -180,8 +184,8 @@ __global__ __launch_bounds__(256, BNB ? 2 : 3) void gemm_nt_split_kernel(const f
             psh[0] = *reinterpret_cast<const float4*>(ib.sh + pk); psh[1] = *reinterpret_cast<const float4*>(ib.sh + pk + 4);
         }
     }
-    split_store<BM, P, true, BNIN>(As, ra, 0, as.split, sa0, sa1, psc, psh, ib.neg, ib.hi);
-    split_store<BN, P, false, false>(Bs, rb, 0, 0, sb0, sb1, psc, psh, 1.f, 0.f);
+    split_store<BM, P, true, BNIN>(As, ra, 0, as.split, sa0, sa1, psc, psh, ib.neg, ib.hi, mvalid, K);
+    split_store<BN, P, false, false>(Bs, rb, 0, 0, sb0, sb1, psc, psh, 1.f, 0.f, nvalid, K);
     __syncthreads();
 
     // fragment addresses: row li of tile t, k-chunk 2s + hi; the swizzle term depends on li only
@@ -238,14 +242,237 @@ __global__ __launch_bounds__(256, BNB ? 2 : 3) void gemm_nt_split_kernel(const f
         }
         __syncthreads();
         if (more) {
-            split_store<BM, P, true, BNIN>(As, ra, (kt + 1) * SPLIT_BK, as.split, sa0, sa1, psc, psh, ib.neg, ib.hi);
-            split_store<BN, P, false, false>(Bs, rb, 0, 0, sb0, sb1, psc, psh, 1.f, 0.f);
+            split_store<BM, P, true, BNIN>(As, ra, (kt + 1) * SPLIT_BK, as.split, sa0, sa1, psc, psh, ib.neg, ib.hi, mvalid, K);
+            split_store<BN, P, false, false>(Bs, rb, (kt + 1) * SPLIT_BK, 0, sb0, sb1, psc, psh, 1.f, 0.f, nvalid, K);
             __syncthreads();
         }
     }
 
     const ConvGather nocg = {0, 0, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, nullptr, nullptr, 0, nullptr, 0, 0, 0, 0, 0, 0};
     nt_epilogue<WM, WN, TM, TN, 0, BNB, SMEM_FLOATS>(smem, acc, C, ldc, M, N, ep, nocg, m0, n0, bid, ntn);
+}
+
+// ---- TN (dW): C[P,Q] = sum_m A[m,p]*sa[m] * B[m,q]*rs(m,q), both operands [m][channel] in memory ----------------
+// The bf16 MFMA wants 8 consecutive k (= m) per lane, i.e. the operands TRANSPOSED: a thread loads a 4(m) x 4(channel)
+// micro-tile (4 float4, channel-contiguous), splits each channel's 4 m-values and writes 8 bytes per (plane, channel) --
+// half of a 16-byte [channel][8 m] atom.  LDS image per plane: atom(c, ch) = c*CH + (ch&3)*(CH/4) + ((ch>>2) ^ (4*(ch&3)))
+// (c = 8-m chunk 0..3 of the 32-m stage): a 16-lane ds_write_b64 group = 8 consecutive channel quads x 2 halves covers
+// all 32 banks, and the fragment reads (lane l: channel l & 31 of the wave tile, chunk 2s + (l >> 5)) hit 16 distinct
+// 16-byte slots per 16-lane group -- both conflict free, no padding (48 KB per block, 3 blocks per CU).
+// Thread -> micro-tile: cq = (lane & 7) | ((lane >> 4) << 3), mq = ((lane >> 3) & 1) | (wave << 1): one global load
+// instruction reads 2 rows x 4 full 128-byte lines per wave.
+template <int CH>
+__device__ __forceinline__ int tn_atom(int c, int ch) { return c * CH + (ch & 3) * (CH / 4) + ((ch >> 2) ^ (4 * (ch & 3))); }
+
+template <int CH>
+__device__ __forceinline__ void tn_split_load(const float* __restrict__ Pm, int64_t ld, int64_t m0, int64_t mend, int c0, int ncols,
+                                              int cq, int mq, float4 (&regs)[4]) {
+    // branch-free like split_load: rows past the chunk end / columns past the matrix are clamped, zeroed by the store pass
+    const char* __restrict__ base = reinterpret_cast<const char*>(Pm + m0 * ld);
+    const int last = (int)((mend - m0 < 32) ? (mend - m0) : 32) - 1;
+    int c = c0 + cq * 4;
+    c = c < ncols - 4 ? c : ncols - 4;                                  // ncols % 4 == 0, ncols >= 4
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        int r = mq * 4 + jj;
+        r = r < last ? r : last;
+        regs[jj] = *reinterpret_cast<const float4*>(base + (unsigned)((r * (int)ld + c) * 4));
+    }
+}
+
+// per-row factors of this thread's 4 rows (small planes, L2 hits): fetched AFTER the MFMA phase, behind the barrier wait
+// (held across the MFMA phase their 16 VGPRs made the kernel spill)
+__device__ __forceinline__ void tn_split_factors(int64_t m0, int64_t mend, const float* __restrict__ rowmul, const RowScale& rs, int mq,
+                                                 float (&f0)[4], float (&f1)[4]) {
+    const int last = (int)((mend - m0 < 32) ? (mend - m0) : 32) - 1;
+    int r[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) { r[jj] = mq * 4 + jj; r[jj] = r[jj] < last ? r[jj] : last; }    // clamped: rows past the end are zeroed by the store
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) { f0[jj] = 1.f; f1[jj] = 1.f; }
+    if (rowmul != nullptr) {            // wave-uniform branches only; the loads inside issue back to back
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { f0[jj] = rowmul[m0 + r[jj]]; f1[jj] = f0[jj]; }
+    }
+    if (rs.r0 != nullptr) {
+        float t0[4], t1[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) t0[jj] = rs.r0[m0 + r[jj]];
+        if (rs.r1 != nullptr) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) t1[jj] = rs.r1[m0 + r[jj]];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { f0[jj] *= t0[jj]; f1[jj] *= t1[jj]; }
+    }
+}
+
+template <int CH, int P, bool BNIN>
+__device__ __forceinline__ void tn_split_store(unsigned char* __restrict__ S, const float4 (&regs)[4], int c0, int split, bool split_active,
+                                               const float (&f0)[4], const float (&f1)[4], int cq, int mq,
+                                               const float4 sc, const float4 sh, float neg, float hi, int left, int ncols) {
+    if (CH != 128 && cq >= CH / 4) return;
+    const bool col_ok = c0 + cq * 4 < ncols;
+    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+    float v[4][4];     // [m][channel]
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        v[jj][0] = regs[jj].x; v[jj][1] = regs[jj].y; v[jj][2] = regs[jj].z; v[jj][3] = regs[jj].w;
+    }
+    const int cbase = c0 + cq * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f32x2 lo = {v[0][e], v[1][e]}, hi2 = {v[2][e], v[3][e]};
+        float x[4] = {v[0][e], v[1][e], v[2][e], v[3][e]};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            if constexpr (BNIN) x[jj] = bn_act_load(x[jj], scv[e], shv[e], neg, hi);
+            x[jj] *= (!split_active || cbase + e < split) ? f0[jj] : f1[jj];
+            x[jj] = (col_ok && mq * 4 + jj < left) ? x[jj] : 0.f;       // clamped loads: outside the matrix = 0 (select: NaN safe)
+        }
+        lo = f32x2{x[0], x[1]}; hi2 = f32x2{x[2], x[3]};
+        unsigned w0[P], w1[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const bf16x2 h0 = __builtin_convertvector(lo, bf16x2), h1 = __builtin_convertvector(hi2, bf16x2);
+            const unsigned u0 = __builtin_bit_cast(unsigned, h0), u1 = __builtin_bit_cast(unsigned, h1);
+            w0[p] = u0; w1[p] = u1;
+            if (p + 1 < P) {
+                lo = lo - f32x2{__builtin_bit_cast(float, u0 << 16), __builtin_bit_cast(float, u0 & 0xffff0000u)};
+                hi2 = hi2 - f32x2{__builtin_bit_cast(float, u1 << 16), __builtin_bit_cast(float, u1 & 0xffff0000u)};
+            }
+        }
+        const int off = tn_atom<CH>(mq >> 1, cq * 4 + e) * 16 + (mq & 1) * 8;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u32x2*>(S + p * (CH * 64) + off) = u32x2{w0[p], w1[p]};
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int PRODUCTS, bool BNIN>
+__global__ __launch_bounds__(256, 3) void gemm_tn_split_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ sa,
+                                                            const float* __restrict__ B, int64_t ldb, RowScale sb,
+                                                            float* __restrict__ Cws, int64_t M, int Pn, int Q, int64_t chunk, InBN ib,
+                                                            unsigned qtiles, unsigned ptiles) {
+    constexpr int P = SplitPlanes<PRODUCTS>::value;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    static_assert(WM * WN == 4, "4 waves per block");
+    static_assert((BM == 128 || BM == 64) && (BN == 128 || BN == 64), "micro-tile mapping: 32 (16) channel quads x 8 m quads");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[P * (BM + BN) * 64];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + P * BM * 64;
+
+    // 1-D grid, XCD-aware: the (p, q) tiles of one m-chunk get consecutive logical ids = one XCD, so the tiles that re-read
+    // the same A / B panels hit that XCD's L2 (the 3-D grid dealt them round-robin to the 8 L2s: 3x HBM re-reads measured)
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned zsplit = bid / (qtiles * ptiles), rem = bid % (qtiles * ptiles);
+    const int q0 = (int)(rem % qtiles) * BN, p0 = (int)(rem / qtiles) * BM;
+    const int64_t mbeg = (int64_t)zsplit * chunk;
+    const int64_t mend = (mbeg + chunk < M) ? mbeg + chunk : M;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, hi = lane >> 5;
+    const int cq = (lane & 7) | ((lane >> 4) << 3), mq = ((lane >> 3) & 1) | (wave << 1);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    float4 ra[4], rb[4];
+    float fa0[4], fa1[4], fb0[4], fb1[4];
+    const RowScale none = {nullptr, nullptr, 0};
+    const bool sb_active = sb.r0 != nullptr;
+    float4 bsc = make_float4(0.f, 0.f, 0.f, 0.f), bsh = bsc;     // BNIN: (scale, shift) of this thread's 4 B columns, fixed for the block
+    if constexpr (BNIN) {
+        const int q = q0 + cq * 4;
+        if ((BN == 128 || cq < BN / 4) && q < Q) { bsc = *reinterpret_cast<const float4*>(ib.sc + q); bsh = *reinterpret_cast<const float4*>(ib.sh + q); }
+    }
+    tn_split_load<BM>(A, lda, mbeg, mend, p0, Pn, cq, mq, ra);
+    tn_split_load<BN>(B, ldb, mbeg, mend, q0, Q, cq, mq, rb);
+    tn_split_factors(mbeg, mend, sa, none, mq, fa0, fa1);
+    tn_split_factors(mbeg, mend, nullptr, sb, mq, fb0, fb1);
+    int left = (int)((mend - mbeg < 32) ? (mend - mbeg) : 32);
+    tn_split_store<BM, P, false>(As, ra, p0, 0, false, fa0, fa1, cq, mq, bsc, bsh, 1.f, 0.f, left, Pn);
+    tn_split_store<BN, P, BNIN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1, cq, mq, bsc, bsh, ib.neg, ib.hi, left, Q);
+    __syncthreads();
+
+    // fragment byte offsets inside a plane: channel li of wave tile t (tile base multiple of 32), chunk 2s + hi
+    int foA[TM][2], foB[TN][2];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) foA[t][s] = tn_atom<BM>(2 * s + hi, (wm * TM + t) * 32 + li) * 16;
+#pragma unroll
+    for (int u = 0; u < TN; ++u)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) foB[u][s] = tn_atom<BN>(2 * s + hi, (wn * TN + u) * 32 + li) * 16;
+
+    // one MFMA phase over the 32-m stage in LDS
+    auto mfma_phase = [&]() {
+        __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 b[TN][P];
+#pragma unroll
+            for (int u = 0; u < TN; ++u)
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    b[u][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + p * (BN * 64) + foB[u][s]));
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                bf16x8 a[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    a[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * (BM * 64) + foA[t][s]));
+#pragma unroll
+                for (int q = 0; q < PRODUCTS; ++q) {
+                    const int pa = PRODUCTS == 6 ? (q == 0 ? 2 : (q == 1 || q == 3) ? 1 : 0) : (q == 0 ? 1 : 0);
+                    const int pb = PRODUCTS == 6 ? (q == 2 ? 2 : (q == 1 || q == 4) ? 1 : 0) : (q == 1 ? 1 : 0);
+#pragma unroll
+                    for (int u = 0; u < TN; ++u)
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[u][pb], acc[t][u], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // every iteration loads the NEXT stage unconditionally (the last stage is peeled): a conditional load made hipcc
+    // merge register copies behind the loads and wait for them before the MFMA phase
+    for (int64_t mt = mbeg; mt + SPLIT_BK < mend; mt += SPLIT_BK) {
+        tn_split_load<BM>(A, lda, mt + SPLIT_BK, mend, p0, Pn, cq, mq, ra);
+        tn_split_load<BN>(B, ldb, mt + SPLIT_BK, mend, q0, Q, cq, mq, rb);
+        mfma_phase();
+        tn_split_factors(mt + SPLIT_BK, mend, sa, none, mq, fa0, fa1);
+        tn_split_factors(mt + SPLIT_BK, mend, nullptr, sb, mq, fb0, fb1);
+        __syncthreads();
+        left = (int)((mend - mt - SPLIT_BK < 32) ? (mend - mt - SPLIT_BK) : 32);
+        tn_split_store<BM, P, false>(As, ra, p0, 0, false, fa0, fa1, cq, mq, bsc, bsh, 1.f, 0.f, left, Pn);
+        tn_split_store<BN, P, BNIN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1, cq, mq, bsc, bsh, ib.neg, ib.hi, left, Q);
+        __syncthreads();
+    }
+    mfma_phase();
+
+    float* Cz = Cws + (int64_t)zsplit * Pn * Q;
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = p0 + (wm * TM + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (p >= Pn) continue;
+#pragma unroll
+            for (int u = 0; u < TN; ++u) {
+                const int q = q0 + (wn * TN + u) * 32 + li;
+                if (q < Q) Cz[(int64_t)p * Q + q] = acc[t][u][r];
+            }
+        }
 }
 
 // ---- mode switch --------------------------------------------------------------------------------------------
@@ -299,6 +526,30 @@ int launch_nt_split(const float* A, int64_t lda, RowScale as, const float* B, in
                    : launch_nt_split_cfg<2, 2, 2, 1, 3>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, stream);
     return six ? launch_nt_split_cfg<4, 1, 1, 1, 6>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, stream)
                : launch_nt_split_cfg<4, 1, 1, 1, 3>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, stream);
+}
+
+
+bool tn_split_ok(const float* A, int64_t lda, const float* B, int64_t ldb, int Pn, int Q) {
+    return g_products != 0 && Pn % 4 == 0 && Q % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) && aligned16(B);
+}
+
+// tile = 0: 128x128, 1: 128x64 (narrow), 2: 64x64 (P or Q below 128); one partial [P,Q] slab per m-chunk in Cws
+int launch_tn_split(const float* A, int64_t lda, const float* sa, const float* B, int64_t ldb, RowScale sb, float* Cws,
+                    int64_t M, int Pn, int Q, int64_t chunk, int splits, int tile, InBN ib, hipStream_t stream) {
+    const int bm = tile == 2 ? 64 : 128, bn = tile == 0 ? 128 : 64;
+    const unsigned qt = (unsigned)cdiv(Q, bn), pt = (unsigned)cdiv(Pn, bm);
+    const int64_t nblocks = (int64_t)qt * pt * splits;
+    TSII_REQUIRE(nblocks < (1ll << 31), "gemm_tn_split: grid too large");
+    const dim3 grid((unsigned)nblocks);
+    const bool six = g_products != 3;
+    if (ib.sc != nullptr) TSII_REQUIRE(aligned16(ib.sc) && aligned16(ib.sh), "gemm_tn_split: input BatchNorm needs 16-byte aligned scale / shift");
+#define TSII_TN_SPLIT(TMV, TNV, PR, BNV) hipLaunchKernelGGL((gemm_tn_split_kernel<2, 2, TMV, TNV, PR, BNV>), grid, dim3(256), 0, stream, A, lda, sa, B, ldb, sb, Cws, M, Pn, Q, chunk, ib, qt, pt)
+#define TSII_TN_SPLIT_T(PR, BNV) do { if (tile == 0) TSII_TN_SPLIT(2, 2, PR, BNV); else if (tile == 1) TSII_TN_SPLIT(2, 1, PR, BNV); else TSII_TN_SPLIT(1, 1, PR, BNV); } while (0)
+    if (ib.sc != nullptr) { if (six) TSII_TN_SPLIT_T(6, true); else TSII_TN_SPLIT_T(3, true); }
+    else { if (six) TSII_TN_SPLIT_T(6, false); else TSII_TN_SPLIT_T(3, false); }
+#undef TSII_TN_SPLIT_T
+#undef TSII_TN_SPLIT
+    return check_launch("gemm_tn_split");
 }
 
 }  // namespace tsii

@@ -238,6 +238,10 @@ bool nt_split_ok(const float* A, int64_t lda, const float* B, int64_t ldb, int K
 int launch_nt_split(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, float* C, int64_t ldc,
                     int64_t M, int N, int K, Epilogue ep, InBN ib, hipStream_t stream);
 
+bool tn_split_ok(const float* A, int64_t lda, const float* B, int64_t ldb, int Pn, int Q);
+int launch_tn_split(const float* A, int64_t lda, const float* sa, const float* B, int64_t ldb, RowScale sb, float* Cws,
+                    int64_t M, int Pn, int Q, int64_t chunk, int splits, int tile, InBN ib, hipStream_t stream);
+
 // ---- epilogue shared by the NT kernels -----------------------------------------------------------------
 // acc[t][u] = 32x32 MFMA accumulators of the wave (D[row=(r&3)+8*(r>>2)+4*hi][col=lane&31], the same map for the
 // f32 32x32x2 and the bf16 32x32x16 instruction); smem = the block's operand LDS, SMEM_FLOATS floats, free to reuse.
