@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """Headline benchmark (BASELINE.json): imgs/s of the partial-conv inpainting training step
 (ImageFill, 512x512, batch 32 per GPU, train-mode BN, fwd + bwd + gradient all-reduce + fused
-SGD update) on N MI355X of one node, with the roofline of the dominant kernel and the CPU
-baseline (the oracle timed on the host cores) in the same JSON line.
+SGD update) on N MI355X of one node, with the roofline of the dominant kernel class, the
+per-class rooflines and the CPU baseline (the oracle timed on the host cores) in the same JSON line.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -21,47 +22,151 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 vector = fp32 MFMA peak (MI355X_MICROARCH.md)
-PEAK_HBM_TBS = 8.0         # HBM3E spec
+PEAK_FP32_TFLOPS = 157.3    # MI355X f32-input MFMA = fp32 vector peak (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak (same guide)
+PEAK_HBM_TBS = 8.0          # HBM3E spec
 # ImageFill 512^2 forward = 58.8 GFLOP and 2934 MB (train-mode BN) per image; fwd+bwd = 3x
 ALG_GFLOP_PER_IMG = 3 * 58.8
 ALG_GB_PER_IMG = 3 * 2.934
+PMC_SUMMARY = "r02_pmc_hbm_traffic_bs32.json"   # tools/collect_profiles.sh -> tools/pmc_summary.py
 
 
-def nt_variant(n_cols: int) -> str:
-    """Tile variant gemm.hip picks for an NT GEMM with this many output columns."""
-    if n_cols % 128 == 0 or n_cols > 192:
-        return "gemm_nt<128x128>"
-    return "gemm_nt<128x64>" if n_cols > 32 else "gemm_nt<128x32>"
+def csrc_sha():
+    """Fingerprint of the kernel sources; the committed PMC summary carries the one it was measured at."""
+    d = os.path.join(ROOT, "text_segmentation_image_inpainting_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
-PMC_SUMMARY = "r01_h_pmc_hbm_traffic_bs32.json"   # tools/collect_profiles.sh -> tools/pmc_summary.py
+# ---- algorithmic work per C-ABI call (SURVEY.md 8(d) traffic model), decoded from the call's scalar arguments ----------
+# class -> what bounds it; every entry: (class, lambda scalar_args -> (algorithmic bytes, MACs))
+def _pw(a):          # (m, k, n, ...): read [m,k] once, write [m,n] once
+    m, k, n = a[0], a[1], a[2]
+    return 4.0 * m * (k + n), float(m) * k * n
 
 
-def pmc_traffic(kernel_label: str):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (separate rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE passes, x2 read correction; see the file's `_how`), launch-weighted over the template
-    instances of the tile variant (plain and BatchNorm-on-load loaders)."""
+def _dw(a, passes):  # (n, h, w, c, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo, ...)
+    n, h, w, c, ho, wo = a[0], a[1], a[2], a[3], a[12], a[13]
+    return 4.0 * n * c * (h * w * passes[0] + ho * wo * passes[1]), float(n) * ho * wo * c * a[4] * a[5]
+
+
+def _bn(a, passes):  # (m, c, ...)
+    return 4.0 * a[0] * a[1] * passes, 0.0
+
+
+def _dense(a, rd_in, rd_out, wr_in, wr_out):
+    # (n, h, w, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo, ...) after the leading int of the _fwd forms is dropped
+    n, h, w, cin, cout, kh, kw, ho, wo = a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[13], a[14]
+    return (4.0 * n * (h * w * cin * (rd_in + wr_in) + ho * wo * cout * (rd_out + wr_out)),
+            float(n) * ho * wo * cout * cin * kh * kw)
+
+
+def _upcat(a, bwd):  # (n, h, w, c1, c2): low [n,h,w,c1] + skip [n,2h,2w,c2] <-> out [n,2h,2w,c1+c2]
+    n, h, w, c1, c2 = a[:5]
+    return 4.0 * n * h * w * (c1 + 4 * c2 + 4 * (c1 + c2)), 0.0
+
+
+CALLS = {
+    "tsii_pw_fwd": ("gemm_nt", _pw), "tsii_pw_fwd_bn": ("gemm_nt", _pw),
+    "tsii_pw_bwd_dx": ("gemm_nt", lambda a: _pw((a[0], a[1], a[2]))),
+    "tsii_pw_bwd_dx_bn": ("gemm_nt", lambda a: (_pw((a[0], a[1], a[2]))[0] + 4.0 * a[0] * a[2], _pw((a[0], a[1], a[2]))[1])),
+    "tsii_pw_bwd_dw": ("gemm_tn", lambda a: _pw((a[0], a[1], a[2]))), "tsii_pw_bwd_dw_bn": ("gemm_tn", lambda a: _pw((a[0], a[1], a[2]))),
+    "tsii_dw_fwd": ("dw_stencil", lambda a: _dw(a, (1, 1))), "tsii_dw_fwd_bn": ("dw_stencil", lambda a: _dw(a, (1, 1))),
+    "tsii_dw_bwd_dx": ("dw_stencil", lambda a: _dw(a, (1, 1))),
+    "tsii_dw_bwd_dx_bn": ("dw_stencil", lambda a: _dw(a, (2, 1))),      # + the raw BatchNorm input read alongside (K6c)
+    "tsii_dw_bwd_dw": ("dw_stencil", lambda a: _dw(a, (1, 1))), "tsii_dw_bwd_dw_bn": ("dw_stencil", lambda a: _dw(a, (1, 1))),
+    "tsii_bn_act_fwd": ("bn_act", lambda a: _bn(a, 2)), "tsii_bn_stats": ("bn_act", lambda a: _bn(a, 1)),
+    "tsii_bn_act_bwd": ("bn_bwd", lambda a: _bn(a, 3)), "tsii_bn_act_bwd_pre": ("bn_bwd", lambda a: _bn(a, 3)),
+    "tsii_act_fwd": ("bn_act", lambda a: (8.0 * a[0], 0.0)), "tsii_act_bwd": ("bn_act", lambda a: (12.0 * a[0], 0.0)),
+    "tsii_dense_fwd": ("dense_conv", lambda a: _dense(a[1:], 1, 0, 0, 1)), "tsii_dense_fwd_bn": ("dense_conv", lambda a: _dense(a[1:], 1, 0, 0, 1)),
+    "tsii_dense_bwd_dx": ("dense_conv", lambda a: _dense(a[1:], 0, 1, 1, 0)),
+    "tsii_dense_bwd_dw": ("dense_conv", lambda a: _dense(a[1:], 1, 1, 0, 0)),
+    "tsii_upcat_fwd": ("upcat", lambda a: _upcat(a, False)), "tsii_upcat_bwd": ("upcat", lambda a: _upcat(a, True)),
+}
+BOUND = {"gemm_nt": None, "gemm_tn": None, "dense_conv": "mfma", "dw_stencil": "hbm", "bn_act": "hbm", "bn_bwd": "hbm", "upcat": "hbm"}
+
+
+def class_table(timed, steps, products):
+    """{class: {ms_per_step, alg GB/step, TB/s, frac of 8 TB/s [, TFLOP/s, frac of the MFMA peak of the arithmetic mode]}}"""
+    agg = {}
+    for name, recs in timed.items():
+        if name not in CALLS:
+            continue
+        cls, fn = CALLS[name]
+        for ms, a in recs:
+            try:
+                by, macs = fn(a)
+            except (IndexError, TypeError):
+                continue
+            d = agg.setdefault(cls, {"ms": 0.0, "bytes": 0.0, "macs": 0.0, "launches": 0})
+            d["ms"] += ms; d["bytes"] += by; d["macs"] += macs; d["launches"] += 1
+    out = {}
+    for cls, d in agg.items():
+        if d["ms"] <= 0:
+            continue
+        t = d["ms"] * 1e-3
+        tbs = d["bytes"] / t / 1e12
+        rec = {"ms_per_step": round(d["ms"] / steps, 3), "launches_per_step": d["launches"] // steps,
+               "alg_gb_per_step": round(d["bytes"] / steps / 1e9, 3), "tb_per_s": round(tbs, 3), "hbm_frac": round(tbs / PEAK_HBM_TBS, 4)}
+        if d["macs"] > 0 and cls.startswith(("gemm", "dense")):
+            tf = 2.0 * d["macs"] / t / 1e12
+            split = products != 0 and cls.startswith("gemm")
+            # matrix-core work actually issued: `products` bf16 MFMA partial products per fp32 product in the split modes
+            peak = PEAK_BF16_TFLOPS / products if split else PEAK_FP32_TFLOPS
+            rec.update({"fp32_equiv_tflops": round(tf, 2), "mfma_peak_fp32_equiv": round(peak, 1), "mfma_frac": round(tf / peak, 4)})
+        out[cls] = rec
+    return out
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the committed PMC summary (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    passes, x2 read correction).  Returned only while the kernel sources are the ones it was measured at."""
     path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
-    prefixes = {"gemm_nt<128x128>": "tsii::gemm_nt_kernel<2, 2, 2, 2, true, 0",
-                "gemm_nt<128x64>": "tsii::gemm_nt_kernel<2, 2, 2, 1, true, 0",
-                "gemm_nt<128x32>": "tsii::gemm_nt_kernel<4, 1, 1, 1, true, 0"}
     try:
-        kernels = json.load(open(path))["kernels"]
-        recs = [r for k, r in kernels.items() if k.startswith(prefixes[kernel_label])]
+        js = json.load(open(path))
+        if js.get("csrc_sha") != csrc_sha():
+            return None, f"profiles/{PMC_SUMMARY} was measured at csrc {js.get('csrc_sha')}, sources are now {csrc_sha()}: stale, not reported"
+        recs = [r for k, r in js["kernels"].items() if k.startswith(kernel_prefix)]
         launches = sum(r["launches"] for r in recs)
-        return sum(r["bytes_per_launch"] * r["launches"] for r in recs) / launches
-    except Exception:  # noqa: BLE001 - no summary committed for this kernel/config
-        return None
+        return sum(r["bytes_per_launch"] * r["launches"] for r in recs) / launches, f"profiles/{PMC_SUMMARY} (csrc {js['csrc_sha']})"
+    except Exception as exc:  # noqa: BLE001 - no summary committed for this kernel/config
+        return None, f"no PMC summary ({type(exc).__name__})"
+
+
+def host_cpu():
+    model, phys = "unknown", None
+    try:
+        cores = set()
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    cores.add((pid, cid))
+                pid = cid = None
+        phys = len(cores) or None
+    except OSError:
+        pass
+    return model, phys, os.cpu_count()
 
 
 def cpu_baseline(size: int, threads: int):
-    """Oracle (stock-PyTorch CPU restatement of the reference) on a bounded sample of the workload."""
+    """Oracle (stock-PyTorch CPU restatement of the reference) on a bounded sample of the workload, SURVEY.md 8(d)
+    protocol: bs 4, 1 warm-up + 3 timed steps, median."""
     from oracle import pconv_oracle as O
     from text_segmentation_image_inpainting_amd.synthetic import make_batch
     import text_segmentation_image_inpainting_amd as T
+    model, phys, logical = host_cpu()
     torch.set_num_threads(threads)
-    bs = 2
+    bs = 4
     torch.manual_seed(0)
     ref_like = T.ImageFill()  # parameter container only (default init); the oracle does the math on CPU
     sd = {k: v.detach().clone() for k, v in ref_like.state_dict().items()}
@@ -70,7 +175,7 @@ def cpu_baseline(size: int, threads: int):
             sd[k].requires_grad_(True)
     corrupted, mask, clean = make_batch(bs, size, seed0=10_000)
     times = []
-    for it in range(3):
+    for it in range(4):
         t0 = time.perf_counter()
         out = O.image_fill(sd, corrupted, mask, training=True)
         loss = O.l1_mean(out, clean)
@@ -79,27 +184,26 @@ def cpu_baseline(size: int, threads: int):
             if v.grad is not None:
                 v.grad = None
         times.append(time.perf_counter() - t0)
-    t = sorted(times[1:])[0]
-    return {"value": bs / t, "unit": "imgs/s", "cores": threads, "kind": "port",
-            "sample": f"ImageFill {size}x{size} bs {bs} fwd+bwd (train-mode BN, L1 loss), 1 warm-up + 2 timed steps, best"}
+    t = sorted(times[1:])[1]
+    return {"value": round(bs / t, 4), "unit": "imgs/s", "cores": threads, "kind": "port",
+            "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
+            "sample": f"ImageFill {size}x{size} bs {bs} fwd+bwd (train-mode BN, L1 loss), 1 warm-up + 3 timed steps, median; "
+                      f"{threads} torch threads (a 4-image batch does not scale past ~32: more threads ran slower)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--model", default="ImageFill", choices=["ImageFill", "ImageFillOrigin", "ImageFillOriginV2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0,
-                    help="threads for the CPU-baseline leg (default: min(host cores, 32); a 2-image batch "
-                         "does not scale past that -- 256 threads ran 50x slower than 32)")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the short run in the bit-exact f32-MFMA arithmetic mode")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU-baseline leg (default: min(physical cores, 32))")
     ap.add_argument("--bernoulli-masks", action="store_true", help="stress variant: i.i.d. per-channel masks")
-    ap.add_argument("--graph", action="store_true",
-                    help="also capture the step into a HIP graph and report the replay rate (measured on MI355X: no gain, "
-                         "120.3 vs 119.9 ms -- the GPU is never starved by the Python launches -- so it is off by default)")
+    ap.add_argument("--graph", action="store_true", help="also replay the step from a HIP graph (measured: no gain; off by default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,7 +226,8 @@ def main():
     from text_segmentation_image_inpainting_amd.synthetic import make_batch
     from text_segmentation_image_inpainting_amd.train_step import FlatSGDTrainer
 
-    _lib.lib()
+    L = _lib.lib()
+    products = int(L.tsii_get_gemm_products())
     torch.manual_seed(0)  # identical random-init weights on every rank
     model = getattr(T, args.model)().to(dev).train()
     trainer = FlatSGDTrainer(model, lr=1e-3, momentum=0.9, weight_decay=1e-4)
@@ -138,12 +243,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # K steps launched from Python, with HIP events around the dominant GEMM entry points (roofline numbers).
-    # --graph: the same step captured once into a HIP graph and replayed (identical work per step).
+    gemm_calls = [n for n, (c, _) in CALLS.items() if c.startswith("gemm")]
     for _ in range(args.warmup):
         loss = trainer.step(corrupted, mask, clean_nhwc)
     sync()
-    _lib.start_timing(["tsii_pw_fwd", "tsii_pw_fwd_bn", "tsii_pw_bwd_dx", "tsii_pw_bwd_dx_bn"])
+    _lib.start_timing(gemm_calls)      # HIP events (launch stream) around the GEMM entry points inside the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.step(corrupted, mask, clean_nhwc)
@@ -151,6 +255,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timed = _lib.stop_timing()
     eager_ms = elapsed / args.steps * 1e3
+    comm = trainer.comm_stats() if hasattr(trainer, "comm_stats") else None
     graphed = False
     if args.graph:
         try:
@@ -168,6 +273,13 @@ def main():
             print(f"[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); reporting the eager loop", file=sys.stderr)
             sync()
     final_loss = float(loss.item())
+    # per-class pass: HIP events around EVERY hot entry point for a few extra steps (outside the timed region: the
+    # ~1800 extra event records per step would perturb `value`)
+    prof_steps = 3
+    _lib.start_timing(list(CALLS))
+    for _ in range(prof_steps):
+        trainer.step(corrupted, mask, clean_nhwc)
+    classes = class_table(_lib.stop_timing(), prof_steps, products)
     # forward-only rate (SURVEY.md 8(d) asks for both): train-mode BatchNorm forward + loss, no autograd tape
     fwd_steps = max(2, args.steps // 2)
     with torch.no_grad():
@@ -178,6 +290,22 @@ def main():
             trainer.loss_fn(model((corrupted, mask)), clean_nhwc)
         sync()
         fwd_elapsed = time.perf_counter() - t1
+    # the same step in the bit-exact f32-MFMA arithmetic mode (tsii_set_gemm_products(0)), short run, for reference
+    f32_leg = None
+    if products != 0 and not args.no_f32_leg:
+        L.tsii_set_gemm_products(0)
+        for _ in range(3):
+            trainer.step(corrupted, mask, clean_nhwc)
+        sync()
+        t2 = time.perf_counter()
+        n2 = max(5, args.steps // 5)
+        for _ in range(n2):
+            trainer.step(corrupted, mask, clean_nhwc)
+        sync()
+        e2 = time.perf_counter() - t2
+        L.tsii_set_gemm_products(products)
+        f32_leg = {"value": round(world * args.batch * n2 / e2, 2), "unit": "imgs/s (rank 0 clock)", "ms_per_step": round(e2 / n2 * 1e3, 3), "steps": n2,
+                   "arithmetic": "v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chain)"}
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -186,57 +314,63 @@ def main():
     if rank == 0:
         imgs = world * args.batch * args.steps
         value = imgs / elapsed
-        # roofline of the dominant kernel: NT fp32-MFMA GEMM, 128x128 tile (forward 1x1 convs and dX)
-        agg = {}
-        for name, recs in timed.items():
-            for ms, a in recs:
-                m, p, q = a[0], a[1], a[2]       # (M, K, N) for pw_fwd[_bn] ; (M, N, K) for pw_bwd_dx[_bn]
-                v = nt_variant(q)
-                d = agg.setdefault(v, {"ms": 0.0, "flop": 0.0, "launches": 0, "alg_bytes": 0.0})
-                d["ms"] += ms
-                d["flop"] += 2.0 * m * p * q
-                d["alg_bytes"] += 4.0 * m * (p + q)   # read the [M, K] operand once, write [M, N] once
-                d["launches"] += 1
-        dom = max(agg.items(), key=lambda kv: kv[1]["ms"]) if agg else None
+        # roofline of the dominant kernel class, from the HIP events of the timed region
+        tt_classes = class_table(timed, args.steps, products)
+        dom = max(tt_classes.items(), key=lambda kv: kv[1]["ms_per_step"]) if tt_classes else None
         roofline = None
         if dom:
             k, d = dom
-            ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
-                        "traffic": (pmc_traffic(k) if (args.batch == 32 and args.size == 512 and args.model == "ImageFill") else None),
-                        "traffic_unit": "HBM bytes per launch (PMC, profiles/" + PMC_SUMMARY + ")",
-                        "alg_bytes_per_launch": round(d["alg_bytes"] / d["launches"]),
-                        "alg_flop_per_launch": round(d["flop"] / d["launches"]),
-                        "launches_per_step": d["launches"] // args.steps,
-                        "avg_launch_ms": round(d["ms"] / d["launches"], 4),
-                        "ms_per_step_in_kernel": round(d["ms"] / args.steps, 3),
-                        "all_gemm_variants": {kk: {"TFLOP/s": round(dd["flop"] / (dd["ms"] * 1e-3) / 1e12, 2),
-                                                    "ms_per_step": round(dd["ms"] / args.steps, 3)} for kk, dd in agg.items()}}
+            kern = {"gemm_nt": ("tsii::gemm_nt_split_kernel<2, 2, 2, 2" if products else "tsii::gemm_nt_kernel<2, 2, 2, 2"),
+                    "gemm_tn": ("tsii::gemm_tn_split_kernel<2, 2, 2, 2" if products else "tsii::gemm_tn_kernel<2, 2, 2, 2")}[k]
+            t_hbm = d["alg_gb_per_step"] / (PEAK_HBM_TBS * 1e3)            # seconds per step at the HBM peak
+            t_mfma = d["ms_per_step"] * 1e-3 * d["mfma_frac"]               # seconds per step at the MFMA peak of the mode
+            hbm_bound = t_hbm >= t_mfma
+            traffic, traffic_src = pmc_traffic(kern) if (args.batch == 32 and args.size == 512 and args.model == "ImageFill") else (None, "not the profiled configuration")
+            roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": kern.split("::")[1] + "...> (class " + k + ": 1x1-conv forward + dX GEMMs)" if k == "gemm_nt" else kern.split("::")[1] + "...> (class " + k + ")",
+                        "achieved": d["tb_per_s"] * 1e3 if hbm_bound else d["fp32_equiv_tflops"],
+                        "peak": PEAK_HBM_TBS * 1e3 if hbm_bound else d["mfma_peak_fp32_equiv"],
+                        "unit": "GB/s" if hbm_bound else "TFLOP/s (fp32-equivalent)",
+                        "frac": d["hbm_frac"] if hbm_bound else d["mfma_frac"],
+                        "hbm_frac": d["hbm_frac"], "mfma_frac": d["mfma_frac"],
+                        "traffic": traffic, "traffic_source": traffic_src,
+                        "alg_bytes_per_launch": round(d["alg_gb_per_step"] * 1e9 / max(1, d["launches_per_step"])),
+                        "launches_per_step": d["launches_per_step"],
+                        "avg_launch_ms": round(d["ms_per_step"] / max(1, d["launches_per_step"]), 4),
+                        "ms_per_step_in_class": d["ms_per_step"],
+                        "arithmetic": (f"split-bf16: {products} v_mfma_f32_32x32x16_bf16 partial products per fp32 product, fp32 accumulate" if products
+                                       else "v_mfma_f32_32x32x2_f32")}
         ms_per_img = elapsed / imgs * world * 1e3  # per-GPU ms per image
         whole = None
         if args.model == "ImageFill" and args.size == 512:
             t_hbm = ALG_GB_PER_IMG / (PEAK_HBM_TBS * 1e3) * 1e3
             t_flop = ALG_GFLOP_PER_IMG / (PEAK_FP32_TFLOPS * 1e3) * 1e3
+            fwd_ms_per_img = fwd_elapsed / fwd_steps / args.batch * 1e3
             whole = {"alg_gflop_per_img": ALG_GFLOP_PER_IMG, "alg_gb_per_img": round(ALG_GB_PER_IMG, 3),
-                     "t_min_ms_per_img_hbm": round(t_hbm, 3), "t_min_ms_per_img_flop": round(t_flop, 3),
-                     "frac_of_roofline": round(max(t_hbm, t_flop) / ms_per_img, 4)}
+                     "t_min_ms_per_img_hbm": round(t_hbm, 3), "t_min_ms_per_img_fp32_flop": round(t_flop, 3),
+                     "frac_of_roofline": round(max(t_hbm, t_flop) / ms_per_img, 4),
+                     "frac_of_hbm_roofline": round(t_hbm / ms_per_img, 4),
+                     "forward_frac_of_roofline": round(max(t_hbm, t_flop) / 3 / fwd_ms_per_img, 4),
+                     "forward_frac_of_hbm_roofline": round(t_hbm / 3 / fwd_ms_per_img, 4)}
         line = {
             "metric": "imgs/sec fwd+bwd on 512x512 partial-conv inpaint",
             "value": round(value, 2), "unit": "imgs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if products == 0 else f"f32 (storage, accumulation, stencils, BatchNorm; matrix products = {products}-term exact bf16 split on the bf16 MFMA, fp32-class error)",
+            "data": "synthetic",
             "config": {"workload": f"{args.model} {args.size}x{args.size} partial-conv inpainting train step "
                                    f"(fwd+bwd, train-mode BN, L1 loss, grad all-reduce, fused SGD), "
                                    f"{args.batch} imgs/GPU, random line/ellipse hole masks",
-                       "global_batch": world * args.batch, "parallelism": f"dp{world}"},
-            "roofline": roofline, "whole_step_roofline": whole, "final_loss": final_loss,
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "gemm_products": products},
+            "roofline": roofline, "kernel_classes": classes, "whole_step_roofline": whole, "final_loss": final_loss,
             "launch": "hip_graph_replay" if graphed else "eager", "eager_ms_per_step": round(eager_ms, 3),
             "forward_only": {"value": round(world * args.batch * fwd_steps / fwd_elapsed, 2), "unit": "imgs/s (rank 0 clock)",
                              "ms_per_step": round(fwd_elapsed / fwd_steps * 1e3, 3), "steps": fwd_steps},
+            "f32_mfma_mode": f32_leg, "comm": comm,
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.size, args.cpu_threads or min(os.cpu_count() or 1, 32))
+            _, phys, logical = host_cpu()
+            line["cpu_baseline"] = cpu_baseline(args.size, args.cpu_threads or min(phys or logical or 1, 32))
         elif world == 1:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -47,6 +47,7 @@ const char* tsii_last_error(void);
  *   6 (default) split-bf16: each fp32 operand is split exactly into 3 bf16 pieces while it is staged, the 6 partial
  *               products of weight >= 2^-16 go through v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- dropped terms
  *               <= 2^-23 |a*b|, i.e. fp32-class results at 2.7x the matrix-core rate of the f32-input MFMA;
+ *   8           the same with the two 2^-24 cross terms as well (only the 2^-32 term is dropped): 2x the f32 MFMA rate;
  *   3           2 pieces / 3 partial products (error <= 2^-15 |a*b|): inference-grade, opt-in;
  *   0           v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chain).
  * The environment variable TSII_GEMM_PRODUCTS sets the initial value.  inputs/outputs are fp32 in every mode. */
@@ -82,14 +83,18 @@ int tsii_mul_mask(const float* x, const float* mask, int64_t numel, float* out, 
 /* dx = dy * mask */
 /* (same entry point: multiplication is its own adjoint) */
 
-/* ---- K3: point-wise (1x1) convolution as fp32-MFMA GEMM ------------------------------
+/* ---- K3: point-wise (1x1) convolution as an MFMA GEMM ---- ------------------------------
  * PartialConv1x1 (:101-105), PartialConvNoHoles k=1 (:121-137), PartialConv k=1.
  *   y[m,n] = keep[m] ? (sum_k x[m,k]*rs(m,k)*w[n,k]) / denom[m] + bias[n] : 0
  * denom/keep/bias/r0 may be NULL (plain conv). */
+/* ws: weight workspace of tsii_pw_ws_bytes(n, k) bytes -- in the split-bf16 arithmetic modes (tsii_set_gemm_products)
+ * the weights are split into bf16 planes there once per call (otherwise every block splits its weight tile again while
+ * staging it); NULL is allowed. */
+size_t tsii_pw_ws_bytes(int n, int k);
 int tsii_pw_fwd(const float* x, int64_t m, int k, const float* w, int n, const float* bias,
                 const float* r0, int split, const float* r1,
-                const float* denom, const float* keep, float* y, void* stream);
-/* dx[m,k] = rs(m,k) * sum_n dy[m,n]*inv[m]*w[n,k];  wt_ws: k*n floats of scratch */
+                const float* denom, const float* keep, float* y, void* ws, size_t ws_bytes, void* stream);
+/* dx[m,k] = rs(m,k) * sum_n dy[m,n]*inv[m]*w[n,k];  wt_ws: tsii_pw_ws_bytes(n, k) bytes of scratch (required) */
 int tsii_pw_bwd_dx(const float* dy, int64_t m, int n, const float* w, int k, const float* inv,
                    const float* r0, int split, const float* r1, float* dx, float* wt_ws, void* stream);
 /* dw[n,k] = sum_m dy[m,n]*inv[m] * x[m,k]*rs(m,k);  dbias[n] = sum_m dy[m,n]*keep[m] (dbias may be
@@ -183,7 +188,7 @@ int64_t tsii_pw_stat_rows(int64_t m);
 int tsii_pw_fwd_bn(const float* x, int64_t m, int k, const float* w, int n, const float* bias,
                    const float* r0, int split, const float* r1, const float* denom, const float* keep,
                    const float* in_scale, const float* in_shift, int in_act, float in_slope,
-                   float* stat_part, float* y, void* stream);
+                   float* stat_part, float* y, void* ws, size_t ws_bytes, void* stream);
 int tsii_pw_bwd_dw_bn(const float* dy, const float* x, int64_t m, int n, int k, const float* inv, const float* keep,
                       const float* r0, int split, const float* r1,
                       const float* in_scale, const float* in_shift, int in_act, float in_slope,

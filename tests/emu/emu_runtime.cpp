@@ -108,10 +108,12 @@ f32x16_emu mfma_32x32x16_bf16(bf16x8_emu a, bf16x8_emu b, f32x16_emu c) {
     auto f = [](unsigned short h) { unsigned u = (unsigned)h << 16; float v; std::memcpy(&v, &u, 4); return v; };
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float acc = c[r];
+        // the 16 exact bf16 products are summed wide and rounded into the fp32 accumulator once (the hardware's internal
+        // order / width is not documented; GPU-side accuracy is pinned by tests/test_parity_r2.py on the real chip)
+        double acc = 0.0;
         for (int k = 0; k < 16; ++k)
-            acc = fmaf(f(bbuf[wave][row + 32 * (k >> 3)][0][k & 7]), f(bbuf[wave][col + 32 * (k >> 3)][1][k & 7]), acc);
-        c[r] = acc;
+            acc += (double)f(bbuf[wave][row + 32 * (k >> 3)][0][k & 7]) * (double)f(bbuf[wave][col + 32 * (k >> 3)][1][k & 7]);
+        c[r] = (float)((double)c[r] + acc);
     }
     wavesync();
     return c;

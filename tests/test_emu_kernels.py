@@ -49,7 +49,8 @@ def test_pointwise_gemms(emu, mode, M, K, N, bias, masked):
     denom = rng.integers(1, 9, size=M).astype(np.float32) if masked else None
     keep = (rng.uniform(size=M) > 0.2).astype(np.float32) if masked else None
     y = np.zeros((M, N), np.float32)
-    assert L.tsii_pw_fwd(P(x), M, K, P(w), N, P(b), P(r0), split, P(r1), P(denom), P(keep), P(y), None) == 0, L.tsii_last_error()
+    wws = np.zeros(L.tsii_pw_ws_bytes(N, K) // 4 + 4, np.float32)
+    assert L.tsii_pw_fwd(P(x), M, K, P(w), N, P(b), P(r0), split, P(r1), P(denom), P(keep), P(y), P(wws), wws.nbytes, None) == 0, L.tsii_last_error()
     xm = x.astype(np.float64).copy()
     if masked:
         xm[:, :split] *= r0[:, None]
@@ -66,7 +67,7 @@ def test_pointwise_gemms(emu, mode, M, K, N, bias, masked):
     dy = rng.standard_normal((M, N)).astype(np.float32)
     inv = (keep / denom).astype(np.float32) if masked else None
     dx = np.zeros((M, K), np.float32)
-    wt = np.zeros(K * N, np.float32)
+    wt = np.zeros(L.tsii_pw_ws_bytes(N, K) // 4 + 4, np.float32)
     assert L.tsii_pw_bwd_dx(P(dy), M, N, P(w), K, P(inv), P(r0), split, P(r1), P(dx), P(wt), None) == 0, L.tsii_last_error()
     g = dy.astype(np.float64) * (inv[:, None] if masked else 1.0)
     rdx = g @ w.astype(np.float64)
@@ -109,7 +110,7 @@ def test_pointwise_fused_batchnorm(emu, mode, M, K, N, act, slope):
     part = np.zeros((rows, 4, N), np.float32)
     y = np.zeros((M, N), np.float32)
     assert L.tsii_pw_fwd_bn(P(xr), M, K, P(w), N, P(b), P(r0), K, None, P(denom), P(keep), P(sc), P(sh), act, slope,
-                            P(part), P(y), None) == 0, L.tsii_last_error()
+                            P(part), P(y), None, 0, None) == 0, L.tsii_last_error()
     ref = (am @ w.T.astype(np.float64) / denom[:, None] + b) * keep[:, None]
     assert np.abs(y - ref).max() <= tol * np.abs(ref).max()
     # statistics of y from the partials

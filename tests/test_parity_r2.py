@@ -286,3 +286,55 @@ def test_textsegament_full_size_properties_gpu():
             assert all(v is not None and bool(torch.isfinite(v).all()) for v in g)
             grads.append(torch.cat([v.reshape(-1) for v in g]))
         assert torch.equal(grads[0], grads[1])
+
+
+@pytest.mark.gpu
+def test_gemm_arithmetic_modes_accuracy_gpu(capsys):
+    """The split-bf16 matrix products (tsii_set_gemm_products 6 / 8) are fp32-class: their error against an fp64
+    reference is within a small factor of the bit-exact f32-MFMA path's (mode 0) own rounding error, for the forward
+    (NT), dX (NT) and dW (TN) forms; mode 3 (2 pieces) is the documented 2^-15 class."""
+    from text_segmentation_image_inpainting_amd import _lib
+    from text_segmentation_image_inpainting_amd._lib import call, ptr
+    with BACKENDS["gpu"]() as dev:
+        L = _lib.lib()
+        st = _lib.stream()
+        rng = np.random.default_rng(1800)
+        M, K, N = 4096, 1024, 256
+        x = rng.standard_normal((M, K)).astype(np.float32)
+        w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+        dy = rng.standard_normal((M, N)).astype(np.float32)
+        x64, w64, dy64 = x.astype(np.float64), w.astype(np.float64), dy.astype(np.float64)
+        refs = {"fwd": x64 @ w64.T, "dx": dy64 @ w64, "dw": dy64.T @ x64}
+        scales = {"fwd": np.abs(x64) @ np.abs(w64).T, "dx": np.abs(dy64) @ np.abs(w64), "dw": np.abs(dy64).T @ np.abs(x64)}
+        xt, wt, dyt = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(dy).to(dev)
+        errs = {}
+        saved = L.tsii_get_gemm_products()
+        try:
+            for mode in (0, 6, 8, 3):
+                assert L.tsii_set_gemm_products(mode) == 0
+                y = torch.empty(M, N, device=dev)
+                wws = torch.empty(L.tsii_pw_ws_bytes(N, K) // 4 + 4, device=dev)
+                call("tsii_pw_fwd", ptr(xt), M, K, ptr(wt), N, None, None, 0, None, None, None, ptr(y), ptr(wws), wws.numel() * 4, st)
+                dx = torch.empty(M, K, device=dev)
+                wtws = torch.empty(L.tsii_pw_ws_bytes(N, K) // 4 + 4, device=dev)
+                call("tsii_pw_bwd_dx", ptr(dyt), M, N, ptr(wt), K, None, None, 0, None, ptr(dx), ptr(wtws), st)
+                nb = L.tsii_pw_bwd_dw_ws_bytes(M, N, K)
+                ws = torch.empty(nb // 4 + 4, device=dev)
+                dw = torch.empty(N, K, device=dev)
+                call("tsii_pw_bwd_dw", ptr(dyt), ptr(xt), M, N, K, None, None, None, 0, None, ptr(dw), None, ptr(ws), nb, st)
+                torch.cuda.synchronize()
+                for name, out in (("fwd", y), ("dx", dx), ("dw", dw)):
+                    e = np.abs(out.cpu().numpy().astype(np.float64) - refs[name]) / scales[name]
+                    errs[(mode, name)] = (float(e.max()), float(np.sqrt((e ** 2).mean())))
+        finally:
+            L.tsii_set_gemm_products(saved)
+        with capsys.disabled():
+            for k, v in errs.items():
+                print(f"\n[gemm accuracy] mode {k[0]} {k[1]:3s}: max |err|/sum|a||b| = {v[0]:.3e}  rms = {v[1]:.3e}", end="")
+            print()
+        for name in ("fwd", "dx", "dw"):
+            base_max, base_rms = errs[(0, name)]
+            for mode in (6, 8):
+                assert errs[(mode, name)][1] <= 2.0 * base_rms + 1e-9, (mode, name, errs[(mode, name)], errs[(0, name)])
+                assert errs[(mode, name)][0] <= 3.0 * base_max + 1e-9, (mode, name, errs[(mode, name)], errs[(0, name)])
+            assert errs[(3, name)][0] <= 2e-5

@@ -24,7 +24,8 @@ SIGNATURES = {
     "tsii_mask_update": (_i, [_p, _f, _p, _f, _i, _i, _i] + _GEOM + [_i, _i, _f, _i, _p, _p, _p, _p]),
     "tsii_plane_upsample2x": (_i, [_p, _i, _i, _i, _p, _p]),
     "tsii_mul_mask": (_i, [_p, _p, _l, _p, _p]),
-    "tsii_pw_fwd": (_i, [_p, _l, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p]),
+    "tsii_pw_ws_bytes": (_z, [_i, _i]),
+    "tsii_pw_fwd": (_i, [_p, _l, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _z, _p]),
     "tsii_pw_bwd_dx": (_i, [_p, _l, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p]),
     "tsii_pw_bwd_dw_ws_bytes": (_z, [_l, _i, _i]),
     "tsii_pw_bwd_dw": (_i, [_p, _p, _l, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _z, _p]),
@@ -45,7 +46,7 @@ SIGNATURES = {
     "tsii_bn_act_fwd": (_i, [_p, _l, _i, _p, _p, _p, _p, _f, _i, _f, _p, _p, _p]),
     "tsii_bn_act_bwd": (_i, [_p, _p, _l, _i, _p, _p, _p, _p, _f, _i, _f, _i, _p, _p, _p, _p, _z, _p]),
     "tsii_pw_stat_rows": (_l, [_l]),
-    "tsii_pw_fwd_bn": (_i, [_p, _l, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _p]),
+    "tsii_pw_fwd_bn": (_i, [_p, _l, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _p, _z, _p]),
     "tsii_pw_bwd_dw_bn": (_i, [_p, _p, _l, _i, _i, _p, _p, _p, _i, _p, _p, _p, _i, _f, _p, _p, _p, _z, _p]),
     "tsii_dw_stat_rows": (_l, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "tsii_dw_fwd_bn": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _i, _f, _p, _p, _p, _p]),

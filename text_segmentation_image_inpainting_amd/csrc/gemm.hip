@@ -421,8 +421,8 @@ static int launch_nt_cfg(const float* A, int64_t lda, RowScale as, const float* 
 }
 
 static int launch_nt(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, float* C, int64_t ldc,
-                     int64_t M, int N, int K, Epilogue ep, hipStream_t stream, InBN ib = kNoBN) {
-    if (nt_split_ok(A, lda, B, ldb, K)) return launch_nt_split(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, stream);
+                     int64_t M, int N, int K, Epilogue ep, hipStream_t stream, InBN ib = kNoBN, void* wsplit = nullptr) {
+    if (nt_split_ok(A, lda, B, ldb, K)) return launch_nt_split(A, lda, as, B, ldb, false, C, ldc, M, N, K, ep, ib, wsplit, stream);
     const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && aligned16(A) && aligned16(B);
     ep.vec_store = (ldc % 4 == 0) && aligned16(C);
     if (N % 128 == 0 || N > 192) return launch_nt_cfg<2, 2, 2, 2>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, vec, ib, stream);
@@ -591,19 +591,29 @@ int launch_conv_gemm_dw(const float* dy, const float* inv, const float* x, const
 
 using namespace tsii;
 
+extern "C" size_t tsii_pw_ws_bytes(int n, int k);
+
 static int pw_fwd_impl(const float* x, int64_t m, int k, const float* w, int n, const float* bias, const float* r0, int split,
-                       const float* r1, const float* denom, const float* keep, InBN ib, float* stats, float* y, void* stream) {
+                       const float* r1, const float* denom, const float* keep, InBN ib, float* stats, float* y, void* ws, size_t ws_bytes,
+                       void* stream) {
     TSII_REQUIRE(x && w && y, "pw_fwd: null pointer");
+    TSII_REQUIRE(ws == nullptr || ws_bytes >= tsii_pw_ws_bytes(n, k), "pw_fwd: workspace too small");
     TSII_REQUIRE(m > 0 && k > 0 && n > 0, "pw_fwd: bad shape m=%lld k=%d n=%d", (long long)m, k, n);
     RowScale as = {r0, r1, r0 != nullptr ? split : 0};
     Epilogue ep = {denom, keep, bias, {nullptr, nullptr, 0}, 0, stats};
-    return launch_nt(x, k, as, w, k, y, n, m, n, k, ep, (hipStream_t)stream, ib);
+    return launch_nt(x, k, as, w, k, y, n, m, n, k, ep, (hipStream_t)stream, ib, ws);
 }
 
 extern "C" int tsii_pw_fwd(const float* x, int64_t m, int k, const float* w, int n, const float* bias,
                            const float* r0, int split, const float* r1, const float* denom, const float* keep,
-                           float* y, void* stream) {
-    return pw_fwd_impl(x, m, k, w, n, bias, r0, split, r1, denom, keep, kNoBN, nullptr, y, stream);
+                           float* y, void* ws, size_t ws_bytes, void* stream) {
+    return pw_fwd_impl(x, m, k, w, n, bias, r0, split, r1, denom, keep, kNoBN, nullptr, y, ws, ws_bytes, stream);
+}
+
+extern "C" size_t tsii_pw_ws_bytes(int n, int k) {   // weight workspace of pw_fwd[_bn] (optional) and pw_bwd_dx[_bn] (wt_ws)
+    if (n <= 0 || k <= 0) return 0;
+    const size_t a = (size_t)n * k * sizeof(float), b = nt_split_ws_bytes(n, k);
+    return a > b ? a : b;
 }
 
 extern "C" int64_t tsii_pw_stat_rows(int64_t m) { return m > 0 ? cdiv64(m, 128) : 0; }   // every NT tile variant has BM = 128
@@ -611,22 +621,25 @@ extern "C" int64_t tsii_pw_stat_rows(int64_t m) { return m > 0 ? cdiv64(m, 128) 
 extern "C" int tsii_pw_fwd_bn(const float* x, int64_t m, int k, const float* w, int n, const float* bias,
                               const float* r0, int split, const float* r1, const float* denom, const float* keep,
                               const float* in_scale, const float* in_shift, int in_act, float in_slope,
-                              float* stat_part, float* y, void* stream) {
+                              float* stat_part, float* y, void* ws, size_t ws_bytes, void* stream) {
     TSII_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "pw_fwd_bn: in_scale / in_shift go together");
     InBN ib;
     TSII_REQUIRE(make_in_bn(in_scale, in_shift, in_act, in_slope, &ib) == 0, "pw_fwd_bn: activation %d has no load-time form", in_act);
-    return pw_fwd_impl(x, m, k, w, n, bias, r0, split, r1, denom, keep, ib, stat_part, y, stream);
+    return pw_fwd_impl(x, m, k, w, n, bias, r0, split, r1, denom, keep, ib, stat_part, y, ws, ws_bytes, stream);
 }
 
 static int pw_bwd_dx_impl(const float* dy, int64_t m, int n, const float* w, int k, const float* inv,
                           const float* r0, int split, const float* r1, Epilogue ep, float* dx, float* wt_ws, void* stream) {
     TSII_REQUIRE(dy && w && dx && wt_ws, "pw_bwd_dx: null pointer");
     TSII_REQUIRE(m > 0 && k > 0 && n > 0, "pw_bwd_dx: bad shape");
+    RowScale as = {inv, nullptr, n};  // g = dy * inv[m]
+    ep.cs = {r0, r1, split};
+    // split-bf16 arithmetic: W^T is split into bf16 planes in wt_ws by one small kernel (transpose folded in)
+    if (nt_split_ok(dy, n, w, k, n) && k % 4 == 0)
+        return launch_nt_split(dy, n, as, w, n, true, dx, k, m, k, n, ep, kNoBN, wt_ws, (hipStream_t)stream);
     // W [n,k] -> Wt [k,n] so both GEMM operands are contraction-contiguous
     int rc = launch_transpose(w, n, k, wt_ws, (hipStream_t)stream);
     if (rc) return rc;
-    RowScale as = {inv, nullptr, n};  // g = dy * inv[m]
-    ep.cs = {r0, r1, split};
     return launch_nt(dy, n, as, wt_ws, n, dx, k, m, k, n, ep, (hipStream_t)stream);
 }
 

@@ -129,11 +129,84 @@ __device__ __forceinline__ void split_store(unsigned char* __restrict__ S, const
     }
 }
 
-// PRODUCTS = 6 -> 3 planes, 3 -> 2 planes
-template <int PRODUCTS>
-struct SplitPlanes { static constexpr int value = PRODUCTS == 6 ? 3 : 2; };
+// ---- weights pre-split (B operand of the NT kernel) --------------------------------------------------------
+// One tiny kernel per call splits the [N,K] weight matrix (or its transpose, for dX) into P bf16 planes
+// planes[p][row][col] in a caller workspace; the GEMM blocks then stage B as plain 16-byte copies -- no VALU work for B,
+// which every one of the M/128 row blocks would otherwise repeat (half of the staging VALU of a 128x128 tile).
+template <int P>
+__global__ void split_w_kernel(const float* __restrict__ w, int rows_in, int cols_in, int transpose, unsigned short* __restrict__ planes) {
+    const int64_t total = (int64_t)rows_in * cols_in;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // i indexes the OUTPUT [rows_out, cols_out]; transpose: out[r][c] = w[c][r]
+        const int cols_out = transpose ? rows_in : cols_in;
+        const int r = (int)(i / cols_out), c = (int)(i % cols_out);
+        float x = transpose ? w[(int64_t)c * cols_in + r] : w[i];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const __bf16 h = (__bf16)x;                               // RNE
+            const unsigned short u = __builtin_bit_cast(unsigned short, h);
+            planes[(int64_t)p * total + i] = u;
+            x -= __builtin_bit_cast(float, (unsigned)u << 16);
+        }
+    }
+}
 
-template <int WM, int WN, int TM, int TN, int PRODUCTS, bool BNIN, bool BNB>
+// pre-split B: this thread's chunks as P 16-byte pieces each (branch-free, clamped like split_load)
+template <int ROWS, int P>
+__device__ __forceinline__ void split_load_pre(const unsigned short* __restrict__ Bp, int64_t plane_stride, int ld, int row0, int nrows,
+                                               int k0, int K, u32x4 (&regs)[SplitChunks<ROWS>::value][P]) {
+    const int tid = threadIdx.x;
+    const int last = ((nrows - row0 < ROWS) ? (nrows - row0) : ROWS) - 1;
+#pragma unroll
+    for (int i = 0; i < SplitChunks<ROWS>::value; ++i) {
+        const int f = tid + 256 * i;
+        int r = f >> 2;
+        r = r < last ? r : last;
+        int k = k0 + (f & 3) * 8;
+        k = k < K - 8 ? k : K - 8;
+        const unsigned off = (unsigned)(((row0 + r) * ld + k) * 2);        // bytes; N*K*2 < 2^31 for every weight matrix here
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            regs[i][p] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(Bp + p * plane_stride) + off);
+    }
+}
+
+template <int ROWS, int P>
+__device__ __forceinline__ void split_store_pre(unsigned char* __restrict__ S, const u32x4 (&regs)[SplitChunks<ROWS>::value][P], int k0,
+                                                int nvalid, int K) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < SplitChunks<ROWS>::value; ++i) {
+        const int f = tid + 256 * i;
+        if (ROWS * 4 % 256 != 0 && f >= ROWS * 4) continue;
+        const int r = f >> 2, c = f & 3;
+        const bool valid = r < nvalid && k0 + c * 8 < K;
+        const int off = split_off(r, c);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int p = 0; p < P; ++p) *reinterpret_cast<u32x4*>(S + p * (ROWS * 64) + off) = valid ? regs[i][p] : z;
+    }
+}
+
+// PRODUCTS = 8 / 6 -> 3 planes, 3 -> 2 planes.  Order of the partial products (smallest first):
+//   8: (2,1) (1,2) (2,0) (1,1) (0,2) (1,0) (0,1) (0,0)   6: the last six of those   3: (1,0) (0,1) (0,0)
+template <int PRODUCTS>
+struct SplitTerm {
+    static __device__ __forceinline__ constexpr int pa(int q) {
+        if (PRODUCTS == 3) return q == 0 ? 1 : 0;
+        const int qq = q + (8 - PRODUCTS);      // index into the 8-term order
+        return qq == 0 ? 2 : qq == 1 ? 1 : qq == 2 ? 2 : qq == 3 ? 1 : qq == 4 ? 0 : qq == 5 ? 1 : 0;
+    }
+    static __device__ __forceinline__ constexpr int pb(int q) {
+        if (PRODUCTS == 3) return q == 1 ? 1 : 0;
+        const int qq = q + (8 - PRODUCTS);
+        return qq == 0 ? 1 : qq == 1 ? 2 : qq == 2 ? 0 : qq == 3 ? 1 : qq == 4 ? 2 : qq == 5 ? 0 : qq == 6 ? 1 : 0;
+    }
+};
+template <int PRODUCTS>
+struct SplitPlanes { static constexpr int value = PRODUCTS == 3 ? 2 : 3; };
+
+template <int WM, int WN, int TM, int TN, int PRODUCTS, bool BNIN, bool BNB, bool BPRE>
 __global__ __launch_bounds__(256, BNB ? 2 : 3) void gemm_nt_split_kernel(const float* __restrict__ A, int64_t lda, RowScale as,
                                                                        const float* __restrict__ B, int64_t ldb,
                                                                        float* __restrict__ C, int64_t ldc,
@@ -141,7 +214,7 @@ __global__ __launch_bounds__(256, BNB ? 2 : 3) void gemm_nt_split_kernel(const f
     constexpr int P = SplitPlanes<PRODUCTS>::value;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per block");
-    static_assert(PRODUCTS == 6 || PRODUCTS == 3, "6 (fp32 class) or 3 partial products");
+    static_assert(PRODUCTS == 8 || PRODUCTS == 6 || PRODUCTS == 3, "8 / 6 (fp32 class) or 3 partial products");
     constexpr int OP_FLOATS = P * (BM + BN) * 16;                 // operand image: P planes x rows x 64 bytes
     constexpr int EP_FLOATS = WM * 32 * (BN + 4);                 // epilogue band
     constexpr int SMEM_FLOATS = OP_FLOATS > EP_FLOATS ? OP_FLOATS : EP_FLOATS;
@@ -167,13 +240,17 @@ __global__ __launch_bounds__(256, BNB ? 2 : 3) void gemm_nt_split_kernel(const f
 
     constexpr int NA = SplitChunks<BM>::value, NB = SplitChunks<BN>::value;
     const int mvalid = (int)((M - m0 < BM) ? (M - m0) : BM), nvalid = (N - n0 < BN) ? (N - n0) : BN;
-    float4 ra[NA][2], rb[NB][2];
+    float4 ra[NA][2], rb[BPRE ? 1 : NB][2];
+    u32x4 rbp[BPRE ? NB : 1][P];                      // BPRE: B arrives as bf16 planes (split_w_kernel), ldb = K
+    const unsigned short* Bpl = reinterpret_cast<const unsigned short*>(B);
+    const int64_t bstride = (int64_t)N * K;
     float sa0[NA], sa1[NA], sb0[NB], sb1[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) { sb0[i] = 1.f; sb1[i] = 1.f; }
     split_row_scales<BM>(as, m0, M, sa0, sa1);
     split_load<BM>(A, lda, m0, M, 0, K, ra);
-    split_load<BN>(B, ldb, n0, N, 0, K, rb);
+    if constexpr (BPRE) split_load_pre<BN, P>(Bpl, bstride, K, n0, N, 0, K, rbp);
+    else split_load<BN>(B, ldb, n0, N, 0, K, rb);
     float4 psc[2], psh[2];                       // BNIN: (scale, shift) of this thread's 8 channels of the tile in flight
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     psc[0] = psc[1] = psh[0] = psh[1] = z4;
@@ -185,7 +262,8 @@ __global__ __launch_bounds__(256, BNB ? 2 : 3) void gemm_nt_split_kernel(const f
         }
     }
     split_store<BM, P, true, BNIN>(As, ra, 0, as.split, sa0, sa1, psc, psh, ib.neg, ib.hi, mvalid, K);
-    split_store<BN, P, false, false>(Bs, rb, 0, 0, sb0, sb1, psc, psh, 1.f, 0.f, nvalid, K);
+    if constexpr (BPRE) split_store_pre<BN, P>(Bs, rbp, 0, nvalid, K);
+    else split_store<BN, P, false, false>(Bs, rb, 0, 0, sb0, sb1, psc, psh, 1.f, 0.f, nvalid, K);
     __syncthreads();
 
     // fragment addresses: row li of tile t, k-chunk 2s + hi; the swizzle term depends on li only
@@ -199,7 +277,8 @@ __global__ __launch_bounds__(256, BNB ? 2 : 3) void gemm_nt_split_kernel(const f
         const bool more = (kt + 1 < nk);
         if (more) {  // next tile's global loads fly during the MFMA phase
             split_load<BM>(A, lda, m0, M, (kt + 1) * SPLIT_BK, K, ra);
-            split_load<BN>(B, ldb, n0, N, (kt + 1) * SPLIT_BK, K, rb);
+            if constexpr (BPRE) split_load_pre<BN, P>(Bpl, bstride, K, n0, N, (kt + 1) * SPLIT_BK, K, rbp);
+            else split_load<BN>(B, ldb, n0, N, (kt + 1) * SPLIT_BK, K, rb);
         }
         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
@@ -220,9 +299,8 @@ __global__ __launch_bounds__(256, BNB ? 2 : 3) void gemm_nt_split_kernel(const f
                 // partial products, smallest first (accumulate chains forward the accumulator: no stall between them)
 #pragma unroll
                 for (int q = 0; q < PRODUCTS; ++q) {
-                    // PRODUCTS 6: (2,0) (1,1) (0,2) (1,0) (0,1) (0,0);  PRODUCTS 3: (1,0) (0,1) (0,0)
-                    const int pa = PRODUCTS == 6 ? (q == 0 ? 2 : (q == 1 || q == 3) ? 1 : 0) : (q == 0 ? 1 : 0);
-                    const int pb = PRODUCTS == 6 ? (q == 2 ? 2 : (q == 1 || q == 4) ? 1 : 0) : (q == 1 ? 1 : 0);
+                    const int pa = SplitTerm<PRODUCTS>::pa(q);
+                    const int pb = SplitTerm<PRODUCTS>::pb(q);
 #pragma unroll
                     for (int u = 0; u < TN; ++u)
                         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[u][pb], acc[t][u], 0, 0, 0);
@@ -243,7 +321,8 @@ __global__ __launch_bounds__(256, BNB ? 2 : 3) void gemm_nt_split_kernel(const f
         __syncthreads();
         if (more) {
             split_store<BM, P, true, BNIN>(As, ra, (kt + 1) * SPLIT_BK, as.split, sa0, sa1, psc, psh, ib.neg, ib.hi, mvalid, K);
-            split_store<BN, P, false, false>(Bs, rb, (kt + 1) * SPLIT_BK, 0, sb0, sb1, psc, psh, 1.f, 0.f, nvalid, K);
+            if constexpr (BPRE) split_store_pre<BN, P>(Bs, rbp, (kt + 1) * SPLIT_BK, nvalid, K);
+            else split_store<BN, P, false, false>(Bs, rb, (kt + 1) * SPLIT_BK, 0, sb0, sb1, psc, psh, 1.f, 0.f, nvalid, K);
             __syncthreads();
         }
     }
@@ -433,8 +512,8 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_split_kernel(const float* __re
                     a[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * (BM * 64) + foA[t][s]));
 #pragma unroll
                 for (int q = 0; q < PRODUCTS; ++q) {
-                    const int pa = PRODUCTS == 6 ? (q == 0 ? 2 : (q == 1 || q == 3) ? 1 : 0) : (q == 0 ? 1 : 0);
-                    const int pb = PRODUCTS == 6 ? (q == 2 ? 2 : (q == 1 || q == 4) ? 1 : 0) : (q == 1 ? 1 : 0);
+                    const int pa = SplitTerm<PRODUCTS>::pa(q);
+                    const int pb = SplitTerm<PRODUCTS>::pb(q);
 #pragma unroll
                     for (int u = 0; u < TN; ++u)
                         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[u][pb], acc[t][u], 0, 0, 0);
@@ -481,7 +560,7 @@ static int env_products() {
     const char* e = getenv("TSII_GEMM_PRODUCTS");
     if (e == nullptr) return 6;
     const int v = atoi(e);
-    return (v == 0 || v == 3 || v == 6) ? v : 6;
+    return (v == 0 || v == 3 || v == 6 || v == 8) ? v : 6;
 }
 static int g_products = env_products();
 
@@ -489,7 +568,7 @@ int gemm_products() { return g_products; }
 
 template <int WM, int WN, int TM, int TN, int PRODUCTS>
 static int launch_nt_split_cfg(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, float* C, int64_t ldc,
-                               int64_t M, int N, int K, Epilogue ep, InBN ib, hipStream_t stream) {
+                               int64_t M, int N, int K, Epilogue ep, InBN ib, bool bpre, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const unsigned ntn = (unsigned)cdiv(N, BN);
     const int64_t nblocks = cdiv64(M, BM) * ntn;
@@ -497,14 +576,20 @@ static int launch_nt_split_cfg(const float* A, int64_t lda, RowScale as, const f
     if (ep.bn_y != nullptr) {
         TSII_REQUIRE(ib.sc == nullptr && N % 4 == 0 && ldc == N && aligned16(ep.bn_y) && ep.vec_store,
                      "gemm_nt_split: the BatchNorm-backward epilogue needs N %% 4 == 0 and 16-byte aligned operands");
-        hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, false, true>), dim3((unsigned)nblocks), dim3(256), 0, stream,
+        if (bpre) hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, false, true, true>), dim3((unsigned)nblocks), dim3(256), 0, stream,
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib);
+        else hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, false, true, false>), dim3((unsigned)nblocks), dim3(256), 0, stream,
                            A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib);
     } else if (ib.sc != nullptr) {
         TSII_REQUIRE(aligned16(ib.sc) && aligned16(ib.sh), "gemm_nt_split: input BatchNorm needs 16-byte aligned scale / shift");
-        hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, true, false>), dim3((unsigned)nblocks), dim3(256), 0, stream,
+        if (bpre) hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, true, false, true>), dim3((unsigned)nblocks), dim3(256), 0, stream,
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib);
+        else hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, true, false, false>), dim3((unsigned)nblocks), dim3(256), 0, stream,
                            A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib);
     } else {
-        hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, false, false>), dim3((unsigned)nblocks), dim3(256), 0, stream,
+        if (bpre) hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, false, false, true>), dim3((unsigned)nblocks), dim3(256), 0, stream,
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib);
+        else hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, false, false, false>), dim3((unsigned)nblocks), dim3(256), 0, stream,
                            A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib);
     }
     return check_launch("gemm_nt_split");
@@ -514,20 +599,38 @@ bool nt_split_ok(const float* A, int64_t lda, const float* B, int64_t ldb, int K
     return g_products != 0 && K % 8 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) && aligned16(B);
 }
 
-int launch_nt_split(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, float* C, int64_t ldc,
-                    int64_t M, int N, int K, Epilogue ep, InBN ib, hipStream_t stream) {
-    ep.vec_store = (ldc % 4 == 0) && aligned16(C);
-    const bool six = g_products != 3;
-    if (N % 128 == 0 || N > 192)
-        return six ? launch_nt_split_cfg<2, 2, 2, 2, 6>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, stream)
-                   : launch_nt_split_cfg<2, 2, 2, 2, 3>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, stream);
-    if (N > 32)
-        return six ? launch_nt_split_cfg<2, 2, 2, 1, 6>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, stream)
-                   : launch_nt_split_cfg<2, 2, 2, 1, 3>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, stream);
-    return six ? launch_nt_split_cfg<4, 1, 1, 1, 6>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, stream)
-               : launch_nt_split_cfg<4, 1, 1, 1, 3>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, stream);
-}
+size_t nt_split_ws_bytes(int n, int k) { return (size_t)3 * n * k * sizeof(unsigned short) + 16; }
 
+// B = fp32 [N,K] (b_transposed: fp32 [K,N], i.e. the weight as stored, for dX).  With a workspace of nt_split_ws_bytes(N, K)
+// the weights are split into bf16 planes once (split_w_kernel) and every block stages them as plain copies; without one
+// (wsplit == nullptr) the blocks split B while staging (needs B as [N,K]).
+int launch_nt_split(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, bool b_transposed, float* C, int64_t ldc,
+                    int64_t M, int N, int K, Epilogue ep, InBN ib, void* wsplit, hipStream_t stream) {
+    ep.vec_store = (ldc % 4 == 0) && aligned16(C);
+    bool bpre = false;
+    if (wsplit != nullptr && (int64_t)N * K * 2 < (1ll << 31)) {
+        unsigned short* planes = reinterpret_cast<unsigned short*>((reinterpret_cast<uintptr_t>(wsplit) + 15) & ~(uintptr_t)15);
+        const int rows_in = b_transposed ? K : N, cols_in = b_transposed ? N : K;
+        const unsigned g = stream_grid((int64_t)N * K, 256);
+        if (g_products == 3) hipLaunchKernelGGL(split_w_kernel<2>, dim3(g), dim3(256), 0, stream, B, rows_in, cols_in, b_transposed ? 1 : 0, planes);
+        else hipLaunchKernelGGL(split_w_kernel<3>, dim3(g), dim3(256), 0, stream, B, rows_in, cols_in, b_transposed ? 1 : 0, planes);
+        int rc = check_launch("split_w");
+        if (rc) return rc;
+        B = reinterpret_cast<const float*>(planes);
+        ldb = K;
+        bpre = true;
+    } else {
+        TSII_REQUIRE(!b_transposed, "gemm_nt_split: a transposed B needs the split workspace");
+    }
+#define TSII_NT_SPLIT(WM, WN, TM, TN) \
+    (g_products == 8 ? launch_nt_split_cfg<WM, WN, TM, TN, 8>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, bpre, stream) \
+     : g_products == 3 ? launch_nt_split_cfg<WM, WN, TM, TN, 3>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, bpre, stream) \
+                       : launch_nt_split_cfg<WM, WN, TM, TN, 6>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, bpre, stream))
+    if (N % 128 == 0 || N > 192) return TSII_NT_SPLIT(2, 2, 2, 2);
+    if (N > 32) return TSII_NT_SPLIT(2, 2, 2, 1);
+    return TSII_NT_SPLIT(4, 1, 1, 1);
+#undef TSII_NT_SPLIT
+}
 
 bool tn_split_ok(const float* A, int64_t lda, const float* B, int64_t ldb, int Pn, int Q) {
     return g_products != 0 && Pn % 4 == 0 && Q % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) && aligned16(B);
@@ -541,12 +644,11 @@ int launch_tn_split(const float* A, int64_t lda, const float* sa, const float* B
     const int64_t nblocks = (int64_t)qt * pt * splits;
     TSII_REQUIRE(nblocks < (1ll << 31), "gemm_tn_split: grid too large");
     const dim3 grid((unsigned)nblocks);
-    const bool six = g_products != 3;
     if (ib.sc != nullptr) TSII_REQUIRE(aligned16(ib.sc) && aligned16(ib.sh), "gemm_tn_split: input BatchNorm needs 16-byte aligned scale / shift");
 #define TSII_TN_SPLIT(TMV, TNV, PR, BNV) hipLaunchKernelGGL((gemm_tn_split_kernel<2, 2, TMV, TNV, PR, BNV>), grid, dim3(256), 0, stream, A, lda, sa, B, ldb, sb, Cws, M, Pn, Q, chunk, ib, qt, pt)
 #define TSII_TN_SPLIT_T(PR, BNV) do { if (tile == 0) TSII_TN_SPLIT(2, 2, PR, BNV); else if (tile == 1) TSII_TN_SPLIT(2, 1, PR, BNV); else TSII_TN_SPLIT(1, 1, PR, BNV); } while (0)
-    if (ib.sc != nullptr) { if (six) TSII_TN_SPLIT_T(6, true); else TSII_TN_SPLIT_T(3, true); }
-    else { if (six) TSII_TN_SPLIT_T(6, false); else TSII_TN_SPLIT_T(3, false); }
+    if (ib.sc != nullptr) { if (g_products == 8) TSII_TN_SPLIT_T(8, true); else if (g_products == 3) TSII_TN_SPLIT_T(3, true); else TSII_TN_SPLIT_T(6, true); }
+    else { if (g_products == 8) TSII_TN_SPLIT_T(8, false); else if (g_products == 3) TSII_TN_SPLIT_T(3, false); else TSII_TN_SPLIT_T(6, false); }
 #undef TSII_TN_SPLIT_T
 #undef TSII_TN_SPLIT
     return check_launch("gemm_tn_split");
@@ -555,7 +657,7 @@ int launch_tn_split(const float* A, int64_t lda, const float* sa, const float* B
 }  // namespace tsii
 
 extern "C" int tsii_set_gemm_products(int products) {
-    TSII_REQUIRE(products == 0 || products == 3 || products == 6, "set_gemm_products: 0 (f32 MFMA), 3 or 6 (split bf16)");
+    TSII_REQUIRE(products == 0 || products == 3 || products == 6 || products == 8, "set_gemm_products: 0 (f32 MFMA), 3, 6 or 8 (split bf16)");
     tsii::g_products = products;
     return 0;
 }

@@ -235,8 +235,9 @@ __device__ __forceinline__ void conv_store(float* __restrict__ S, const float4 (
 // ---- split-bf16 kernels (gemm_split.hip) ----------------------------------------------------------------
 int gemm_products();     // 0: f32-input MFMA | 3 / 6: split-bf16 partial products (tsii_set_gemm_products)
 bool nt_split_ok(const float* A, int64_t lda, const float* B, int64_t ldb, int K);
-int launch_nt_split(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, float* C, int64_t ldc,
-                    int64_t M, int N, int K, Epilogue ep, InBN ib, hipStream_t stream);
+size_t nt_split_ws_bytes(int n, int k);
+int launch_nt_split(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, bool b_transposed, float* C, int64_t ldc,
+                    int64_t M, int N, int K, Epilogue ep, InBN ib, void* wsplit, hipStream_t stream);
 
 bool tn_split_ok(const float* A, int64_t lda, const float* B, int64_t ldb, int Pn, int Q);
 int launch_tn_split(const float* A, int64_t lda, const float* sa, const float* B, int64_t ldb, RowScale sb, float* Cws,

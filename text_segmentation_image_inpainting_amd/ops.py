@@ -121,16 +121,18 @@ class _Pointwise(torch.autograd.Function):
         m = n * h * wd
         y = torch.empty((n, h, wd, cout), dtype=torch.float32, device=x.device)
         part = None
+        wbytes = _lib.lib().tsii_pw_ws_bytes(cout, k)
+        wws = _ws(wbytes, x)
         if in_scale is None and not want_stats:
             call("tsii_pw_fwd", ptr(x), m, k, ptr(w), cout, ptr(bias), ptr(r0), int(split), ptr(r1),
-                 ptr(denom), ptr(keep), ptr(y), _lib.stream())
+                 ptr(denom), ptr(keep), ptr(y), ptr(wws), wbytes, _lib.stream())
         else:
             if want_stats:
                 rows = _lib.lib().tsii_pw_stat_rows(m)
                 part = torch.empty((rows, 4, cout), dtype=torch.float32, device=x.device)
             call("tsii_pw_fwd_bn", ptr(x), m, k, ptr(w), cout, ptr(bias), ptr(r0), int(split), ptr(r1),
                  ptr(denom), ptr(keep), ptr(in_scale), ptr(in_shift), int(in_act), float(in_slope), ptr(part), ptr(y),
-                 _lib.stream())
+                 ptr(wws), wbytes, _lib.stream())
         ctx.save_for_backward(x, w, r0, r1, inv, keep, in_scale, in_shift)
         ctx.split, ctx.has_bias, ctx.in_cfg = int(split), bias is not None, (int(in_act), float(in_slope))
         ctx.set_materialize_grads(False)   # no zero tensors for the statistics output (one tiny fill kernel each otherwise)
@@ -152,7 +154,7 @@ class _Pointwise(torch.autograd.Function):
         st = _lib.stream()
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)   # gradient w.r.t. the (virtual) normalised input when in_scale is set
-            wt = _ws(4 * k * cout, x)
+            wt = _ws(_lib.lib().tsii_pw_ws_bytes(cout, k), x)
             if ctx.bn is not None and FUSE_BN_BWD_PW and k % 4 == 0 and cout % 4 == 0 and load_time_act(*ctx.in_cfg):
                 mean, var, gamma, beta, eps, slot = ctx.bn
                 part = torch.empty((int(_lib.lib().tsii_pw_stat_rows(m)), 2, k), dtype=torch.float32, device=x.device)
@@ -1099,7 +1101,7 @@ class _Gram(torch.autograd.Function):
         df = torch.empty_like(f)
         st = _lib.stream()
         for i in range(n):
-            call("tsii_pw_fwd", ptr(f[i]), hw, c, ptr(sym[i]), c, None, None, 0, None, None, None, ptr(df[i]), st)
+            call("tsii_pw_fwd", ptr(f[i]), hw, c, ptr(sym[i]), c, None, None, 0, None, None, None, ptr(df[i]), None, 0, st)
         return df
 
 

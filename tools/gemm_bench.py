@@ -58,7 +58,8 @@ def main():
         y = torch.empty(M, N, device=dev)
         dx = torch.empty(M, K, device=dev)
         dw = torch.empty(N, K, device=dev)
-        wt = torch.empty(K * N, device=dev)
+        wt = torch.empty(L.tsii_pw_ws_bytes(N, K) // 4 + 4, device=dev)
+        wws = torch.empty(L.tsii_pw_ws_bytes(N, K) // 4 + 4, device=dev)
         r0 = r1 = denom = keep = inv = None
         split = 0
         if masked:
@@ -72,7 +73,7 @@ def main():
         fl = 2.0 * M * K * N
         res = []
         if args.only in ("", "fwd"):
-            t = timeit(lambda: call("tsii_pw_fwd", ptr(x), M, K, ptr(w), N, None, ptr(r0), split, ptr(r1), ptr(denom), None, ptr(y), st))
+            t = timeit(lambda: call("tsii_pw_fwd", ptr(x), M, K, ptr(w), N, None, ptr(r0), split, ptr(r1), ptr(denom), None, ptr(y), ptr(wws), wws.numel() * 4, st))
             res.append(f"fwd {t:7.3f} ms {fl / t / 1e9:6.1f} TF/s {4.0 * M * (K + N) / t / 1e9:5.2f} TB/s")
         if args.only in ("", "dx"):
             t = timeit(lambda: call("tsii_pw_bwd_dx", ptr(dy), M, N, ptr(w), K, ptr(inv), ptr(r0), split, ptr(r1), ptr(dx), ptr(wt), st))

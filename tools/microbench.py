@@ -45,7 +45,7 @@ def main():
         a = torch.randn(M, K, device=dev)
         w = torch.randn(N, K, device=dev) * 0.02
         o = torch.empty(M, N, device=dev)
-        ms = timeit(lambda: call("tsii_pw_fwd", ptr(a), M, K, ptr(w), N, None, None, 0, None, None, None, ptr(o), st), iters=3)
+        ms = timeit(lambda: call("tsii_pw_fwd", ptr(a), M, K, ptr(w), N, None, None, 0, None, None, None, ptr(o), None, 0, st), iters=3)
         print(f"fp32 MFMA GEMM {M} x {K} x {N}: {ms:.3f} ms  {2.0 * M * K * N / ms / 1e9:.1f} TFLOP/s ({2.0 * M * K * N / ms / 1e9 / 157.3 * 100:.0f} % of 157.3)")
 
 

@@ -65,7 +65,14 @@ def hbm(fetch_csv, write_csv, prefix, note):
                 "HBM_write_bytes_per_launch,HBM_bytes_per_launch\n")
         for r in rows:
             f.write('"%s",%d,%.0f,%.0f,%.0f,%.0f,%.0f\n' % r)
-    js = {"_how": how, "kernels": {r[0]: {"launches": r[1], "read_bytes_per_launch": r[4], "write_bytes_per_launch": r[5],
+    import hashlib, os
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "text_segmentation_image_inpainting_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".h")):
+            h.update(open(os.path.join(csrc, fn), "rb").read())
+    # fingerprint of the kernel sources this was measured at: bench.py reports `roofline.traffic` only while it matches
+    js = {"_how": how, "csrc_sha": h.hexdigest()[:16], "kernels": {r[0]: {"launches": r[1], "read_bytes_per_launch": r[4], "write_bytes_per_launch": r[5],
                                           "bytes_per_launch": r[6]} for r in rows}}
     with open(prefix + ".json", "w") as f:
         json.dump(js, f, indent=1)
