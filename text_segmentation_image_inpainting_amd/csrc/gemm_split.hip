@@ -207,7 +207,7 @@ template <int PRODUCTS>
 struct SplitPlanes { static constexpr int value = PRODUCTS == 3 ? 2 : 3; };
 
 template <int WM, int WN, int TM, int TN, int PRODUCTS, bool BNIN, bool BNB, bool BPRE>
-__global__ __launch_bounds__(256, BNB ? 2 : 3) void gemm_nt_split_kernel(const float* __restrict__ A, int64_t lda, RowScale as,
+__global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_split_kernel(const float* __restrict__ A, int64_t lda, RowScale as,
                                                                        const float* __restrict__ B, int64_t ldb,
                                                                        float* __restrict__ C, int64_t ldc,
                                                                        int64_t M, int N, int K, Epilogue ep, unsigned ntn, InBN ib) {
