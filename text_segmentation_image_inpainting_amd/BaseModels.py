@@ -4,8 +4,9 @@ Same public surface -- ``BaseModule`` (tolerant ``load_state_dict``, ``initializ
 ``set_activation_inplace``, ``total_parameters``) -- so checkpoints and calling code written for
 the reference keep working; the arithmetic itself lives in the HIP kernels (see ops.py).
 """
-import math
 from contextlib import contextmanager
+
+from typing import NamedTuple, Optional
 
 import torch
 from torch import nn
@@ -14,60 +15,67 @@ from . import ops
 
 
 class BaseModule(nn.Module):
+    """Base class of every mirrored network: the reference's public helpers (models/BaseModels.py:12-71) --
+    ``initialize_weights``, the tolerant ``load_state_dict``, ``set_activation_inplace``, ``total_parameters`` --
+    with the same names and call signatures."""
+
     def __init__(self):
-        self.act_fn = None
         super().__init__()
+        self.act_fn = None
 
-    def selu_init_params(self):  # models/BaseModels.py:17-29
-        for m in self.modules():
-            if isinstance(m, nn.Conv2d) and m.weight.requires_grad:
-                m.weight.data.normal_(0.0, 1.0 / math.sqrt(m.weight.numel()))
-                if m.bias is not None:
-                    m.bias.data.fill_(0)
-            elif isinstance(m, nn.BatchNorm2d) and m.weight.requires_grad:
-                m.weight.data.fill_(1)
-                m.bias.data.zero_()
-            elif isinstance(m, nn.Linear) and m.weight.requires_grad:
-                m.weight.data.normal_(0, 1.0 / math.sqrt(m.weight.numel()))
-                m.bias.data.zero_()
-
-    def initialize_weights(self):  # models/BaseModels.py:31-39
-        for m in self.modules():
-            if isinstance(m, nn.Conv2d) and m.weight.requires_grad:
-                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="leaky_relu")
-                if m.bias is not None:
-                    m.bias.data.zero_()
-            elif isinstance(m, nn.BatchNorm2d) and m.weight.requires_grad:
-                m.weight.data.fill_(1)
-                m.bias.data.zero_()
+    def initialize_weights(self):
+        """Kaiming-normal (fan_out, leaky_relu gain) for trainable convolutions with zeroed biases; BatchNorm
+        affine parameters to (1, 0).  Frozen tensors (the all-ones ``mask_conv`` weights) are left alone."""
+        for mod in self.modules():
+            weight = getattr(mod, "weight", None)
+            if weight is None or not weight.requires_grad:
+                continue
+            if isinstance(mod, nn.Conv2d):
+                nn.init.kaiming_normal_(weight, mode="fan_out", nonlinearity="leaky_relu")
+                if mod.bias is not None:
+                    nn.init.zeros_(mod.bias)
+            elif isinstance(mod, nn.BatchNorm2d):
+                nn.init.ones_(weight)
+                nn.init.zeros_(mod.bias)
 
     def load_state_dict(self, state_dict, strict=True, self_state=False):
-        """Copy-by-name, print-and-continue loader (models/BaseModels.py:41-52): never raises."""
-        own_state = self_state if self_state else self.state_dict()
-        for name, param in state_dict.items():
-            if name in own_state:
-                try:
-                    own_state[name].copy_(param.data)
-                except Exception as e:  # noqa: BLE001 - mirrors the reference's tolerance
-                    print("Parameter {} fails to load.".format(name))
-                    print("-----------------------------------------")
-                    print(e)
-            else:
-                print("Parameter {} is not in the model. ".format(name))
+        """Copy-by-name loader that never raises (the reference's checkpoints are loaded into nets whose heads
+        changed): entries with a matching name and shape are copied, everything else is reported and skipped.
+        ``self_state`` may supply the destination mapping.  Returns (missing_in_model, failed) name lists."""
+        target = self_state if self_state else self.state_dict()
+        unknown, failed = [], []
+        for key, value in state_dict.items():
+            dst = target.get(key)
+            if dst is None:
+                unknown.append(key)
+                continue
+            try:
+                dst.copy_(getattr(value, "data", value))
+            except Exception as err:  # noqa: BLE001 - tolerance is the contract here
+                failed.append(key)
+                print(f"[load_state_dict] {key}: not loaded ({err})")
+        for key in unknown:
+            print(f"[load_state_dict] {key}: no entry of that name in this model")
+        return unknown, failed
 
     @contextmanager
-    def set_activation_inplace(self):  # models/BaseModels.py:54-62
-        if hasattr(self, "act_fn") and hasattr(self.act_fn, "inplace"):
-            self.act_fn.inplace = True
+    def set_activation_inplace(self):
+        """Switch the shared activation module to in-place for the duration of the block (memory saver of the
+        reference's checkpointed forward; a no-op for the HIP kernels, which never keep the activation output)."""
+        act = getattr(self, "act_fn", None)
+        flip = act is not None and hasattr(act, "inplace")
+        if flip:
+            act.inplace = True
+        try:
             yield
-            self.act_fn.inplace = False
-        else:
-            yield
+        finally:
+            if flip:
+                act.inplace = False
 
     def total_parameters(self):
-        total = sum(i.numel() for i in self.parameters())
-        trainable = sum(i.numel() for i in self.parameters() if i.requires_grad)
-        print("Total parameters : {}. Trainable parameters : {}".format(total, trainable))
+        counts = [(p.numel(), p.requires_grad) for p in self.parameters()]
+        total, trainable = sum(n for n, _ in counts), sum(n for n, t in counts if t)
+        print(f"parameters: {total} total, {trainable} trainable")
         return total
 
     def forward(self, *x):
@@ -83,6 +91,51 @@ def to_nhwc(x: torch.Tensor) -> torch.Tensor:
 def to_nchw(y: torch.Tensor) -> torch.Tensor:
     """NHWC-contiguous -> [N,C,H,W]-shaped view (channels_last memory), as callers of the reference expect."""
     return y.permute(0, 3, 1, 2)
+
+
+# num_batches_tracked bookkeeping: eager ``add_(1)`` per BatchNorm call (one tiny kernel each: 105 per ImageFill
+# forward) unless a trainer batches them -- inside ``deferred_batch_counters()`` the increments are tallied on the host
+# and applied with one multi-tensor add per distinct count when the block exits.
+_DEFERRED_COUNTS = None
+
+
+@contextmanager
+def deferred_batch_counters():
+    global _DEFERRED_COUNTS
+    if _DEFERRED_COUNTS is not None:          # nested: the outer block flushes
+        yield
+        return
+    _DEFERRED_COUNTS = {}
+    try:
+        yield
+    finally:
+        pending, _DEFERRED_COUNTS = _DEFERRED_COUNTS, None
+        by_count = {}
+        for tensor, n in pending.values():
+            by_count.setdefault(n, []).append(tensor)
+        for n, tensors in by_count.items():
+            torch._foreach_add_(tensors, n)
+
+
+def bn_state(bn):
+    """(training, momentum, running_mean, running_var) for one BatchNorm2d call, and the batch-counter increment.
+    While a checkpointed segment is recomputed (memory.recomputing()) the running statistics and the counter are
+    left alone: batch statistics as in the first pass, no second update."""
+    from .memory import recomputing
+    training = bn.training or bn.running_mean is None
+    if not training:
+        return False, 0.0, bn.running_mean, bn.running_var
+    momentum = bn_momentum(bn)
+    if recomputing():
+        return True, momentum, None, None
+    counter = bn.num_batches_tracked
+    if counter is not None:
+        if _DEFERRED_COUNTS is None:
+            counter.add_(1)
+        else:
+            rec = _DEFERRED_COUNTS.setdefault(id(counter), [counter, 0])
+            rec[1] += 1
+    return True, momentum, bn.running_mean, bn.running_var
 
 
 def bn_momentum(bn) -> float:
@@ -135,10 +188,7 @@ class BNAct(nn.Sequential):
     def forward(self, x, residual=None):
         bn = self[0]
         act, slope = act_code(self[1] if len(self) > 1 else None)
-        training = bn.training or bn.running_mean is None
-        if training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
-        momentum = bn_momentum(bn)
+        training, momentum, rmean, rvar = bn_state(bn)
         res = None if residual is None else to_nhwc(residual)
         # statistics partials the producing Conv2d left on this very tensor object (K6b); used only while the tensor
         # still is that conv's untouched output (same storage, same version counter), otherwise the separate pass runs
@@ -146,8 +196,7 @@ class BNAct(nn.Sequential):
         tag = getattr(x, "_tsii_stat_part", None) if training else None
         if tag is not None and tag[1] == x.data_ptr() and tag[2] == x._version and tag[0].shape[-1] == x.shape[1]:
             part = tag[0]
-        y = ops.bn_act(to_nhwc(x), bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps,
-                       act, slope, res, part)
+        y = ops.bn_act(to_nhwc(x), bn.weight, bn.bias, rmean, rvar, training, momentum, bn.eps, act, slope, res, part)
         return to_nchw(y)
 
 
@@ -195,18 +244,51 @@ def cat_channels(xs):
     return to_nchw(ops.concat([to_nhwc(x) for x in xs]))
 
 
+class ConvSpec(NamedTuple):
+    """One ``conv [-> BatchNorm [-> activation]]`` piece of a network table.  ``groups="dw"`` = depth-wise
+    (groups = input channels); ``out=None`` keeps the channel count."""
+    out: Optional[int]
+    kernel: object = 1
+    stride: int = 1
+    padding: object = 0
+    dilation: int = 1
+    groups: object = 1
+    bias: bool = False
+    bn: bool = True
+    act: bool = True
+
+
+def conv_pieces(cin, spec: ConvSpec, activation):
+    """Modules of one ConvSpec in the reference's container layout (models/BaseModels.py:91-102): the conv, then
+    ``BNAct(BatchNorm2d[, act])`` if normalised, else the bare activation -- this index layout IS the state_dict key
+    layout.  Returns (modules, output channels)."""
+    cout = cin if spec.out is None else spec.out
+    groups = cin if spec.groups == "dw" else spec.groups
+    conv = Conv2d(cin, cout, spec.kernel, spec.stride, spec.padding, spec.dilation, groups, spec.bias)
+    conv.bn_follows = bool(spec.bn)
+    act = activation if spec.act else None
+    mods = [conv]
+    if spec.bn:
+        mods.append(BNAct(nn.BatchNorm2d(cout), act) if act else BNAct(nn.BatchNorm2d(cout)))
+    elif act is not None:
+        mods.append(Activation(act))
+    return mods, cout
+
+
+def build_chain(cin, specs, activation):
+    """Flat module list of a table of ConvSpecs (for ``nn.Sequential(*...)``) and its output channel count."""
+    mods = []
+    for spec in specs:
+        piece, cin = conv_pieces(cin, spec, activation)
+        mods += piece
+    return mods, cin
+
+
 def Conv_block(in_channels, out_channels, kernel_size, stride=1, padding=0,
                dilation=1, groups=1, bias=True, BN=False, activation=None):
-    m = [Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)]
-    m[0].bn_follows = bool(BN)
-    if BN:
-        if activation:
-            m += [BNAct(nn.BatchNorm2d(out_channels), activation)]
-        else:
-            m += [BNAct(nn.BatchNorm2d(out_channels))]
-    if BN is False and activation is not None:
-        m += [Activation(activation)]
-    return m
+    """The reference's list-returning factory (models/BaseModels.py:91-102), kept for code written against it."""
+    spec = ConvSpec(out_channels, kernel_size, stride, padding, dilation, groups, bias, bool(BN), bool(activation))
+    return conv_pieces(in_channels, spec, activation if activation else None)[0]
 
 
 def run_chain(mods, x):
@@ -220,17 +302,14 @@ def run_chain(mods, x):
         if isinstance(m, Conv2d) and i + 1 < n and isinstance(mods[i + 1], BNAct) and m.padding_mode == "zeros":
             bn = mods[i + 1][0]
             act, slope = act_code(mods[i + 1][1] if len(mods[i + 1]) > 1 else None)
-            training = bn.training or bn.running_mean is None
-            if training and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
-            momentum = bn_momentum(bn)
+            training, momentum, rmean, rvar = bn_state(bn)
             g = ops.make_geom(m.kernel_size, m.stride, m.padding, m.dilation)
             src = lazy if lazy is not None else h
             if training:
                 y, part = ops.conv2d(src, m.weight, m.bias, g, m.groups, want_stats=True)
             else:
                 y, part = ops.conv2d(src, m.weight, m.bias, g, m.groups), None
-            lz = ops.bn_lazy(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, act, slope, part)
+            lz = ops.bn_lazy(y, bn.weight, bn.bias, rmean, rvar, training, momentum, bn.eps, act, slope, part)
             if i + 2 < n and isinstance(mods[i + 2], Conv2d) and ops.load_time_act(act, slope):
                 h, lazy = None, lz
             else:

@@ -3,73 +3,64 @@ construction in the reference itself -- SURVEY.md F7 -- and is out of scope.)"""
 from torch import nn
 
 from . import ops
-from .BaseModels import BaseModule, Conv_block, DSConvBlock, to_nchw, to_nhwc
+from .BaseModels import BaseModule, ConvSpec, DSConvBlock, build_chain, to_nchw, to_nhwc
 
 
 class ResidualBlock(BaseModule):
+    """Three depth-wise-separable convs (the last one strided, without activation) plus a shortcut: identity, or a
+    strided 1x1 conv + BatchNorm when the shape changes (models/Xception.py:13-44)."""
+
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0,
                  dilation=1, bias=False, BN=True, activation=None, expand_channel_first=True):
         super().__init__()
-        middle_channel = out_channels if expand_channel_first else in_channels
-        self.conv = nn.Sequential(
-            DSConvBlock(in_channels, middle_channel, kernel_size, 1, padding, dilation, bias, BN, activation, activation),
-            DSConvBlock(middle_channel, out_channels, kernel_size, 1, padding, dilation, bias, BN, activation, activation),
-            DSConvBlock(out_channels, out_channels, kernel_size, stride, padding, dilation, bias, BN, activation, None))
-        if (stride > 1) or (in_channels != out_channels):
-            self.residual_conv = nn.Sequential(
-                *Conv_block(in_channels, out_channels, kernel_size=1, stride=stride, bias=False, BN=True, activation=None))
-        else:
-            self.residual_conv = None
+        mid = out_channels if expand_channel_first else in_channels
+        # (cin, cout, stride, point-wise activation) of the three DSConvBlocks
+        rows = ((in_channels, mid, 1, activation), (mid, out_channels, 1, activation), (out_channels, out_channels, stride, None))
+        self.conv = nn.Sequential(*[DSConvBlock(ci, co, kernel_size, st, padding, dilation, bias, BN, activation, pw_act)
+                                    for ci, co, st, pw_act in rows])
+        self.residual_conv = None
+        if stride > 1 or in_channels != out_channels:
+            self.residual_conv = nn.Sequential(*build_chain(in_channels, (ConvSpec(out_channels, 1, stride, act=False),), None)[0])
 
     def forward(self, x):
-        residual = x
-        x = self.conv(x)
-        if self.residual_conv is not None:
-            residual = self.residual_conv(residual)
-        return to_nchw(ops.add_act(to_nhwc(x), to_nhwc(residual)))                  # x + residual (:44)
+        shortcut = x if self.residual_conv is None else self.residual_conv(x)
+        return to_nchw(ops.add_act(to_nhwc(self.conv(x)), to_nhwc(shortcut)))
+
+
+# flow tables: ("conv", out, stride) = 3x3 conv + BN + act; ("res", out, stride, dilation) = ResidualBlock (k 3, pad = dilation)
+XCEPTION_FLOWS = (
+    ("entry_flow_1", (("conv", 32, 2), ("conv", 64, 1), ("res", 128, 2, 1))),                     # -> 1/4, 128 channels
+    ("entry_flow_2", (("res", 256, 2, 1), ("res", 512, 1, 2))),                                   # -> 1/8 (dilated from here)
+    ("middle_flow", (("res", 512, 1, 2),) * 4 + (("res", 512, 1, 4),) * 4),
+    ("exit_flow", (("res", 512, 1, 2),) * 2 + (("res", 512, 1, 1),) * 2),
+)
 
 
 class Xception(BaseModule):
+    """Output stride 8; returns (features at 1/8 with 512 channels, features at 1/4 with 128 channels)
+    (models/Xception.py:47-114)."""
+
     def __init__(self, color_channel=3, act_fn=nn.LeakyReLU(0.3)):
         super().__init__()
         self.act_fn = act_fn
-        self.entry_flow_1 = self.make_entry_flow_1(color_channel, 128)  # 1/4
-        self.entry_flow_2 = self.make_entry_flow_2(128, 512)            # 1/8 (dilated)
-        self.middle_flow = self.make_middle_flow(512, 512, repeat_blocks=8, rate=(2, 4))
-        self.exit_flow = self.make_exit_flow(512, 512, rate=(2, 1))
-        self.x4_feature_channels = 128
-        self.last_feature_channels = 512
-
-    def make_entry_flow_1(self, in_channel, out_channel):
-        return nn.Sequential(
-            *Conv_block(in_channel, 32, 3, stride=2, padding=1, bias=False, BN=True, activation=self.act_fn),
-            *Conv_block(32, 64, 3, stride=1, padding=1, bias=False, BN=True, activation=self.act_fn),
-            ResidualBlock(64, out_channel, 3, stride=2, padding=1, dilation=1, bias=False, BN=True, activation=self.act_fn))
-
-    def make_entry_flow_2(self, in_channel, out_channel):
-        return nn.Sequential(
-            ResidualBlock(in_channel, 256, 3, stride=2, padding=1, dilation=1, bias=False, BN=True, activation=self.act_fn),
-            ResidualBlock(256, out_channel, 3, stride=1, padding=2, dilation=2, bias=False, BN=True, activation=self.act_fn))
-
-    def make_middle_flow(self, in_channel=728, out_channel=728, repeat_blocks=16, rate=(2, 4)):
-        m = []
-        for r in (rate[0], rate[1]):
-            for _ in range(repeat_blocks // 2):
-                m.append(ResidualBlock(in_channel, out_channel, 3, stride=1, padding=r, dilation=r, bias=False,
-                                       BN=True, activation=self.act_fn))
-        return nn.Sequential(*m)
-
-    def make_exit_flow(self, in_channel=728, out_channel=2048, rate=(2, 1)):
-        return nn.Sequential(
-            ResidualBlock(in_channel, 512, 3, stride=1, padding=rate[0], dilation=rate[0], bias=False, BN=True, activation=self.act_fn),
-            ResidualBlock(512, 512, 3, stride=1, padding=rate[0], dilation=rate[0], bias=False, BN=True, activation=self.act_fn),
-            ResidualBlock(512, 512, 3, stride=1, padding=rate[1], dilation=rate[1], bias=False, BN=True, activation=self.act_fn),
-            ResidualBlock(512, out_channel, 3, stride=1, padding=rate[1], dilation=rate[1], bias=False, BN=True, activation=self.act_fn))
+        width = color_channel
+        for name, rows in XCEPTION_FLOWS:
+            mods = []
+            for row in rows:
+                if row[0] == "conv":
+                    piece, width = build_chain(width, (ConvSpec(row[1], 3, row[2], 1),), act_fn)
+                    mods += piece
+                else:
+                    _, cout, stride, rate = row
+                    mods.append(ResidualBlock(width, cout, 3, stride=stride, padding=rate, dilation=rate, bias=False,
+                                              BN=True, activation=act_fn))
+                    width = cout
+            setattr(self, name, nn.Sequential(*mods))
+            if name == "entry_flow_1":
+                self.x4_feature_channels = width
+        self.last_feature_channels = width
 
     def forward(self, x):
-        x = self.entry_flow_1(x)
-        x4_features = x
-        x = self.entry_flow_2(x)
-        x = self.middle_flow(x)
-        x = self.exit_flow(x)
-        return x, x4_features
+        quarter = self.entry_flow_1(x)
+        deep = self.exit_flow(self.middle_flow(self.entry_flow_2(quarter)))
+        return deep, quarter

@@ -3,7 +3,7 @@
 from torch import nn
 
 from . import ops
-from .BaseModels import BaseModule, Conv2d, Conv_block, AvgPool2d, act_code, cat_channels, to_nchw, to_nhwc
+from .BaseModels import AvgPool2d, BaseModule, Conv2d, ConvSpec, act_code, build_chain, cat_channels, to_nchw, to_nhwc
 
 
 class SpatialChannelSqueezeExcitation(BaseModule):
@@ -37,75 +37,53 @@ class SpatialChannelSqueezeExcitation(BaseModule):
         return to_nchw(ops.scse_combine(xs, cse, sse))                # x*cSE + x*sSE (:38-43)
 
 
-def add_SCSE_block(model_block, in_channel=None):
-    if in_channel is None:
-        in_channel = model_block[0].out_channels
-    model_block.add_module("SCSE", SpatialChannelSqueezeExcitation(in_channel))
-
-
 class ASP(BaseModule):
-    # Atrous Spatial Pyramid Pooling with vortex pooling (models/common.py:53-93)
+    """Atrous spatial pyramid with vortex pooling (models/common.py:53-93): a plain 3x3 branch plus, per rate r,
+    ``AvgPool(r, stride 1) -> 3x3 dilated by r``; the four branches are concatenated and fused by a 1x1 conv."""
+
     def __init__(self, in_channel=256, out_channel=256, act_fn=None, asp_rate=(3, 9, 27)):
         super().__init__()
-        self.asp = nn.Sequential(
-            nn.Sequential(*Conv_block(in_channel, out_channel, kernel_size=3, stride=1, padding=1,
-                                      bias=False, BN=True, activation=act_fn)),
-            *[nn.Sequential(AvgPool2d(kernel_size=r, stride=1, padding=(r - 1) // 2),
-                            *Conv_block(in_channel, out_channel, kernel_size=3, stride=1, padding=r,
-                                        dilation=r, bias=False, BN=True, activation=act_fn)) for r in asp_rate])
-        self.out_conv = nn.Sequential(*Conv_block(out_channel * 4, out_channel, kernel_size=1, bias=False,
-                                                  BN=True, activation=act_fn))
+        branches = [nn.Sequential(*build_chain(in_channel, (ConvSpec(out_channel, 3, 1, 1),), act_fn)[0])]
+        for r in asp_rate:
+            conv, _ = build_chain(in_channel, (ConvSpec(out_channel, 3, 1, r, r),), act_fn)
+            branches.append(nn.Sequential(AvgPool2d(kernel_size=r, stride=1, padding=(r - 1) // 2), *conv))
+        self.asp = nn.Sequential(*branches)
+        self.out_conv = nn.Sequential(*build_chain(out_channel * len(branches), (ConvSpec(out_channel, 1),), act_fn)[0])
 
     def forward(self, x):
-        asp_pool = [layer(x) for layer in self.asp.children()]
-        return self.out_conv(cat_channels(asp_pool))
+        return self.out_conv(cat_channels([branch(x) for branch in self.asp]))
+
+
+# RFB branch table: (first-conv kernel k, dilation of the closing depth-wise 3x3); k == 1: 1x1 -> dw3x3, else the
+# factorised form 1x1 (to half width) -> (1 x k) -> (k x 1) -> dw3x3 (models/common.py:102,116-143)
+RFB_BRANCHES = ((1, 1), (3, 5), (5, 17), (7, 29))
+
+
+def rfb_branch_specs(width, k, rate):
+    tail = ConvSpec(None, 3, 1, rate, rate, "dw")
+    if k == 1:
+        return (ConvSpec(width, 1), tail)
+    half = width // 2
+    return (ConvSpec(half, 1), ConvSpec(3 * half // 2, (1, k), 1, (0, (k - 1) // 2), act=False),
+            ConvSpec(width, (k, 1), 1, ((k - 1) // 2, 0), act=False), tail)
 
 
 class RFB(BaseModule):
-    # receptive field block with (1xk)+(kx1) factorised convs (models/common.py:96-156)
+    """Receptive-field block (models/common.py:96-156): four branches of growing kernel / dilation, concatenated,
+    fused by a biased 1x1 conv (+ scSE), added to a 1x1 projection of the input, then the activation."""
+
     def __init__(self, in_channel, out_channel, activation, add_sece=False):
         super().__init__()
-        asp_rate = [5, 17, 29]
         self.act_fn = activation
-        self.input_down_channel = nn.Sequential(
-            *Conv_block(in_channel, out_channel, kernel_size=1, bias=True, BN=True, activation=activation))
-        rfb_linear_conv = [Conv2d(out_channel * 4, out_channel, kernel_size=1, bias=True)]
+        self.input_down_channel = nn.Sequential(*build_chain(in_channel, (ConvSpec(out_channel, 1, bias=True),), activation)[0])
+        fuse = [Conv2d(out_channel * len(RFB_BRANCHES), out_channel, kernel_size=1, bias=True)]
         if add_sece:
-            rfb_linear_conv.append(SpatialChannelSqueezeExcitation(in_channel=out_channel, activation=activation))
-        self.rfb_linear_conv = nn.Sequential(*rfb_linear_conv)
-        self.rfb = nn.Sequential(
-            self.make_pooling_branch(in_channel, out_channel, out_channel, conv_kernel=1,
-                                     astro_rate=1, activation=activation, half_conv=False),
-            self.make_pooling_branch(in_channel, out_channel // 2, out_channel, conv_kernel=3,
-                                     astro_rate=asp_rate[0], activation=activation, half_conv=True),
-            self.make_pooling_branch(in_channel, out_channel // 2, out_channel, conv_kernel=5,
-                                     astro_rate=asp_rate[1], activation=activation, half_conv=True),
-            self.make_pooling_branch(in_channel, out_channel // 2, out_channel, conv_kernel=7,
-                                     astro_rate=asp_rate[2], activation=activation, half_conv=True))
-
-    @staticmethod
-    def make_pooling_branch(in_channel, mid_channel, out_channel, conv_kernel, astro_rate, activation, half_conv=False):
-        if half_conv:
-            m = nn.Sequential(
-                *Conv_block(in_channel, mid_channel, kernel_size=1, padding=0,
-                            bias=False, BN=True, activation=activation),
-                *Conv_block(mid_channel, 3 * mid_channel // 2, kernel_size=(1, conv_kernel),
-                            padding=(0, (conv_kernel - 1) // 2), bias=False, BN=True, activation=None),
-                *Conv_block(3 * mid_channel // 2, out_channel, kernel_size=(conv_kernel, 1),
-                            padding=((conv_kernel - 1) // 2, 0), bias=False, BN=True, activation=None),
-                *Conv_block(out_channel, out_channel, kernel_size=3, dilation=astro_rate, padding=astro_rate,
-                            bias=False, BN=True, activation=activation, groups=out_channel))
-        else:
-            m = nn.Sequential(
-                *Conv_block(in_channel, out_channel, kernel_size=conv_kernel, padding=(conv_kernel - 1) // 2,
-                            bias=False, BN=True, activation=activation),
-                *Conv_block(out_channel, out_channel, kernel_size=3, dilation=astro_rate, padding=astro_rate,
-                            bias=False, BN=True, activation=activation, groups=out_channel))
-        return m
+            fuse.append(SpatialChannelSqueezeExcitation(in_channel=out_channel, activation=activation))
+        self.rfb_linear_conv = nn.Sequential(*fuse)
+        self.rfb = nn.Sequential(*[nn.Sequential(*build_chain(in_channel, rfb_branch_specs(out_channel, k, rate), activation)[0])
+                                   for k, rate in RFB_BRANCHES])
 
     def forward(self, x):
-        rfb_pool = cat_channels([layer(x) for layer in self.rfb.children()])
-        rfb_pool = self.rfb_linear_conv(rfb_pool)
-        resi = self.input_down_channel(x)                                        # skip connection (:155)
+        fused = self.rfb_linear_conv(cat_channels([branch(x) for branch in self.rfb]))
         code, slope = act_code(self.act_fn)
-        return to_nchw(ops.add_act(to_nhwc(rfb_pool), to_nhwc(resi), code, slope))   # act_fn(rfb_pool + resi) (:156)
+        return to_nchw(ops.add_act(to_nhwc(fused), to_nhwc(self.input_down_channel(x)), code, slope))

@@ -48,90 +48,82 @@ class _UNetBase(BaseModule):
         return x
 
 
+# Level tables.  A row is (cin, cout, kernel, stride, padding, dilation, expansion t, repeats n); decoder rows list
+# cin as (up-sampled channels + skip channels).  Values: models/image_inpainting.py:15-41, :116-146, :225-252.
+IMAGEFILL = dict(
+    stem=(3, 64, 7, 2, 3, 1),
+    encoder=((64, 128, 3, 2, 1, 1, 4, 2), (128, 256, 3, 2, 1, 1, 4, 2), (256, 256, 3, 2, 1, 1, 4, 2)),
+    dilated=((256, 256, 3, 1, 2, 2, 4, 2), (256, 256, 3, 1, 4, 4, 4, 2), (256, 256, 3, 1, 8, 8, 4, 2)),
+    decoder=((256 + 256, 256, 3, 1, 1, 1, 2, 1), (256 + 128, 128, 3, 1, 1, 1, 2, 1), (128 + 64, 32, 3, 1, 1, 1, 2, 1)),
+    head=(32 + 3, 3, 3, 1, 1, 1))
+ORIGIN = dict(
+    stem=(3, 64, 7, 2, 3, 1),
+    encoder=((64, 128, 5, 2, 2, 1, 1, 1), (128, 256, 5, 2, 2, 1, 1, 1), (256, 512, 3, 2, 1, 1, 1, 1)) + ((512, 512, 3, 2, 1, 1, 1, 1),) * 4,
+    decoder=((512 + 512, 512, 3, 1, 1, 1, 1, 1),) * 4 + ((512 + 256, 256, 3, 1, 1, 1, 1, 1), (256 + 128, 128, 3, 1, 1, 1, 1, 1),
+                                                          (128 + 64, 64, 3, 1, 1, 1, 1, 1)),
+    head=(64 + 3, 3, 3, 1, 1, 1))
+ORIGIN_V2 = dict(
+    stem=(3, 64, 5, 2, 2, 1),
+    encoder=((64, 128, 3, 2, 1, 1, 1, 1), (128, 256, 3, 2, 1, 1, 1, 1), (256, 256, 3, 2, 1, 1, 1, 1), (256, 256, 3, 2, 1, 1, 1, 1),
+             (256, 512, 3, 2, 1, 1, 1, 1), (512, 512, 3, 2, 1, 1, 1, 1), (512, 512, 3, 2, 1, 1, 1, 1)),
+    decoder=((512 + 512, 512, 3, 1, 1, 1, 1, 1), (512 + 512, 512, 3, 1, 1, 1, 1, 1), (512 + 256, 256, 3, 1, 1, 1, 1, 1),
+             (256 + 256, 256, 3, 1, 1, 1, 1, 1), (256 + 256, 256, 3, 1, 1, 1, 1, 1), (256 + 128, 128, 3, 1, 1, 1, 1, 1),
+             (128 + 64, 64, 3, 1, 1, 1, 1, 1)),
+    head=(64 + 3, 3, 3, 1, 1, 1))
+
+
+def build_levels(rows, make_block):
+    """One ``nn.Sequential`` per table row holding its ``n`` blocks; only the first block of a level strides and
+    changes the channel count.  ``make_block(cin, cout, k, s, p, d, t)`` builds one block."""
+    levels = []
+    for cin, cout, k, s, p, d, t, n in rows:
+        levels.append(nn.Sequential(*[make_block(cin if i == 0 else cout, cout, k, s if i == 0 else 1, p, d, t) for i in range(n)]))
+    return levels
+
+
 class ImageFill(_UNetBase):
+    """MobileNetV2-style partial-conv U-Net (models/image_inpainting.py:9-86): 7x7 stem, three encoder levels of
+    inverted residuals (t = 4), three dilated levels (2 / 4 / 8), three decoder levels (t = 2) on up-sampled +
+    skip features, 3x3 head over the concatenation with the raw input."""
+
     def __init__(self):
         super().__init__()
-        self.act_fn = nn.LeakyReLU(0.3)
+        act = self.act_fn = nn.LeakyReLU(0.3)
         self.double_upscale = DoubleUpSample(scale_factor=2, mode="nearest")
-        encoder = [  # i, o, k, s, p, d, t, n
-            [64, 128, 3, 2, 1, 1, 4, 2],
-            [128, 256, 3, 2, 1, 1, 4, 2],
-            [256, 256, 3, 2, 1, 1, 4, 2],
-        ]
-        self.encoder = nn.Sequential(
-            partial_convolution_block(3, 64, 7, 2, 3, 1, bias=True, BN=False, activation=self.act_fn),
-            *self.make_layers(encoder, use_1_conv=True, same_holes=True))
-        dilated_layers = [
-            [256, 256, 3, 1, 2, 2, 4, 2],
-            [256, 256, 3, 1, 4, 4, 4, 2],
-            [256, 256, 3, 1, 8, 8, 4, 2],
-        ]
-        self.dilated_layers = nn.Sequential(*self.make_layers(dilated_layers, no_holes_1_conv=True, same_holes=True))
-        decoder = [
-            [256 + 256, 256, 3, 1, 1, 1, 2, 1],
-            [256 + 128, 128, 3, 1, 1, 1, 2, 1],
-            [128 + 64, 32, 3, 1, 1, 1, 2, 1],
-        ]
-        self.decoder = nn.Sequential(
-            *self.make_layers(decoder, no_holes_1_conv=True, same_holes=True),
-            partial_convolution_block(32 + 3, 3, 3, 1, 1, 1, bias=True, BN=False, activation=False))
 
-    def make_layers(self, settings, use_1_conv=False, no_holes_1_conv=False, same_holes=False):
-        m = []
-        for in_c, out_c, k, s, p, d, t, n in settings:
-            layer = []
-            for i in range(n):
-                layer.append(PartialInvertedResidual(in_c, out_c, k, s if i == 0 else 1, p, d, t, bias=False,
-                                                     BN=True, activation=self.act_fn, use_1_conv=use_1_conv,
-                                                     no_holes_1_conv=no_holes_1_conv, same_holes=same_holes))
-                in_c = out_c
-            m.append(nn.Sequential(*layer))
-        return m
+        def pir(**flags):
+            return lambda cin, cout, k, s, p, d, t: PartialInvertedResidual(cin, cout, k, s, p, d, t, bias=False, BN=True,
+                                                                            activation=act, same_holes=True, **flags)
+        cfg = IMAGEFILL
+        self.encoder = nn.Sequential(partial_convolution_block(*cfg["stem"], bias=True, BN=False, activation=act),
+                                     *build_levels(cfg["encoder"], pir(use_1_conv=True)))
+        self.dilated_layers = nn.Sequential(*build_levels(cfg["dilated"], pir(no_holes_1_conv=True)))
+        self.decoder = nn.Sequential(*build_levels(cfg["decoder"], pir(no_holes_1_conv=True)),
+                                     partial_convolution_block(*cfg["head"], bias=True, BN=False, activation=False))
 
     def forward(self, args):
-        # mask: 1: ground truth, 0: holes
-        x, mask = args
+        x, mask = args                      # mask: 1 = known pixel, 0 = hole
         x, mp, fx, fm = self._encode(to_nhwc(x), as_parts(mask))
         x, mp = run_nhwc(self.dilated_layers, x, mp)
         return to_nchw(self._decode(x, mp, fx, fm))
 
 
 class ImageFillOrigin(_UNetBase):
+    """The partial-convolution paper's U-Net (models/image_inpainting.py:110-191): eight stride-2 encoder convs
+    (ReLU, same_holes), seven decoder convs (LeakyReLU 0.2, per-channel hole bookkeeping) and a 3x3 head."""
+
     def __init__(self):
         super().__init__()
         self.double_upscale = DoubleUpSample(scale_factor=2, mode="nearest")
-        encoder = [
-            [64, 128, 5, 2, 2, 1, 1, 1],
-            [128, 256, 5, 2, 2, 1, 1, 1],
-            [256, 512, 3, 2, 1, 1, 1, 1],
-            [512, 512, 3, 2, 1, 1, 1, 1],
-            [512, 512, 3, 2, 1, 1, 1, 1],
-            [512, 512, 3, 2, 1, 1, 1, 1],
-            [512, 512, 3, 2, 1, 1, 1, 1],
-        ]
-        self.encoder = nn.Sequential(
-            partial_convolution_block(3, 64, 7, 2, 3, 1, bias=True, BN=False, activation=nn.ReLU(), same_holes=True),
-            *self.make_layer_v2(encoder, act_fn=nn.ReLU(), same_holes=True))
-        decoder = [
-            [512 + 512, 512, 3, 1, 1, 1, 1, 1],
-            [512 + 512, 512, 3, 1, 1, 1, 1, 1],
-            [512 + 512, 512, 3, 1, 1, 1, 1, 1],
-            [512 + 512, 512, 3, 1, 1, 1, 1, 1],
-            [512 + 256, 256, 3, 1, 1, 1, 1, 1],
-            [256 + 128, 128, 3, 1, 1, 1, 1, 1],
-            [128 + 64, 64, 3, 1, 1, 1, 1, 1],
-        ]
-        self.decoder = nn.Sequential(
-            *self.make_layer_v2(decoder, act_fn=nn.LeakyReLU(0.2), same_holes=False),
-            partial_convolution_block(64 + 3, 3, 3, 1, 1, 1, bias=True, BN=False, activation=False, same_holes=False))
 
-    def make_layer_v2(self, settings, act_fn, no_holes_1_conv=False, same_holes=False):
-        m = []
-        for in_c, out_c, k, s, p, d, t, n in settings:
-            layer = partial_convolution_block(in_c, out_c, k, s, p, d, groups=1, BN=True, activation=act_fn,
-                                              bias=False, no_holes_1_conv=no_holes_1_conv, same_holes=same_holes)
-            m.append(nn.Sequential(layer))
-        return m
+        def conv(act, same_holes):
+            return lambda cin, cout, k, s, p, d, t: partial_convolution_block(cin, cout, k, s, p, d, groups=1, BN=True, activation=act,
+                                                                              bias=False, no_holes_1_conv=False, same_holes=same_holes)
+        cfg = ORIGIN
+        self.encoder = nn.Sequential(partial_convolution_block(*cfg["stem"], bias=True, BN=False, activation=nn.ReLU(), same_holes=True),
+                                     *build_levels(cfg["encoder"], conv(nn.ReLU(), True)))
+        self.decoder = nn.Sequential(*build_levels(cfg["decoder"], conv(nn.LeakyReLU(0.2), False)),
+                                     partial_convolution_block(*cfg["head"], bias=True, BN=False, activation=False, same_holes=False))
 
     def forward(self, args):
         x, mask = args
@@ -140,30 +132,28 @@ class ImageFillOrigin(_UNetBase):
 
 
 class DoublePartialResidual(BaseModule):
+    """Two partial-conv blocks, ``conv2(conv1(x)) + conv1(x)`` (models/image_inpainting.py:194-216).  Like the
+    reference, the ``padding`` / ``dilation`` arguments are ignored: both come from ``dilation_rate``."""
+
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0,
                  dilation=1, expansion=1, BN=True, activation=True, bias=False,
                  use_1_conv=False, no_holes_1_conv=False, same_holes=False,
                  dilation_rate=(1, 1), *args, **kwargs):
         super().__init__()
-        # padding / dilation arguments are ignored, like the reference (:201-210)
-        self.conv1 = partial_convolution_block(in_channels, out_channels, kernel_size, stride,
-                                               padding=dilation_rate[0], dilation=dilation_rate[0],
-                                               BN=BN, activation=activation, bias=bias, use_1_conv=use_1_conv,
-                                               no_holes_1_conv=no_holes_1_conv, same_holes=same_holes)
-        self.conv2 = partial_convolution_block(out_channels, out_channels, kernel_size, 1,
-                                               padding=dilation_rate[1], dilation=dilation_rate[1],
-                                               BN=BN, activation=activation, bias=bias, use_1_conv=use_1_conv,
-                                               no_holes_1_conv=no_holes_1_conv, same_holes=same_holes)
+        flags = dict(BN=BN, activation=activation, bias=bias, use_1_conv=use_1_conv, no_holes_1_conv=no_holes_1_conv,
+                     same_holes=same_holes)
+        r1, r2 = dilation_rate
+        self.conv1 = partial_convolution_block(in_channels, out_channels, kernel_size, stride, padding=r1, dilation=r1, **flags)
+        self.conv2 = partial_convolution_block(out_channels, out_channels, kernel_size, 1, padding=r2, dilation=r2, **flags)
 
     def forward_nhwc(self, x, mp):
         from .partial_convolution import PartialActivatedBN
         x1, m1 = run_nhwc(self.conv1, x, mp)
         if len(self.conv2) == 2 and isinstance(self.conv2[1], PartialActivatedBN):
             h, m2 = self.conv2[0].forward_nhwc(x1, m1)
-            h, m2 = self.conv2[1].forward_nhwc(h, m2, residual=x1)               # x + out_x (:216)
-            return h, m2
+            return self.conv2[1].forward_nhwc(h, m2, residual=x1)                # the add rides in the BatchNorm apply kernel
         x2, m2 = run_nhwc(self.conv2, x1, m1)
-        return x2 + x1, m2
+        return ops.add_act(x2, x1), m2
 
     def forward(self, args):
         x, mask = args
@@ -173,44 +163,22 @@ class DoublePartialResidual(BaseModule):
 
 
 class ImageFillOriginV2(_UNetBase):
+    """ImageFillOrigin with a DoublePartialResidual per level (encoder rates (1, 2), decoder (2, 1)), a 5x5 stem with
+    BatchNorm and a ReLU after the head (models/image_inpainting.py:219-290)."""
+
     def __init__(self):
         super().__init__()
         self.double_upscale = DoubleUpSample(scale_factor=2, mode="nearest")
-        encoder = [
-            [64, 128, 3, 2, 1, 1, 1, 1],
-            [128, 256, 3, 2, 1, 1, 1, 1],
-            [256, 256, 3, 2, 1, 1, 1, 1],
-            [256, 256, 3, 2, 1, 1, 1, 1],
-            [256, 512, 3, 2, 1, 1, 1, 1],
-            [512, 512, 3, 2, 1, 1, 1, 1],
-            [512, 512, 3, 2, 1, 1, 1, 1],
-        ]
-        self.encoder = nn.Sequential(
-            partial_convolution_block(3, 64, 5, 2, 2, 1, bias=False, BN=True,
-                                      activation=nn.LeakyReLU(0.2), same_holes=True),
-            *self.make_layer_v2(encoder, act_fn=nn.LeakyReLU(0.2), same_holes=True, dilation_rate=(1, 2)))
-        decoder = [
-            [512 + 512, 512, 3, 1, 1, 1, 1, 1],
-            [512 + 512, 512, 3, 1, 1, 1, 1, 1],
-            [512 + 256, 256, 3, 1, 1, 1, 1, 1],
-            [256 + 256, 256, 3, 1, 1, 1, 1, 1],
-            [256 + 256, 256, 3, 1, 1, 1, 1, 1],
-            [256 + 128, 128, 3, 1, 1, 1, 1, 1],
-            [128 + 64, 64, 3, 1, 1, 1, 1, 1],
-        ]
-        self.decoder = nn.Sequential(
-            *self.make_layer_v2(decoder, act_fn=nn.LeakyReLU(0.2), same_holes=False, dilation_rate=(2, 1)),
-            partial_convolution_block(64 + 3, 3, 3, 1, 1, 1, bias=True, BN=False,
-                                      activation=nn.ReLU(), same_holes=False))
+        act = nn.LeakyReLU(0.2)
 
-    @staticmethod
-    def make_layer_v2(settings, act_fn, same_holes=False, dilation_rate=(1, 1)):
-        m = []
-        for in_c, out_c, k, s, p, d, t, n in settings:
-            layer = DoublePartialResidual(in_c, out_c, k, s, p, d, BN=True, activation=act_fn, bias=False,
-                                          same_holes=same_holes, dilation_rate=dilation_rate)
-            m.append(nn.Sequential(layer))
-        return m
+        def dpr(same_holes, rates):
+            return lambda cin, cout, k, s, p, d, t: DoublePartialResidual(cin, cout, k, s, p, d, BN=True, activation=act, bias=False,
+                                                                          same_holes=same_holes, dilation_rate=rates)
+        cfg = ORIGIN_V2
+        self.encoder = nn.Sequential(partial_convolution_block(*cfg["stem"], bias=False, BN=True, activation=act, same_holes=True),
+                                     *build_levels(cfg["encoder"], dpr(True, (1, 2))))
+        self.decoder = nn.Sequential(*build_levels(cfg["decoder"], dpr(False, (2, 1))),
+                                     partial_convolution_block(*cfg["head"], bias=True, BN=False, activation=nn.ReLU(), same_holes=False))
 
     def forward(self, args):
         x, mask = args

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .BaseModels import BaseModule, act_code, bn_momentum, to_nchw, to_nhwc
+from .BaseModels import BaseModule, act_code, bn_state, to_nchw, to_nhwc
 from .masks import MaskParts, as_parts
 
 import os
@@ -168,27 +168,23 @@ class PartialActivatedBN(BaseModule):
     def _cfg(self):
         bn = self.bn_act[0]
         act, slope = act_code(self.bn_act[1] if len(self.bn_act) > 1 else None)
-        training = bn.training or bn.running_mean is None
-        if training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
-        momentum = bn_momentum(bn)
-        return bn, act, slope, training, momentum
+        training, momentum, rmean, rvar = bn_state(bn)
+        return bn, act, slope, training, momentum, rmean, rvar
 
     def forward_nhwc(self, x, mp, residual=None):
-        bn, act, slope, training, momentum = self._cfg()
+        bn, act, slope, training, momentum, rmean, rvar = self._cfg()
         if isinstance(x, ops.LazyBN):
             x = x.materialize()
-        y = ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
-                       momentum, bn.eps, act, slope, residual)
+        y = ops.bn_act(x, bn.weight, bn.bias, rmean, rvar, training, momentum, bn.eps, act, slope, residual)
         return y, mp
 
     def forward_lazy(self, y, mp, part=None):
         """K6b: statistics from the partials the producing conv left behind (``part``); the normalised activation
         stays virtual (ops.LazyBN) until a consumer loads it or ``materialize()`` writes it."""
-        bn, act, slope, training, momentum = self._cfg()
+        bn, act, slope, training, momentum, rmean, rvar = self._cfg()
         if bn.weight is None:
             raise NotImplementedError("BatchNorm2d(affine=False) is not used by the reference networks")
-        lazy = ops.bn_lazy(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, act, slope,
+        lazy = ops.bn_lazy(y, bn.weight, bn.bias, rmean, rvar, training, momentum, bn.eps, act, slope,
                            part if training else None)
         return lazy, mp
 

@@ -13,7 +13,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .BaseModels import to_nhwc
+from .BaseModels import deferred_batch_counters, to_nhwc
 
 
 class FlatSGDTrainer:
@@ -72,7 +72,8 @@ class FlatSGDTrainer:
     def forward_backward(self, corrupted, mask, clean_nhwc):
         for p in self.params:
             p.grad = None
-        out = self.model((corrupted, mask))
+        with deferred_batch_counters():      # the BatchNorm batch counters: one multi-tensor add instead of one kernel each
+            out = self.model((corrupted, mask))
         loss = self.loss_fn(out, clean_nhwc)
         # mean over ranks folded into the backward seed: sum-all-reduce then yields the average
         loss.backward(torch.full((), 1.0 / self.world, dtype=torch.float32, device=loss.device))
