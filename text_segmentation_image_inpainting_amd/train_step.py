@@ -17,9 +17,17 @@ from .BaseModels import deferred_batch_counters, to_nhwc
 
 
 class FlatSGDTrainer:
-    def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=None, loss_fn=None):
+    """``bucket_mb``: size of the gradient buckets (contiguous ranges of the flat gradient buffer, laid out in the order
+    gradients become ready in backward = reverse registration order).  With more than one rank every bucket is
+    all-reduced asynchronously as soon as its last gradient has been produced (``post_accumulate_grad`` hooks), so
+    the exchange overlaps the rest of the backward pass; ``step()`` waits for the outstanding buckets before the
+    update.  ImageFill's 26 MB is two buckets at the default 16 MB, ImageFillOrigin / V2 (131 / 149 MB) nine / ten."""
+
+    def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=None, loss_fn=None, bucket_mb=16.0,
+                 overlap=True):
         self.model = model
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        named = [p for p in model.parameters() if p.requires_grad]
+        self.params = list(reversed(named))          # flat layout = expected gradient-ready order
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.pg = process_group
         self.distributed = dist.is_available() and dist.is_initialized()
@@ -44,7 +52,26 @@ class FlatSGDTrainer:
         self.flat_buf = torch.zeros(numel, dtype=torch.float32, device=dev)
         self.grad_views = [self.flat_grad[off:off + n].view_as(p) for p, (off, n) in zip(self.params, self.slices)]
         self.loss_fn = loss_fn or (lambda out_nchw, clean_nhwc: ops.l1_mean(to_nhwc(out_nchw), clean_nhwc))
+        # ---- buckets: consecutive parameters up to bucket_mb; bucket b covers flat range [lo, hi)
+        limit = max(1, int(bucket_mb * 2**20 / 4))
+        self.buckets, cur, lo = [], [], 0
+        for i, (o, n) in enumerate(self.slices):
+            cur.append(i)
+            hi = o + pad(n)
+            if hi - lo >= limit or i == len(self.slices) - 1:
+                self.buckets.append({"params": cur, "lo": lo, "hi": hi})
+                cur, lo = [], hi
+        self._bucket_of = {}
+        for b, bk in enumerate(self.buckets):
+            for i in bk["params"]:
+                self._bucket_of[i] = b
+        self.overlap = bool(overlap) and self.world > 1
+        self._pending, self._works, self._launched = None, [], None
+        if self.overlap:
+            for i, p in enumerate(self.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
 
+    # ---- replication ---------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src=0):
         """Rank ``src``'s weights, optimizer state and module buffers (BatchNorm running statistics and batch
         counters) become every rank's: after a checkpoint load on one rank or a restart all replicas agree."""
@@ -69,19 +96,21 @@ class FlatSGDTrainer:
                     b.copy_(flat[off:off + b.numel()].view_as(b))
                     off += b.numel()
 
-    def forward_backward(self, corrupted, mask, clean_nhwc):
-        for p in self.params:
-            p.grad = None
-        with deferred_batch_counters():      # the BatchNorm batch counters: one multi-tensor add instead of one kernel each
-            out = self.model((corrupted, mask))
-        loss = self.loss_fn(out, clean_nhwc)
-        # mean over ranks folded into the backward seed: sum-all-reduce then yields the average
-        loss.backward(torch.full((), 1.0 / self.world, dtype=torch.float32, device=loss.device))
-        return loss.detach()    # do not hand the autograd graph (and its AccumulateGrad nodes) to the caller
+    # ---- gradient exchange ---------------------------------------------------------------------------------------
+    def _make_hook(self, i):
+        def hook(param):
+            if self._pending is None:          # outside forward_backward (e.g. a user's own backward): nothing to do
+                return
+            b = self._bucket_of[i]
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._launch_bucket(b)
+        return hook
 
-    def _pack_gradients(self):
+    def _pack_bucket(self, b):
         dst, src = [], []
-        for v, p in zip(self.grad_views, self.params):
+        for i in self.buckets[b]["params"]:
+            p, v = self.params[i], self.grad_views[i]
             if p.grad is None:          # parameter not reached by this step's graph (unused / frozen branch)
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():
@@ -90,10 +119,43 @@ class FlatSGDTrainer:
         if dst:
             torch._foreach_copy_(dst, src)
 
-    def reduce_gradients(self):
-        self._pack_gradients()
+    def _launch_bucket(self, b):
+        """Pack bucket b's gradients into their flat range and start its sum all-reduce (asynchronous: RCCL runs it
+        on its own stream while backward keeps producing the earlier layers' gradients)."""
+        self._pack_bucket(b)
+        self._launched[b] = True
         if self.distributed:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
+            bk = self.buckets[b]
+            self._works.append(dist.all_reduce(self.flat_grad[bk["lo"]:bk["hi"]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def forward_backward(self, corrupted, mask, clean_nhwc):
+        for p in self.params:
+            p.grad = None
+        self._works = []
+        self._launched = [False] * len(self.buckets)
+        self._pending = [len(bk["params"]) for bk in self.buckets] if self.overlap else None
+        with deferred_batch_counters():      # the BatchNorm batch counters: one multi-tensor add instead of one kernel each
+            out = self.model((corrupted, mask))
+        loss = self.loss_fn(out, clean_nhwc)
+        # mean over ranks folded into the backward seed: sum-all-reduce then yields the average
+        loss.backward(torch.full((), 1.0 / self.world, dtype=torch.float32, device=loss.device))
+        self._pending = None
+        return loss.detach()    # do not hand the autograd graph (and its AccumulateGrad nodes) to the caller
+
+    def _pack_gradients(self):
+        for b in range(len(self.buckets)):
+            self._pack_bucket(b)
+
+    def reduce_gradients(self):
+        """Finish the exchange: buckets whose hooks did not fire (no overlap, or parameters without a gradient) are
+        packed and reduced now, then every outstanding all-reduce is waited for."""
+        launched = self._launched or [False] * len(self.buckets)
+        for b in range(len(self.buckets)):
+            if not launched[b]:
+                self._launch_bucket(b) if self.distributed else self._pack_bucket(b)
+        for w in self._works:
+            w.wait()
+        self._works, self._launched = [], None
         for p, v in zip(self.params, self.grad_views):
             p.grad = v
 
@@ -106,6 +168,33 @@ class FlatSGDTrainer:
         self.update()
         return loss
 
+    def comm_stats(self, iters=10):
+        """What bench.py prints for N > 1: ranks the collective library saw, bucket layout, and the time / bus bandwidth
+        of all-reducing the whole gradient buffer bucket by bucket (blocking, after a barrier; ring bus bandwidth =
+        2 (n-1)/n x bytes / time)."""
+        info = {"world": self.world, "backend": dist.get_backend(self.pg) if self.distributed else None,
+                "buckets": len(self.buckets), "bucket_mb": [round((bk["hi"] - bk["lo"]) * 4 / 2**20, 2) for bk in self.buckets],
+                "grad_mb": round(self.flat_grad.numel() * 4 / 2**20, 2), "overlap_with_backward": self.overlap}
+        if not self.distributed or self.world < 2:
+            return info
+        import time
+        scratch = torch.zeros_like(self.flat_grad)
+        sync = torch.cuda.synchronize if scratch.is_cuda else (lambda: None)
+        for timed in (False, True):
+            dist.barrier(group=self.pg)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(iters if timed else 2):
+                works = [dist.all_reduce(scratch[bk["lo"]:bk["hi"]], group=self.pg, async_op=True) for bk in self.buckets]
+                for w in works:
+                    w.wait()
+            sync()
+            dt = (time.perf_counter() - t0) / (iters if timed else 2)
+        nbytes = scratch.numel() * 4
+        info.update({"allreduce_ms": round(dt * 1e3, 3), "alg_gb_s": round(nbytes / dt / 1e9, 2),
+                     "bus_gb_s": round(2 * (self.world - 1) / self.world * nbytes / dt / 1e9, 2)})
+        return info
+
     # ---- HIP-graph replay of the step --------------------------------------------------------------------------
     # One step is ~900 kernel launches from Python; captured once into a HIP graph the whole chain is replayed
     # with a single launch, which removes the host-side gaps between kernels (~2.5 % of the step on MI355X).
@@ -116,6 +205,7 @@ class FlatSGDTrainer:
         are restored after the warm-up runs, so capturing does not advance training."""
         dev = self.flat_param.device
         self._static_in = (corrupted, mask, clean_nhwc)
+        self.overlap = False           # a captured step cannot launch collectives from hooks: exchange after the replay
         buffers = [b for b in self.model.buffers()]
         saved = [self.flat_param.clone(), self.flat_buf.clone()] + [b.clone() for b in buffers]
         side = torch.cuda.Stream(device=dev)
