@@ -123,10 +123,15 @@ def test_rfb_64x64_gpu():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["TextSegament", "XceptionTextSegment"])
-def test_seg_nets_256_vs_oracle_gpu(name):
+def test_seg_nets_256_vs_oracle_gpu(name, capsys):
     """cfg 1 size (256x256 -> 32x32 map at 1/8): eval and train forward, focal loss and every trainable gradient vs
-    the CPU oracle (itself pinned to the reference at 64x64 by tests/test_oracle_seg_golden.py).  Gradient tolerance
-    as in test_golden_seg_nets_64_gpu: noise-aware against an fp64 run of the oracle."""
+    the CPU oracle (itself pinned to the reference at 64x64 by tests/test_oracle_seg_golden.py).
+
+    Train-mode gradients of these ~100-layer BatchNorm nets are at the fp32 noise floor (two valid fp32
+    evaluations of the REFERENCE differ by ~1e-3 already in the forward output).  The yardstick is therefore the
+    oracle's own fp32-vs-fp64 discrepancy per tensor: the HIP result must be as close to the fp64 gradient as a
+    different fp32 evaluation order can be expected to be -- RMS error within 4x, largest element error within 10x of
+    the oracle's fp32 run (floors: 1e-3 RMS, 3e-3 max).  The worst ratios are printed."""
     keys = json.load(open(os.path.join(GOLD, "seg_state_dict_keys.json")))[name]
     fn = S.SEG_MODELS[name]
     rng = np.random.default_rng(1500)
@@ -164,13 +169,24 @@ def test_seg_nets_256_vs_oracle_gpu(name):
         loss.backward()
         params = dict(m.named_parameters())
         gmax = max(float(v.abs().max()) for v in g64.values())
-        n = 0
+        worst_max, worst_rms, bad = (0.0, ""), (0.0, ""), []
         for k, ref64 in g64.items():
+            ours = params[k].grad.detach().cpu().double()
             scale = max(float(ref64.abs().max()), 1e-3 * gmax)
-            noise = float((g32[k].double() - ref64).abs().max()) / scale
-            assert_close(params[k].grad, ref64.float(), max(3e-3, 4 * noise), f"{name} 256 grad {k}", floor=1e-3 * gmax)
-            n += 1
-        assert n >= 100
+            rscale = max(float(ref64.pow(2).mean().sqrt()), 1e-3 * gmax)
+            n_max = float((g32[k].double() - ref64).abs().max()) / scale
+            n_rms = float((g32[k].double() - ref64).pow(2).mean().sqrt()) / rscale
+            e_max = float((ours - ref64).abs().max()) / scale
+            e_rms = float((ours - ref64).pow(2).mean().sqrt()) / rscale
+            r_max, r_rms = e_max / max(n_max, 3e-4), e_rms / max(n_rms, 2.5e-4)
+            worst_max, worst_rms = max(worst_max, (r_max, k)), max(worst_rms, (r_rms, k))
+            if e_max > max(3e-3, 10 * n_max) or e_rms > max(1e-3, 4 * n_rms):
+                bad.append((k, e_max, n_max, e_rms, n_rms))
+        with capsys.disabled():
+            print(f"\n[{name} 256 grads] {len(g64)} tensors; worst max-error ratio to the oracle's own fp32 noise {worst_max[0]:.2f} "
+                  f"({worst_max[1]}), worst RMS ratio {worst_rms[0]:.2f} ({worst_rms[1]})")
+        assert not bad, bad[:5]
+        assert len(g64) >= 100
 
 
 @pytest.mark.gpu

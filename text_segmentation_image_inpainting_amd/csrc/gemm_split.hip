@@ -210,7 +210,9 @@ template <int WM, int WN, int TM, int TN, int PRODUCTS, bool BNIN, bool BNB, boo
 __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_split_kernel(const float* __restrict__ A, int64_t lda, RowScale as,
                                                                        const float* __restrict__ B, int64_t ldb,
                                                                        float* __restrict__ C, int64_t ldc,
-                                                                       int64_t M, int N, int K, Epilogue ep, unsigned ntn, InBN ib) {
+                                                                       int64_t M, int N, int K, Epilogue ep, unsigned ntn, InBN ib, int abl) {
+    // abl: ablation switches of tools/gemm_bench.py (0 in production; wave-uniform kernel argument): 1 no epilogue,
+    // 2 no global loads inside the K loop, 8 no staging pass (+ its barrier), 16 no fragment reads
     constexpr int P = SplitPlanes<PRODUCTS>::value;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per block");
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_
     const int nk = (K + SPLIT_BK - 1) / SPLIT_BK;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = (kt + 1 < nk);
-        if (more) {  // next tile's global loads fly during the MFMA phase
+        if (more && !(abl & 2)) {  // next tile's global loads fly during the MFMA phase
             split_load<BM>(A, lda, m0, M, (kt + 1) * SPLIT_BK, K, ra);
             if constexpr (BPRE) split_load_pre<BN, P>(Bpl, bstride, K, n0, N, (kt + 1) * SPLIT_BK, K, rbp);
             else split_load<BN>(B, ldb, n0, N, (kt + 1) * SPLIT_BK, K, rb);
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_
         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const int fo = s == 0 ? fo0 : fo1;
+            const int fo = (abl & 16) ? fo0 : (s == 0 ? fo0 : fo1);
             bf16x8 b[TN][P];
 #pragma unroll
             for (int u = 0; u < TN; ++u)
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_
             }
         }
         __syncthreads();
-        if (more) {
+        if (more && !(abl & 8)) {
             split_store<BM, P, true, BNIN>(As, ra, (kt + 1) * SPLIT_BK, as.split, sa0, sa1, psc, psh, ib.neg, ib.hi, mvalid, K);
             if constexpr (BPRE) split_store_pre<BN, P>(Bs, rbp, (kt + 1) * SPLIT_BK, nvalid, K);
             else split_store<BN, P, false, false>(Bs, rb, (kt + 1) * SPLIT_BK, 0, sb0, sb1, psc, psh, 1.f, 0.f, nvalid, K);
@@ -328,6 +330,17 @@ __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_
     }
 
     const ConvGather nocg = {0, 0, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, nullptr, nullptr, 0, nullptr, 0, 0, 0, 0, 0, 0};
+    if (abl & 1) {          // ablation: keep the accumulators alive with one store per thread
+        float sacc = 0.f;
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int u = 0; u < TN; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[t][u][r];
+        if (m0 + tid < M) C[(m0 + tid) * ldc + n0] = sacc;
+        return;
+    }
     nt_epilogue<WM, WN, TM, TN, 0, BNB, SMEM_FLOATS>(smem, acc, C, ldc, M, N, ep, nocg, m0, n0, bid, ntn);
 }
 
@@ -563,6 +576,7 @@ static int env_products() {
     return (v == 0 || v == 3 || v == 6 || v == 8) ? v : 6;
 }
 static int g_products = env_products();
+static int g_abl = getenv("TSII_GEMM_ABL") ? atoi(getenv("TSII_GEMM_ABL")) : 0;     // tools/gemm_bench.py ablations only
 
 int gemm_products() { return g_products; }
 
@@ -577,20 +591,20 @@ static int launch_nt_split_cfg(const float* A, int64_t lda, RowScale as, const f
         TSII_REQUIRE(ib.sc == nullptr && N % 4 == 0 && ldc == N && aligned16(ep.bn_y) && ep.vec_store,
                      "gemm_nt_split: the BatchNorm-backward epilogue needs N %% 4 == 0 and 16-byte aligned operands");
         if (bpre) hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, false, true, true>), dim3((unsigned)nblocks), dim3(256), 0, stream,
-                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib);
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib, g_abl);
         else hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, false, true, false>), dim3((unsigned)nblocks), dim3(256), 0, stream,
-                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib);
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib, g_abl);
     } else if (ib.sc != nullptr) {
         TSII_REQUIRE(aligned16(ib.sc) && aligned16(ib.sh), "gemm_nt_split: input BatchNorm needs 16-byte aligned scale / shift");
         if (bpre) hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, true, false, true>), dim3((unsigned)nblocks), dim3(256), 0, stream,
-                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib);
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib, g_abl);
         else hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, true, false, false>), dim3((unsigned)nblocks), dim3(256), 0, stream,
-                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib);
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib, g_abl);
     } else {
         if (bpre) hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, false, false, true>), dim3((unsigned)nblocks), dim3(256), 0, stream,
-                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib);
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib, g_abl);
         else hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, false, false, false>), dim3((unsigned)nblocks), dim3(256), 0, stream,
-                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib);
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib, g_abl);
     }
     return check_launch("gemm_nt_split");
 }
