@@ -119,6 +119,7 @@ def test_rfb_64x64_gpu():
     with BACKENDS["gpu"]() as dev:
         _rfb_case(dev, 64, 64, 32, seed=1401)
         _rfb_case(dev, 32, 48, 16, seed=1402)
+        _rfb_case(dev, 32, 1344, 256, seed=1403)      # TextSegament's own RFB (in 1344, out 256) on cfg 1's 32x32 map
 
 
 @pytest.mark.gpu
@@ -152,6 +153,11 @@ def test_seg_nets_256_vs_oracle_gpu(name, capsys):
 
     ye32, y32, l32, g32 = oracle(torch.float32)
     ye64, y64, l64, g64 = oracle(torch.float64)
+    # second estimate of the fp32 noise: the oracle's fp32 gradients after a 1-ulp (1e-7 relative) perturbation of the input
+    x_keep = x
+    x = x_keep * (1 + 1e-7 * torch.from_numpy(rng.standard_normal(tuple(x_keep.shape)).astype(np.float32)))
+    _, _, _, gpert = oracle(torch.float32)
+    x = x_keep
     with BACKENDS["gpu"]() as dev:
         m = getattr(T, name)()
         fill_state_dict_(m.state_dict(), seed=43, gain=1.0)
@@ -169,22 +175,25 @@ def test_seg_nets_256_vs_oracle_gpu(name, capsys):
         loss.backward()
         params = dict(m.named_parameters())
         gmax = max(float(v.abs().max()) for v in g64.values())
-        worst_max, worst_rms, bad = (0.0, ""), (0.0, ""), []
+        rows, bad = [], []
         for k, ref64 in g64.items():
             ours = params[k].grad.detach().cpu().double()
             scale = max(float(ref64.abs().max()), 1e-3 * gmax)
             rscale = max(float(ref64.pow(2).mean().sqrt()), 1e-3 * gmax)
-            n_max = float((g32[k].double() - ref64).abs().max()) / scale
-            n_rms = float((g32[k].double() - ref64).pow(2).mean().sqrt()) / rscale
+            d32, dp = g32[k].double() - ref64, gpert[k].double() - g32[k].double()
+            n_max = max(float(d32.abs().max()), float(dp.abs().max())) / scale
+            n_rms = max(float(d32.pow(2).mean().sqrt()), float(dp.pow(2).mean().sqrt())) / rscale
             e_max = float((ours - ref64).abs().max()) / scale
             e_rms = float((ours - ref64).pow(2).mean().sqrt()) / rscale
-            r_max, r_rms = e_max / max(n_max, 3e-4), e_rms / max(n_rms, 2.5e-4)
-            worst_max, worst_rms = max(worst_max, (r_max, k)), max(worst_rms, (r_rms, k))
+            rows.append((e_max / max(n_max, 3e-4), e_rms / max(n_rms, 2.5e-4), k, e_max, n_max, e_rms, n_rms))
             if e_max > max(3e-3, 10 * n_max) or e_rms > max(1e-3, 4 * n_rms):
                 bad.append((k, e_max, n_max, e_rms, n_rms))
+        rows.sort(reverse=True)
         with capsys.disabled():
-            print(f"\n[{name} 256 grads] {len(g64)} tensors; worst max-error ratio to the oracle's own fp32 noise {worst_max[0]:.2f} "
-                  f"({worst_max[1]}), worst RMS ratio {worst_rms[0]:.2f} ({worst_rms[1]})")
+            print(f"\n[{name} 256 grads] {len(g64)} tensors; error vs the fp64 gradient relative to the oracle's own fp32 noise "
+                  f"(max of fp32-vs-fp64 and a 1-ulp input perturbation); worst tensors:")
+            for r in rows[:8]:
+                print(f"   max-ratio {r[0]:7.2f}  rms-ratio {r[1]:6.2f}  {r[2]:60s} e_max {r[3]:.2e} n_max {r[4]:.2e} e_rms {r[5]:.2e} n_rms {r[6]:.2e}")
         assert not bad, bad[:5]
         assert len(g64) >= 100
 
@@ -354,3 +363,46 @@ def test_gemm_arithmetic_modes_accuracy_gpu(capsys):
                 assert errs[(mode, name)][1] <= 2.0 * base_rms + 1e-9, (mode, name, errs[(mode, name)], errs[(0, name)])
                 assert errs[(mode, name)][0] <= 3.0 * base_max + 1e-9, (mode, name, errs[(mode, name)], errs[(0, name)])
             assert errs[(3, name)][0] <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["XceptionTextSegment", "TextSegament"])
+def test_demo_end_to_end_gpu(name, tmp_path):
+    """n2: examples/demo_segmentation.py end to end on a synthetic tile (Examples/demo_segmentation.py:17-70): a
+    checkpoint in the public format (a plain ``state_dict`` saved with ``torch.save``; here with one foreign key and one
+    wrongly-shaped entry, as after a head change) goes through the tolerant loader; EvaluateSet pads / normalises; the
+    net runs on the GPU; sigmoid > 0.5, 3x3 max-pool, un-pad + resize give the mask.  Checked against the CPU oracle
+    run on the very same network input (pixels within rounding distance of the threshold may flip: <= 0.5 %)."""
+    import importlib.util
+    from PIL import Image
+    from text_segmentation_image_inpainting_amd.Dataloader import EvaluateSet
+    from text_segmentation_image_inpainting_amd.synthetic import manga_tile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("demo", os.path.join(root, "examples", "demo_segmentation.py"))
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    keys = json.load(open(os.path.join(GOLD, "seg_state_dict_keys.json")))[name]
+    sd = make_state_dict([(k, s) for k, s in keys], seed=51, gain=1.0)
+    ckpt = dict(sd)
+    ckpt["classifier.weight"] = torch.zeros(3)                                   # not in the model: reported, skipped
+    ckpt[keys[0][0]] = torch.zeros(1)                                            # wrong shape: reported, skipped
+    torch.save(ckpt, tmp_path / "ckpt.pt")
+    tile = (manga_tile(200, np.random.default_rng(3)).transpose(1, 2, 0) * 255).astype(np.uint8)
+    Image.fromarray(tile).save(tmp_path / "tile.png")
+    with BACKENDS["gpu"]() as dev:
+        torch.manual_seed(0)
+        model = getattr(T, name)()
+        fill_state_dict_(model.state_dict(), seed=51, gain=1.0)               # what the skipped entry keeps
+        unknown, failed = model.load_state_dict(torch.load(tmp_path / "ckpt.pt", map_location="cpu"))
+        assert unknown == ["classifier.weight"] and failed == [keys[0][0]]
+        model = model.to(dev).eval()
+        evalset = EvaluateSet(mean=[0.4935, 0.4563, 0.4544], std=[0.3769, 0.3615, 0.3566], img_folder=str(tmp_path), resize=256)
+        item = evalset[0]
+        mask = demo.process(model, item, dev)
+        (img, origin, unpadder), fname = item
+        assert os.path.exists(fname + "_mask.jpg") and os.path.exists(fname + "_contour.jpg")
+        assert tuple(mask.shape[-2:]) == tuple(origin.shape[-2:]) and set(torch.unique(mask).tolist()) <= {0.0, 1.0}
+        with torch.no_grad():
+            ref_logits = S.SEG_MODELS[name](sd, img, training=False)
+        ref = unpadder(demo.max_pool3x3_binary((ref_logits > 0)).byte()).float()
+        assert float((ref != mask).float().mean()) <= 5e-3

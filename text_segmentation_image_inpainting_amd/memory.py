@@ -50,7 +50,9 @@ class _Segment(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
-        xin = x.detach().requires_grad_(True)
+        # the recomputation sees the input exactly as the first pass did (a data tensor stays a data tensor: kernels
+        # may pick a different -- equally valid, differently rounded -- form when an input gradient is wanted)
+        xin = x.detach().requires_grad_(ctx.needs_input_grad[1])
         with torch.enable_grad(), _recompute_pass():
             y = ctx.run(xin)
         torch.autograd.backward(y, gy)
