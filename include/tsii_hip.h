@@ -49,6 +49,8 @@ const char* tsii_last_error(void);
  *               <= 2^-23 |a*b|, i.e. fp32-class results at 2.7x the matrix-core rate of the f32-input MFMA;
  *   8           the same with the two 2^-24 cross terms as well (only the 2^-32 term is dropped): 2x the f32 MFMA rate;
  *   3           2 pieces / 3 partial products (error <= 2^-15 |a*b|): inference-grade, opt-in;
+ *   1           operands rounded to bf16, one product (fp32 accumulation, fp32 storage everywhere else): the "mixed bf16"
+ *               arithmetic of BASELINE config 5, tolerance 1e-2 class, opt-in;
  *   0           v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chain).
  * The environment variable TSII_GEMM_PRODUCTS sets the initial value.  inputs/outputs are fp32 in every mode. */
 int tsii_set_gemm_products(int products);

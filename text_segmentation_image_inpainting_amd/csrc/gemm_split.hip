@@ -189,22 +189,24 @@ __device__ __forceinline__ void split_store_pre(unsigned char* __restrict__ S, c
 }
 
 // PRODUCTS = 8 / 6 -> 3 planes, 3 -> 2 planes.  Order of the partial products (smallest first):
-//   8: (2,1) (1,2) (2,0) (1,1) (0,2) (1,0) (0,1) (0,0)   6: the last six of those   3: (1,0) (0,1) (0,0)
+//   8: (2,1) (1,2) (2,0) (1,1) (0,2) (1,0) (0,1) (0,0)   6: the last six of those   3: (1,0) (0,1) (0,0)   1: (0,0) = plain bf16 operands
 template <int PRODUCTS>
 struct SplitTerm {
     static __device__ __forceinline__ constexpr int pa(int q) {
+        if (PRODUCTS == 1) return 0;
         if (PRODUCTS == 3) return q == 0 ? 1 : 0;
         const int qq = q + (8 - PRODUCTS);      // index into the 8-term order
         return qq == 0 ? 2 : qq == 1 ? 1 : qq == 2 ? 2 : qq == 3 ? 1 : qq == 4 ? 0 : qq == 5 ? 1 : 0;
     }
     static __device__ __forceinline__ constexpr int pb(int q) {
+        if (PRODUCTS == 1) return 0;
         if (PRODUCTS == 3) return q == 1 ? 1 : 0;
         const int qq = q + (8 - PRODUCTS);
         return qq == 0 ? 1 : qq == 1 ? 2 : qq == 2 ? 0 : qq == 3 ? 1 : qq == 4 ? 2 : qq == 5 ? 0 : qq == 6 ? 1 : 0;
     }
 };
 template <int PRODUCTS>
-struct SplitPlanes { static constexpr int value = PRODUCTS == 3 ? 2 : 3; };
+struct SplitPlanes { static constexpr int value = PRODUCTS == 1 ? 1 : PRODUCTS == 3 ? 2 : 3; };
 
 template <int WM, int WN, int TM, int TN, int PRODUCTS, bool BNIN, bool BNB, bool BPRE>
 __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_split_kernel(const float* __restrict__ A, int64_t lda, RowScale as,
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_
     constexpr int P = SplitPlanes<PRODUCTS>::value;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per block");
-    static_assert(PRODUCTS == 8 || PRODUCTS == 6 || PRODUCTS == 3, "8 / 6 (fp32 class) or 3 partial products");
+    static_assert(PRODUCTS == 8 || PRODUCTS == 6 || PRODUCTS == 3 || PRODUCTS == 1, "8 / 6 (fp32 class), 3 or 1 partial products");
     constexpr int OP_FLOATS = P * (BM + BN) * 16;                 // operand image: P planes x rows x 64 bytes
     constexpr int EP_FLOATS = WM * 32 * (BN + 4);                 // epilogue band
     constexpr int SMEM_FLOATS = OP_FLOATS > EP_FLOATS ? OP_FLOATS : EP_FLOATS;
@@ -573,7 +575,7 @@ static int env_products() {
     const char* e = getenv("TSII_GEMM_PRODUCTS");
     if (e == nullptr) return 6;
     const int v = atoi(e);
-    return (v == 0 || v == 3 || v == 6 || v == 8) ? v : 6;
+    return (v == 0 || v == 1 || v == 3 || v == 6 || v == 8) ? v : 6;
 }
 static int g_products = env_products();
 static int g_abl = getenv("TSII_GEMM_ABL") ? atoi(getenv("TSII_GEMM_ABL")) : 0;     // tools/gemm_bench.py ablations only
@@ -613,7 +615,7 @@ bool nt_split_ok(const float* A, int64_t lda, const float* B, int64_t ldb, int K
     return g_products != 0 && K % 8 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) && aligned16(B);
 }
 
-size_t nt_split_ws_bytes(int n, int k) { return (size_t)3 * n * k * sizeof(unsigned short) + 16; }
+size_t nt_split_ws_bytes(int n, int k) { return (size_t)3 * n * k * sizeof(unsigned short) + 16; }   // 3 planes (fewer in modes 1 / 3)
 
 // B = fp32 [N,K] (b_transposed: fp32 [K,N], i.e. the weight as stored, for dX).  With a workspace of nt_split_ws_bytes(N, K)
 // the weights are split into bf16 planes once (split_w_kernel) and every block stages them as plain copies; without one
@@ -626,7 +628,8 @@ int launch_nt_split(const float* A, int64_t lda, RowScale as, const float* B, in
         unsigned short* planes = reinterpret_cast<unsigned short*>((reinterpret_cast<uintptr_t>(wsplit) + 15) & ~(uintptr_t)15);
         const int rows_in = b_transposed ? K : N, cols_in = b_transposed ? N : K;
         const unsigned g = stream_grid((int64_t)N * K, 256);
-        if (g_products == 3) hipLaunchKernelGGL(split_w_kernel<2>, dim3(g), dim3(256), 0, stream, B, rows_in, cols_in, b_transposed ? 1 : 0, planes);
+        if (g_products == 1) hipLaunchKernelGGL(split_w_kernel<1>, dim3(g), dim3(256), 0, stream, B, rows_in, cols_in, b_transposed ? 1 : 0, planes);
+        else if (g_products == 3) hipLaunchKernelGGL(split_w_kernel<2>, dim3(g), dim3(256), 0, stream, B, rows_in, cols_in, b_transposed ? 1 : 0, planes);
         else hipLaunchKernelGGL(split_w_kernel<3>, dim3(g), dim3(256), 0, stream, B, rows_in, cols_in, b_transposed ? 1 : 0, planes);
         int rc = check_launch("split_w");
         if (rc) return rc;
@@ -637,7 +640,8 @@ int launch_nt_split(const float* A, int64_t lda, RowScale as, const float* B, in
         TSII_REQUIRE(!b_transposed, "gemm_nt_split: a transposed B needs the split workspace");
     }
 #define TSII_NT_SPLIT(WM, WN, TM, TN) \
-    (g_products == 8 ? launch_nt_split_cfg<WM, WN, TM, TN, 8>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, bpre, stream) \
+    (g_products == 1 ? launch_nt_split_cfg<WM, WN, TM, TN, 1>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, bpre, stream) \
+     : g_products == 8 ? launch_nt_split_cfg<WM, WN, TM, TN, 8>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, bpre, stream) \
      : g_products == 3 ? launch_nt_split_cfg<WM, WN, TM, TN, 3>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, bpre, stream) \
                        : launch_nt_split_cfg<WM, WN, TM, TN, 6>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, bpre, stream))
     if (N % 128 == 0 || N > 192) return TSII_NT_SPLIT(2, 2, 2, 2);
@@ -661,8 +665,8 @@ int launch_tn_split(const float* A, int64_t lda, const float* sa, const float* B
     if (ib.sc != nullptr) TSII_REQUIRE(aligned16(ib.sc) && aligned16(ib.sh), "gemm_tn_split: input BatchNorm needs 16-byte aligned scale / shift");
 #define TSII_TN_SPLIT(TMV, TNV, PR, BNV) hipLaunchKernelGGL((gemm_tn_split_kernel<2, 2, TMV, TNV, PR, BNV>), grid, dim3(256), 0, stream, A, lda, sa, B, ldb, sb, Cws, M, Pn, Q, chunk, ib, qt, pt)
 #define TSII_TN_SPLIT_T(PR, BNV) do { if (tile == 0) TSII_TN_SPLIT(2, 2, PR, BNV); else if (tile == 1) TSII_TN_SPLIT(2, 1, PR, BNV); else TSII_TN_SPLIT(1, 1, PR, BNV); } while (0)
-    if (ib.sc != nullptr) { if (g_products == 8) TSII_TN_SPLIT_T(8, true); else if (g_products == 3) TSII_TN_SPLIT_T(3, true); else TSII_TN_SPLIT_T(6, true); }
-    else { if (g_products == 8) TSII_TN_SPLIT_T(8, false); else if (g_products == 3) TSII_TN_SPLIT_T(3, false); else TSII_TN_SPLIT_T(6, false); }
+    if (ib.sc != nullptr) { if (g_products == 1) TSII_TN_SPLIT_T(1, true); else if (g_products == 8) TSII_TN_SPLIT_T(8, true); else if (g_products == 3) TSII_TN_SPLIT_T(3, true); else TSII_TN_SPLIT_T(6, true); }
+    else { if (g_products == 1) TSII_TN_SPLIT_T(1, false); else if (g_products == 8) TSII_TN_SPLIT_T(8, false); else if (g_products == 3) TSII_TN_SPLIT_T(3, false); else TSII_TN_SPLIT_T(6, false); }
 #undef TSII_TN_SPLIT_T
 #undef TSII_TN_SPLIT
     return check_launch("gemm_tn_split");
@@ -671,7 +675,7 @@ int launch_tn_split(const float* A, int64_t lda, const float* sa, const float* B
 }  // namespace tsii
 
 extern "C" int tsii_set_gemm_products(int products) {
-    TSII_REQUIRE(products == 0 || products == 3 || products == 6 || products == 8, "set_gemm_products: 0 (f32 MFMA), 3, 6 or 8 (split bf16)");
+    TSII_REQUIRE(products == 0 || products == 1 || products == 3 || products == 6 || products == 8, "set_gemm_products: 0 (f32 MFMA), 1 (bf16 operands), 3, 6 or 8 (split bf16)");
     tsii::g_products = products;
     return 0;
 }

@@ -18,11 +18,20 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--pixel-shuffle", action="store_true", help="TextSegament with the Conv(128,16)+PixelShuffle(4) head (cfg 3, SURVEY.md F3)")
+    ap.add_argument("--checkpoint", action="store_true", help="recompute the encoder stages in backward (memory saver)")
+    ap.add_argument("--products", type=int, default=-1, help="tsii_set_gemm_products (default: library default)")
     args = ap.parse_args()
     import text_segmentation_image_inpainting_amd as T
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    m = getattr(T, args.model)().to(dev).train()
+    from text_segmentation_image_inpainting_amd import _lib
+    if args.products >= 0:
+        _lib.lib().tsii_set_gemm_products(args.products)
+    kw = {"pixel_shuffle_head": True} if (args.pixel_shuffle and args.model == "TextSegament") else {}
+    m = getattr(T, args.model)(**kw).to(dev).train()
+    if args.checkpoint and hasattr(m, "checkpoint_encoder"):
+        m.checkpoint_encoder = True
     x = torch.randn(args.batch, 3, args.size, args.size, device=dev)
     t = (torch.rand(args.batch, 1, args.size, args.size, device=dev) > 0.9).float()
     lossf = T.BinaryFocalLoss(0, 1, 2)
@@ -35,7 +44,8 @@ def main():
         loss.backward()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print(f"{args.model} {args.size}x{args.size} bs{args.batch}: {dt * 1e3:.1f} ms/step, {args.batch / dt:.1f} img/s, "
+    print(f"{args.model}{' +pixel-shuffle head' if kw else ''}{' +checkpointed encoder' if args.checkpoint else ''} products={_lib.lib().tsii_get_gemm_products()} "
+          f"{args.size}x{args.size} bs{args.batch}: {dt * 1e3:.1f} ms/step, {args.batch / dt:.1f} img/s, "
           f"loss {loss.item():.4f}, peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 
 
