@@ -90,10 +90,11 @@ def test_golden_pir_blocks(backend):
 
 @both_backends
 def test_golden_pir_blocks_all_batchnorm_fusions(backend, monkeypatch):
-    """The PartialInvertedResidual fixtures again with the opt-in point-wise K6c form (BatchNorm-backward reductions in
-    the dX GEMM epilogue) switched on, so every fused BatchNorm entry point is held to the reference-generated grads."""
+    """The PartialInvertedResidual fixtures again with the point-wise K6c form (BatchNorm-backward reductions in the dX
+    GEMM epilogue, the default) switched off, so both forms of every fused BatchNorm entry point are held to the
+    reference-generated grads."""
     from text_segmentation_image_inpainting_amd import ops
-    monkeypatch.setattr(ops, "FUSE_BN_BWD_PW", True)
+    monkeypatch.setattr(ops, "FUSE_BN_BWD_PW", False)       # the default takes the GEMM-epilogue form; here: without it
     test_golden_pir_blocks.__wrapped__(backend) if hasattr(test_golden_pir_blocks, "__wrapped__") else test_golden_pir_blocks(backend)
 
 

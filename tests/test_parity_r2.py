@@ -20,7 +20,7 @@ from oracle import pconv_oracle as O
 from oracle import seg_oracle as S
 from oracle.filler import fill_state_dict_, make_state_dict
 from tests.backends import BACKENDS, both_backends
-from tests.util import assert_close
+from tests.util import assert_close, rel_err
 
 TOL = 1e-3
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -77,34 +77,52 @@ def test_depthwise_large_dilation_taps_in_range(backend):
             assert_close(m.feature_conv.weight.grad, w.grad, TOL, f"pconv dw d={d} dw")
 
 
-def _rfb_case(dev, hw, cin, cout, seed):
+def _rfb_case(dev, hw, cin, cout, seed, report=False):
+    """RFB forward / dX / every parameter gradient vs the oracle.  Train-mode BatchNorm over few samples makes some of
+    these gradients ill-conditioned (at TextSegament's channel counts the oracle's own fp32 run is 1.3e-2 away from its
+    fp64 run in dX), so the target is the fp64 oracle and the tolerance per tensor is max(floor, 4x the oracle's
+    fp32-vs-fp64 discrepancy)."""
     act = torch.nn.LeakyReLU(0.3)
     m = T.RFB(cin, cout, activation=act, add_sece=True)
     fill_state_dict_(m.state_dict(), seed=seed)
-    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    for k, v in sd.items():
-        if v.dtype.is_floating_point and "running" not in k:
-            v.requires_grad_(True)
     rng = np.random.default_rng(seed)
     x = torch.from_numpy(rng.standard_normal((2, cin, hw, hw)).astype(np.float32))
-    xo = x.clone().requires_grad_(True)
-    yo = S.rfb(sd, "", xo, cout, O.leaky(0.3), True)
-    gy = torch.from_numpy(rng.standard_normal(tuple(yo.shape)).astype(np.float32))
-    yo.backward(gy)
+    gy = torch.from_numpy(rng.standard_normal((2, cout, hw, hw)).astype(np.float32))
+
+    def oracle(dtype):
+        sd = {k: (v.detach().clone().to(dtype) if v.dtype.is_floating_point else v.clone()) for k, v in m.state_dict().items()}
+        for k, v in sd.items():
+            if v.dtype.is_floating_point and "running" not in k:
+                v.requires_grad_(True)
+        xo = x.to(dtype).clone().requires_grad_(True)
+        yo = S.rfb(sd, "", xo, cout, O.leaky(0.3), True)
+        yo.backward(gy.to(dtype))
+        return yo.detach(), xo.grad, {k: v.grad for k, v in sd.items() if v.grad is not None}
+
+    y32, dx32, g32 = oracle(torch.float32)
+    y64, dx64, g64 = oracle(torch.float64)
     m = m.to(dev).train()
     xd = x.to(dev).requires_grad_(True)
     y = m(xd)
-    assert_close(y, yo, TOL, f"RFB {hw}x{hw} y")
+    assert_close(y, y64, max(TOL, 4 * rel_err(y32, y64)), f"RFB {hw}x{hw} y")
     y.backward(gy.to(dev))
-    assert_close(xd.grad, xo.grad, 2e-3, f"RFB {hw}x{hw} dx")
+    assert_close(xd.grad, dx64, max(2e-3, 4 * rel_err(dx32, dx64)), f"RFB {hw}x{hw} dx")
     params = dict(m.named_parameters())
-    gmax = max(float(v.grad.abs().max()) for k, v in sd.items() if v.grad is not None)
-    n = 0
-    for k, v in sd.items():
-        if v.grad is not None:
-            assert_close(params[k].grad, v.grad, 3e-3, f"RFB {hw}x{hw} grad {k}", floor=1e-3 * gmax)
-            n += 1
-    assert n >= 20
+    gmax = max(float(v.abs().max()) for v in g64.values())
+    rows = []
+    for k, ref in g64.items():
+        floor = 1e-3 * gmax
+        noise = rel_err(g32[k], ref, floor)
+        e = rel_err(params[k].grad, ref, floor)
+        rows.append((e / max(noise, 7.5e-4), k, e, noise))
+    rows.sort(reverse=True)
+    if report:
+        print(f"\n[RFB {cin}->{cout} {hw}x{hw}] dx err {rel_err(xd.grad, dx64):.2e} (oracle fp32-vs-fp64 {rel_err(dx32, dx64):.2e}); worst gradient tensors:")
+        for r in rows[:6]:
+            print(f"   ratio {r[0]:6.2f}  {r[1]:40s} err {r[2]:.2e}  oracle fp32 noise {r[3]:.2e}")
+    for ratio, k, e, noise in rows:
+        assert e <= max(3e-3, 4 * noise), f"RFB {hw}x{hw} grad {k}: {e:.2e} vs fp32 noise {noise:.2e}"
+    assert len(rows) >= 20
 
 
 def test_rfb_32x32_emu():
@@ -114,12 +132,12 @@ def test_rfb_32x32_emu():
 
 
 @pytest.mark.gpu
-def test_rfb_64x64_gpu():
+def test_rfb_64x64_gpu(capsys):
     """RFB at cfg 3's 64x64 map: every branch dilation (5 / 17 / 29) has live off-centre taps."""
-    with BACKENDS["gpu"]() as dev:
+    with BACKENDS["gpu"]() as dev, capsys.disabled():
         _rfb_case(dev, 64, 64, 32, seed=1401)
         _rfb_case(dev, 32, 48, 16, seed=1402)
-        _rfb_case(dev, 32, 1344, 256, seed=1403)      # TextSegament's own RFB (in 1344, out 256) on cfg 1's 32x32 map
+        _rfb_case(dev, 32, 1344, 256, seed=1403, report=True)      # TextSegament's own RFB (in 1344, out 256) on cfg 1's 32x32 map
 
 
 @pytest.mark.gpu
@@ -385,7 +403,7 @@ def test_demo_end_to_end_gpu(name, tmp_path):
     sd = make_state_dict([(k, s) for k, s in keys], seed=51, gain=1.0)
     ckpt = dict(sd)
     ckpt["classifier.weight"] = torch.zeros(3)                                   # not in the model: reported, skipped
-    ckpt[keys[0][0]] = torch.zeros(1)                                            # wrong shape: reported, skipped
+    ckpt[keys[0][0]] = torch.zeros(5, 7)                                         # incompatible shape: reported, skipped
     torch.save(ckpt, tmp_path / "ckpt.pt")
     tile = (manga_tile(200, np.random.default_rng(3)).transpose(1, 2, 0) * 255).astype(np.uint8)
     Image.fromarray(tile).save(tmp_path / "tile.png")

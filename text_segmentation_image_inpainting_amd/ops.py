@@ -18,12 +18,11 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3, 4
 import os as _os
 
 # A/B knobs for K6c (BatchNorm-backward reductions taken by the kernel that produces the incoming gradient):
-# TSII_FUSE_BN_BWD = 0 off | 1 (default) in the depth-wise dX strip kernel | 2 also in the point-wise dX GEMM epilogue.
-# Measured on MI355X (ImageFill 512^2 bs 32): 107.8 -> 106.0 ms with 1, 105.6 ms with 2 -- the GEMM form saves 3.3 ms of
-# BatchNorm backward for 2.4 ms of extra epilogue (it runs at 2 blocks/CU) and drags the dominant kernel's MFMA
-# fraction down 3 points for 0.4 ms, so it stays opt-in.
-FUSE_BN_BWD = _os.environ.get("TSII_FUSE_BN_BWD", "1") != "0"
-FUSE_BN_BWD_PW = _os.environ.get("TSII_FUSE_BN_BWD", "1") == "2"
+# TSII_FUSE_BN_BWD = 0 off | 1 in the depth-wise dX strip kernel only | 2 (default) also in the point-wise dX GEMM epilogue.
+# Measured on MI355X (ImageFill 512^2 bs 32, split-bf16 GEMMs): 2 vs 1 = BatchNorm backward 19.9 -> 16.3 ms for +2.0 ms of
+# GEMM epilogue (the raw BatchNorm input is read alongside the store): 90.5 -> 89.3 ms per step.
+FUSE_BN_BWD = _os.environ.get("TSII_FUSE_BN_BWD", "2") != "0"
+FUSE_BN_BWD_PW = _os.environ.get("TSII_FUSE_BN_BWD", "2") == "2"
 # A/B knob for K4b (stems as a space-to-depth stride-1 conv on the vector-gather GEMM)
 USE_STEM_S2D = _os.environ.get("TSII_STEM_S2D", "1") != "0"
 
