@@ -554,8 +554,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     }
 }
 
-// dW partials: persistent block of 320 threads; thread k owns im2col column(s) k, k + 320 (= (tap, ci)) x NCO
-// output channels in registers and walks the pixels of each tile (x from LDS, dy*inv broadcast from LDS)
+// dW partials: persistent block of 320 threads.  Thread (ci = tid % CP, strip = tid / CP) owns input channel ci and the
+// output rows of its strip, with all 9 taps x NCO output channels (27 / 36 accumulators) in registers.  Per 8-pixel row
+// segment it pulls a 3 x 10 window of x (30 ds_read_b32, consecutive lanes = consecutive channels: conflict free) and the
+// 8 dy*inv pixels (8 ds_read_b128, broadcast within the strip) and issues 9 x 8 x NCO FMAs: ~6 FMAs per LDS read.
+// (The first version gave every thread one im2col column and walked the pixels: 1 ds_read_b32 + 1 broadcast b128 per 3
+// FMAs -- LDS-issue bound at 9 % of the HBM roofline, 2.4 ms for ImageFill's 35 -> 3 head.)
 template <int CG, int NCO>
 __global__ __launch_bounds__(320) void head_dw_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
                                                       const float* __restrict__ x, RowScale rs, ConvGeom g,
@@ -563,24 +567,18 @@ __global__ __launch_bounds__(320) void head_dw_kernel(const float* __restrict__ 
     using H = Head<CG>;
     __shared__ __attribute__((aligned(16))) float tile[H::TILE];
     __shared__ __attribute__((aligned(16))) float side[H::SIDE];
-    constexpr int NP = (9 * H::CP + 319) / 320;
-    const int KK = 9 * g.cin;
-    const int nq = (KK + 319) / 320;
+    constexpr int CP = H::CP, NS = 320 / CP, RPS = H::TH / NS, W = 8;
+    static_assert(NS >= 1 && H::TH % NS == 0 && H::TW % W == 0, "strip geometry");
+    static_assert(NS * 9 * NCO * CP <= H::TILE, "strip reduction must fit the patch LDS");
     const int ntx = (g.wo + H::TW - 1) / H::TW, nty = (g.ho + H::TH - 1) / H::TH;
     const int total_tiles = g.n * nty * ntx;
-    int toff[NP], tci[NP], tt[NP];
+    const int ci = threadIdx.x % CP, strip = threadIdx.x / CP;
+    const bool worker = strip < NS;
+    float acc[9][NCO];
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        const int k = threadIdx.x + 320 * q;
-        tt[q] = k < KK ? k / g.cin : 0;
-        tci[q] = k < KK ? k % g.cin : 0;
-        toff[q] = ((tt[q] / 3) * H::PW + tt[q] % 3) * H::CP + tci[q];
-    }
-    float acc[NP][NCO];
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int q = 0; q < NP; ++q)
-#pragma unroll
-        for (int e = 0; e < NCO; ++e) acc[q][e] = 0.f;
+        for (int e = 0; e < NCO; ++e) acc[t][e] = 0.f;
     const int t_beg = blockIdx.x * tiles_per_block;
     const int t_end = t_beg + tiles_per_block < total_tiles ? t_beg + tiles_per_block : total_tiles;
     for (int tl = t_beg; tl < t_end; ++tl) {
@@ -603,30 +601,49 @@ __global__ __launch_bounds__(320) void head_dw_kernel(const float* __restrict__ 
         __syncthreads();                               // patch ready, mask planes dead
         if (threadIdx.x < H::NPX) *reinterpret_cast<float4*>(side + threadIdx.x * 4) = make_float4(gv[0], gv[1], gv[2], gv[3]);
         __syncthreads();
-        for (int py = 0; py < H::TH; ++py) {
-#pragma unroll 8
-            for (int px = 0; px < H::TW; ++px) {
-                const float4 gq = *reinterpret_cast<const float4*>(side + (py * H::TW + px) * 4);
-                const float gg[4] = {gq.x, gq.y, gq.z, gq.w};
-                const int base = (py * H::PW + px) * H::CP;
+        if (worker) {
 #pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    if (q >= nq) break;
-                    const float xv = tile[base + toff[q]];
+            for (int r = 0; r < RPS; ++r) {
+                const int py = strip * RPS + r;
+#pragma unroll 1
+                for (int px0 = 0; px0 < H::TW; px0 += W) {
+                    float xr[3][W + 2];
 #pragma unroll
-                    for (int e = 0; e < NCO; ++e) acc[q][e] = fmaf(xv, gg[e], acc[q][e]);
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int j = 0; j < W + 2; ++j) xr[ky][j] = tile[((py + ky) * H::PW + px0 + j) * CP + ci];
+#pragma unroll
+                    for (int j = 0; j < W; ++j) {
+                        const float4 gq = *reinterpret_cast<const float4*>(side + (py * H::TW + px0 + j) * 4);
+                        const float gg[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                                for (int e = 0; e < NCO; ++e) acc[ky * 3 + kx][e] = fmaf(xr[ky][j + kx], gg[e], acc[ky * 3 + kx][e]);
+                    }
                 }
             }
         }
     }
+    // strips -> one partial per block: red[(strip * 9*NCO + t*NCO + e) * CP + ci]
+    __syncthreads();
+    if (worker) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < NCO; ++e) tile[((strip * 9 + t) * NCO + e) * CP + ci] = acc[t][e];
+    }
+    __syncthreads();
     float* pz = part + (int64_t)blockIdx.x * g.cout * g.cin * 9;
+    for (int k = threadIdx.x; k < 9 * NCO * CP; k += 320) {
+        const int c = k % CP, e = (k / CP) % NCO, t = k / (CP * NCO);
+        if (c >= g.cin || e >= g.cout) continue;
+        float a = 0.f;
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        const int k = threadIdx.x + 320 * q;
-        if (k >= KK) break;
-#pragma unroll
-        for (int e = 0; e < NCO; ++e)
-            if (e < g.cout) pz[((int64_t)e * g.cin + tci[q]) * 9 + tt[q]] = acc[q][e];
+        for (int sidx = 0; sidx < NS; ++sidx) a += tile[((sidx * 9 + t) * NCO + e) * CP + c];
+        pz[((int64_t)e * g.cin + c) * 9 + t] = a;
     }
 }
 
