@@ -151,8 +151,8 @@ def test_seg_nets_256_vs_oracle_gpu(name, capsys):
     (LeakyReLU kinks under train-mode BatchNorm; the RFB alone, at these channel counts, has an fp32-vs-fp64 discrepancy
     of 1.3e-2 in dX on the CPU -- the HIP RFB is at 4e-4 of the fp64 result, see test_rfb_64x64_gpu).  A kernel bug
     gives O(1) errors on the affected tensors; rounding chaos gives a heavy-tailed few-percent scatter.  The yardstick is
-    therefore the oracle's own fp32 noise per tensor (max of its fp32-vs-fp64 discrepancy and a 1-ulp input perturbation
-    run), and the bars are: every tensor within 64x (max error) / 16x (RMS) of that noise (floors 3e-3 / 1e-3), and the
+    therefore the oracle's own fp32 noise per tensor (largest deviation from the fp64 gradient over its plain fp32 run and
+    three 1-ulp input perturbation runs), and the bars are: every tensor within 64x (max error) / 16x (RMS) of that noise (floors 3e-3 / 1e-3), and the
     MEDIAN tensor within 2x -- i.e. the bulk agrees at noise level and nothing is off by more than the heavy tail
     allows.  The worst tensors are printed with their ratios."""
     keys = json.load(open(os.path.join(GOLD, "seg_state_dict_keys.json")))[name]
@@ -175,10 +175,13 @@ def test_seg_nets_256_vs_oracle_gpu(name, capsys):
 
     ye32, y32, l32, g32 = oracle(torch.float32)
     ye64, y64, l64, g64 = oracle(torch.float64)
-    # second estimate of the fp32 noise: the oracle's fp32 gradients after a 1-ulp (1e-7 relative) perturbation of the input
-    x_keep = x
-    x = x_keep * (1 + 1e-7 * torch.from_numpy(rng.standard_normal(tuple(x_keep.shape)).astype(np.float32)))
-    _, _, _, gpert = oracle(torch.float32)
+    # further samples of the fp32 noise: the oracle's fp32 gradients under 1-ulp (1e-7 relative) perturbations of the input.
+    # Measured on the CPU: the error of rfb.3.4.weight against the fp64 gradient across five such runs is
+    # 7.7e-3, 7.8e-3, 2.9e-2, 1.3e-4, 7.6e-3 -- discrete jumps (an activation crossing a LeakyReLU kink), not a smooth spread.
+    x_keep, gperts = x, []
+    for sample in range(3):
+        x = x_keep * (1 + 1e-7 * torch.from_numpy(np.random.default_rng(100 + sample).standard_normal(tuple(x_keep.shape)).astype(np.float32)))
+        gperts.append(oracle(torch.float32)[3])
     x = x_keep
     with BACKENDS["gpu"]() as dev:
         m = getattr(T, name)()
@@ -202,9 +205,9 @@ def test_seg_nets_256_vs_oracle_gpu(name, capsys):
             ours = params[k].grad.detach().cpu().double()
             scale = max(float(ref64.abs().max()), 1e-3 * gmax)
             rscale = max(float(ref64.pow(2).mean().sqrt()), 1e-3 * gmax)
-            d32, dp = g32[k].double() - ref64, gpert[k].double() - g32[k].double()
-            n_max = max(float(d32.abs().max()), float(dp.abs().max())) / scale
-            n_rms = max(float(d32.pow(2).mean().sqrt()), float(dp.pow(2).mean().sqrt())) / rscale
+            devs = [g32[k].double() - ref64] + [gp[k].double() - ref64 for gp in gperts]
+            n_max = max(float(d.abs().max()) for d in devs) / scale
+            n_rms = max(float(d.pow(2).mean().sqrt()) for d in devs) / rscale
             e_max = float((ours - ref64).abs().max()) / scale
             e_rms = float((ours - ref64).pow(2).mean().sqrt()) / rscale
             rows.append((e_max / max(n_max, 3e-4), e_rms / max(n_rms, 2.5e-4), k, e_max, n_max, e_rms, n_rms))
@@ -214,7 +217,7 @@ def test_seg_nets_256_vs_oracle_gpu(name, capsys):
         median_ratio = float(np.median([r[0] for r in rows]))
         with capsys.disabled():
             print(f"\n[{name} 256 grads] {len(g64)} tensors; error vs the fp64 gradient relative to the oracle's own fp32 noise "
-                  f"(max of fp32-vs-fp64 and a 1-ulp input perturbation); worst tensors:")
+                  f"(worst of 4 fp32 oracle runs); worst tensors:")
             for r in rows[:8]:
                 print(f"   max-ratio {r[0]:7.2f}  rms-ratio {r[1]:6.2f}  {r[2]:60s} e_max {r[3]:.2e} n_max {r[4]:.2e} e_rms {r[5]:.2e} n_rms {r[6]:.2e}")
             print(f"   median max-ratio over all tensors: {median_ratio:.2f}")

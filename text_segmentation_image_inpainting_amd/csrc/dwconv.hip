@@ -264,9 +264,11 @@ static constexpr int ST_R = 8, ST_TW = 16, ST_CB = 32;
 static constexpr int ST_UNROLL_K = ST_UNROLL;   // pixels of a thread processed together (all 4: ~150 VGPRs of LDS data in flight)
 
 // MODE 0: plain; 1: forward with BatchNorm on load and / or statistics partials (K6b; either may be off at run time);
-// 2: dX feeding a BatchNorm backward (K6c)
-template <int S, int D, int MODE, bool HI = false>
-__global__ __launch_bounds__(256, (MODE == 2 || (MODE == 1 && !HI)) ? 2 : 3) void dw_strip_kernel(
+// 2: dX feeding a BatchNorm backward (K6c).  MODE 1 / 2 need ~210 VGPRs = 2 waves per SIMD.  (Tried for MODE 1: a build capped
+// at 3 waves per SIMD with the 9 x 4 weights read from LDS per tap and one pixel in flight -- 18-20 spilled registers and
+// 17.2 -> 20.4 ms over the depth-wise kernels of a step: the plain-register form stays.)
+template <int S, int D, int MODE>
+__global__ __launch_bounds__(256, MODE != 0 ? 2 : 3) void dw_strip_kernel(
     const float* __restrict__ in, const float* __restrict__ pre, const float* __restrict__ wT, const float* __restrict__ bias,
     const float* __restrict__ denom, const float* __restrict__ keep, const float* __restrict__ post_mul, DtGeom g, int chunk_rows,
     unsigned strips_x, unsigned chunks_y, unsigned cblocks, DwBN ib, float* __restrict__ stats, DwBnBwd bb,
@@ -299,24 +301,11 @@ __global__ __launch_bounds__(256, (MODE == 2 || (MODE == 1 && !HI)) ? 2 : 3) voi
     float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool bn_in = FUSED && ib.sc != nullptr;
     if (bn_in && cok) { isc = *reinterpret_cast<const float4*>(ib.sc + c); ish = *reinterpret_cast<const float4*>(ib.sh + c); }
-    // FUSED: the 9 x 4 weights of this thread's channel group live in LDS (one ds_read_b128 per tap) instead of 36 VGPRs:
-    // with them in registers the kernel needs 209 VGPRs = 2 waves per SIMD and streams at 3.6-3.9 TB/s; at 3 waves per
-    // SIMD more loads are in flight per CU (the plain form, 154 VGPRs, streams at 5 TB/s)
-    constexpr bool WLDS = FUSED && HI;     // HI: the 3-waves-per-SIMD build of the fused forward (TSII_DW_OCC3=1; A/B on MI355X)
-    __shared__ __attribute__((aligned(16))) float wl[WLDS ? 9 * ST_CB : 4];
-    float4 w[WLDS ? 1 : 9];
+    float4 w[9];
     float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cok) {
-        if constexpr (WLDS) {
-            if (lane == 0) {
 #pragma unroll
-                for (int t = 0; t < 9; ++t)
-                    *reinterpret_cast<float4*>(wl + t * ST_CB + cg * 4) = *reinterpret_cast<const float4*>(wT + (g.flip ? 8 - t : t) * g.c + c);
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const float4*>(wT + (g.flip ? 8 - t : t) * g.c + c);
-        }
+        for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const float4*>(wT + (g.flip ? 8 - t : t) * g.c + c);
         if (bias != nullptr) bq = make_float4(bias[c], bias[c + 1], bias[c + 2], bias[c + 3]);
     }
 
@@ -422,23 +411,19 @@ __global__ __launch_bounds__(256, (MODE == 2 || (MODE == 1 && !HI)) ? 2 : 3) voi
             }
         }
         // two pixels' LDS reads in flight; K6c: fully unrolled (static yv[k]), one pixel at a time
-#pragma unroll (BNB ? NP : ((FUSED && HI) ? 1 : ST_UNROLL_K))
+#pragma unroll (BNB ? NP : ST_UNROLL_K)
         for (int k = 0; k < NP; ++k) {
             if (BNB) __builtin_amdgcn_sched_barrier(0);
             const int ty = ty0 + TYS * k;
             if (!(xok && oyb + ty < oy_end)) continue;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            int wbase = cg * 4;
-            if constexpr (WLDS) asm volatile("" : "+v"(wbase));     // opaque per pixel: keeps the weight reads from being hoisted back into 36 VGPRs
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const float* rp = ring + ((((R * s + ty) * S + ky * D) % NR) * PW + tx * S) * ST_CB + cg * 4;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const float4 v = *reinterpret_cast<const float4*>(rp + kx * D * ST_CB);
-                    float4 ww;
-                    if constexpr (WLDS) ww = *reinterpret_cast<const float4*>(wl + (ky * 3 + kx) * ST_CB + wbase);
-                    else ww = w[ky * 3 + kx];
+                    const float4 ww = w[ky * 3 + kx];
                     a.x = fmaf(v.x, ww.x, a.x); a.y = fmaf(v.y, ww.y, a.y); a.z = fmaf(v.z, ww.z, a.z); a.w = fmaf(v.w, ww.w, a.w);
                 }
             }
@@ -700,10 +685,7 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
     const bool fused = ib.sc != nullptr || stats != nullptr || bb.y != nullptr;
     if (fused && !dw_fused_ok(g.s, g.d)) return 1;
     if (bb.y != nullptr && g.s != 1) return 1;
-    static const bool occ3 = getenv("TSII_DW_OCC3") != nullptr && atoi(getenv("TSII_DW_OCC3")) != 0;
-    if (g.s == 2 && fused && occ3) hipLaunchKernelGGL((dw_strip_kernel<2, 1, 1, true>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
-                                              sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
-    else if (g.s == 2 && fused) hipLaunchKernelGGL((dw_strip_kernel<2, 1, 1>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+    if (g.s == 2 && fused) hipLaunchKernelGGL((dw_strip_kernel<2, 1, 1>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
                                               sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
     else if (g.s == 2) hipLaunchKernelGGL((dw_strip_kernel<2, 1, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
                                      sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
@@ -715,8 +697,6 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
                                           sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
     else if (bb.y != nullptr) hipLaunchKernelGGL((dw_strip_kernel<1, 1, 2>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
                                                  sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
-    else if (fused && occ3) hipLaunchKernelGGL((dw_strip_kernel<1, 1, 1, true>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
-                                       sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
     else if (fused) hipLaunchKernelGGL((dw_strip_kernel<1, 1, 1>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
                                        sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
     else hipLaunchKernelGGL((dw_strip_kernel<1, 1, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,

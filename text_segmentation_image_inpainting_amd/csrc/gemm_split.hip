@@ -644,6 +644,8 @@ int launch_nt_split(const float* A, int64_t lda, RowScale as, const float* B, in
      : g_products == 8 ? launch_nt_split_cfg<WM, WN, TM, TN, 8>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, bpre, stream) \
      : g_products == 3 ? launch_nt_split_cfg<WM, WN, TM, TN, 3>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, bpre, stream) \
                        : launch_nt_split_cfg<WM, WN, TM, TN, 6>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, bpre, stream))
+    static const int force_tile = getenv("TSII_GEMM_TILE") ? atoi(getenv("TSII_GEMM_TILE")) : 0;   // A/B knob: 1 = 128x64 tiles everywhere
+    if (force_tile == 1 && N > 32) return TSII_NT_SPLIT(2, 2, 2, 1);
     if (N % 128 == 0 || N > 192) return TSII_NT_SPLIT(2, 2, 2, 2);
     if (N > 32) return TSII_NT_SPLIT(2, 2, 2, 1);
     return TSII_NT_SPLIT(4, 1, 1, 1);
