@@ -318,11 +318,14 @@ __global__ __launch_bounds__(256, MODE != 0 ? 2 : 3) void dw_strip_kernel(
         bga = *reinterpret_cast<const float4*>(bb.gamma + c);
         bbe = *reinterpret_cast<const float4*>(bb.beta + c);
     }
-    float4 pf[PF];
-    float pm[PF];
+    // DEEP (fused forward): a second register set, so the slab of step s + 2 is in flight too (2 waves per SIMD leave the
+    // registers for it; one slab of 5 x 16 B per thread in flight does not keep HBM busy at that occupancy)
+    constexpr bool DEEP = FUSED;
+    float4 pf[PF], pf2[PF];
+    float pm[PF], pm2[PF];
     // global -> registers for ring rows [rr0, rr0 + cnt): slab pixel p = lane + 32 i -> (row, px); wave-uniform 64-bit
     // base + 32-bit offsets
-    auto fetch = [&](int rr0, int cnt) {
+    auto fetch = [&](int rr0, int cnt, float4 (&pf)[PF], float (&pm)[PF]) {
         const int iyb = iy_base + rr0;
         const int64_t pixbase = (n * g.hin + iyb) * (int64_t)g.win + ix0;
         const float* __restrict__ src = in + pixbase * g.c + c;
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(256, MODE != 0 ? 2 : 3) void dw_strip_kernel(
         }
     };
     // registers -> ring (BatchNorm + activation of the producer, then the per-pixel plane; out-of-image stays 0)
-    auto commit = [&](int rr0, int cnt) {
+    auto commit = [&](int rr0, int cnt, const float4 (&pf)[PF], const float (&pm)[PF]) {
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             const int p = lane + LANES * i;
@@ -379,11 +382,11 @@ __global__ __launch_bounds__(256, MODE != 0 ? 2 : 3) void dw_strip_kernel(
     fetch_planes(0);
 #pragma unroll
     for (int r = 0; r < PRO; r += NEW) {               // halo rows first (more than one round for large dilations)
-        fetch(r, PRO - r < NEW ? PRO - r : NEW);
-        commit(r, PRO - r < NEW ? PRO - r : NEW);
+        fetch(r, PRO - r < NEW ? PRO - r : NEW, pf, pm);
+        commit(r, PRO - r < NEW ? PRO - r : NEW, pf, pm);
     }
-    fetch(PRO, NEW);
-    commit(PRO, NEW);
+    fetch(PRO, NEW, pf, pm);
+    commit(PRO, NEW, pf, pm);
     commit_planes(0);
     __syncthreads();
 
@@ -394,9 +397,11 @@ __global__ __launch_bounds__(256, MODE != 0 ? 2 : 3) void dw_strip_kernel(
     float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
     float vals[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int cnt = 0;
-    for (int s = 0; s < nsteps; ++s) {
+    // one step: fetch slab `fstep` into the (fpf, fpm) set, compute step s, commit slab s + 1 from the (cpf, cpm) set
+    auto do_step = [&](int s, int fstep, float4 (&fpf)[PF], float (&fpm)[PF], const float4 (&cpf)[PF], const float (&cpm)[PF]) {
         const bool more = s + 1 < nsteps;
-        if (more) { fetch(PRO + NEW * (s + 1), NEW); fetch_planes(s + 1); }   // in flight during the compute below
+        if (fstep < nsteps) fetch(PRO + NEW * fstep, NEW, fpf, fpm);          // in flight during the compute below
+        if (more) fetch_planes(s + 1);
         const int oyb = oy_beg + R * s;
         float* __restrict__ out_b = out + ((n * g.hout + oyb) * (int64_t)g.wout + ox0) * g.c + c;
         const float* __restrict__ pls = &planes[s & 1][0][0];
@@ -459,8 +464,17 @@ __global__ __launch_bounds__(256, MODE != 0 ? 2 : 3) void dw_strip_kernel(
             }
         }
         __syncthreads();                                    // every read of this step's rows is done
-        if (more) { commit(PRO + NEW * (s + 1), NEW); commit_planes(s + 1); }   // into the slots this step no longer needs
+        if (more) { commit(PRO + NEW * (s + 1), NEW, cpf, cpm); commit_planes(s + 1); }   // into the slots this step no longer needs
         __syncthreads();
+    };
+    if constexpr (DEEP) {
+        if (nsteps > 1) fetch(PRO + NEW, NEW, pf, pm);
+        for (int s = 0; s < nsteps; s += 2) {
+            do_step(s, s + 2, pf2, pm2, pf, pm);
+            if (s + 1 < nsteps) do_step(s + 1, s + 3, pf, pm, pf2, pm2);
+        }
+    } else {
+        for (int s = 0; s < nsteps; ++s) do_step(s, s + 1, pf, pm, pf, pm);
     }
     if (bnb) {
         float* mrg = ring;                                   // [256][8]
