@@ -109,8 +109,10 @@ def test_pointwise_fused_batchnorm(emu, mode, M, K, N, act, slope):
     rows = L.tsii_pw_stat_rows(M)
     part = np.zeros((rows, 4, N), np.float32)
     y = np.zeros((M, N), np.float32)
+    wws = np.zeros(L.tsii_pw_ws_bytes(N, K) // 4 + 4, np.float32)        # pre-split weights (None: split while staging)
+    use_ws = (M + N) % 2 == 0
     assert L.tsii_pw_fwd_bn(P(xr), M, K, P(w), N, P(b), P(r0), K, None, P(denom), P(keep), P(sc), P(sh), act, slope,
-                            P(part), P(y), None, 0, None) == 0, L.tsii_last_error()
+                            P(part), P(y), P(wws) if use_ws else None, wws.nbytes if use_ws else 0, None) == 0, L.tsii_last_error()
     ref = (am @ w.T.astype(np.float64) / denom[:, None] + b) * keep[:, None]
     assert np.abs(y - ref).max() <= tol * np.abs(ref).max()
     # statistics of y from the partials

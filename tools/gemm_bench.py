@@ -75,6 +75,13 @@ def main():
         if args.only in ("", "fwd"):
             t = timeit(lambda: call("tsii_pw_fwd", ptr(x), M, K, ptr(w), N, None, ptr(r0), split, ptr(r1), ptr(denom), None, ptr(y), ptr(wws), wws.numel() * 4, st))
             res.append(f"fwd {t:7.3f} ms {fl / t / 1e9:6.1f} TF/s {4.0 * M * (K + N) / t / 1e9:5.2f} TB/s")
+        if args.only in ("", "fwdbn"):      # forward with the producer's BatchNorm + LeakyReLU applied on load and the statistics epilogue
+            sc = torch.rand(K, device=dev) + 0.5
+            sh = torch.randn(K, device=dev)
+            part = torch.empty(L.tsii_pw_stat_rows(M), 4, N, device=dev)
+            t = timeit(lambda: call("tsii_pw_fwd_bn", ptr(x), M, K, ptr(w), N, None, ptr(r0), split, ptr(r1), ptr(denom), None, ptr(sc), ptr(sh), 2, 0.3,
+                                    ptr(part), ptr(y), ptr(wws), wws.numel() * 4, st))
+            res.append(f"fwdbn {t:7.3f} ms {fl / t / 1e9:6.1f} TF/s {4.0 * M * (K + N) / t / 1e9:5.2f} TB/s")
         if args.only in ("", "dx"):
             t = timeit(lambda: call("tsii_pw_bwd_dx", ptr(dy), M, N, ptr(w), K, ptr(inv), ptr(r0), split, ptr(r1), ptr(dx), ptr(wt), st))
             res.append(f"dx {t:7.3f} ms {fl / t / 1e9:6.1f} TF/s {4.0 * M * (K + N) / t / 1e9:5.2f} TB/s")
