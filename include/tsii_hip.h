@@ -222,10 +222,11 @@ int tsii_bn_finalize(const float* stat_part, int64_t rows, int c, int64_t m,
                      const float* gamma, const float* beta, float eps, float* scale, float* shift,
                      void* ws, size_t ws_bytes, void* stream);
 /* ---- K6c: the two reductions of the BatchNorm backward taken by the kernel that PRODUCES its incoming gradient.
- * tsii_dw_bwd_dx_bn: depth-wise dX (stride 1, 3x3, marching-strip path: tsii_dw_stat_rows(n,h,wd,c,...) > 0 rows) whose
- *   output dx is the gradient w.r.t. a = act(BN(bn_y)), bn_y being the raw [n,h,wd,c] tensor the depth-wise conv consumed
+ * tsii_dw_bwd_dx_bn: depth-wise dX (3x3; stride 1 / dilation 1, or stride 2 / pad 1 / dilation 1: the marching-strip paths,
+ *   rows = tsii_dw_bwd_stat_rows(n,h,wd,c,...) > 0) whose output dx is the gradient w.r.t. a = act(BN(bn_y)), bn_y being the raw [n,h,wd,c] tensor the depth-wise conv consumed
  *   through its load-time BatchNorm; it also writes bwd_part[rows][2][c] = per-strip (sum dz, sum dz*xhat),
  *   dz = dx*act'(z).  tsii_bn_act_bwd_pre is tsii_bn_act_bwd without its reduction pass (ws: tsii_bn_ws_bytes(m, c)). */
+int64_t tsii_dw_bwd_stat_rows(int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw);
 int tsii_dw_bwd_dx_bn(const float* dy, const float* inv, const float* w, const float* rmask,
                       int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
                       int ho, int wo, const float* bn_y, const float* bn_mean, const float* bn_var,

@@ -49,6 +49,7 @@ SIGNATURES = {
     "tsii_pw_fwd_bn": (_i, [_p, _l, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _p, _z, _p]),
     "tsii_pw_bwd_dw_bn": (_i, [_p, _p, _l, _i, _i, _p, _p, _p, _i, _p, _p, _p, _i, _f, _p, _p, _p, _z, _p]),
     "tsii_dw_stat_rows": (_l, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "tsii_dw_bwd_stat_rows": (_l, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "tsii_dw_fwd_bn": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _i, _f, _p, _p, _p, _p]),
     "tsii_dw_bwd_dw_bn": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _i, _f, _p, _p, _p, _z, _p]),
     "tsii_dense_stat_rows": (_l, [_i, _i, _i, _i, _i, _i] + _GEOM + [_i, _i]),

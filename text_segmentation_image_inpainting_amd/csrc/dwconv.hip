@@ -537,10 +537,13 @@ __global__ __launch_bounds__(256, MODE != 0 ? 2 : 3) void dw_strip_kernel(
 // 5 x 9 dy*inv pixels a step needs (4 new dy rows per step: dy is a quarter of dx, the kernel is write-bound).  A
 // thread's pixels all have the same (row, column) parity -- rows ty0 + 2k, one column -- so its tap set is fixed: two
 // candidate taps per axis, the second one zero-weighted where the parity admits a single tap.
+// BNB (K6c): dx is the gradient w.r.t. act(bn(y)) of the raw tensor y on the same grid; sum(dz), sum(dz*xhat) per strip
+// chunk go to bb.part like in the stride-1 strip kernel.
+template <bool BNB>
 __global__ __launch_bounds__(256, 3) void dw_strip_dx2_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
                                                               const float* __restrict__ wT, const float* __restrict__ rmask,
                                                               int n_img, int h, int w_in, int c_all, int ho, int wo, int chunk_rows,
-                                                              unsigned strips_x, unsigned chunks_y, unsigned cblocks,
+                                                              unsigned strips_x, unsigned chunks_y, unsigned cblocks, DwBnBwd bb,
                                                               float* __restrict__ dx) {
     constexpr int R = 8, TW = 16, NEW = 4, PRO = 1, NR = 5, PW = 9;
     constexpr int CGS = ST_CB / 4, LANES = 256 / CGS, NP = R * TW / LANES, PF = (NEW * PW + LANES - 1) / LANES;
@@ -620,6 +623,17 @@ __global__ __launch_bounds__(256, 3) void dw_strip_dx2_kernel(const float* __res
         if (ey && ex) wBB = *reinterpret_cast<const float4*>(wT + (kyB * 3 + kxB) * c_all + c);
     }
     const int cxA = (tx + 1 - kxA) / 2, cxB = (tx + 1 - kxB) / 2;     // slab columns of the two candidates
+    float4 bmu = make_float4(0.f, 0.f, 0.f, 0.f), bis = bmu, bga = bmu, bbe = bmu;
+    float vals[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (BNB) {
+        if (cok) {
+            bmu = *reinterpret_cast<const float4*>(bb.mean + c);
+            const float4 vv = *reinterpret_cast<const float4*>(bb.var + c);
+            bis = make_float4(1.0f / sqrtf(vv.x + bb.eps), 1.0f / sqrtf(vv.y + bb.eps), 1.0f / sqrtf(vv.z + bb.eps), 1.0f / sqrtf(vv.w + bb.eps));
+            bga = *reinterpret_cast<const float4*>(bb.gamma + c);
+            bbe = *reinterpret_cast<const float4*>(bb.beta + c);
+        }
+    }
 
     fetch_planes(0);
     fetch(0, PRO);
@@ -635,6 +649,16 @@ __global__ __launch_bounds__(256, 3) void dw_strip_dx2_kernel(const float* __res
         const int iyb = iy_beg + R * s;
         float* __restrict__ out_b = dx + ((n * h + iyb) * (int64_t)w_in + ix0) * c_all + c;
         const float* __restrict__ pls = &planes[s & 1][0];
+        float4 yv[BNB ? NP : 1];                              // K6c: raw BatchNorm input at this thread's pixels
+        if constexpr (BNB) {
+            const float* __restrict__ y_b = bb.y + ((n * h + iyb) * (int64_t)w_in + ix0) * c_all + c;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int ty = ty0 + 2 * k;
+                yv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (xok && iyb + ty < iy_end) yv[k] = *reinterpret_cast<const float4*>(y_b + (ty * w_in + tx) * c_all);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int ty = ty0 + 2 * k;
@@ -653,10 +677,46 @@ __global__ __launch_bounds__(256, 3) void dw_strip_dx2_kernel(const float* __res
             a.x = pmk != 0.f ? a.x * pmk : 0.f; a.y = pmk != 0.f ? a.y * pmk : 0.f;
             a.z = pmk != 0.f ? a.z * pmk : 0.f; a.w = pmk != 0.f ? a.w * pmk : 0.f;
             *reinterpret_cast<float4*>(out_b + (ty * w_in + tx) * c_all) = a;
+            if constexpr (BNB) {
+                const float4 yq = yv[k];
+                const float hx = (yq.x - bmu.x) * bis.x, hy = (yq.y - bmu.y) * bis.y, hz = (yq.z - bmu.z) * bis.z, hw = (yq.w - bmu.w) * bis.w;
+                const float zx = fmaf(hx, bga.x, bbe.x), zy = fmaf(hy, bga.y, bbe.y), zz = fmaf(hz, bga.z, bbe.z), zw = fmaf(hw, bga.w, bbe.w);
+                const float gx = a.x * ((zx > 0.f && zx < bb.hi) ? 1.f : (zx > 0.f ? 0.f : bb.neg));
+                const float gy = a.y * ((zy > 0.f && zy < bb.hi) ? 1.f : (zy > 0.f ? 0.f : bb.neg));
+                const float gz = a.z * ((zz > 0.f && zz < bb.hi) ? 1.f : (zz > 0.f ? 0.f : bb.neg));
+                const float gw = a.w * ((zw > 0.f && zw < bb.hi) ? 1.f : (zw > 0.f ? 0.f : bb.neg));
+                vals[0] += gx; vals[1] += gy; vals[2] += gz; vals[3] += gw;
+                vals[4] = fmaf(gx, hx, vals[4]); vals[5] = fmaf(gy, hy, vals[5]);
+                vals[6] = fmaf(gz, hz, vals[6]); vals[7] = fmaf(gw, hw, vals[7]);
+            }
         }
         __syncthreads();
         if (more) { commit(PRO + NEW * (s + 1), NEW); commit_planes(s + 1); }
         __syncthreads();
+    }
+    if constexpr (BNB) {
+        // lanes of a wave with the same channel group sit 8 threads apart: butterfly over them, then 4 wave rows through LDS
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v = vals[i];
+            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            vals[i] = v;
+        }
+        float* mrg = ring;                                   // [4 waves][CGS][8]; the loop ended on a barrier: the ring is free
+        if ((threadIdx.x & 63) < CGS) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mrg[((threadIdx.x >> 6) * CGS + cg) * 8 + i] = vals[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * ST_CB) {
+            const int which = threadIdx.x / ST_CB, ch = threadIdx.x % ST_CB;
+            if ((int)cb * ST_CB + ch < c_all) {
+                float sum = 0.f;
+                for (int wv = 0; wv < 4; ++wv) sum += mrg[(wv * CGS + ch / 4) * 8 + which * 4 + ch % 4];
+                const int64_t prow = (n * chunks_y + cy) * strips_x + sx;
+                bb.part[(prow * 2 + which) * c_all + (int)cb * ST_CB + ch] = sum;
+            }
+        }
     }
 }
 
@@ -685,7 +745,8 @@ static StripPlan plan_strip(int n, int hout, int wout, int c, int s, int d) {
 static const DwBN kNoDwBN = {nullptr, nullptr, 1.f, 0.f};
 static const DwBnBwd kNoBnBwd = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
 
-static bool dw_fused_ok(int s, int d) { return (s == 1 || s == 2) && d == 1; }   // geometries with the K6b strip variants (K6c: stride 1 only)
+// geometries with the K6b / K6c strip variants (stride 2: forward only here; its dX has its own kernel)
+static bool dw_fused_ok(int s, int d) { return (s == 2 && d == 1) || (s == 1 && (d == 1 || d == 2 || d == 4 || d == 8)); }
 
 static int try_launch_dw_strip(const float* in, const float* pre, const float* wT, const float* bias, const float* denom,
                                const float* keep, const float* post_mul, DtGeom g, float* out, hipStream_t st,
@@ -699,16 +760,14 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
     const bool fused = ib.sc != nullptr || stats != nullptr || bb.y != nullptr;
     if (fused && !dw_fused_ok(g.s, g.d)) return 1;
     if (bb.y != nullptr && g.s != 1) return 1;
-    if (g.s == 2 && fused) hipLaunchKernelGGL((dw_strip_kernel<2, 1, 1>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
-                                              sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
-    else if (g.s == 2) hipLaunchKernelGGL((dw_strip_kernel<2, 1, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
-                                     sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
-    else if (g.d == 2) hipLaunchKernelGGL((dw_strip_kernel<1, 2, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
-                                          sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
-    else if (g.d == 4) hipLaunchKernelGGL((dw_strip_kernel<1, 4, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
-                                          sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
-    else if (g.d == 8) hipLaunchKernelGGL((dw_strip_kernel<1, 8, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
-                                          sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
+#define TSII_DW_STRIP(S, D, MODE) hipLaunchKernelGGL((dw_strip_kernel<S, D, MODE>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, \
+                                                     sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out)
+#define TSII_DW_STRIP_D(D) do { if (bb.y != nullptr) TSII_DW_STRIP(1, D, 2); else if (fused) TSII_DW_STRIP(1, D, 1); else TSII_DW_STRIP(1, D, 0); } while (0)
+    if (g.s == 2 && fused) TSII_DW_STRIP(2, 1, 1);
+    else if (g.s == 2) TSII_DW_STRIP(2, 1, 0);
+    else if (g.d == 2) TSII_DW_STRIP_D(2);
+    else if (g.d == 4) TSII_DW_STRIP_D(4);
+    else if (g.d == 8) TSII_DW_STRIP_D(8);
     else if (bb.y != nullptr) hipLaunchKernelGGL((dw_strip_kernel<1, 1, 2>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
                                                  sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
     else if (fused) hipLaunchKernelGGL((dw_strip_kernel<1, 1, 1>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
@@ -1002,6 +1061,16 @@ extern "C" int64_t tsii_dw_stat_rows(int n, int ho, int wo, int c, int kh, int k
     return sp.ok ? (int64_t)n * sp.chunks_y * sp.strips_x : 0;          // one partial row per strip chunk
 }
 
+// rows of the partials tsii_dw_bwd_dx_bn writes (0: that geometry has no fused form): strip chunks of the dX (= input) grid
+extern "C" int64_t tsii_dw_bwd_stat_rows(int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw) {
+    if (n <= 0 || h <= 0 || wd <= 0 || c <= 0 || c % 4 != 0 || !(kh == 3 && kw == 3 && sh == sw && dh == dw)) return 0;
+    StripPlan sp;
+    if (sh == 1 && (dh == 1 || dh == 2 || dh == 4 || dh == 8)) sp = plan_strip(n, h, wd, c, 1, dh);
+    else if (sh == 2 && dh == 1 && ph == 1 && pw == 1) sp = plan_strip(n, h, wd, c, 1, 1);
+    else return 0;
+    return sp.ok ? (int64_t)n * sp.chunks_y * sp.strips_x : 0;
+}
+
 extern "C" int tsii_dw_fwd_bn(const float* x, const float* rmask, const float* w, const float* bias,
                               const float* denom, const float* keep, int n, int h, int wd, int c, int kh, int kw,
                               int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo,
@@ -1030,16 +1099,20 @@ static int dw_bwd_dx_impl(const float* dy, const float* inv, const float* w, con
         rc = try_launch_dw_strip(dy, inv, ws, nullptr, nullptr, nullptr, rmask, tg, dx, st, kNoDwBN, nullptr, bb);
         if (rc <= 0) return rc;
     }
-    TSII_REQUIRE(bb.y == nullptr, "dw_bwd_dx_bn: the BatchNorm-backward form needs the marching-strip path (tsii_dw_stat_rows() > 0)");
     if (vec && kh == 3 && kw == 3 && sh == 2 && sw == 2 && dh == 1 && dw == 1 && ph == 1 && pw == 1) {   // marching strips
         const StripPlan sp = plan_strip(n, h, wd, c, 1, 1);     // strips of the input grid
         if (sp.ok) {
             const int64_t nblk2 = (int64_t)sp.strips_x * sp.chunks_y * sp.cblocks * n;
-            hipLaunchKernelGGL(dw_strip_dx2_kernel, dim3((unsigned)nblk2), dim3(256), 0, st, dy, inv, ws, rmask, n, h, wd, c, ho, wo,
-                               sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, dx);
+            if (bb.y != nullptr)
+                hipLaunchKernelGGL(dw_strip_dx2_kernel<true>, dim3((unsigned)nblk2), dim3(256), 0, st, dy, inv, ws, rmask, n, h, wd, c, ho, wo,
+                                   sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, bb, dx);
+            else
+                hipLaunchKernelGGL(dw_strip_dx2_kernel<false>, dim3((unsigned)nblk2), dim3(256), 0, st, dy, inv, ws, rmask, n, h, wd, c, ho, wo,
+                                   sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, bb, dx);
             return check_launch("dw_strip_dx2");
         }
     }
+    TSII_REQUIRE(bb.y == nullptr, "dw_bwd_dx_bn: the BatchNorm-backward form needs a marching-strip path (tsii_dw_bwd_stat_rows() > 0)");
     const bool k3 = false;  // see dw_fwd
     const int px = (vec && k3) ? DwPx<true>::value : DwPx<false>::value;
     const int64_t nblk = (int64_t)cdiv(cdiv(wd, px) * (vec ? c / 4 : c), 256) * h * n;

@@ -247,9 +247,8 @@ class _Depthwise(torch.autograd.Function):
             dx = torch.empty_like(x)
             ws = _ws(4 * c * g.kh * g.kw, x)
             rows = 0
-            if (ctx.bn is not None and FUSE_BN_BWD and load_time_act(*ctx.in_cfg) and g.sh == 1 and g.sw == 1   # K6c: stride-1 dX only
-                    and _al16(gy, x)):
-                rows = int(_lib.lib().tsii_dw_stat_rows(n, h, wd, c, g.kh, g.kw, g.sh, g.sw, g.dh, g.dw))   # strips of the dX grid
+            if ctx.bn is not None and FUSE_BN_BWD and load_time_act(*ctx.in_cfg) and _al16(gy, x):   # K6c: strip paths of the dX grid
+                rows = int(_lib.lib().tsii_dw_bwd_stat_rows(n, h, wd, c, *g))
             if rows > 0:
                 mean, var, gamma, beta, eps, slot = ctx.bn
                 part = torch.empty((rows, 2, c), dtype=torch.float32, device=x.device)

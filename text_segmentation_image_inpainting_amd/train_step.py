@@ -86,7 +86,7 @@ class FlatSGDTrainer:
         if not self.distributed:
             return
         bufs = [b for b in self.model.buffers()]
-        for dtype in {b.dtype for b in bufs}:
+        for dtype in dict.fromkeys(b.dtype for b in bufs):      # first-seen order: identical on every rank (a set's is not)
             group = [b for b in bufs if b.dtype == dtype]
             flat = torch.cat([b.detach().reshape(-1) for b in group])
             dist.broadcast(flat, src=src, group=self.pg)
