@@ -1172,7 +1172,7 @@ static int dw_bwd_dw_impl(const float* dy, const float* inv, const float* keep, 
     const bool vec = (c % 4 == 0) && aligned16(dy) && aligned16(x) && (ib.sc == nullptr || (aligned16(ib.sc) && aligned16(ib.sh)));
     float* part = (float*)ws;
     if (vec && kh == 3 && kw == 3 && sh == sw && dh == dw &&
-        ((sh == 1 && (dh == 1 || ((dh == 2 || dh == 4 || dh == 8) && ib.sc == nullptr))) || (sh == 2 && dh == 1))) {
+        ((sh == 1 && (dh == 1 || dh == 2 || dh == 4 || dh == 8)) || (sh == 2 && dh == 1))) {
         const StripPlan sp = plan_strip(n, ho, wo, c, sh, dh);   // marching strips
         if (sp.ok) {
             DtGeom tg = {n, h, wd, c, sh, dh, ph, pw, ho, wo, 0};
