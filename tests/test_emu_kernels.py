@@ -185,3 +185,84 @@ def test_stem_space_to_depth_entry_points(emu, k, cin, h, w):
         for kx in range(k):
             e0 = ((ky & 1) * 2 + (kx & 1)) * cin
             assert np.array_equal(dw[:, :, ky, kx], dwk[:, e0:e0 + cin, ky // 2, kx // 2])
+
+
+def _conv_ref(x, w, s, p, d):
+    """float64 NHWC convolution: x [n,h,w,ci], w [co,ci,kh,kw] -> [n,ho,wo,co]"""
+    n, h, wd, ci = x.shape
+    co, _, kh, kw = w.shape
+    ho = (h + 2 * p - d * (kh - 1) - 1) // s + 1
+    wo = (wd + 2 * p - d * (kw - 1) - 1) // s + 1
+    xp = np.zeros((n, h + 2 * p, wd + 2 * p, ci))
+    xp[:, p:p + h, p:p + wd] = x
+    y = np.zeros((n, ho, wo, co))
+    for ky in range(kh):
+        for kx in range(kw):
+            patch = xp[:, ky * d:ky * d + (ho - 1) * s + 1:s, kx * d:kx * d + (wo - 1) * s + 1:s]
+            y += patch @ w[:, :, ky, kx].T.astype(np.float64)
+    return y
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,d,h", [(16, 32, 3, 1, 1, 1, 11), (8, 136, 3, 2, 1, 1, 13), (24, 16, 3, 1, 2, 2, 9),
+                                                (16, 40, 5, 2, 2, 1, 12)])
+def test_dense_conv_gather_gemms(emu, mode, cin, cout, k, s, p, d, h):
+    """K4 entry points on the gather forms of the GEMM kernels (split-bf16 loaders in modes 6 / 3 / 1, f32 MFMA in mode 0):
+    forward with the x*mask planes and the count division, dX (stride phases for s = 2), dW -- against float64 numpy."""
+    L = emu
+    tol = MODE_TOL[mode]
+    rng = np.random.default_rng(cin + cout + k + h)
+    n = 2
+    x = rng.standard_normal((n, h, h, cin)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, k, k)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    r0 = (rng.uniform(size=(n, h, h)) > 0.25).astype(np.float32)
+    r1 = (rng.uniform(size=(n, h, h)) > 0.25).astype(np.float32)
+    split = (cin // 2 // 4) * 4
+    ho = (h + 2 * p - d * (k - 1) - 1) // s + 1
+    denom = rng.integers(1, 9, size=(n, ho, ho)).astype(np.float32)
+    keep = (rng.uniform(size=(n, ho, ho)) > 0.2).astype(np.float32)
+    geom = (n, h, h, cin, cout, k, k, s, s, p, p, d, d, ho, ho)
+    nb = L.tsii_dense_ws_bytes(cin, cout, k, k)
+    ws = np.zeros(nb // 4 + 4, np.float32)
+    y = np.zeros((n, ho, ho, cout), np.float32)
+    assert L.tsii_dense_fwd(P(x), None, P(r0), split, P(r1), P(w), P(b), P(denom), P(keep), *geom, P(y), P(ws), nb, None) == 0, L.tsii_last_error()
+    xm = x.astype(np.float64).copy()
+    xm[..., :split] *= r0[..., None]
+    xm[..., split:] *= r1[..., None]
+    ref = (_conv_ref(xm, w, s, p, d) / denom[..., None] + b) * keep[..., None]
+    assert np.abs(y - ref).max() <= tol * np.abs(ref).max()
+    if mode == 1:       # the gather form really runs on the bf16 loaders (an f32-MFMA fallback would be ~1e-7 here)
+        assert np.abs(y - ref).max() >= 1e-5 * np.abs(ref).max()
+
+    dy = rng.standard_normal((n, ho, ho, cout)).astype(np.float32)
+    inv = (keep / denom).astype(np.float32)
+    g = dy.astype(np.float64) * inv[..., None]
+    # dW[co,ci,ky,kx] = sum g[n,oy,ox,co] * xm[n, oy*s - p + ky*d, ox*s - p + kx*d, ci]
+    xp = np.zeros((n, h + 2 * p, h + 2 * p, cin))
+    xp[:, p:p + h, p:p + h] = xm
+    rdw = np.zeros((cout, cin, k, k))
+    for ky in range(k):
+        for kx in range(k):
+            patch = xp[:, ky * d:ky * d + (ho - 1) * s + 1:s, kx * d:kx * d + (ho - 1) * s + 1:s]
+            rdw[:, :, ky, kx] = np.einsum("nyxo,nyxi->oi", g, patch)
+    nbw = L.tsii_dense_bwd_dw_ws_bytes(n, ho, ho, cin, cout, k, k)
+    wsw = np.zeros(nbw // 4 + 4, np.float32)
+    dw = np.zeros_like(w)
+    db = np.zeros(cout, np.float32)
+    assert L.tsii_dense_bwd_dw(P(dy), P(inv), P(keep), P(x), None, P(r0), split, P(r1), *geom, P(dw), P(db), P(wsw), nbw, None) == 0, L.tsii_last_error()
+    assert np.abs(dw - rdw).max() <= tol * np.abs(rdw).max()
+    rdb = (dy.astype(np.float64) * keep[..., None]).sum((0, 1, 2))
+    assert np.abs(db - rdb).max() <= 1e-5 * np.abs(rdb).max()
+
+    # dX = (transposed conv of g) * mask planes
+    rdx = np.zeros((n, h + 2 * p, h + 2 * p, cin))
+    for ky in range(k):
+        for kx in range(k):
+            rdx[:, ky * d:ky * d + (ho - 1) * s + 1:s, kx * d:kx * d + (ho - 1) * s + 1:s] += g @ w[:, :, ky, kx].astype(np.float64)
+    rdx = rdx[:, p:p + h, p:p + h]
+    rdx[..., :split] *= r0[..., None]
+    rdx[..., split:] *= r1[..., None]
+    dx = np.zeros_like(x)
+    ws2 = np.zeros(nb // 4 + 4, np.float32)
+    assert L.tsii_dense_bwd_dx(P(dy), P(inv), P(w), None, P(r0), split, P(r1), *geom, P(dx), P(ws2), nb, None) == 0, L.tsii_last_error()
+    assert np.abs(dx - rdx).max() <= tol * np.abs(rdx).max()

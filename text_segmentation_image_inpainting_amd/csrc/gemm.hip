@@ -390,6 +390,9 @@ template <int AMODE>
 static int launch_nt_conv(const float* A, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
                           Epilogue ep, ConvGather cg, hipStream_t stream) {
     ep.vec_store = (ldc % 4 == 0) && aligned16(C);
+    if constexpr (AMODE == 1 || AMODE == 2) {
+        if (nt_split_conv_ok(A, B, ldb, K, cg)) return launch_nt_split_conv(AMODE, A, B, ldb, C, ldc, M, N, K, ep, cg, stream);
+    }
     if (N % 128 == 0 || N > 192) return launch_nt_conv_cfg<2, 2, 2, 2, AMODE>(A, B, ldb, C, ldc, M, N, K, ep, cg, stream);
     if (N > 32) return launch_nt_conv_cfg<2, 2, 2, 1, AMODE>(A, B, ldb, C, ldc, M, N, K, ep, cg, stream);
     return launch_nt_conv_cfg<4, 1, 1, 1, AMODE>(A, B, ldb, C, ldc, M, N, K, ep, cg, stream);
@@ -577,6 +580,12 @@ int launch_conv_gemm_dw(const float* dy, const float* inv, const float* x, const
     const RowScale none = {nullptr, nullptr, 0};
     dim3 grid(cdiv(K, pl.bn), cdiv(g.cout, pl.bm), pl.splits);
     const bool elem = (mfull != nullptr || g.cin % 4 != 0);
+    if (!elem && tn_split_conv_ok(dy, g.cout, x, M, g.cout, K, cg)) {
+        int rc = launch_tn_split_conv(dy, g.cout, inv, x, cg, ws, M, g.cout, K, pl.chunk, pl.splits, pl.big, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3(stream_grid((int64_t)g.cout * K, 256)), dim3(256), 0, st, ws, pl.splits, g.cout, g.cin, T, dwgt);
+        return check_launch("conv_dw_reduce");
+    }
     if (pl.big && !elem) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 1>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg, kNoBN);
     else if (!elem) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, 1>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg, kNoBN);
     else if (pl.big) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 2>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg, kNoBN);

@@ -129,6 +129,82 @@ __device__ __forceinline__ void split_store(unsigned char* __restrict__ S, const
     }
 }
 
+// ---- implicit-GEMM gather for the A operand (dense k x k convolutions, gemm_tiles.h ConvGather) ---------------------
+// Row m = a pixel of the row grid, column k = (tap, channel); with c % 8 == 0 a chunk of 8 k lies inside one tap = 32
+// contiguous bytes of the NHWC source.  This thread's rows are fixed for the tile (decoded once), its chunk column
+// advances with the K loop.  Branch-free like split_load: taps outside the image read pixel 0 and are zeroed by the store
+// (bit i of `okm`); the per-source-pixel planes p0 / p1 (x*mask, 1/count) arrive next to the data.
+template <int ROWS>
+__device__ __forceinline__ void split_conv_rows(const ConvGather& cg, int64_t row0, int64_t nrows, int (&rn)[SplitChunks<ROWS>::value],
+                                                int (&ry)[SplitChunks<ROWS>::value], int (&rx)[SplitChunks<ROWS>::value]) {
+#pragma unroll
+    for (int i = 0; i < SplitChunks<ROWS>::value; ++i) {
+        const int64_t row = row0 + ((threadIdx.x + 256 * i) >> 2);
+        rn[i] = -1; ry[i] = 0; rx[i] = 0;
+        if (row < nrows) {
+            rx[i] = (int)(row % cg.rw);
+            ry[i] = (int)((row / cg.rw) % cg.rh);
+            rn[i] = (int)(row / ((int64_t)cg.rw * cg.rh));
+        }
+    }
+}
+
+template <int ROWS, int AMODE>
+__device__ __forceinline__ void split_conv_load(const float* __restrict__ src, const ConvGather& cg, const int (&rn)[SplitChunks<ROWS>::value],
+                                                const int (&ry)[SplitChunks<ROWS>::value], const int (&rx)[SplitChunks<ROWS>::value],
+                                                int k0, int K, float4 (&regs)[SplitChunks<ROWS>::value][2],
+                                                float (&f0)[SplitChunks<ROWS>::value], float (&f1)[SplitChunks<ROWS>::value],
+                                                unsigned& okm, int& ci_out) {
+    int k = k0 + (threadIdx.x & 3) * 8;
+    const bool kok = k < K;
+    k = kok ? k : K - 8;                                                // K % 8 == 0
+    const int t = k / cg.c, ci = k - t * cg.c;
+    const int ky = t / cg.kw, kx = t - ky * cg.kw;
+    ci_out = ci;
+    okm = 0u;
+#pragma unroll
+    for (int i = 0; i < SplitChunks<ROWS>::value; ++i) {
+        int sy = 0, sx = 0;
+        const bool ok = kok && rn[i] >= 0 && conv_src<AMODE>(cg, ry[i], rx[i], ky, kx, sy, sx);
+        const int64_t spix = ok ? ((int64_t)rn[i] * cg.h + sy) * cg.w + sx : 0;
+        const float* p = src + spix * cg.c + ci;
+        regs[i][0] = *reinterpret_cast<const float4*>(p);
+        regs[i][1] = *reinterpret_cast<const float4*>(p + 4);
+        float a0 = 1.f, a1 = 1.f;
+        if (cg.p0 != nullptr) {                                          // wave-uniform
+            a0 = cg.p0[spix];
+            a1 = cg.p1 != nullptr ? cg.p1[spix] : 1.f;
+        }
+        f0[i] = a0; f1[i] = a1;
+        okm |= ok ? (1u << i) : 0u;
+    }
+}
+
+template <int ROWS, int P>
+__device__ __forceinline__ void split_conv_store(unsigned char* __restrict__ S, const float4 (&regs)[SplitChunks<ROWS>::value][2], int ci,
+                                                 int split, const float (&f0)[SplitChunks<ROWS>::value],
+                                                 const float (&f1)[SplitChunks<ROWS>::value], unsigned okm) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < SplitChunks<ROWS>::value; ++i) {
+        const int f = tid + 256 * i;
+        if (ROWS * 4 % 256 != 0 && f >= ROWS * 4) continue;
+        const int r = f >> 2, c = f & 3;
+        float v[8] = {regs[i][0].x, regs[i][0].y, regs[i][0].z, regs[i][0].w, regs[i][1].x, regs[i][1].y, regs[i][1].z, regs[i][1].w};
+        const bool valid = (okm >> i) & 1u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] *= (ci + e < split) ? f0[i] : f1[i];
+            v[e] = valid ? v[e] : 0.f;
+        }
+        u32x4 pl[P];
+        split8<P>(v, pl);
+        const int off = split_off(r, c);
+#pragma unroll
+        for (int p = 0; p < P; ++p) *reinterpret_cast<u32x4*>(S + p * (ROWS * 64) + off) = pl[p];
+    }
+}
+
 // ---- weights pre-split (B operand of the NT kernel) --------------------------------------------------------
 // One tiny kernel per call splits the [N,K] weight matrix (or its transpose, for dX) into P bf16 planes
 // planes[p][row][col] in a caller workspace; the GEMM blocks then stage B as plain 16-byte copies -- no VALU work for B,
@@ -208,11 +284,15 @@ struct SplitTerm {
 template <int PRODUCTS>
 struct SplitPlanes { static constexpr int value = PRODUCTS == 1 ? 1 : PRODUCTS == 3 ? 2 : 3; };
 
-template <int WM, int WN, int TM, int TN, int PRODUCTS, bool BNIN, bool BNB, bool BPRE>
+template <int WM, int WN, int TM, int TN, int PRODUCTS, bool BNIN, bool BNB, bool BPRE, int AMODE = 0>
 __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_split_kernel(const float* __restrict__ A, int64_t lda, RowScale as,
                                                                        const float* __restrict__ B, int64_t ldb,
                                                                        float* __restrict__ C, int64_t ldc,
-                                                                       int64_t M, int N, int K, Epilogue ep, unsigned ntn, InBN ib, int abl) {
+                                                                       int64_t M, int N, int K, Epilogue ep, unsigned ntn, InBN ib, int abl,
+                                                                       ConvGather cg) {
+    // AMODE 1 / 2: A is the im2col view of an NHWC tensor (forward / dX of a dense convolution, cg; c % 8 == 0)
+    constexpr bool CONV = AMODE != 0;
+    static_assert(!CONV || (!BNIN && !BNB && !BPRE), "the gather form has no fused BatchNorm variants");
     // abl: ablation switches of tools/gemm_bench.py (0 in production; wave-uniform kernel argument): 1 no epilogue,
     // 2 no global loads inside the K loop, 8 no staging pass (+ its barrier), 16 no fragment reads
     constexpr int P = SplitPlanes<PRODUCTS>::value;
@@ -251,8 +331,15 @@ __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_
     float sa0[NA], sa1[NA], sb0[NB], sb1[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) { sb0[i] = 1.f; sb1[i] = 1.f; }
-    split_row_scales<BM>(as, m0, M, sa0, sa1);
-    split_load<BM>(A, lda, m0, M, 0, K, ra);
+    int rn[NA], ry[NA], rx[NA], cci = 0;         // CONV: this thread's rows on the row grid; channel of its chunk in flight
+    unsigned okm = 0u;
+    if constexpr (CONV) {
+        split_conv_rows<BM>(cg, m0, M, rn, ry, rx);
+        split_conv_load<BM, AMODE>(A, cg, rn, ry, rx, 0, K, ra, sa0, sa1, okm, cci);
+    } else {
+        split_row_scales<BM>(as, m0, M, sa0, sa1);
+        split_load<BM>(A, lda, m0, M, 0, K, ra);
+    }
     if constexpr (BPRE) split_load_pre<BN, P>(Bpl, bstride, K, n0, N, 0, K, rbp);
     else split_load<BN>(B, ldb, n0, N, 0, K, rb);
     float4 psc[2], psh[2];                       // BNIN: (scale, shift) of this thread's 8 channels of the tile in flight
@@ -265,7 +352,8 @@ __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_
             psh[0] = *reinterpret_cast<const float4*>(ib.sh + pk); psh[1] = *reinterpret_cast<const float4*>(ib.sh + pk + 4);
         }
     }
-    split_store<BM, P, true, BNIN>(As, ra, 0, as.split, sa0, sa1, psc, psh, ib.neg, ib.hi, mvalid, K);
+    if constexpr (CONV) split_conv_store<BM, P>(As, ra, cci, cg.split, sa0, sa1, okm);
+    else split_store<BM, P, true, BNIN>(As, ra, 0, as.split, sa0, sa1, psc, psh, ib.neg, ib.hi, mvalid, K);
     if constexpr (BPRE) split_store_pre<BN, P>(Bs, rbp, 0, nvalid, K);
     else split_store<BN, P, false, false>(Bs, rb, 0, 0, sb0, sb1, psc, psh, 1.f, 0.f, nvalid, K);
     __syncthreads();
@@ -280,7 +368,8 @@ __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = (kt + 1 < nk);
         if (more && !(abl & 2)) {  // next tile's global loads fly during the MFMA phase
-            split_load<BM>(A, lda, m0, M, (kt + 1) * SPLIT_BK, K, ra);
+            if constexpr (CONV) split_conv_load<BM, AMODE>(A, cg, rn, ry, rx, (kt + 1) * SPLIT_BK, K, ra, sa0, sa1, okm, cci);
+            else split_load<BM>(A, lda, m0, M, (kt + 1) * SPLIT_BK, K, ra);
             if constexpr (BPRE) split_load_pre<BN, P>(Bpl, bstride, K, n0, N, (kt + 1) * SPLIT_BK, K, rbp);
             else split_load<BN>(B, ldb, n0, N, (kt + 1) * SPLIT_BK, K, rb);
         }
@@ -324,14 +413,14 @@ __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_
         }
         __syncthreads();
         if (more && !(abl & 8)) {
-            split_store<BM, P, true, BNIN>(As, ra, (kt + 1) * SPLIT_BK, as.split, sa0, sa1, psc, psh, ib.neg, ib.hi, mvalid, K);
+            if constexpr (CONV) split_conv_store<BM, P>(As, ra, cci, cg.split, sa0, sa1, okm);
+            else split_store<BM, P, true, BNIN>(As, ra, (kt + 1) * SPLIT_BK, as.split, sa0, sa1, psc, psh, ib.neg, ib.hi, mvalid, K);
             if constexpr (BPRE) split_store_pre<BN, P>(Bs, rbp, (kt + 1) * SPLIT_BK, nvalid, K);
             else split_store<BN, P, false, false>(Bs, rb, (kt + 1) * SPLIT_BK, 0, sb0, sb1, psc, psh, 1.f, 0.f, nvalid, K);
             __syncthreads();
         }
     }
 
-    const ConvGather nocg = {0, 0, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, nullptr, nullptr, 0, nullptr, 0, 0, 0, 0, 0, 0};
     if (abl & 1) {          // ablation: keep the accumulators alive with one store per thread
         float sacc = 0.f;
 #pragma unroll
@@ -343,7 +432,7 @@ __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_
         if (m0 + tid < M) C[(m0 + tid) * ldc + n0] = sacc;
         return;
     }
-    nt_epilogue<WM, WN, TM, TN, 0, BNB, SMEM_FLOATS>(smem, acc, C, ldc, M, N, ep, nocg, m0, n0, bid, ntn);
+    nt_epilogue<WM, WN, TM, TN, AMODE, BNB, SMEM_FLOATS>(smem, acc, C, ldc, M, N, ep, cg, m0, n0, bid, ntn);
 }
 
 // ---- TN (dW): C[P,Q] = sum_m A[m,p]*sa[m] * B[m,q]*rs(m,q), both operands [m][channel] in memory ----------------
@@ -404,7 +493,9 @@ __device__ __forceinline__ void tn_split_factors(int64_t m0, int64_t mend, const
 template <int CH, int P, bool BNIN>
 __device__ __forceinline__ void tn_split_store(unsigned char* __restrict__ S, const float4 (&regs)[4], int c0, int split, bool split_active,
                                                const float (&f0)[4], const float (&f1)[4], int cq, int mq,
-                                               const float4 sc, const float4 sh, float neg, float hi, int left, int ncols) {
+                                               const float4 sc, const float4 sh, float neg, float hi, int left, int ncols,
+                                               int conv_ci = -1, unsigned conv_ok = 0u) {
+    // conv_ci >= 0 (gathered B of a dense conv's dW): the split index is the source channel, row validity comes as a bit mask
     if (CH != 128 && cq >= CH / 4) return;
     const bool col_ok = c0 + cq * 4 < ncols;
     const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
@@ -413,7 +504,7 @@ __device__ __forceinline__ void tn_split_store(unsigned char* __restrict__ S, co
     for (int jj = 0; jj < 4; ++jj) {
         v[jj][0] = regs[jj].x; v[jj][1] = regs[jj].y; v[jj][2] = regs[jj].z; v[jj][3] = regs[jj].w;
     }
-    const int cbase = c0 + cq * 4;
+    const int cbase = conv_ci >= 0 ? conv_ci : c0 + cq * 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         f32x2 lo = {v[0][e], v[1][e]}, hi2 = {v[2][e], v[3][e]};
@@ -422,7 +513,8 @@ __device__ __forceinline__ void tn_split_store(unsigned char* __restrict__ S, co
         for (int jj = 0; jj < 4; ++jj) {
             if constexpr (BNIN) x[jj] = bn_act_load(x[jj], scv[e], shv[e], neg, hi);
             x[jj] *= (!split_active || cbase + e < split) ? f0[jj] : f1[jj];
-            x[jj] = (col_ok && mq * 4 + jj < left) ? x[jj] : 0.f;       // clamped loads: outside the matrix = 0 (select: NaN safe)
+            const bool row_ok = conv_ci >= 0 ? ((conv_ok >> jj) & 1u) != 0u : mq * 4 + jj < left;
+            x[jj] = (col_ok && row_ok) ? x[jj] : 0.f;                   // clamped loads: outside the matrix = 0 (select: NaN safe)
         }
         lo = f32x2{x[0], x[1]}; hi2 = f32x2{x[2], x[3]};
         unsigned w0[P], w1[P];
@@ -445,14 +537,50 @@ __device__ __forceinline__ void tn_split_store(unsigned char* __restrict__ S, co
     }
 }
 
-template <int WM, int WN, int TM, int TN, int PRODUCTS, bool BNIN>
+// gathered B operand (dW of a dense conv): rows m = output pixels, this thread's column quad = one (tap, 4 channels) for the
+// whole tile.  Branch-free: rows past the chunk / taps outside the image read pixel 0 and are zeroed by the store (okm).
+// spx: the 4 source pixels (32-bit), kept for the plane factors fetched after the MFMA phase.
+__device__ __forceinline__ void tn_conv_split_load(const float* __restrict__ src, const ConvGather& cg, int64_t m0, int64_t mend, int ky, int kx,
+                                                   int ci, bool kok, int mq, float4 (&regs)[4], int (&spx)[4], unsigned& okm) {
+    okm = 0u;
+    const int last = (int)(mend - 1);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        int row = (int)m0 + mq * 4 + jj;
+        const bool in = row <= last;
+        row = in ? row : last;
+        const int q = row / cg.rw, rx = row - q * cg.rw;
+        const int n = q / cg.rh, ry = q - n * cg.rh;
+        int sy = 0, sx = 0;
+        const bool ok = in && kok && conv_src<1>(cg, ry, rx, ky, kx, sy, sx);
+        const int spix = ok ? (n * cg.h + sy) * cg.w + sx : 0;
+        regs[jj] = *reinterpret_cast<const float4*>(src + (int64_t)spix * cg.c + ci);
+        spx[jj] = spix;
+        okm |= ok ? (1u << jj) : 0u;
+    }
+}
+__device__ __forceinline__ void tn_conv_factors(const ConvGather& cg, const int (&spx)[4], float (&f0)[4], float (&f1)[4]) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) { f0[jj] = 1.f; f1[jj] = 1.f; }
+    if (cg.p0 != nullptr) {                       // wave-uniform branches; the loads inside issue back to back
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) f0[jj] = cg.p0[spx[jj]];
+        if (cg.p1 != nullptr) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) f1[jj] = cg.p1[spx[jj]];
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int PRODUCTS, bool BNIN, bool BCONV = false>
 __global__ __launch_bounds__(256, 3) void gemm_tn_split_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ sa,
                                                             const float* __restrict__ B, int64_t ldb, RowScale sb,
                                                             float* __restrict__ Cws, int64_t M, int Pn, int Q, int64_t chunk, InBN ib,
-                                                            unsigned qtiles, unsigned ptiles) {
+                                                            unsigned qtiles, unsigned ptiles, ConvGather cg) {
     constexpr int P = SplitPlanes<PRODUCTS>::value;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(!BCONV || !BNIN, "the gathered B operand has no BatchNorm-on-load form");
     static_assert((BM == 128 || BM == 64) && (BN == 128 || BN == 64), "micro-tile mapping: 32 (16) channel quads x 8 m quads");
     __shared__ __attribute__((aligned(16))) unsigned char smem[P * (BM + BN) * 64];
     unsigned char* As = smem;
@@ -488,13 +616,28 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_split_kernel(const float* __re
         const int q = q0 + cq * 4;
         if ((BN == 128 || cq < BN / 4) && q < Q) { bsc = *reinterpret_cast<const float4*>(ib.sc + q); bsh = *reinterpret_cast<const float4*>(ib.sh + q); }
     }
+    // BCONV: this thread's B column quad = (tap ky, kx; channels cci .. cci + 3) of the source tensor, fixed for the block
+    int cky = 0, ckx = 0, cci = -1, spx[4] = {0, 0, 0, 0};
+    bool ckok = false;
+    unsigned okm = 0u;
+    if constexpr (BCONV) {
+        int k = q0 + cq * 4;
+        ckok = k < Q;
+        k = ckok ? k : Q - 4;
+        const int t = k / cg.c;
+        cci = k - t * cg.c;
+        cky = t / cg.kw; ckx = t - cky * cg.kw;
+    }
     tn_split_load<BM>(A, lda, mbeg, mend, p0, Pn, cq, mq, ra);
-    tn_split_load<BN>(B, ldb, mbeg, mend, q0, Q, cq, mq, rb);
+    if constexpr (BCONV) tn_conv_split_load(B, cg, mbeg, mend, cky, ckx, cci, ckok, mq, rb, spx, okm);
+    else tn_split_load<BN>(B, ldb, mbeg, mend, q0, Q, cq, mq, rb);
     tn_split_factors(mbeg, mend, sa, none, mq, fa0, fa1);
-    tn_split_factors(mbeg, mend, nullptr, sb, mq, fb0, fb1);
+    if constexpr (BCONV) tn_conv_factors(cg, spx, fb0, fb1);
+    else tn_split_factors(mbeg, mend, nullptr, sb, mq, fb0, fb1);
     int left = (int)((mend - mbeg < 32) ? (mend - mbeg) : 32);
     tn_split_store<BM, P, false>(As, ra, p0, 0, false, fa0, fa1, cq, mq, bsc, bsh, 1.f, 0.f, left, Pn);
-    tn_split_store<BN, P, BNIN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1, cq, mq, bsc, bsh, ib.neg, ib.hi, left, Q);
+    if constexpr (BCONV) tn_split_store<BN, P, false>(Bs, rb, q0, cg.split, true, fb0, fb1, cq, mq, bsc, bsh, 1.f, 0.f, left, Q, cci, okm);
+    else tn_split_store<BN, P, BNIN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1, cq, mq, bsc, bsh, ib.neg, ib.hi, left, Q);
     __syncthreads();
 
     // fragment byte offsets inside a plane: channel li of wave tile t (tile base multiple of 32), chunk 2s + hi
@@ -542,14 +685,17 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_split_kernel(const float* __re
     // merge register copies behind the loads and wait for them before the MFMA phase
     for (int64_t mt = mbeg; mt + SPLIT_BK < mend; mt += SPLIT_BK) {
         tn_split_load<BM>(A, lda, mt + SPLIT_BK, mend, p0, Pn, cq, mq, ra);
-        tn_split_load<BN>(B, ldb, mt + SPLIT_BK, mend, q0, Q, cq, mq, rb);
+        if constexpr (BCONV) tn_conv_split_load(B, cg, mt + SPLIT_BK, mend, cky, ckx, cci, ckok, mq, rb, spx, okm);
+        else tn_split_load<BN>(B, ldb, mt + SPLIT_BK, mend, q0, Q, cq, mq, rb);
         mfma_phase();
         tn_split_factors(mt + SPLIT_BK, mend, sa, none, mq, fa0, fa1);
-        tn_split_factors(mt + SPLIT_BK, mend, nullptr, sb, mq, fb0, fb1);
+        if constexpr (BCONV) tn_conv_factors(cg, spx, fb0, fb1);
+        else tn_split_factors(mt + SPLIT_BK, mend, nullptr, sb, mq, fb0, fb1);
         __syncthreads();
         left = (int)((mend - mt - SPLIT_BK < 32) ? (mend - mt - SPLIT_BK) : 32);
         tn_split_store<BM, P, false>(As, ra, p0, 0, false, fa0, fa1, cq, mq, bsc, bsh, 1.f, 0.f, left, Pn);
-        tn_split_store<BN, P, BNIN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1, cq, mq, bsc, bsh, ib.neg, ib.hi, left, Q);
+        if constexpr (BCONV) tn_split_store<BN, P, false>(Bs, rb, q0, cg.split, true, fb0, fb1, cq, mq, bsc, bsh, 1.f, 0.f, left, Q, cci, okm);
+        else tn_split_store<BN, P, BNIN>(Bs, rb, q0, sb.split, sb_active, fb0, fb1, cq, mq, bsc, bsh, ib.neg, ib.hi, left, Q);
         __syncthreads();
     }
     mfma_phase();
@@ -582,6 +728,8 @@ static int g_abl = getenv("TSII_GEMM_ABL") ? atoi(getenv("TSII_GEMM_ABL")) : 0; 
 
 int gemm_products() { return g_products; }
 
+static const ConvGather kNoGather = {0, 0, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, nullptr, nullptr, 0, nullptr, 0, 0, 0, 0, 0, 0};
+
 template <int WM, int WN, int TM, int TN, int PRODUCTS>
 static int launch_nt_split_cfg(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, float* C, int64_t ldc,
                                int64_t M, int N, int K, Epilogue ep, InBN ib, bool bpre, hipStream_t stream) {
@@ -593,20 +741,20 @@ static int launch_nt_split_cfg(const float* A, int64_t lda, RowScale as, const f
         TSII_REQUIRE(ib.sc == nullptr && N % 4 == 0 && ldc == N && aligned16(ep.bn_y) && ep.vec_store,
                      "gemm_nt_split: the BatchNorm-backward epilogue needs N %% 4 == 0 and 16-byte aligned operands");
         if (bpre) hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, false, true, true>), dim3((unsigned)nblocks), dim3(256), 0, stream,
-                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib, g_abl);
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib, g_abl, kNoGather);
         else hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, false, true, false>), dim3((unsigned)nblocks), dim3(256), 0, stream,
-                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib, g_abl);
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib, g_abl, kNoGather);
     } else if (ib.sc != nullptr) {
         TSII_REQUIRE(aligned16(ib.sc) && aligned16(ib.sh), "gemm_nt_split: input BatchNorm needs 16-byte aligned scale / shift");
         if (bpre) hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, true, false, true>), dim3((unsigned)nblocks), dim3(256), 0, stream,
-                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib, g_abl);
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib, g_abl, kNoGather);
         else hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, true, false, false>), dim3((unsigned)nblocks), dim3(256), 0, stream,
-                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib, g_abl);
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib, g_abl, kNoGather);
     } else {
         if (bpre) hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, false, false, true>), dim3((unsigned)nblocks), dim3(256), 0, stream,
-                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib, g_abl);
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib, g_abl, kNoGather);
         else hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PRODUCTS, false, false, false>), dim3((unsigned)nblocks), dim3(256), 0, stream,
-                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib, g_abl);
+                           A, lda, as, B, ldb, C, ldc, M, N, K, ep, ntn, ib, g_abl, kNoGather);
     }
     return check_launch("gemm_nt_split");
 }
@@ -652,6 +800,41 @@ int launch_nt_split(const float* A, int64_t lda, RowScale as, const float* B, in
 #undef TSII_NT_SPLIT
 }
 
+// ---- dense convolutions: A gathered (AMODE 1 forward, 2 dX), B = the fp32 [N,K] weight layout, split while staged ----
+bool nt_split_conv_ok(const float* A, const float* B, int64_t ldb, int K, const ConvGather& cg) {
+    return g_products != 0 && cg.c % 8 == 0 && K % 8 == 0 && ldb % 4 == 0 && cg.pfull == nullptr && aligned16(A) && aligned16(B);
+}
+
+template <int WM, int WN, int TM, int TN, int AMODE>
+static int launch_nt_split_conv_cfg(const float* A, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                                    Epilogue ep, const ConvGather& cg, hipStream_t stream) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const unsigned ntn = (unsigned)cdiv(N, BN);
+    const int64_t nblocks = cdiv64(M, BM) * ntn;
+    TSII_REQUIRE(nblocks < (1ll << 31), "conv gemm (split): grid too large");
+    const RowScale none = {nullptr, nullptr, 0};
+    const InBN nobn = {nullptr, nullptr, 1.f, 0.f};
+#define TSII_NT_CONV(PR) hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, PR, false, false, false, AMODE>), dim3((unsigned)nblocks), dim3(256), 0, stream, \
+                                            A, (int64_t)0, none, B, ldb, C, ldc, M, N, K, ep, ntn, nobn, 0, cg)
+    if (g_products == 1) TSII_NT_CONV(1);
+    else if (g_products == 3) TSII_NT_CONV(3);
+    else TSII_NT_CONV(6);                        // 8 products: not instantiated for the gather form, the 6-product form is fp32 class
+#undef TSII_NT_CONV
+    return check_launch("conv_gemm_nt_split");
+}
+
+int launch_nt_split_conv(int amode, const float* A, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                         Epilogue ep, const ConvGather& cg, hipStream_t stream) {
+    ep.vec_store = (ldc % 4 == 0) && aligned16(C);
+#define TSII_NT_CONV_T(WM, WN, TM, TN) \
+    (amode == 1 ? launch_nt_split_conv_cfg<WM, WN, TM, TN, 1>(A, B, ldb, C, ldc, M, N, K, ep, cg, stream) \
+                : launch_nt_split_conv_cfg<WM, WN, TM, TN, 2>(A, B, ldb, C, ldc, M, N, K, ep, cg, stream))
+    if (N % 128 == 0 || N > 192) return TSII_NT_CONV_T(2, 2, 2, 2);
+    if (N > 32) return TSII_NT_CONV_T(2, 2, 2, 1);
+    return TSII_NT_CONV_T(4, 1, 1, 1);
+#undef TSII_NT_CONV_T
+}
+
 bool tn_split_ok(const float* A, int64_t lda, const float* B, int64_t ldb, int Pn, int Q) {
     return g_products != 0 && Pn % 4 == 0 && Q % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) && aligned16(B);
 }
@@ -665,13 +848,37 @@ int launch_tn_split(const float* A, int64_t lda, const float* sa, const float* B
     TSII_REQUIRE(nblocks < (1ll << 31), "gemm_tn_split: grid too large");
     const dim3 grid((unsigned)nblocks);
     if (ib.sc != nullptr) TSII_REQUIRE(aligned16(ib.sc) && aligned16(ib.sh), "gemm_tn_split: input BatchNorm needs 16-byte aligned scale / shift");
-#define TSII_TN_SPLIT(TMV, TNV, PR, BNV) hipLaunchKernelGGL((gemm_tn_split_kernel<2, 2, TMV, TNV, PR, BNV>), grid, dim3(256), 0, stream, A, lda, sa, B, ldb, sb, Cws, M, Pn, Q, chunk, ib, qt, pt)
+#define TSII_TN_SPLIT(TMV, TNV, PR, BNV) hipLaunchKernelGGL((gemm_tn_split_kernel<2, 2, TMV, TNV, PR, BNV>), grid, dim3(256), 0, stream, A, lda, sa, B, ldb, sb, Cws, M, Pn, Q, chunk, ib, qt, pt, kNoGather)
 #define TSII_TN_SPLIT_T(PR, BNV) do { if (tile == 0) TSII_TN_SPLIT(2, 2, PR, BNV); else if (tile == 1) TSII_TN_SPLIT(2, 1, PR, BNV); else TSII_TN_SPLIT(1, 1, PR, BNV); } while (0)
     if (ib.sc != nullptr) { if (g_products == 1) TSII_TN_SPLIT_T(1, true); else if (g_products == 8) TSII_TN_SPLIT_T(8, true); else if (g_products == 3) TSII_TN_SPLIT_T(3, true); else TSII_TN_SPLIT_T(6, true); }
     else { if (g_products == 1) TSII_TN_SPLIT_T(1, false); else if (g_products == 8) TSII_TN_SPLIT_T(8, false); else if (g_products == 3) TSII_TN_SPLIT_T(3, false); else TSII_TN_SPLIT_T(6, false); }
 #undef TSII_TN_SPLIT_T
 #undef TSII_TN_SPLIT
     return check_launch("gemm_tn_split");
+}
+
+// dW of a dense convolution: A = dy [M, Pn = cout] (x sa = 1/count), B = im2col view of x by cg (Q = taps * cin, cin % 4 == 0)
+bool tn_split_conv_ok(const float* A, int64_t lda, const float* B, int64_t M, int Pn, int Q, const ConvGather& cg) {
+    return g_products != 0 && Pn % 4 == 0 && Q % 4 == 0 && cg.c % 4 == 0 && lda % 4 == 0 && cg.pfull == nullptr && aligned16(A) && aligned16(B) &&
+           M < (1ll << 31) && (M / ((int64_t)cg.rh * cg.rw) + 1) * cg.h * cg.w < (1ll << 31);      // 32-bit row / source-pixel indices
+}
+
+int launch_tn_split_conv(const float* A, int64_t lda, const float* sa, const float* B, const ConvGather& cg, float* Cws, int64_t M, int Pn, int Q,
+                         int64_t chunk, int splits, bool big, hipStream_t stream) {
+    const int bm = big ? 128 : 64, bn = bm;
+    const unsigned qt = (unsigned)cdiv(Q, bn), pt = (unsigned)cdiv(Pn, bm);
+    const int64_t nblocks = (int64_t)qt * pt * splits;
+    TSII_REQUIRE(nblocks < (1ll << 31), "conv gemm_tn_split: grid too large");
+    const dim3 grid((unsigned)nblocks);
+    const RowScale none = {nullptr, nullptr, 0};
+    const InBN nobn = {nullptr, nullptr, 1.f, 0.f};
+#define TSII_TN_CONV(TMV, PR) hipLaunchKernelGGL((gemm_tn_split_kernel<2, 2, TMV, TMV, PR, false, true>), grid, dim3(256), 0, stream, A, lda, sa, B, (int64_t)0, none, \
+                                                 Cws, M, Pn, Q, chunk, nobn, qt, pt, cg)
+#define TSII_TN_CONV_T(PR) do { if (big) TSII_TN_CONV(2, PR); else TSII_TN_CONV(1, PR); } while (0)
+    if (g_products == 1) TSII_TN_CONV_T(1); else if (g_products == 3) TSII_TN_CONV_T(3); else TSII_TN_CONV_T(6);
+#undef TSII_TN_CONV_T
+#undef TSII_TN_CONV
+    return check_launch("conv_gemm_tn_split");
 }
 
 }  // namespace tsii

@@ -239,7 +239,16 @@ size_t nt_split_ws_bytes(int n, int k);
 int launch_nt_split(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, bool b_transposed, float* C, int64_t ldc,
                     int64_t M, int N, int K, Epilogue ep, InBN ib, void* wsplit, hipStream_t stream);
 
+// dense convolutions on the split kernels: A gathered by cg (amode 1 forward, 2 dX; cg.c % 8 == 0), B = fp32 [N,K]
+bool nt_split_conv_ok(const float* A, const float* B, int64_t ldb, int K, const ConvGather& cg);
+int launch_nt_split_conv(int amode, const float* A, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                         Epilogue ep, const ConvGather& cg, hipStream_t stream);
+
 bool tn_split_ok(const float* A, int64_t lda, const float* B, int64_t ldb, int Pn, int Q);
+// dW of a dense convolution on the split TN kernel: B gathered by cg (cg.c % 4 == 0); big: 128x128 tiles, else 64x64
+bool tn_split_conv_ok(const float* A, int64_t lda, const float* B, int64_t M, int Pn, int Q, const ConvGather& cg);
+int launch_tn_split_conv(const float* A, int64_t lda, const float* sa, const float* B, const ConvGather& cg, float* Cws, int64_t M, int Pn, int Q,
+                         int64_t chunk, int splits, bool big, hipStream_t stream);
 int launch_tn_split(const float* A, int64_t lda, const float* sa, const float* B, int64_t ldb, RowScale sb, float* Cws,
                     int64_t M, int Pn, int Q, int64_t chunk, int splits, int tile, InBN ib, hipStream_t stream);
 
