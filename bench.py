@@ -113,7 +113,7 @@ def class_table(timed, steps, products):
                "alg_gb_per_step": round(d["bytes"] / steps / 1e9, 3), "tb_per_s": round(tbs, 3), "hbm_frac": round(tbs / PEAK_HBM_TBS, 4)}
         if d["macs"] > 0 and cls.startswith(("gemm", "dense")):
             tf = 2.0 * d["macs"] / t / 1e12
-            split = products != 0 and cls.startswith("gemm")
+            split = products != 0      # point-wise GEMMs and the implicit-GEMM dense convolutions both run on the split kernels
             # matrix-core work actually issued: `products` bf16 MFMA partial products per fp32 product in the split modes
             peak = PEAK_BF16_TFLOPS / products if split else PEAK_FP32_TFLOPS
             rec.update({"fp32_equiv_tflops": round(tf, 2), "mfma_peak_fp32_equiv": round(peak, 1), "mfma_frac": round(tf / peak, 4)})
