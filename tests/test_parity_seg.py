@@ -105,7 +105,7 @@ def test_golden_seg_nets_64_gpu(name):
                 # fp64 gradient.  The fixture holds ONE fp32 run of the reference, i.e. one sample of that noise: on
                 # entry_flow_1.2.weight (sample 6.9e-4) this package's bit-exact fp32-FMA mode lands at 1.9e-3 (2.7x) on
                 # the emulator and the split-bf16 default at 3.8e-3 (5.6x) on the chip, with every kernel involved
-                # exact against float64 at kernel level (tests/test_emu_kernels.py).  The 256^2 test below measures the
+                # exact against float64 at kernel level (tests/test_emu_kernels.py).  The 256^2 test (tests/test_parity_r2.py) measures the
                 # oracle's spread over several perturbed fp32 runs instead of assuming a factor.
                 assert_close(params[k[5:]].grad, ref64.astype(np.float32), max(3e-3, 8 * noise), k + " vs fp64", floor=1e-3 * gmax)
                 assert_close(params[k[5:]].grad, G[k], max(3e-3, 5 * noise), k, floor=1e-3 * gmax)
