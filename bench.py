@@ -198,7 +198,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--model", default="ImageFill", choices=["ImageFill", "ImageFillOrigin", "ImageFillOriginV2"])
+    ap.add_argument("--model", default="ImageFill", choices=["ImageFill", "ImageFillOrigin", "ImageFillOriginV2", "TextSegament", "XceptionTextSegment"],
+                    help="ImageFill = the headline workload (BASELINE configs[1]); the segmentation nets are the secondary configs "
+                         "(cfg 3: --model TextSegament --batch 64 --pixel-shuffle; cfg 5: --model XceptionTextSegment --size 1024 --batch 8 --products 1)")
+    ap.add_argument("--pixel-shuffle", action="store_true", help="TextSegament with the Conv(128,16) + PixelShuffle(4) head (cfg 3)")
+    ap.add_argument("--checkpoint", action="store_true", help="TextSegament: recompute the encoder stages in backward (memory saver)")
+    ap.add_argument("--products", type=int, default=-1, help="tsii_set_gemm_products for this run (1 = the 'mixed bf16' arithmetic of cfg 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the short run in the bit-exact f32-MFMA arithmetic mode")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU-baseline leg (default: min(physical cores, 32))")
@@ -227,15 +232,39 @@ def main():
     from text_segmentation_image_inpainting_amd.train_step import FlatSGDTrainer
 
     L = _lib.lib()
+    if args.products >= 0:
+        assert L.tsii_set_gemm_products(args.products) == 0, "--products: 0, 1, 3, 6 or 8"
     products = int(L.tsii_get_gemm_products())
     torch.manual_seed(0)  # identical random-init weights on every rank
-    model = getattr(T, args.model)().to(dev).train()
-    trainer = FlatSGDTrainer(model, lr=1e-3, momentum=0.9, weight_decay=1e-4)
-    trainer.broadcast_parameters()
+    seg = args.model in ("TextSegament", "XceptionTextSegment")
+    if seg:
+        # secondary workloads: logits = net(image), BinaryFocalLoss against the text mask (train.py of the reference); the
+        # trainer sees the same (inputs, mask, target) step signature through a one-line adapter
+        from text_segmentation_image_inpainting_amd.synthetic import make_seg_batch
+        net = getattr(T, args.model)(**({"pixel_shuffle_head": True} if (args.pixel_shuffle and args.model == "TextSegament") else {}))
+        if args.checkpoint and hasattr(net, "checkpoint_encoder"):
+            net.checkpoint_encoder = True
 
-    corrupted, mask, clean = make_batch(args.batch, args.size, seed0=rank * args.batch, bernoulli=args.bernoulli_masks)
-    corrupted, mask = corrupted.to(dev), mask.to(dev)   # inputs resident in HBM before the timed region
-    clean_nhwc = to_nhwc(clean.to(dev))
+        class SegStep(torch.nn.Module):
+            def __init__(self, net):
+                super().__init__()
+                self.net = net
+
+            def forward(self, args_):
+                return self.net(args_[0])
+        model = SegStep(net).to(dev).train()
+        focal = T.BinaryFocalLoss(0, 1, 2)
+        trainer = FlatSGDTrainer(model, lr=1e-3, momentum=0.9, weight_decay=1e-4, loss_fn=lambda out, tgt: focal(out, tgt))
+        trainer.broadcast_parameters()
+        corrupted, clean_nhwc = (t.to(dev) for t in make_seg_batch(args.batch, args.size, seed0=rank * args.batch))
+        mask = None
+    else:
+        model = getattr(T, args.model)().to(dev).train()
+        trainer = FlatSGDTrainer(model, lr=1e-3, momentum=0.9, weight_decay=1e-4)
+        trainer.broadcast_parameters()
+        corrupted, mask, clean = make_batch(args.batch, args.size, seed0=rank * args.batch, bernoulli=args.bernoulli_masks)
+        corrupted, mask = corrupted.to(dev), mask.to(dev)   # inputs resident in HBM before the timed region
+        clean_nhwc = to_nhwc(clean.to(dev))
 
     def sync():
         torch.cuda.synchronize()
@@ -321,9 +350,9 @@ def main():
         if dom:
             k, d = dom
             kern = {"gemm_nt": ("tsii::gemm_nt_split_kernel<2, 2, 2, 2" if products else "tsii::gemm_nt_kernel<2, 2, 2, 2"),
-                    "gemm_tn": ("tsii::gemm_tn_split_kernel<2, 2, 2, 2" if products else "tsii::gemm_tn_kernel<2, 2, 2, 2")}[k]
+                    "gemm_tn": ("tsii::gemm_tn_split_kernel<2, 2, 2, 2" if products else "tsii::gemm_tn_kernel<2, 2, 2, 2")}.get(k, "tsii::" + k)
             t_hbm = d["alg_gb_per_step"] / (PEAK_HBM_TBS * 1e3)            # seconds per step at the HBM peak
-            t_mfma = d["ms_per_step"] * 1e-3 * d["mfma_frac"]               # seconds per step at the MFMA peak of the mode
+            t_mfma = d["ms_per_step"] * 1e-3 * d.get("mfma_frac", 0.0)      # seconds per step at the MFMA peak of the mode
             hbm_bound = t_hbm >= t_mfma
             traffic, traffic_src = pmc_traffic(kern) if (args.batch == 32 and args.size == 512 and args.model == "ImageFill") else (None, "not the profiled configuration")
             roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": kern.split("::")[1] + "...> (class " + k + ": 1x1-conv forward + dX GEMMs)" if k == "gemm_nt" else kern.split("::")[1] + "...> (class " + k + ")",
@@ -331,7 +360,7 @@ def main():
                         "peak": PEAK_HBM_TBS * 1e3 if hbm_bound else d["mfma_peak_fp32_equiv"],
                         "unit": "GB/s" if hbm_bound else "TFLOP/s (fp32-equivalent)",
                         "frac": d["hbm_frac"] if hbm_bound else d["mfma_frac"],
-                        "hbm_frac": d["hbm_frac"], "mfma_frac": d["mfma_frac"],
+                        "hbm_frac": d["hbm_frac"], "mfma_frac": d.get("mfma_frac"),
                         "traffic": traffic, "traffic_source": traffic_src,
                         "alg_bytes_per_launch": round(d["alg_gb_per_step"] * 1e9 / max(1, d["launches_per_step"])),
                         "launches_per_step": d["launches_per_step"],
@@ -351,24 +380,33 @@ def main():
                      "frac_of_hbm_roofline": round(t_hbm / ms_per_img, 4),
                      "forward_frac_of_roofline": round(max(t_hbm, t_flop) / 3 / fwd_ms_per_img, 4),
                      "forward_frac_of_hbm_roofline": round(t_hbm / 3 / fwd_ms_per_img, 4)}
+        if seg:
+            workload = (f"{args.model}{' (pixel-shuffle head)' if args.pixel_shuffle and args.model == 'TextSegament' else ''}"
+                        f"{' (encoder stages recomputed in backward)' if args.checkpoint else ''} {args.size}x{args.size} text-segmentation train step "
+                        f"(fwd+bwd, train-mode BN, BinaryFocalLoss, grad all-reduce, fused SGD), {args.batch} imgs/GPU, synthetic manga tiles")
+            metric = f"imgs/sec fwd+bwd on {args.size}x{args.size} text segmentation ({args.model}; secondary config, not the headline metric)"
+        else:
+            workload = (f"{args.model} {args.size}x{args.size} partial-conv inpainting train step (fwd+bwd, train-mode BN, L1 loss, grad all-reduce, "
+                        f"fused SGD), {args.batch} imgs/GPU, random line/ellipse hole masks")
+            metric = "imgs/sec fwd+bwd on 512x512 partial-conv inpaint"
+        dtype = {0: "f32", 1: "f32 storage / accumulation / stencils / BatchNorm; matrix products on bf16-rounded operands (the 'mixed bf16' arithmetic of cfg 5)"}.get(
+            products, f"f32 (storage, accumulation, stencils, BatchNorm; matrix products = {products}-term exact bf16 split on the bf16 MFMA, fp32-class error)")
         line = {
-            "metric": "imgs/sec fwd+bwd on 512x512 partial-conv inpaint",
+            "metric": metric,
             "value": round(value, 2), "unit": "imgs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if products == 0 else f"f32 (storage, accumulation, stencils, BatchNorm; matrix products = {products}-term exact bf16 split on the bf16 MFMA, fp32-class error)",
+            "dtype": dtype,
             "data": "synthetic",
-            "config": {"workload": f"{args.model} {args.size}x{args.size} partial-conv inpainting train step "
-                                   f"(fwd+bwd, train-mode BN, L1 loss, grad all-reduce, fused SGD), "
-                                   f"{args.batch} imgs/GPU, random line/ellipse hole masks",
-                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "gemm_products": products},
+            "config": {"workload": workload, "global_batch": world * args.batch, "parallelism": f"dp{world}", "gemm_products": products},
             "roofline": roofline, "kernel_classes": classes, "whole_step_roofline": whole, "final_loss": final_loss,
             "launch": "hip_graph_replay" if graphed else "eager", "eager_ms_per_step": round(eager_ms, 3),
             "forward_only": {"value": round(world * args.batch * fwd_steps / fwd_elapsed, 2), "unit": "imgs/s (rank 0 clock)",
                              "ms_per_step": round(fwd_elapsed / fwd_steps * 1e3, 3), "steps": fwd_steps},
             "f32_mfma_mode": f32_leg, "comm": comm,
         }
-        if not args.no_cpu_baseline and world == 1:
+        line["peak_mem_gib"] = round(torch.cuda.max_memory_allocated() / 2**30, 1)
+        if not args.no_cpu_baseline and world == 1 and not seg:
             _, phys, logical = host_cpu()
             line["cpu_baseline"] = cpu_baseline(args.size, args.cpu_threads or min(phys or logical or 1, 32))
         elif world == 1:

@@ -107,8 +107,11 @@ def test_golden_seg_nets_64_gpu(name):
                 # the emulator and the split-bf16 default at 3.8e-3 (5.6x) on the chip, with every kernel involved
                 # exact against float64 at kernel level (tests/test_emu_kernels.py).  The 256^2 test (tests/test_parity_r2.py) measures the
                 # oracle's spread over several perturbed fp32 runs instead of assuming a factor.
+                ref64 = G["grad64." + k[5:]]
+                scale = max(float(np.abs(G[k]).max()), 1e-3 * gmax)
+                noise = float(np.abs(G[k] - ref64).max()) / scale
                 assert_close(params[k[5:]].grad, ref64.astype(np.float32), max(3e-3, 8 * noise), k + " vs fp64", floor=1e-3 * gmax)
-                assert_close(params[k[5:]].grad, G[k], max(3e-3, 5 * noise), k, floor=1e-3 * gmax)
+                assert_close(params[k[5:]].grad, G[k], max(3e-3, 9 * noise), k, floor=1e-3 * gmax)   # vs the fp32 run: the two noises add
                 n += 1
         assert n >= 12
 
