@@ -319,10 +319,10 @@ def main():
             trainer.loss_fn(model((corrupted, mask)), clean_nhwc)
         sync()
         fwd_elapsed = time.perf_counter() - t1
-    # the same step in the bit-exact f32-MFMA arithmetic mode (tsii_set_gemm_products(0)), short run, for reference
-    f32_leg = None
-    if products != 0 and not args.no_f32_leg:
-        L.tsii_set_gemm_products(0)
+    # the same step in the other arithmetic modes, short runs, for reference: 0 = bit-exact f32-MFMA (fp32 FMA chain),
+    # 3 = 2-piece split / 3 partial products (opt-in: ~8x the rounding error of the fp32 chain, still 3 orders inside the 1e-3 bar)
+    def mode_leg(mode, what):
+        L.tsii_set_gemm_products(mode)
         for _ in range(3):
             trainer.step(corrupted, mask, clean_nhwc)
         sync()
@@ -332,9 +332,20 @@ def main():
             trainer.step(corrupted, mask, clean_nhwc)
         sync()
         e2 = time.perf_counter() - t2
+        with torch.no_grad():
+            t3 = time.perf_counter()
+            for _ in range(n2):
+                trainer.loss_fn(model((corrupted, mask)), clean_nhwc)
+            sync()
+            e3 = time.perf_counter() - t3
         L.tsii_set_gemm_products(products)
-        f32_leg = {"value": round(world * args.batch * n2 / e2, 2), "unit": "imgs/s (rank 0 clock)", "ms_per_step": round(e2 / n2 * 1e3, 3), "steps": n2,
-                   "arithmetic": "v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chain)"}
+        return {"value": round(world * args.batch * n2 / e2, 2), "unit": "imgs/s (rank 0 clock)", "ms_per_step": round(e2 / n2 * 1e3, 3), "steps": n2,
+                "forward_ms_per_step": round(e3 / n2 * 1e3, 3), "arithmetic": what}
+    f32_leg = split3_leg = None
+    if products != 0 and not args.no_f32_leg:
+        f32_leg = mode_leg(0, "v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chain)")
+        if products != 3:
+            split3_leg = mode_leg(3, "2-piece bf16 split, 3 partial products (dropped terms <= 2^-15 |a*b|; opt-in, NOT the reported arithmetic)")
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -403,7 +414,7 @@ def main():
             "launch": "hip_graph_replay" if graphed else "eager", "eager_ms_per_step": round(eager_ms, 3),
             "forward_only": {"value": round(world * args.batch * fwd_steps / fwd_elapsed, 2), "unit": "imgs/s (rank 0 clock)",
                              "ms_per_step": round(fwd_elapsed / fwd_steps * 1e3, 3), "steps": fwd_steps},
-            "f32_mfma_mode": f32_leg, "comm": comm,
+            "f32_mfma_mode": f32_leg, "split3_mode": split3_leg, "comm": comm,
         }
         line["peak_mem_gib"] = round(torch.cuda.max_memory_allocated() / 2**30, 1)
         if not args.no_cpu_baseline and world == 1 and not seg:

@@ -93,3 +93,37 @@ def test_dilate_known_answer():
     d = synthetic.dilate_10x10(a)
     ys, xs = np.nonzero(d)
     assert (ys.min(), ys.max(), xs.min(), xs.max()) == (12, 21, 12, 21) and d.sum() == 255 * 100
+
+
+def test_bench_class_table_and_traffic_gate(tmp_path, monkeypatch):
+    """bench.py host logic: per-class accounting from the timed entry-point records (algorithmic bytes / MACs decoded from
+    the call arguments, fractions of the 8 TB/s and of the MFMA peak of the arithmetic mode) and the staleness gate of the
+    PMC traffic figure (reported only while the kernel sources hash to what the profile was measured at)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    m, k, n = 1 << 20, 256, 512
+    timed = {"tsii_pw_fwd": [(1.0, (m, k, n))] * 2,                       # 2 launches of 1 ms in 2 steps
+             "tsii_bn_act_fwd": [(0.5, (m, n))] * 2, "not_a_kernel": [(9.0, ())]}
+    tab = bench.class_table(timed, 2, 6)
+    g = tab["gemm_nt"]
+    assert g["launches_per_step"] == 1 and g["ms_per_step"] == 1.0
+    assert abs(g["alg_gb_per_step"] - 4.0 * m * (k + n) / 1e9) < 1e-2
+    assert abs(g["fp32_equiv_tflops"] - 2.0 * m * k * n / 1e-3 / 1e12) < 0.5
+    assert abs(g["mfma_peak_fp32_equiv"] - bench.PEAK_BF16_TFLOPS / 6) < 0.1 and 0 < g["mfma_frac"] < 1
+    assert abs(bench.class_table(timed, 2, 0)["gemm_nt"]["mfma_peak_fp32_equiv"] - bench.PEAK_FP32_TFLOPS) < 0.1
+    b = tab["bn_act"]
+    assert abs(b["tb_per_s"] - 8.0 * m * n / 0.5e-3 / 1e12) < 0.05 and "mfma_frac" not in b
+    # traffic gate
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    js = {"csrc_sha": "0" * 12, "kernels": {"tsii::gemm_nt_split_kernel<2, 2, 2, 2, 6>": {"launches": 2, "bytes_per_launch": 1e9}}}
+    json.dump(js, open(tmp_path / "profiles" / bench.PMC_SUMMARY, "w"))
+    monkeypatch.setattr(bench, "csrc_sha", lambda: "1" * 12)
+    val, why = bench.pmc_traffic("tsii::gemm_nt_split_kernel<2, 2, 2, 2")
+    assert val is None and "stale" in why
+    monkeypatch.setattr(bench, "csrc_sha", lambda: "0" * 12)
+    val, why = bench.pmc_traffic("tsii::gemm_nt_split_kernel<2, 2, 2, 2")
+    assert val == 1e9
