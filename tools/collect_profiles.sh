@@ -13,6 +13,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"; mkdir -p gpurun_out
 timeout 900 python bench.py > gpurun_out/${TAG}_bench_bs32.log 2>&1; tail -1 gpurun_out/${TAG}_bench_bs32.log | cut -c1-200
 timeout 600 python tools/profile_step.py > gpurun_out/${TAG}_per_shape.log 2>&1
+# secondary configs (BASELINE cfg 3 / cfg 5 shapes), same bench contract, short runs
+timeout 600 python bench.py --model TextSegament --batch 64 --pixel-shuffle --steps 8 --warmup 2 --no-f32-leg 2>&1 | tail -1 > gpurun_out/${TAG}_bench_cfg3_textsegament_bs64.log
+timeout 600 python bench.py --model XceptionTextSegment --size 1024 --batch 8 --products 1 --steps 8 --warmup 2 --no-f32-leg 2>&1 | tail -1 > gpurun_out/${TAG}_bench_cfg5_xception1024_bf16.log
+timeout 600 python bench.py --model XceptionTextSegment --size 1024 --batch 8 --steps 8 --warmup 2 --no-f32-leg 2>&1 | tail -1 > gpurun_out/${TAG}_bench_cfg5_xception1024_fp32class.log
+timeout 300 python tools/microbench.py > gpurun_out/${TAG}_microbench.log 2>&1
 export TMPDIR=/tmp; cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof -o b32 --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-f32-leg > $R/gpurun_out/${TAG}_rocprof.log 2>&1; echo "rocprof stats rc=$?"
 cp $R/gpurun_out/${TAG}_prof/b32_kernel_stats.csv $R/gpurun_out/${TAG}_kernel_stats_bs32.csv

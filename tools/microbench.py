@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The two machine numbers SURVEY.md 8(d) asks to be measured on the box, through the library's own kernels:
   * stream: tsii_act_fwd (1 read + 1 write) and tsii_bn_stats (read only) over a 3.2 GB tensor -> GB/s
-  * MFMA:   tsii_pw_fwd (fp32 v_mfma_f32_32x32x2) on 65536 x 4096 x 4096 and 8192^3-like shapes -> TFLOP/s
+  * MFMA:   tsii_pw_fwd on 65536 x 4096 x 4096 and 8192^3-like shapes in the f32-MFMA, 6-product split and plain-bf16 arithmetic -> TFLOP/s
     python tools/microbench.py
 """
 import os
@@ -45,9 +45,14 @@ def main():
         a = torch.randn(M, K, device=dev)
         w = torch.randn(N, K, device=dev) * 0.02
         o = torch.empty(M, N, device=dev)
-        ms = timeit(lambda: call("tsii_pw_fwd", ptr(a), M, K, ptr(w), N, None, None, 0, None, None, None, ptr(o), None, 0, st), iters=3)
-        print(f"fp32 MFMA GEMM {M} x {K} x {N}: {ms:.3f} ms  {2.0 * M * K * N / ms / 1e9:.1f} TFLOP/s ({2.0 * M * K * N / ms / 1e9 / 157.3 * 100:.0f} % of 157.3)")
-
+        wws = torch.empty(L.tsii_pw_ws_bytes(N, K) // 4 + 4, device=dev)
+        for mode, label, peak in ((0, "f32 MFMA (v_mfma_f32_32x32x2_f32)", 157.3), (6, "split-bf16, 6 products (v_mfma_f32_32x32x16_bf16)", 2500.0 / 6),
+                                  (1, "bf16 operands, 1 product", 2500.0)):
+            L.tsii_set_gemm_products(mode)
+            ms = timeit(lambda: call("tsii_pw_fwd", ptr(a), M, K, ptr(w), N, None, None, 0, None, None, None, ptr(o), ptr(wws), wws.numel() * 4, st), iters=3)
+            tf = 2.0 * M * K * N / ms / 1e9
+            print(f"GEMM {M} x {K} x {N} {label}: {ms:.3f} ms  {tf:.1f} TFLOP/s fp32-equivalent ({tf / peak * 100:.0f} % of {peak:.1f})")
+        L.tsii_set_gemm_products(6)
 
 if __name__ == "__main__":
     main()
