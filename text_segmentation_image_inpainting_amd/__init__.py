@@ -10,3 +10,4 @@ from .Xception import ResidualBlock, Xception  # noqa: F401,E402
 from .common import ASP, RFB, SpatialChannelSqueezeExcitation  # noqa: F401,E402
 from .text_segmentation import TextSegament, XceptionTextSegment  # noqa: F401,E402
 from .loss import BinaryFocalLoss, FeatureExtractor, InpaintingLoss, gram_matrix, total_variation_loss  # noqa: F401,E402
+from .recipes import InpaintingRecipe, SegmentationRecipe  # noqa: F401,E402
