@@ -30,6 +30,15 @@ def _torch_loop(params, base_lr, max_lr, step_size, wd):
     return opt, sched
 
 
+def _check_losses(losses, ref):
+    """Step 0 sees identical parameters: tight.  Later steps see parameters that already carry the (noise-limited, SURVEY.md
+    F11) gradient error of the earlier updates, which moves the loss by a fraction of what the update itself moved it:
+    bound the error by 5 % of the reference's loss change over that step."""
+    assert abs(losses[0] - ref[0]) <= 2e-5 * abs(ref[0]), (losses, ref)
+    for i in range(1, len(ref)):
+        assert abs(losses[i] - ref[i]) <= 5e-2 * abs(ref[i] - ref[i - 1]) + 2e-5 * abs(ref[i]), (i, losses, ref)
+
+
 def _update_error(p_hip, p_ref, p_start):
     """|p_hip - p_ref| relative to the size of the update the optimizer made to this tensor, after allowing 4 ulp of the
     parameter itself (at lr 1e-4 an update is a few dozen ulp of a weight: the comparison must not be made on the
@@ -97,8 +106,7 @@ def _inpainting_recipe_case(backend, make_model, oracle_fwd, key_shapes, trainab
             lrs.append(rec.lr)
         assert all(not p.requires_grad for p in rec.criterion.parameters())
         assert np.allclose(lrs, ref_lrs, rtol=1e-12) and lrs[0] == cfg["base_lr"] and lrs[2] == cfg["max_lr"]   # 1e-4, 5.05e-3, 1e-2
-        for a, b in zip(losses, ref_losses):
-            assert abs(a - b) <= 2e-4 * abs(b), (losses, ref_losses)
+        _check_losses(losses, ref_losses)
         params = dict(model.named_parameters())
         assert sorted(k for k, p in params.items() if p.requires_grad) == sorted(trainable)
         worst = max((_update_error(params[k].detach().cpu(), sd[k].detach(), start[k]), k) for k in trainable)
@@ -165,8 +173,7 @@ def _segmentation_recipe_case(backend, width_mult, x, t, tol):
         losses.append(float(rec.step(x.to(dev), t.to(dev))))
         params = dict(net.named_parameters())
         worst2 = max((_update_error(params[k].detach().cpu(), sd[k].detach(), mid[k]), k) for k in all_params)
-        for a, b in zip(losses, ref_losses):
-            assert abs(a - b) <= 2e-4 * abs(b), (losses, ref_losses)
+        _check_losses(losses, ref_losses)
         assert worst1[0] <= tol and worst2[0] <= tol, (worst1, worst2)
         assert any(not torch.equal(v, params["encoder." + k].detach()) for k, v in enc0.items())     # stage 2 trains the encoder
 
