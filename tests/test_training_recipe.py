@@ -194,3 +194,28 @@ def test_segmentation_two_stage_recipe_emu():
 def test_segmentation_two_stage_recipe_gpu():
     G = np.load(os.path.join(GOLD, "textsegament_64.npz"))
     _segmentation_recipe_case("gpu", 2, torch.from_numpy(G["x"]), torch.from_numpy(G["t"]), tol=5e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--model", "XceptionTextSegment", "--size", "128", "--batch", "2", "--products", "1"],
+                                   ["--model", "TextSegament", "--size", "128", "--batch", "2", "--pixel-shuffle", "--checkpoint"],
+                                   ["--model", "ImageFill", "--size", "128", "--batch", "2"]])
+def test_bench_line_contract_gpu(extra):
+    """bench.py end to end on small shapes: ONE JSON line with the contract's keys, for the headline workload and for the
+    secondary configs (cfg 3 / cfg 5 flags)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "kernel_classes", "forward_only", "f32_mfma_mode", "split3_mode", "comm"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["roofline"]["bound"] in ("hbm", "mfma") and 0 < d["roofline"]["frac"] < 1
+    assert d["config"]["gemm_products"] == (1 if "--products" in extra else 6)
+    assert ("headline" not in d["metric"]) == (extra[1] == "ImageFill")
