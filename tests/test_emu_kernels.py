@@ -205,7 +205,8 @@ def _conv_ref(x, w, s, p, d):
 
 @pytest.mark.parametrize("cin,cout,k,s,p,d,h", [(16, 32, 3, 1, 1, 1, 11), (8, 136, 3, 2, 1, 1, 13), (24, 16, 3, 1, 2, 2, 9),
                                                 (16, 40, 5, 2, 2, 1, 12), (16, 136, 3, 1, 1, 1, 9), (8, 256, 3, 1, 1, 1, 7),
-                                                (128, 16, 3, 1, 1, 1, 6)])     # 128-wide tiles of the NT / TN forms, dX with N = 128
+                                                (128, 16, 3, 1, 1, 1, 6),      # 128-wide tiles of the NT / TN forms, dX with N = 128
+                                                (12, 64, 4, 1, 0, 1, 11), (20, 16, 2, 1, 1, 1, 8)])   # c % 4 only: half-chunks straddle taps (s2d stems)
 def test_dense_conv_gather_gemms(emu, mode, cin, cout, k, s, p, d, h):
     """K4 entry points on the gather forms of the GEMM kernels (split-bf16 loaders in modes 6 / 3 / 1, f32 MFMA in mode 0):
     forward with the x*mask planes and the count division, dX (stride phases for s = 2), dW -- against float64 numpy."""

@@ -391,7 +391,7 @@ static int launch_nt_conv(const float* A, const float* B, int64_t ldb, float* C,
                           Epilogue ep, ConvGather cg, hipStream_t stream) {
     ep.vec_store = (ldc % 4 == 0) && aligned16(C);
     if constexpr (AMODE == 1 || AMODE == 2) {
-        if (nt_split_conv_ok(A, B, ldb, K, cg)) return launch_nt_split_conv(AMODE, A, B, ldb, C, ldc, M, N, K, ep, cg, stream);
+        if (nt_split_conv_ok(AMODE, A, B, ldb, K, cg)) return launch_nt_split_conv(AMODE, A, B, ldb, C, ldc, M, N, K, ep, cg, stream);
     }
     if (N % 128 == 0 || N > 192) return launch_nt_conv_cfg<2, 2, 2, 2, AMODE>(A, B, ldb, C, ldc, M, N, K, ep, cg, stream);
     if (N > 32) return launch_nt_conv_cfg<2, 2, 2, 1, AMODE>(A, B, ldb, C, ldc, M, N, K, ep, cg, stream);

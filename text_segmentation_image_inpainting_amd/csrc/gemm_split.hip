@@ -130,8 +130,8 @@ __device__ __forceinline__ void split_store(unsigned char* __restrict__ S, const
 }
 
 // ---- implicit-GEMM gather for the A operand (dense k x k convolutions, gemm_tiles.h ConvGather) ---------------------
-// Row m = a pixel of the row grid, column k = (tap, channel); with c % 8 == 0 a chunk of 8 k lies inside one tap = 32
-// contiguous bytes of the NHWC source.  This thread's rows are fixed for the tile (decoded once), its chunk column
+// Row m = a pixel of the row grid, column k = (tap, channel); c % 4 == 0: a chunk of 8 k is two float4 gathers (one tap when
+// c % 8 == 0).  This thread's rows are fixed for the tile (decoded once), its chunk column
 // advances with the K loop.  Branch-free like split_load: taps outside the image read pixel 0 and are zeroed by the store
 // (bit i of `okm`); the per-source-pixel planes p0 / p1 (x*mask, 1/count) arrive next to the data.
 template <int ROWS>
@@ -153,37 +153,54 @@ template <int ROWS, int AMODE>
 __device__ __forceinline__ void split_conv_load(const float* __restrict__ src, const ConvGather& cg, const int (&rn)[SplitChunks<ROWS>::value],
                                                 const int (&ry)[SplitChunks<ROWS>::value], const int (&rx)[SplitChunks<ROWS>::value],
                                                 int k0, int K, float4 (&regs)[SplitChunks<ROWS>::value][2],
-                                                float (&f0)[SplitChunks<ROWS>::value], float (&f1)[SplitChunks<ROWS>::value],
-                                                unsigned& okm, int& ci_out) {
+                                                float (&f0)[SplitChunks<ROWS>::value][2], float (&f1)[SplitChunks<ROWS>::value][2],
+                                                unsigned& okm, int (&ci_out)[2]) {
+    // the chunk's two float4 halves are gathered separately: with c % 8 == 0 they are neighbours inside one tap (decoded
+    // once), with c % 4 == 0 only (12-channel space-to-depth stems) the second half may belong to the next tap
     int k = k0 + (threadIdx.x & 3) * 8;
     const bool kok = k < K;
     k = kok ? k : K - 8;                                                // K % 8 == 0
-    const int t = k / cg.c, ci = k - t * cg.c;
-    const int ky = t / cg.kw, kx = t - ky * cg.kw;
-    ci_out = ci;
+    const bool c8 = (cg.c & 7) == 0;                                    // wave-uniform
     okm = 0u;
+    int t = k / cg.c, ci = k - t * cg.c;
+    int ky = t / cg.kw, kx = t - ky * cg.kw;
+    constexpr bool ONE_TAP = (AMODE == 2);          // dX gathers over cout: the launcher admits c % 8 == 0 only (one decode)
+    int64_t spix0[SplitChunks<ROWS>::value];
 #pragma unroll
-    for (int i = 0; i < SplitChunks<ROWS>::value; ++i) {
-        int sy = 0, sx = 0;
-        const bool ok = kok && rn[i] >= 0 && conv_src<AMODE>(cg, ry[i], rx[i], ky, kx, sy, sx);
-        const int64_t spix = ok ? ((int64_t)rn[i] * cg.h + sy) * cg.w + sx : 0;
-        const float* p = src + spix * cg.c + ci;
-        regs[i][0] = *reinterpret_cast<const float4*>(p);
-        regs[i][1] = *reinterpret_cast<const float4*>(p + 4);
-        float a0 = 1.f, a1 = 1.f;
-        if (cg.p0 != nullptr) {                                          // wave-uniform
-            a0 = cg.p0[spix];
-            a1 = cg.p1 != nullptr ? cg.p1[spix] : 1.f;
+    for (int h = 0; h < 2; ++h) {
+        if (h == 1) {
+            ci += 4;
+            if (!ONE_TAP && !c8 && ci >= cg.c) { ci -= cg.c; ++kx; if (kx == cg.kw) { kx = 0; ++ky; } }
         }
-        f0[i] = a0; f1[i] = a1;
-        okm |= ok ? (1u << i) : 0u;
+        ci_out[h] = ci;
+#pragma unroll
+        for (int i = 0; i < SplitChunks<ROWS>::value; ++i) {
+            if ((ONE_TAP || c8) && h == 1) {          // same source pixel as the first half (wave-uniform test)
+                regs[i][1] = *reinterpret_cast<const float4*>(src + spix0[i] * cg.c + ci);
+                f0[i][1] = f0[i][0]; f1[i][1] = f1[i][0];
+                okm |= ((okm >> (2 * i)) & 1u) << (2 * i + 1);
+                continue;
+            }
+            int sy = 0, sx = 0;
+            const bool ok = kok && rn[i] >= 0 && conv_src<AMODE>(cg, ry[i], rx[i], ky, kx, sy, sx);
+            const int64_t spix = ok ? ((int64_t)rn[i] * cg.h + sy) * cg.w + sx : 0;
+            if (h == 0) spix0[i] = spix;
+            regs[i][h] = *reinterpret_cast<const float4*>(src + spix * cg.c + ci);
+            float a0 = 1.f, a1 = 1.f;
+            if (cg.p0 != nullptr) {                                      // wave-uniform
+                a0 = cg.p0[spix];
+                a1 = cg.p1 != nullptr ? cg.p1[spix] : 1.f;
+            }
+            f0[i][h] = a0; f1[i][h] = a1;
+            okm |= ok ? (1u << (2 * i + h)) : 0u;
+        }
     }
 }
 
 template <int ROWS, int P>
-__device__ __forceinline__ void split_conv_store(unsigned char* __restrict__ S, const float4 (&regs)[SplitChunks<ROWS>::value][2], int ci,
-                                                 int split, const float (&f0)[SplitChunks<ROWS>::value],
-                                                 const float (&f1)[SplitChunks<ROWS>::value], unsigned okm) {
+__device__ __forceinline__ void split_conv_store(unsigned char* __restrict__ S, const float4 (&regs)[SplitChunks<ROWS>::value][2], const int (&ci)[2],
+                                                 int split, const float (&f0)[SplitChunks<ROWS>::value][2],
+                                                 const float (&f1)[SplitChunks<ROWS>::value][2], unsigned okm) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < SplitChunks<ROWS>::value; ++i) {
@@ -191,11 +208,11 @@ __device__ __forceinline__ void split_conv_store(unsigned char* __restrict__ S, 
         if (ROWS * 4 % 256 != 0 && f >= ROWS * 4) continue;
         const int r = f >> 2, c = f & 3;
         float v[8] = {regs[i][0].x, regs[i][0].y, regs[i][0].z, regs[i][0].w, regs[i][1].x, regs[i][1].y, regs[i][1].z, regs[i][1].w};
-        const bool valid = (okm >> i) & 1u;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            v[e] *= (ci + e < split) ? f0[i] : f1[i];
-            v[e] = valid ? v[e] : 0.f;
+            const int h = e >> 2;
+            v[e] *= (ci[h] + (e & 3) < split) ? f0[i][h] : f1[i][h];
+            v[e] = ((okm >> (2 * i + h)) & 1u) ? v[e] : 0.f;
         }
         u32x4 pl[P];
         split8<P>(v, pl);
@@ -290,7 +307,7 @@ __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_
                                                                        float* __restrict__ C, int64_t ldc,
                                                                        int64_t M, int N, int K, Epilogue ep, unsigned ntn, InBN ib, int abl,
                                                                        ConvGather cg) {
-    // AMODE 1 / 2: A is the im2col view of an NHWC tensor (forward / dX of a dense convolution, cg; c % 8 == 0)
+    // AMODE 1 / 2: A is the im2col view of an NHWC tensor (forward / dX of a dense convolution, cg; c % 4 == 0 / c % 8 == 0)
     constexpr bool CONV = AMODE != 0;
     static_assert(!CONV || (!BNIN && !BNB && !BPRE), "the gather form has no fused BatchNorm variants");
     // abl: ablation switches of tools/gemm_bench.py (0 in production; wave-uniform kernel argument): 1 no epilogue,
@@ -331,11 +348,12 @@ __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_
     float sa0[NA], sa1[NA], sb0[NB], sb1[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) { sb0[i] = 1.f; sb1[i] = 1.f; }
-    int rn[NA], ry[NA], rx[NA], cci = 0;         // CONV: this thread's rows on the row grid; channel of its chunk in flight
+    int rn[NA], ry[NA], rx[NA], cci[2] = {0, 0}; // CONV: this thread's rows on the row grid; channels of its two half-chunks in flight
+    float ca0[CONV ? NA : 1][2], ca1[CONV ? NA : 1][2];   // CONV: plane factors per row and half-chunk
     unsigned okm = 0u;
     if constexpr (CONV) {
         split_conv_rows<BM>(cg, m0, M, rn, ry, rx);
-        split_conv_load<BM, AMODE>(A, cg, rn, ry, rx, 0, K, ra, sa0, sa1, okm, cci);
+        split_conv_load<BM, AMODE>(A, cg, rn, ry, rx, 0, K, ra, ca0, ca1, okm, cci);
     } else {
         split_row_scales<BM>(as, m0, M, sa0, sa1);
         split_load<BM>(A, lda, m0, M, 0, K, ra);
@@ -352,7 +370,7 @@ __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_
             psh[0] = *reinterpret_cast<const float4*>(ib.sh + pk); psh[1] = *reinterpret_cast<const float4*>(ib.sh + pk + 4);
         }
     }
-    if constexpr (CONV) split_conv_store<BM, P>(As, ra, cci, cg.split, sa0, sa1, okm);
+    if constexpr (CONV) split_conv_store<BM, P>(As, ra, cci, cg.split, ca0, ca1, okm);
     else split_store<BM, P, true, BNIN>(As, ra, 0, as.split, sa0, sa1, psc, psh, ib.neg, ib.hi, mvalid, K);
     if constexpr (BPRE) split_store_pre<BN, P>(Bs, rbp, 0, nvalid, K);
     else split_store<BN, P, false, false>(Bs, rb, 0, 0, sb0, sb1, psc, psh, 1.f, 0.f, nvalid, K);
@@ -368,7 +386,7 @@ __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = (kt + 1 < nk);
         if (more && !(abl & 2)) {  // next tile's global loads fly during the MFMA phase
-            if constexpr (CONV) split_conv_load<BM, AMODE>(A, cg, rn, ry, rx, (kt + 1) * SPLIT_BK, K, ra, sa0, sa1, okm, cci);
+            if constexpr (CONV) split_conv_load<BM, AMODE>(A, cg, rn, ry, rx, (kt + 1) * SPLIT_BK, K, ra, ca0, ca1, okm, cci);
             else split_load<BM>(A, lda, m0, M, (kt + 1) * SPLIT_BK, K, ra);
             if constexpr (BPRE) split_load_pre<BN, P>(Bpl, bstride, K, n0, N, (kt + 1) * SPLIT_BK, K, rbp);
             else split_load<BN>(B, ldb, n0, N, (kt + 1) * SPLIT_BK, K, rb);
@@ -413,7 +431,7 @@ __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_
         }
         __syncthreads();
         if (more && !(abl & 8)) {
-            if constexpr (CONV) split_conv_store<BM, P>(As, ra, cci, cg.split, sa0, sa1, okm);
+            if constexpr (CONV) split_conv_store<BM, P>(As, ra, cci, cg.split, ca0, ca1, okm);
             else split_store<BM, P, true, BNIN>(As, ra, (kt + 1) * SPLIT_BK, as.split, sa0, sa1, psc, psh, ib.neg, ib.hi, mvalid, K);
             if constexpr (BPRE) split_store_pre<BN, P>(Bs, rbp, (kt + 1) * SPLIT_BK, nvalid, K);
             else split_store<BN, P, false, false>(Bs, rb, (kt + 1) * SPLIT_BK, 0, sb0, sb1, psc, psh, 1.f, 0.f, nvalid, K);
@@ -801,8 +819,8 @@ int launch_nt_split(const float* A, int64_t lda, RowScale as, const float* B, in
 }
 
 // ---- dense convolutions: A gathered (AMODE 1 forward, 2 dX), B = the fp32 [N,K] weight layout, split while staged ----
-bool nt_split_conv_ok(const float* A, const float* B, int64_t ldb, int K, const ConvGather& cg) {
-    return g_products != 0 && cg.c % 8 == 0 && K % 8 == 0 && ldb % 4 == 0 && cg.pfull == nullptr && aligned16(A) && aligned16(B);
+bool nt_split_conv_ok(int amode, const float* A, const float* B, int64_t ldb, int K, const ConvGather& cg) {
+    return g_products != 0 && cg.c % (amode == 2 ? 8 : 4) == 0 && K % 8 == 0 && ldb % 4 == 0 && cg.pfull == nullptr && aligned16(A) && aligned16(B);
 }
 
 template <int WM, int WN, int TM, int TN, int AMODE>
