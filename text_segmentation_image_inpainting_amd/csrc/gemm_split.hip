@@ -892,9 +892,10 @@ int launch_tn_split_conv(const float* A, int64_t lda, const float* sa, const flo
     const InBN nobn = {nullptr, nullptr, 1.f, 0.f};
 #define TSII_TN_CONV(TMV, PR) hipLaunchKernelGGL((gemm_tn_split_kernel<2, 2, TMV, TMV, PR, false, true>), grid, dim3(256), 0, stream, A, lda, sa, B, (int64_t)0, none, \
                                                  Cws, M, Pn, Q, chunk, nobn, qt, pt, cg)
-#define TSII_TN_CONV_T(PR) do { if (big) TSII_TN_CONV(2, PR); else TSII_TN_CONV(1, PR); } while (0)
-    if (g_products == 1) TSII_TN_CONV_T(1); else if (g_products == 3) TSII_TN_CONV_T(3); else TSII_TN_CONV_T(6);
-#undef TSII_TN_CONV_T
+    TSII_REQUIRE(big || g_products == 1, "conv gemm_tn_split: 64x64 tiles exist in the plain-bf16 mode only (the caller keeps the f32 kernel)");
+    if (g_products == 1) { if (big) TSII_TN_CONV(2, 1); else TSII_TN_CONV(1, 1); }
+    else if (g_products == 3) TSII_TN_CONV(2, 3);
+    else TSII_TN_CONV(2, 6);
 #undef TSII_TN_CONV
     return check_launch("conv_gemm_tn_split");
 }

@@ -245,7 +245,7 @@ int launch_nt_split_conv(int amode, const float* A, const float* B, int64_t ldb,
                          Epilogue ep, const ConvGather& cg, hipStream_t stream);
 
 bool tn_split_ok(const float* A, int64_t lda, const float* B, int64_t ldb, int Pn, int Q);
-// dW of a dense convolution on the split TN kernel: B gathered by cg (cg.c % 4 == 0); big: 128x128 tiles, else 64x64
+// dW of a dense convolution on the split TN kernel: B gathered by cg (cg.c % 4 == 0); big: 128x128 tiles, else 64x64 (plain-bf16 mode only)
 bool tn_split_conv_ok(const float* A, int64_t lda, const float* B, int64_t M, int Pn, int Q, const ConvGather& cg);
 int launch_tn_split_conv(const float* A, int64_t lda, const float* sa, const float* B, const ConvGather& cg, float* Cws, int64_t M, int Pn, int Q,
                          int64_t chunk, int splits, bool big, hipStream_t stream);
