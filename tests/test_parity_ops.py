@@ -110,6 +110,18 @@ def _imagefill_case(dev, size, batch, seed, per_channel_mask, hole_frac=0.12):
     yo = O.image_fill(sd, x, mask, training=True)
     lo = O.l1_mean(yo, clean)
     lo.backward()
+    # the same oracle in float64: how far the oracle's OWN fp32 gradients sit from the exact ones (train-mode BatchNorm chains
+    # amplify rounding noise) -- one sample of the noise floor per tensor
+    sd64 = {k: (v.detach().double() if v.is_floating_point() else v.detach().clone()) for k, v in
+            make_state_dict([(k, s) for k, s in keys["ImageFill"]], seed=seed).items()}
+    for k in keys["ImageFill.trainable"]:
+        sd64[k].requires_grad_(True)
+    O.l1_mean(O.image_fill(sd64, x.double(), mask.double(), training=True), clean.double()).backward()
+    for k in keys["ImageFill.trainable"]:
+        g32, g64 = sd[k].grad, sd64[k].grad
+        # normalised like the assertion below (per tensor, floor 1e-6: mathematically-zero gradients -- a bias in front of a
+        # BatchNorm -- do not count).  Measured at 64^2: 7e-4 on the stem bias, 8e-3 on encoder.1.1's expand weight.
+        sd[k].noise = float((g32.double() - g64).abs().max()) / max(float(g32.abs().max()), 1e-6)
     # product
     model = T.ImageFill()
     fill_state_dict_(model.state_dict(), seed=seed)
@@ -132,7 +144,10 @@ def _check_imagefill(dev, size, batch, seed, pcm):
         if not p.requires_grad:
             continue
         assert p.grad is not None, k
-        worst = max(worst, assert_close(p.grad, sd[k].grad, 2e-3, "grad " + k, floor=1e-6))
+        # 2e-3, or 8x this tensor's fp32-vs-fp64 noise sample of the oracle itself when that is larger (the same rule as the
+        # segmentation-net fixtures; never more than 5e-2: the stem bias of the 64^2 case has moved between 1.5e-3 and 3.1e-3
+        # across kernel revisions whose arithmetic differs only in rounding, the oracle's own fp32 run is 7e-4 off there)
+        worst = max(worst, assert_close(p.grad, sd[k].grad, min(5e-2, max(2e-3, 8 * getattr(sd[k], "noise", 0.0))), "grad " + k, floor=1e-6))
     for k, v in model.state_dict().items():
         if k.endswith("running_mean") or k.endswith("running_var"):
             assert_close(v, sd[k], TOL, k)
