@@ -26,3 +26,26 @@ def assert_close(a, b, tol=1e-3, what="", floor=1e-30):
     e = rel_err(a, b, floor)
     assert e <= tol, f"{what}: max-normalised rel err {e:.3e} > {tol:.1e}"
     return e
+
+
+def assert_gradients_close(errs, tol=2e-3, what=""):
+    """Whole-network gradient comparison, ``errs`` = {tensor name: rel_err vs the oracle}.
+
+    These nets are piecewise linear in their activations (LeakyReLU / ReLU, |.| of the L1 loss): two fp32 implementations
+    disagree on the side of a kink for about one element in a million, and ONE such flip moves the weight gradients of the
+    layers around it by 1e-3 .. 1e-2 of their largest entry at test sizes (a few hundred pixels per channel), whereas a wrong
+    kernel moves whole families of tensors.  Measured on ImageFill 64^2: every tensor within 7e-4 on the emulator; on the chip
+    the same build had one tensor at 2.5e-3 .. 3.1e-3 -- a different tensor after unrelated upstream changes -- where the
+    oracle's own fp32-vs-fp64 distance was 3e-6 (no flip between its two runs).  ``tools/kink_probe.py`` on the chip
+    (profiles/r02r_kink_probe.log): the three tensors beyond 2e-3 (6.3e-3, 3.1e-3, 2.5e-3: the 1x1 weight of one decoder block,
+    the BatchNorm bias behind it, the stem bias) have an error matrix of rank 1 / a single-entry error vector -- 100.0 % of the
+    Frobenius norm in the top singular value -- i.e. one pixel's contribution; the median over all 139 tensors is 5e-7.
+    Rule: every tensor within 15 x tol, all but 4 % of them (at least 4: one flip touches the weight, the BatchNorm
+    parameters around it and the biases upstream) within tol, the median within tol / 10."""
+    assert errs, what
+    vals = sorted(errs.values())
+    over = sorted(((e, k) for k, e in errs.items() if e > tol), reverse=True)
+    assert vals[-1] <= 15 * tol, (what, over[:5])
+    assert len(over) <= max(4, len(vals) // 25), (what, over[:8])
+    assert vals[len(vals) // 2] <= tol / 10, (what, vals[len(vals) // 2])
+    return vals[-1]
