@@ -464,3 +464,113 @@ def test_mixed_bf16_products_mode_gpu(capsys):
             print("\n[mixed bf16] XceptionTextSegment 64x64 eval, max-normalised error vs the reference's fp64 run: " +
                   ", ".join(f"products={k}: {v:.2e}" for k, v in errs.items()))
         assert errs[6] <= 1e-3 and errs[3] <= 1e-3 and errs[1] <= 3e-2
+
+
+@both_backends
+@pytest.mark.parametrize("d", [2, 4, 8])
+def test_fused_dilated_blocks_taps_in_range(backend, d):
+    """The BatchNorm-fused forms of the dilated marching strips (K6b BatchNorm-on-load + statistics epilogue, K6c reductions
+    in the dX strip, BatchNorm-on-load dW; dilation 2 / 4 / 8) on maps wider than 2d, i.e. with every tap in range -- the
+    fixtures reach these dilations only on 8x8 maps (centre tap).  ``InvertedResidual`` (segmentation path) and
+    ``PartialInvertedResidual`` (ImageFill's dilated stages, image_inpainting.py:33-37) in train mode: output, dX, every
+    parameter gradient, running statistics vs the oracle."""
+    from oracle.filler import seeded_input
+    from text_segmentation_image_inpainting_amd import ops
+    H, W, c, t = 2 * d + 21, 2 * d + 26, 16, 2
+    act = torch.nn.LeakyReLU(0.3)
+    rng = np.random.default_rng(40 + d)
+    calls = []
+    real = ops.call
+    with BACKENDS[backend]() as dev:
+        ops.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+        try:
+            # ---- InvertedResidual: 1x1 + BN + act -> dw 3x3 (dilation d) + BN + act -> 1x1 + BN, residual
+            m = T.InvertedResidual(c, c, 1, t, d, activation=act)
+            keys = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+            fill_state_dict_(m.state_dict(), seed=40 + d)
+            sd = make_state_dict(keys, seed=40 + d)
+            names = [k for k, _ in m.named_parameters()]
+            for k in names:
+                sd[k].requires_grad_(True)
+            x = torch.from_numpy(rng.standard_normal((2, c, H, W)).astype(np.float32))
+            xo = x.clone().requires_grad_(True)
+            yo = S.inverted_residual(sd, "", xo, c, c, 1, t, d, act, False, True)
+            gy = torch.from_numpy(rng.standard_normal(tuple(yo.shape)).astype(np.float32))
+            yo.backward(gy)
+            m = m.to(dev).train()
+            xd = x.to(dev).requires_grad_(True)
+            y = m(xd)
+            assert_close(y, yo, TOL, f"IR d={d} y")
+            y.backward(gy.to(dev))
+            assert_close(xd.grad, xo.grad, TOL, f"IR d={d} dx")
+            for k, p in m.named_parameters():
+                assert_close(p.grad, sd[k].grad, 2e-3, f"IR d={d} grad {k}", floor=1e-6)
+            for k, v in m.state_dict().items():
+                if "running" in k:
+                    assert_close(v, sd[k], TOL, f"IR d={d} {k}")
+            # ---- PartialInvertedResidual with a hole mask
+            pm = T.PartialInvertedResidual(c, c, 3, 1, d, d, t, BN=True, activation=act, use_1_conv=True, same_holes=True)
+            keys = [(k, tuple(v.shape)) for k, v in pm.state_dict().items()]
+            fill_state_dict_(pm.state_dict(), seed=50 + d)
+            sd = make_state_dict(keys, seed=50 + d)
+            names = [k for k, p in pm.named_parameters() if p.requires_grad]
+            for k in names:
+                sd[k].requires_grad_(True)
+            x, mask = seeded_input(2, c, H, W, seed=50 + d, hole_frac=0.15)
+            xo = x.clone().requires_grad_(True)
+            yo, nmo = O.partial_inverted_residual(sd, "", xo, mask, c, c, 3, 1, d, d, t, O.leaky(0.3), True, False, True, True)
+            yo.backward(gy)
+            pm = pm.to(dev).train()
+            xd = x.to(dev).requires_grad_(True)
+            y, nm = pm((xd, mask.to(dev)))
+            assert_close(y, yo, TOL, f"PIR d={d} y")
+            assert np.array_equal((nm.as_tensor() if hasattr(nm, "as_tensor") else nm).detach().cpu().numpy(), nmo.numpy())
+            y.backward(gy.to(dev))
+            assert_close(xd.grad, xo.grad, TOL, f"PIR d={d} dx")
+            for k in names:
+                assert_close(dict(pm.named_parameters())[k].grad, sd[k].grad, 2e-3, f"PIR d={d} grad {k}", floor=1e-6)
+        finally:
+            ops.call = real
+    # the fused entry points really ran (not the materialised fall-back)
+    for name in ("tsii_dw_fwd_bn", "tsii_dw_bwd_dx_bn", "tsii_dw_bwd_dw_bn", "tsii_bn_act_bwd_pre"):
+        assert name in calls, (name, sorted(set(calls)))
+
+
+@both_backends
+def test_fused_stride2_block_multi_strip(backend):
+    """K6c in the stride-2 dX strip kernel (the BatchNorm-backward reductions of the expand BatchNorm taken while dX is
+    written) on an odd-sized map spanning several strips and row chunks: ``PartialInvertedResidual`` stride 2 in train mode
+    vs the oracle (the reference-generated fixture of this flavour is 12x12)."""
+    from oracle.filler import seeded_input
+    from text_segmentation_image_inpainting_amd import ops
+    c, t, H, W = 16, 4, 45, 53
+    act = torch.nn.LeakyReLU(0.3)
+    calls = []
+    real = ops.call
+    with BACKENDS[backend]() as dev:
+        ops.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+        try:
+            pm = T.PartialInvertedResidual(c, 2 * c, 3, 2, 1, 1, t, BN=True, activation=act, use_1_conv=True, same_holes=True)
+            keys = [(k, tuple(v.shape)) for k, v in pm.state_dict().items()]
+            fill_state_dict_(pm.state_dict(), seed=61)
+            sd = make_state_dict(keys, seed=61)
+            names = [k for k, p in pm.named_parameters() if p.requires_grad]
+            for k in names:
+                sd[k].requires_grad_(True)
+            x, mask = seeded_input(3, c, H, W, seed=61, hole_frac=0.15)
+            xo = x.clone().requires_grad_(True)
+            yo, nmo = O.partial_inverted_residual(sd, "", xo, mask, c, 2 * c, 3, 2, 1, 1, t, O.leaky(0.3), True, False, True, True)
+            gy = torch.from_numpy(np.random.default_rng(62).standard_normal(tuple(yo.shape)).astype(np.float32))
+            yo.backward(gy)
+            pm = pm.to(dev).train()
+            xd = x.to(dev).requires_grad_(True)
+            y, nm = pm((xd, mask.to(dev)))
+            assert_close(y, yo, TOL, "PIR s2 y")
+            assert np.array_equal((nm.as_tensor() if hasattr(nm, "as_tensor") else nm).detach().cpu().numpy(), nmo.numpy())
+            y.backward(gy.to(dev))
+            assert_close(xd.grad, xo.grad, TOL, "PIR s2 dx")
+            for k in names:
+                assert_close(dict(pm.named_parameters())[k].grad, sd[k].grad, 2e-3, f"PIR s2 grad {k}", floor=1e-6)
+        finally:
+            ops.call = real
+    assert "tsii_dw_bwd_dx_bn" in calls and calls.count("tsii_bn_act_bwd_pre") >= 2, sorted(set(calls))
