@@ -3,7 +3,7 @@ construction in the reference itself -- SURVEY.md F7 -- and is out of scope.)"""
 from torch import nn
 
 from . import ops
-from .BaseModels import BaseModule, ConvSpec, DSConvBlock, build_chain, to_nchw, to_nhwc
+from .BaseModels import BaseModule, ConvSpec, DSConvBlock, build_chain, run_chain, to_nchw, to_nhwc
 
 
 class ResidualBlock(BaseModule):
@@ -23,8 +23,11 @@ class ResidualBlock(BaseModule):
             self.residual_conv = nn.Sequential(*build_chain(in_channels, (ConvSpec(out_channels, 1, stride, act=False),), None)[0])
 
     def forward(self, x):
-        shortcut = x if self.residual_conv is None else self.residual_conv(x)
-        return to_nchw(ops.add_act(to_nhwc(self.conv(x)), to_nhwc(shortcut)))
+        shortcut = x if self.residual_conv is None else run_chain(list(self.residual_conv), x)
+        # the six conv + BatchNorm pairs of the three DSConvBlocks as ONE chain: every BatchNorm but the last stays virtual
+        # (applied by the next conv while loading, K6b) and takes its backward reductions from that conv's dX kernel (K6c)
+        mods = [m for block in self.conv for m in list(block.depth_wise_conv) + list(block.point_wise_conv)]
+        return to_nchw(ops.add_act(to_nhwc(run_chain(mods, x)), to_nhwc(shortcut)))
 
 
 # flow tables: ("conv", out, stride) = 3x3 conv + BN + act; ("res", out, stride, dilation) = ResidualBlock (k 3, pad = dilation)
@@ -61,6 +64,6 @@ class Xception(BaseModule):
         self.last_feature_channels = width
 
     def forward(self, x):
-        quarter = self.entry_flow_1(x)
+        quarter = run_chain(list(self.entry_flow_1), x)       # folds the two stem conv + BatchNorm pairs (K6b)
         deep = self.exit_flow(self.middle_flow(self.entry_flow_2(quarter)))
         return deep, quarter

@@ -3,7 +3,7 @@
 from torch import nn
 
 from . import ops
-from .BaseModels import AvgPool2d, BaseModule, Conv2d, ConvSpec, act_code, build_chain, cat_channels, to_nchw, to_nhwc
+from .BaseModels import AvgPool2d, BaseModule, Conv2d, ConvSpec, act_code, build_chain, cat_channels, run_chain, to_nchw, to_nhwc
 
 
 class SpatialChannelSqueezeExcitation(BaseModule):
@@ -51,7 +51,8 @@ class ASP(BaseModule):
         self.out_conv = nn.Sequential(*build_chain(out_channel * len(branches), (ConvSpec(out_channel, 1),), act_fn)[0])
 
     def forward(self, x):
-        return self.out_conv(cat_channels([branch(x) for branch in self.asp]))
+        # run_chain: every conv + BatchNorm pair folded (K6b), other members (the average pools) through their own forward
+        return run_chain(list(self.out_conv), cat_channels([run_chain(list(branch), x) for branch in self.asp]))
 
 
 # RFB branch table: (first-conv kernel k, dilation of the closing depth-wise 3x3); k == 1: 1x1 -> dw3x3, else the
@@ -84,6 +85,6 @@ class RFB(BaseModule):
                                    for k, rate in RFB_BRANCHES])
 
     def forward(self, x):
-        fused = self.rfb_linear_conv(cat_channels([branch(x) for branch in self.rfb]))
+        fused = self.rfb_linear_conv(cat_channels([run_chain(list(branch), x) for branch in self.rfb]))
         code, slope = act_code(self.act_fn)
         return to_nchw(ops.add_act(to_nhwc(fused), to_nhwc(self.input_down_channel(x)), code, slope))

@@ -3,7 +3,7 @@ with scSE / Xception) -> feature pooling (RFB / ASP) -> DeepLabV3+-style bilinea
 logits; the caller applies the sigmoid (Examples/demo_segmentation.py:33)."""
 from torch import nn
 
-from .BaseModels import (AvgPool2d, BaseModule, Conv2d, ConvSpec, PixelShuffle, Upsample, build_chain, cat_channels,
+from .BaseModels import (AvgPool2d, BaseModule, Conv2d, ConvSpec, PixelShuffle, Upsample, build_chain, cat_channels, run_chain,
                          interpolate_bilinear)
 from .MobileNetV2 import DilatedMobileNetV2, InvertedResidual
 from .Xception import Xception
@@ -84,5 +84,5 @@ class XceptionTextSegment(BaseModule):
     def forward(self, x):
         deep, quarter = self.encoder(x)
         pooled = interpolate_bilinear(self.feature_pooling(deep), 2)
-        logits = self.out_conv(cat_channels([pooled, self.feature_4x_conv(quarter)]))
+        logits = run_chain(list(self.out_conv), cat_channels([pooled, run_chain(list(self.feature_4x_conv), quarter)]))
         return interpolate_bilinear(logits, 4)
