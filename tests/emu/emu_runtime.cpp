@@ -173,8 +173,11 @@ static void run_block(int nthreads) {
     }
 }
 
+static long launches_by_threads[1025];
+
 void launch(dim3 grid, dim3 block, const std::function<void()>& fn) {
     const int nthreads = (int)(block.x * block.y * block.z);
+    if (nthreads <= 1024) ++launches_by_threads[nthreads];
     if (nthreads > 1024) { std::fprintf(stderr, "hipemu: block too large\n"); std::abort(); }
     if ((int)fibers.size() < nthreads) {
         size_t old = fibers.size();
@@ -194,3 +197,8 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& fn) {
 }
 
 }  // namespace hipemu
+
+// test introspection: kernel launches so far with the given block size (e.g. 768 = the producer / consumer GEMM)
+extern "C" long hipemu_launches(int block_threads) {
+    return (block_threads >= 0 && block_threads <= 1024) ? hipemu::launches_by_threads[block_threads] : -1;
+}

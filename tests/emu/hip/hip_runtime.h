@@ -18,6 +18,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 
@@ -29,6 +30,7 @@
 #define __launch_bounds__(...)
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
 #define TSII_HIP_EMU 1
+#define TSII_OPAQUE_U32(x) asm volatile("" : "+r"(x))
 
 struct dim3 {
     unsigned x, y, z;
@@ -112,6 +114,14 @@ static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { std::memmove(d, s, n); return 0; }
 #define hipMemcpyDeviceToDevice 3
+// device properties: a small CU count, so persistent kernels walk several tiles per block in the tests (TSII_EMU_CUS overrides)
+#define hipDeviceAttributeMultiprocessorCount 0
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) {
+    const char* e = std::getenv("TSII_EMU_CUS");
+    *v = e ? std::atoi(e) : 3;
+    return 0;
+}
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipemu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })

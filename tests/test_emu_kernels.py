@@ -268,3 +268,86 @@ def test_dense_conv_gather_gemms(emu, mode, cin, cout, k, s, p, d, h):
     ws2 = np.zeros(nb // 4 + 4, np.float32)
     assert L.tsii_dense_bwd_dx(P(dy), P(inv), P(w), None, P(r0), split, P(r1), *geom, P(dx), P(ws2), nb, None) == 0, L.tsii_last_error()
     assert np.abs(dx - rdx).max() <= tol * np.abs(rdx).max()
+
+
+@pytest.mark.parametrize("M,K,N", [(700, 64, 256), (513, 40, 128), (300, 96, 384), (260, 32, 64), (1100, 160, 192), (129, 8, 72)])
+def test_producer_consumer_gemm(emu, M, K, N):
+    """K3p (gemm_pc.hip) at kernel level on the emulator (3 'CUs': several tiles and k stages per persistent block, row /
+    column / k tails, both tile shapes): forward with BatchNorm-on-load + statistics, dX with and without the K6c
+    BatchNorm-backward reductions, against float64 numpy -- and the 768-thread kernel must be the one that ran."""
+    L = emu
+    assert L.tsii_set_gemm_products(6) == 0
+    lib = L._lib if hasattr(L, "_lib") else None
+    rng = np.random.default_rng(M + 3 * K + N)
+    from tests.emu import build_emu
+    raw = ctypes.CDLL(build_emu.build())
+    raw.hipemu_launches.restype = ctypes.c_long
+    before = raw.hipemu_launches(768)
+    x = (rng.standard_normal((M, K)) * 2 + 0.5).astype(np.float32)
+    w = rng.standard_normal((N, K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    sh = rng.standard_normal(K).astype(np.float32)
+    r0 = (rng.uniform(size=M) > 0.3).astype(np.float32)
+    r1 = (rng.uniform(size=M) > 0.3).astype(np.float32)
+    split = (K // 2 // 4) * 4
+    denom = rng.integers(1, 9, size=M).astype(np.float32)
+    keep = (rng.uniform(size=M) > 0.2).astype(np.float32)
+    z = x.astype(np.float64) * sc + sh
+    a = np.where(z > 0, z, 0.3 * z)
+    am = a.copy()
+    am[:, :split] *= r0[:, None]
+    am[:, split:] *= r1[:, None]
+    rows = L.tsii_pw_stat_rows(M)
+    part = np.zeros((rows, 4, N), np.float32)
+    y = np.zeros((M, N), np.float32)
+    wws = np.zeros(L.tsii_pw_ws_bytes(N, K) // 4 + 4, np.float32)
+    assert L.tsii_pw_fwd_bn(P(x), M, K, P(w), N, P(b), P(r0), split, P(r1), P(denom), P(keep), P(sc), P(sh), 2, 0.3,
+                            P(part), P(y), P(wws), wws.nbytes, None) == 0, L.tsii_last_error()
+    ref = (am @ w.T.astype(np.float64) / denom[:, None] + b) * keep[:, None]
+    assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert raw.hipemu_launches(768) == before + 1
+    # the statistics partials: per 128-row block (count, pivot, sum(y - pivot), sum((y - pivot)^2))
+    y64 = y.astype(np.float64)
+    for rb in range(rows):
+        blk = y64[rb * 128:(rb + 1) * 128]
+        assert np.all(part[rb, 0] == blk.shape[0])
+        d = blk - part[rb, 1].astype(np.float64)
+        assert np.abs(part[rb, 2] - d.sum(0)).max() <= 1e-5 * (np.abs(d).sum(0).max() + 1e-30)
+        assert np.abs(part[rb, 3] - (d * d).sum(0)).max() <= 1e-5 * (d * d).sum(0).max()
+    # plain forward without any epilogue side input
+    y2 = np.zeros((M, N), np.float32)
+    assert L.tsii_pw_fwd(P(x), M, K, P(w), N, None, None, 0, None, None, None, P(y2), P(wws), wws.nbytes, None) == 0, L.tsii_last_error()
+    ref2 = x.astype(np.float64) @ w.T.astype(np.float64)
+    assert np.abs(y2 - ref2).max() <= 1e-5 * np.abs(ref2).max()
+    # dX, plain and with the BatchNorm-backward reductions of the tensor it feeds (x is that BatchNorm's raw input)
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    inv = (keep / denom).astype(np.float32)
+    g = dy.astype(np.float64) * inv[:, None]
+    rdx = g @ w.astype(np.float64)
+    rdx[:, :split] *= r0[:, None]
+    rdx[:, split:] *= r1[:, None]
+    dx = np.zeros((M, K), np.float32)
+    wt = np.zeros(L.tsii_pw_ws_bytes(N, K) // 4 + 4, np.float32)
+    before = raw.hipemu_launches(768)
+    assert L.tsii_pw_bwd_dx(P(dy), M, N, P(w), K, P(inv), P(r0), split, P(r1), P(dx), P(wt), None) == 0, L.tsii_last_error()
+    pc_dx = raw.hipemu_launches(768) - before          # K < 64 columns: the 4-wave kernel keeps the narrow outputs
+    assert pc_dx == (1 if K >= 64 else 0)
+    assert np.abs(dx - rdx).max() <= 1e-5 * np.abs(rdx).max()
+    if K % 4 == 0:
+        mean = x.astype(np.float64).mean(0).astype(np.float32)
+        var = x.astype(np.float64).var(0).astype(np.float32)
+        gamma = rng.uniform(0.5, 1.5, K).astype(np.float32)
+        beta = rng.standard_normal(K).astype(np.float32)
+        bpart = np.zeros((rows, 2, K), np.float32)
+        dx2 = np.zeros((M, K), np.float32)
+        assert L.tsii_pw_bwd_dx_bn(P(dy), M, N, P(w), K, P(inv), P(r0), split, P(r1), P(x), P(mean), P(var), P(gamma), P(beta), 1e-5, 2, 0.3,
+                                   P(dx2), P(bpart), P(wt), None) == 0, L.tsii_last_error()
+        assert np.abs(dx2 - rdx).max() <= 1e-5 * np.abs(rdx).max()
+        xh = (x.astype(np.float64) - mean) / np.sqrt(var.astype(np.float64) + 1e-5)
+        zz = xh * gamma + beta
+        dz = dx2.astype(np.float64) * np.where(zz > 0, 1.0, 0.3)
+        s1 = bpart[:, 0].astype(np.float64).sum(0)
+        s2 = bpart[:, 1].astype(np.float64).sum(0)
+        assert np.abs(s1 - dz.sum(0)).max() <= 2e-5 * np.abs(dz).sum(0).max()
+        assert np.abs(s2 - (dz * xh).sum(0)).max() <= 2e-5 * np.abs(dz * xh).sum(0).max()

@@ -425,6 +425,8 @@ static int launch_nt_cfg(const float* A, int64_t lda, RowScale as, const float* 
 
 static int launch_nt(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, float* C, int64_t ldc,
                      int64_t M, int N, int K, Epilogue ep, hipStream_t stream, InBN ib = kNoBN, void* wsplit = nullptr) {
+    if (wsplit != nullptr && ldb == K && nt_split_ok(A, lda, B, ldb, K) && nt_pc_ok(A, lda, N, K, ep, ib))
+        return launch_nt_pc(A, lda, as, B, ldb, false, C, ldc, M, N, K, ep, ib, wsplit, stream);
     if (nt_split_ok(A, lda, B, ldb, K)) return launch_nt_split(A, lda, as, B, ldb, false, C, ldc, M, N, K, ep, ib, wsplit, stream);
     const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && aligned16(A) && aligned16(B);
     ep.vec_store = (ldc % 4 == 0) && aligned16(C);
@@ -623,8 +625,8 @@ extern "C" int tsii_pw_fwd(const float* x, int64_t m, int k, const float* w, int
 
 extern "C" size_t tsii_pw_ws_bytes(int n, int k) {   // weight workspace of pw_fwd[_bn] (optional) and pw_bwd_dx[_bn] (wt_ws)
     if (n <= 0 || k <= 0) return 0;
-    const size_t a = (size_t)n * k * sizeof(float), b = nt_split_ws_bytes(n, k);
-    return a > b ? a : b;
+    const size_t a = (size_t)n * k * sizeof(float), b = nt_split_ws_bytes(n, k), c = nt_pc_ws_bytes(n, k);
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 extern "C" int64_t tsii_pw_stat_rows(int64_t m) { return m > 0 ? cdiv64(m, 128) : 0; }   // every NT tile variant has BM = 128
@@ -646,6 +648,8 @@ static int pw_bwd_dx_impl(const float* dy, int64_t m, int n, const float* w, int
     RowScale as = {inv, nullptr, n};  // g = dy * inv[m]
     ep.cs = {r0, r1, split};
     // split-bf16 arithmetic: W^T is split into bf16 planes in wt_ws by one small kernel (transpose folded in)
+    if (nt_split_ok(dy, n, w, k, n) && k % 4 == 0 && nt_pc_ok(dy, n, k, n, ep, kNoBN))
+        return launch_nt_pc(dy, n, as, w, k, true, dx, k, m, k, n, ep, kNoBN, wt_ws, (hipStream_t)stream);
     if (nt_split_ok(dy, n, w, k, n) && k % 4 == 0)
         return launch_nt_split(dy, n, as, w, n, true, dx, k, m, k, n, ep, kNoBN, wt_ws, (hipStream_t)stream);
     // W [n,k] -> Wt [k,n] so both GEMM operands are contraction-contiguous

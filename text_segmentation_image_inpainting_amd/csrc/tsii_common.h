@@ -174,6 +174,12 @@ __device__ __forceinline__ void vstore(float* __restrict__ p, const VecF<W>& r) 
 
 }  // namespace tsii
 
+// optimisation barrier on a 32-bit VGPR value: the compiler may not re-derive it algebraically (used to keep running
+// address offsets running); the test emulator's hip_runtime.h supplies a host form
+#ifndef TSII_OPAQUE_U32
+#define TSII_OPAQUE_U32(x) asm volatile("" : "+v"(x))
+#endif
+
 #define TSII_REQUIRE(cond, ...)                 \
     do {                                        \
         if (!(cond)) {                          \

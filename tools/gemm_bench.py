@@ -72,19 +72,26 @@ def main():
         ws = torch.empty(nb // 4 + 4, device=dev)
         fl = 2.0 * M * K * N
         res = []
-        if args.only in ("", "fwd"):
+        if args.only in ("", "fwd", "nt"):
             t = timeit(lambda: call("tsii_pw_fwd", ptr(x), M, K, ptr(w), N, None, ptr(r0), split, ptr(r1), ptr(denom), None, ptr(y), ptr(wws), wws.numel() * 4, st))
             res.append(f"fwd {t:7.3f} ms {fl / t / 1e9:6.1f} TF/s {4.0 * M * (K + N) / t / 1e9:5.2f} TB/s")
-        if args.only in ("", "fwdbn"):      # forward with the producer's BatchNorm + LeakyReLU applied on load and the statistics epilogue
+        if args.only in ("", "fwdbn", "nt"):      # forward with the producer's BatchNorm + LeakyReLU applied on load and the statistics epilogue
             sc = torch.rand(K, device=dev) + 0.5
             sh = torch.randn(K, device=dev)
             part = torch.empty(L.tsii_pw_stat_rows(M), 4, N, device=dev)
             t = timeit(lambda: call("tsii_pw_fwd_bn", ptr(x), M, K, ptr(w), N, None, ptr(r0), split, ptr(r1), ptr(denom), None, ptr(sc), ptr(sh), 2, 0.3,
                                     ptr(part), ptr(y), ptr(wws), wws.numel() * 4, st))
             res.append(f"fwdbn {t:7.3f} ms {fl / t / 1e9:6.1f} TF/s {4.0 * M * (K + N) / t / 1e9:5.2f} TB/s")
-        if args.only in ("", "dx"):
+        if args.only in ("", "dx", "nt"):
             t = timeit(lambda: call("tsii_pw_bwd_dx", ptr(dy), M, N, ptr(w), K, ptr(inv), ptr(r0), split, ptr(r1), ptr(dx), ptr(wt), st))
             res.append(f"dx {t:7.3f} ms {fl / t / 1e9:6.1f} TF/s {4.0 * M * (K + N) / t / 1e9:5.2f} TB/s")
+        if args.only in ("", "dxbn", "nt"):   # dX with the K6c BatchNorm-backward reductions in the epilogue
+            mean = torch.zeros(K, device=dev); var = torch.ones(K, device=dev)
+            gamma = torch.ones(K, device=dev); beta = torch.zeros(K, device=dev)
+            bpart = torch.empty(L.tsii_pw_stat_rows(M), 2, K, device=dev)
+            t = timeit(lambda: call("tsii_pw_bwd_dx_bn", ptr(dy), M, N, ptr(w), K, ptr(inv), ptr(r0), split, ptr(r1), ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta),
+                                    1e-5, 2, 0.3, ptr(dx), ptr(bpart), ptr(wt), st))
+            res.append(f"dxbn {t:7.3f} ms {fl / t / 1e9:6.1f} TF/s {4.0 * M * (2 * K + N) / t / 1e9:5.2f} TB/s")
         if args.only in ("", "dw"):
             t = timeit(lambda: call("tsii_pw_bwd_dw", ptr(dy), ptr(x), M, N, K, ptr(inv), None, ptr(r0), split, ptr(r1), ptr(dw), None, ptr(ws), nb, st))
             res.append(f"dw {t:7.3f} ms {fl / t / 1e9:6.1f} TF/s")
