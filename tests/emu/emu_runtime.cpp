@@ -37,6 +37,11 @@ static void yield_to_sched(int st) {
 }
 
 void syncthreads() { yield_to_sched(WAIT_BLOCK); }
+static long spins = 0;
+void yield() {
+    if (++spins > 200000000L) { std::fprintf(stderr, "hipemu: livelock (spin-wait never satisfied)\n"); std::abort(); }
+    yield_to_sched(RUN);
+}
 static void wavesync() { yield_to_sched(WAIT_WAVE); }
 
 int lane_id() { return cur & 63; }
@@ -142,7 +147,7 @@ static void run_block(int nthreads) {
             tIdx.z = t / (bDim.x * bDim.y);
             swapcontext(&sched_ctx, &f.ctx);
             progressed = true;
-            if (f.state == DONE) --live;
+            if (f.state == DONE) { --live; spins = 0; }
         }
         bool released = false;
         for (int w = 0; w < nwaves; ++w) {  // wave collectives
@@ -163,6 +168,7 @@ static void run_block(int nthreads) {
             if (live > 0 && waiting == live) {
                 for (int t = 0; t < nthreads; ++t) if (fibers[t].state == WAIT_BLOCK) fibers[t].state = RUN;
                 released = true;
+                spins = 0;
             }
         }
         if (!progressed && !released && live > 0) {

@@ -425,7 +425,7 @@ static int launch_nt_cfg(const float* A, int64_t lda, RowScale as, const float* 
 
 static int launch_nt(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, float* C, int64_t ldc,
                      int64_t M, int N, int K, Epilogue ep, hipStream_t stream, InBN ib = kNoBN, void* wsplit = nullptr) {
-    if (wsplit != nullptr && ldb == K && nt_split_ok(A, lda, B, ldb, K) && nt_pc_ok(A, lda, N, K, ep, ib))
+    if (wsplit != nullptr && ldb == K && nt_split_ok(A, lda, B, ldb, K) && nt_pc_ok(A, lda, as, M, N, K, ep, ib))
         return launch_nt_pc(A, lda, as, B, ldb, false, C, ldc, M, N, K, ep, ib, wsplit, stream);
     if (nt_split_ok(A, lda, B, ldb, K)) return launch_nt_split(A, lda, as, B, ldb, false, C, ldc, M, N, K, ep, ib, wsplit, stream);
     const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && aligned16(A) && aligned16(B);
@@ -648,7 +648,7 @@ static int pw_bwd_dx_impl(const float* dy, int64_t m, int n, const float* w, int
     RowScale as = {inv, nullptr, n};  // g = dy * inv[m]
     ep.cs = {r0, r1, split};
     // split-bf16 arithmetic: W^T is split into bf16 planes in wt_ws by one small kernel (transpose folded in)
-    if (nt_split_ok(dy, n, w, k, n) && k % 4 == 0 && nt_pc_ok(dy, n, k, n, ep, kNoBN))
+    if (nt_split_ok(dy, n, w, k, n) && k % 4 == 0 && nt_pc_ok(dy, n, as, m, k, n, ep, kNoBN))
         return launch_nt_pc(dy, n, as, w, k, true, dx, k, m, k, n, ep, kNoBN, wt_ws, (hipStream_t)stream);
     if (nt_split_ok(dy, n, w, k, n) && k % 4 == 0)
         return launch_nt_split(dy, n, as, w, n, true, dx, k, m, k, n, ep, kNoBN, wt_ws, (hipStream_t)stream);

@@ -2,31 +2,30 @@
 //
 // Why: in the 4-wave kernel of gemm_split.hip every wave does load -> split -> LDS -> barrier -> MFMA -> epilogue in
 // turn; memory phases and matrix phases add up instead of overlapping (MFMA pipe 46 % busy, HBM 28 % at the same
-// time).  Here the roles are separated by wave and a block walks many output tiles, so none of the phases ever
-// drains:
+// time).  Here the roles are separated by wave, a block walks many output tiles, and NO block-wide barrier exists after
+// the start: waves meet through per-stage LDS counters only, so a wave waits for data, never for its neighbours.
 //
-//   768 threads = 12 waves = 3 per SIMD (a workgroup's waves go to the SIMDs round robin, so every SIMD hosts two
-//   consumer waves and one producer wave), ONE block per CU, 168 VGPRs per lane.
+//   768 threads = 12 waves = 3 per SIMD (a workgroup's waves go to the SIMDs round robin: every SIMD hosts two consumer
+//   waves and one producer wave), ONE block per CU, <= 168 VGPRs per lane.
 //
-//   consumers (waves 0-7):  wave (wm, wn) owns a 128-row x 32-column piece of the block tile (4 MFMA tiles, 64
-//     accumulator registers).  Tile shapes: WM x WN = 1 x 8 -> 128 x 256, 2 x 4 -> 256 x 128.  Per 16-deep k step a
-//     wave issues 24 v_mfma_f32_32x32x16_bf16 (6 partial products x 4 tiles) and, between them, the 15 ds_read_b128
-//     of the NEXT k step's fragments (second register set for B, A registers recycled tile by tile), so after a
-//     barrier the matrix pipe restarts from registers.  The epilogue runs straight from the accumulator layout
-//     (lane = column): per-row factors come from a small LDS array the producers staged, BatchNorm statistics
-//     (K6b) / BatchNorm-backward reductions (K6c) are per-lane sums over the 64 accumulators + one cross-half
-//     shuffle, rows leave as 128-byte row segments (dword per lane).  While the consumers of a tile are in the
-//     epilogue the producers are already two stages into the next tile.
-//   producers (waves 8-11): stream the fp32 A rows (3 stages = 48 registers of loads in flight per lane at 128
-//     rows), apply the producer's BatchNorm + activation (K6b) and the x*mask row scale, split into 3 bf16 planes
-//     and write the XOR-swizzled LDS image of gemm_split.hip; B arrives pre-split and stage-tiled
-//     ([k stage][plane][n][32 bf16], split_w_tiled_kernel) so a wave's 16-byte loads cover whole lines.
-//
-//   LDS: two stage buffers of 3 x (BM + BN) x 64 B = 72 KB.  One barrier per 16-deep k step: in interval j the
-//   consumers multiply half-stage j from registers and read half-stage j + 1, the producers write stage
-//   (j + 3) / 2 -- the buffer whose last reads completed before the previous barrier -- half of their items per
-//   interval, and re-issue each item's global load for DA stages ahead right after its LDS store.
-//   Hazards: a stage buffer is read in intervals 2s - 1 and 2s, rewritten (stage s + 2) in 2s + 1 and 2s + 2.
+//   producers (waves 8-11) own the fp32 operand A: rows are requested DA stages ahead (5 x 16 KB per CU at 128-row
+//     tiles) with counted asynchronous loads (tsii_common.h: hipcc's own waitcnt insertion made this loop run at one
+//     memory latency per stage), get the producer layer's BatchNorm + activation (K6b) and the x*mask row scale, are
+//     split into 3 bf16 planes and written into a ring of R LDS stages ([plane][row][32 k], 64-byte rows, 16-byte
+//     chunks XOR-swizzled as in gemm_split.hip).  Per stage a wave waits for empty[slot] (all 8 consumers done with
+//     the slot's previous use) and bumps full[slot] after its stores.
+//   consumers (waves 0-7): wave (wm, wn) owns 128 rows x 32 columns of the block tile (4 MFMA tiles, 64 accumulators;
+//     WM x WN = 1 x 8 -> 128 x 256 tiles, 2 x 4 -> 256 x 128).  Its B fragments never touch LDS: the weights arrive
+//     pre-split and tiled as [k half-step][plane][n][16 k] (split_w_tiled_kernel), i.e. exactly one MFMA operand row
+//     (32 bytes) per output column, and every lane loads its 16 bytes straight from L2 one k step ahead.  Per 16-deep k
+//     step a wave issues 24 v_mfma_f32_32x32x16_bf16 (6 partial products x 4 tiles) and, between them, the next
+//     step's 12 ds_read_b128 (A) + 3 global loads (B) into registers that are free by then (hand-scheduled,
+//     sched_barrier).  It polls full[slot] before the first fragment read of a stage and releases empty[slot] when its
+//     last fragment reads of the stage have been issued (the release orders them).
+//   Epilogue straight from the accumulator layout (lane = column): per-row factors from a small LDS ring the
+//     producers fill (1/denominator and keep for the forward, the two mask planes for dX), BatchNorm statistics (K6b)
+//     / BatchNorm-backward reductions (K6c) as per-lane sums + one cross-half shuffle, rows leave as 128-byte row
+//     segments.  The producers are up to R stages into the next tiles meanwhile.
 //
 // Tiles are dealt to the blocks as contiguous ranges in (row block, column block) order, so the column blocks of one
 // row block are consecutive on one CU (A re-reads hit L2) and every block streams B in the same order.
@@ -35,9 +34,6 @@
 #include "split_bf16.h"
 
 namespace tsii {
-
-struct PfYes { static constexpr bool value = true; };      // tags of the consumers' k step: prefetch the next fragments or not
-struct PfNo { static constexpr bool value = false; };
 
 struct PcCursor {      // a k stage of an output tile; wave-uniform
     unsigned tile;
@@ -59,20 +55,47 @@ __device__ __forceinline__ void pc_advance(PcCursor& c, int nst, unsigned ntn, u
     if (c.tile < tlast) { c.ks = 0; pc_locate<BM, BN>(c, c.tile + 1, ntn); }
 }
 
-// epilogue of one consumer wave: 128 rows x 32 columns from acc[4] (D[row=(r&3)+8*(r>>2)+4*hi][col=li]).
-// sideX / sideY: this tile's per-row factors in LDS (always staged, 1.0 when absent):
-//   FWD:  y = keep ? acc * (1/denom) + bias : 0          (sideX = 1/denom, sideY = keep)
-//   DX :  y = acc * (col < cs.split ? cs.r0 : cs.r1)      (sideX = cs.r0,  sideY = cs.r1)
-// FULL: the wave's 128 x 32 piece lies inside the matrix (wave-uniform): no predicates on the stores / sums.
+__device__ __forceinline__ unsigned pc_flag(const unsigned* f) { return __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void pc_wait_flag(const unsigned* f, unsigned need) {
+    while (pc_flag(f) < need) __builtin_amdgcn_s_sleep(1);
+}
+// the producers' form: they run R stages ahead, so a slow poll costs nothing -- and every instruction a spinning wave issues
+// is taken from the matrix stream of its SIMD
+__device__ __forceinline__ void pc_wait_flag_lazy(const unsigned* f, unsigned need) {
+    while (pc_flag(f) < need) __builtin_amdgcn_s_sleep(6);
+}
+__device__ __forceinline__ void pc_bump_flag(unsigned* f) { __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// Epilogue of one consumer wave: 128 rows x 32 columns from acc[4] (D[row=(r&3)+8*(r>>2)+4*hi][col=li]); the launcher
+// only sends shapes whose tiles are full in M and whose columns come in whole 32-blocks (a wave past N skips it).
+// sideX / sideY: the tile's per-row factors in LDS (always staged, 1.0 when absent).  EPI:
+//   0 / 1 (forward without / with BatchNorm statistics):  y = keep ? acc * (1/denom) + bias : 0      (sideX = 1/denom, sideY = keep)
+//   2 / 3 (dX without / with the K6c reductions):          y = acc * (col < cs.split ? cs.r0 : cs.r1)  (sideX = cs.r0,  sideY = cs.r1)
 // Addresses: wave-uniform 64-bit bases + RUNNING 32-bit byte offsets (one add per row); written as 64 independent
 // row * ldc products the compiler hoists all of them out of the tile loop and spills them.
-template <bool BNB, bool FULL>
-__device__ __forceinline__ void pc_epilogue_rows(f32x16 (&acc)[4], char* __restrict__ Cb, unsigned ldc4, const char* __restrict__ Yb, unsigned n4,
-                                                 unsigned colb, int last, bool col_ok, int hi, const float* __restrict__ sideX,
-                                                 const float* __restrict__ sideY, bool use_cs, bool cs_lo, float bias, bool stats, float pvt,
-                                                 float bmu, float bis, float bga, float bbe, float bn_hi, float bn_neg, float& st1, float& st2) {
-    unsigned coff = (unsigned)(4 * hi) * ldc4 + colb;
-    unsigned yoff = (unsigned)(4 * hi) * n4 + colb;
+template <int EPI>
+__device__ __forceinline__ void pc_epilogue(f32x16 (&acc)[4], float* __restrict__ C, int64_t ldc, int N, const Epilogue& ep,
+                                            int64_t mw0, int col0, int li, int hi, const float* __restrict__ sideX,
+                                            const float* __restrict__ sideY, float bias) {
+    constexpr bool DX = EPI >= 2, STATS = EPI == 1, BNB = EPI == 3;
+    const int col = col0 + li;
+    const bool cs_lo = col < ep.cs.split;
+    float st1 = 0.f, st2 = 0.f, pvt = 0.f;
+    if constexpr (STATS) {      // pivot of the 128-row block: the value at its middle row, same for both lane halves
+        float pv = fmaf(acc[2][0], sideX[64], bias);
+        pv = sideY[64] == 0.f ? 0.f : pv;
+        pvt = __shfl(pv, li, 64);
+    }
+    float bmu = 0.f, bis = 0.f, bga = 0.f, bbe = 0.f;
+    if constexpr (BNB) {
+        bmu = ep.bn_mean[col]; bis = 1.0f / sqrtf(ep.bn_var[col] + ep.bn_eps);
+        bga = ep.bn_gamma[col]; bbe = ep.bn_beta[col];
+    }
+    char* __restrict__ Cb = reinterpret_cast<char*>(C + mw0 * ldc);
+    const char* __restrict__ Yb = BNB ? reinterpret_cast<const char*>(ep.bn_y + mw0 * (int64_t)N) : nullptr;
+    const unsigned ldc4 = (unsigned)ldc * 4u, n4 = (unsigned)N * 4u;
+    unsigned coff = (unsigned)(4 * hi) * ldc4 + (unsigned)col * 4u;
+    unsigned yoff = (unsigned)(4 * hi) * n4 + (unsigned)col * 4u;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -82,12 +105,9 @@ __device__ __forceinline__ void pc_epilogue_rows(f32x16 (&acc)[4], char* __restr
             TSII_OPAQUE_U32(yoff);
             const int rb4 = t * 32 + 8 * g + 4 * hi;
             float yv[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (BNB) {     // raw BatchNorm input at the positions this lane stores (rows past the end read row 0 of the base)
+            if constexpr (BNB) {     // raw BatchNorm input at the positions this lane stores
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool ok = FULL || rb4 + j <= last;
-                    yv[j] = *reinterpret_cast<const float*>(Yb + (ok ? yoff + (unsigned)j * n4 : colb));
-                }
+                for (int j = 0; j < 4; ++j) yv[j] = *reinterpret_cast<const float*>(Yb + yoff + (unsigned)j * n4);
             }
             const float4 x4 = *reinterpret_cast<const float4*>(sideX + rb4);
             const float4 y4 = *reinterpret_cast<const float4*>(sideY + rb4);
@@ -96,70 +116,31 @@ __device__ __forceinline__ void pc_epilogue_rows(f32x16 (&acc)[4], char* __restr
             for (int j = 0; j < 4; ++j) {
                 const int r = 4 * g + j;
                 float v;
-                if (use_cs) v = acc[t][r] * (cs_lo ? xs[j] : ys[j]);
+                if constexpr (DX) v = acc[t][r] * (cs_lo ? xs[j] : ys[j]);
                 else { v = fmaf(acc[t][r], xs[j], bias); v = ys[j] == 0.f ? 0.f : v; }
-                const bool ok = FULL || (rb4 + j <= last && col_ok);
-                if (stats) {
-                    const float d = ok ? v - pvt : 0.f;
+                if constexpr (STATS) {
+                    const float d = v - pvt;
                     st1 += d;
                     st2 = fmaf(d, d, st2);
                 }
                 if constexpr (BNB) {
                     const float xh = (yv[j] - bmu) * bis;
                     const float z = fmaf(xh, bga, bbe);
-                    float dz = v * ((z > 0.f && z < bn_hi) ? 1.f : (z > 0.f ? 0.f : bn_neg));
-                    dz = ok ? dz : 0.f;
+                    const float dz = v * ((z > 0.f && z < ep.bn_hi) ? 1.f : (z > 0.f ? 0.f : ep.bn_neg));
                     st1 += dz;
                     st2 = fmaf(dz, xh, st2);
                 }
-                if (ok) *reinterpret_cast<float*>(Cb + coff) = v;
+                *reinterpret_cast<float*>(Cb + coff) = v;
                 coff += ldc4;
             }
             coff += 4u * ldc4;
             yoff += 8u * n4;
         }
     }
-}
-
-template <bool BNB>
-__device__ __forceinline__ void pc_epilogue(f32x16 (&acc)[4], float* __restrict__ C, int64_t ldc, int64_t M, int N, const Epilogue& ep,
-                                            int64_t mw0, int col0, int li, int hi, const float* __restrict__ sideX,
-                                            const float* __restrict__ sideY, bool use_cs) {
-    const int col = col0 + li;
-    const bool col_ok = col < N;
-    const int colc = col_ok ? col : N - 1;
-    const float bias = ep.bias != nullptr ? ep.bias[colc] : 0.f;
-    const bool cs_lo = col < ep.cs.split;
-    const int64_t left = M - mw0;                           // rows of this wave inside the matrix (may be <= 0 or > 128)
-    const int last = (int)(left < 128 ? left : 128) - 1;    // last valid local row (< 0: none)
-    float st1 = 0.f, st2 = 0.f, pvt = 0.f;
-    const bool stats = ep.stats != nullptr;
-    if (stats) {
-        // pivot of the 128-row block: the value at its middle row (row 0 when the block is short), same for both lane halves
-        const bool mid = left > 64;
-        const float a0 = mid ? acc[2][0] : acc[0][0], x0 = mid ? sideX[64] : sideX[0], y0 = mid ? sideY[64] : sideY[0];
-        float pv = fmaf(a0, x0, bias);
-        pv = y0 == 0.f ? 0.f : pv;
-        pvt = __shfl(pv, li, 64);
-    }
-    float bmu = 0.f, bis = 0.f, bga = 0.f, bbe = 0.f;
-    if constexpr (BNB) {
-        bmu = ep.bn_mean[colc]; bis = 1.0f / sqrtf(ep.bn_var[colc] + ep.bn_eps);
-        bga = ep.bn_gamma[colc]; bbe = ep.bn_beta[colc];
-    }
-    char* __restrict__ Cb = reinterpret_cast<char*>(C + (last >= 0 ? mw0 : 0) * ldc);
-    const char* __restrict__ Yb = BNB ? reinterpret_cast<const char*>(ep.bn_y + (last >= 0 ? mw0 : 0) * (int64_t)N) : nullptr;
-    const unsigned ldc4 = (unsigned)ldc * 4u, n4 = (unsigned)N * 4u, colb = (unsigned)colc * 4u;
-    if (last == 127 && col0 + 32 <= N)
-        pc_epilogue_rows<BNB, true>(acc, Cb, ldc4, Yb, n4, colb, last, col_ok, hi, sideX, sideY, use_cs, cs_lo, bias, stats, pvt, bmu, bis, bga, bbe,
-                                    ep.bn_hi, ep.bn_neg, st1, st2);
-    else
-        pc_epilogue_rows<BNB, false>(acc, Cb, ldc4, Yb, n4, colb, last, col_ok, hi, sideX, sideY, use_cs, cs_lo, bias, stats, pvt, bmu, bis, bga, bbe,
-                                     ep.bn_hi, ep.bn_neg, st1, st2);
-    if (stats || BNB) {
+    if constexpr (STATS || BNB) {
         st1 += __shfl_xor(st1, 32, 64);
         st2 += __shfl_xor(st2, 32, 64);
-        if (hi == 0 && col_ok && left > 0) {
+        if (hi == 0) {
             const int64_t rb = mw0 >> 7;                    // 128-row block index (tsii_pw_stat_rows)
             if constexpr (BNB) {
                 float* sp = ep.bn_part + rb * 2 * N;
@@ -167,7 +148,7 @@ __device__ __forceinline__ void pc_epilogue(f32x16 (&acc)[4], float* __restrict_
                 sp[N + col] = st2;
             } else {
                 float* sp = ep.stats + rb * 4 * N;
-                sp[col] = (float)(left < 128 ? left : 128);
+                sp[col] = 128.f;
                 sp[N + col] = pvt;
                 sp[2 * N + col] = st1;
                 sp[3 * N + col] = st2;
@@ -176,22 +157,31 @@ __device__ __forceinline__ void pc_epilogue(f32x16 (&acc)[4], float* __restrict_
     }
 }
 
-template <int WM, int WN, int PRODUCTS, bool BNIN, bool BNB>
+// ABL (compile time; TSII_GEMM_PC_ABL, tools/pc_probe.py only, results are garbage): 16 no A-fragment reads, 32 no producer LDS
+// stores, 64 no producer global loads, 128 no epilogue, 256 no B-fragment loads, 512 no row-scale / row-factor loads (A only),
+// 1024 producer loads issued but never waited for
+template <int WM, int WN, int PRODUCTS, bool BNIN, int EPI, int ABL = 0>
 __global__ __launch_bounds__(768, 3) void gemm_nt_pc_kernel(const float* __restrict__ A, int64_t lda, RowScale as,
                                                             const unsigned short* __restrict__ Bp, float* __restrict__ C, int64_t ldc,
-                                                            int64_t M, int N, int K, Epilogue ep, InBN ib, unsigned ntn, unsigned tiles) {
+                                                            int64_t M, int N, int K, Epilogue ep, InBN ib, unsigned ntn, unsigned tiles, int opt) {
+    // opt: wave priorities (A/B knob TSII_GEMM_PC_OPT; wave-uniform): bits 0-1 consumers, bits 2-3 producers
     static_assert(WM * WN == 8, "8 consumer waves");
     constexpr int P = SplitPlanes<PRODUCTS>::value;
     constexpr int BM = WM * 128, BN = WN * 32;
-    constexpr int STAGE = P * (BM + BN) * 64;                 // bytes of one stage buffer
-    constexpr int DA = (BM == 128) ? 3 : 2;                   // stages of A loads in flight per producer lane
+    constexpr int ASTAGE = P * BM * 64;                       // bytes of one LDS stage (A only)
+    constexpr int R = (BM == 128) ? 5 : (BNIN ? 2 : 3);       // LDS stages
+    constexpr int DA = (ABL & 16384) ? 2 : (BM == 128) ? 5 : 3;   // stages of A loads in flight per producer lane
     constexpr int NA = BM / 64;                               // A items (row, 8-k chunk) per producer thread and stage
-    constexpr int NBP = BN / 64;                              // B pieces per plane, producer thread and stage
-    constexpr int SIDE_FLOATS = 2 * 2 * BM;                   // [tile parity][X, Y][row]
+    constexpr int LT = (ABL & 512) ? NA * 2 : NA * 4 + 2;     // counted loads per producer thread and stage
+    constexpr int SLOTS = (BM == 128) ? 8 : 6;                // ring of per-tile epilogue row factors (> R: the producers run at most R tiles ahead)
+    constexpr int SIDE_FLOATS = SLOTS * 2 * BM;               // [slot][X, Y][row]
     constexpr int BNV_FLOATS = BNIN ? 2048 : 0;               // input BatchNorm (scale, shift) of all K <= 1024 channels
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + (SIDE_FLOATS + BNV_FLOATS) * 4];
-    float* side = reinterpret_cast<float*>(smem + 2 * STAGE);
+    static_assert(DA * LT - 2 <= 63 && DA * LT >= 4, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[R * ASTAGE + (SIDE_FLOATS + BNV_FLOATS) * 4 + 64];
+    float* side = reinterpret_cast<float*>(smem + R * ASTAGE);
     float* bnv = side + SIDE_FLOATS;
+    unsigned* full = reinterpret_cast<unsigned*>(bnv + BNV_FLOATS);      // [8]: producer waves done with the slot, ever
+    unsigned* empty = full + 8;                                          // [8]: consumer waves done with the slot, ever
 
     const int tid = threadIdx.x;
     // this block's tiles: [t0, t1)
@@ -199,52 +189,65 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_pc_kernel(const float* __restr
     const unsigned t1 = (unsigned)(((uint64_t)(blockIdx.x + 1) * tiles) / gridDim.x);
     const int nst = (K + 31) >> 5;
     const unsigned stages = (t1 - t0) * (unsigned)nst;        // >= 1: the launcher never starts more blocks than tiles
-    // epilogue modes (wave-uniform): FWD (1/denom, keep) or DX (cs.r0, cs.r1); the launcher rejects both at once
-    const bool use_cs = ep.cs.r0 != nullptr;
+    constexpr bool use_cs = EPI >= 2;                         // dX epilogue: row factors = the two mask planes
 
+    if (tid < 16) full[tid] = 0u;
     if constexpr (BNIN) {
         for (int i = tid; i < 2048; i += 768) {
             const int k = i & 1023;
             bnv[i] = k < K ? (i < 1024 ? ib.sc[k] : ib.sh[k]) : 0.f;
         }
-        __syncthreads();
     }
+    __syncthreads();                                          // the only block-wide barrier
 
     if (tid < 512) {
         // ------------------------------------------------ consumers ------------------------------------------------
-        __builtin_amdgcn_s_setprio(1);
+        if ((opt & 3) == 1) __builtin_amdgcn_s_setprio(1);
+        else if ((opt & 3) == 2) __builtin_amdgcn_s_setprio(2);
+        else if ((opt & 3) == 3) __builtin_amdgcn_s_setprio(3);
         const int cw = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
         const int wm = cw / WN, wn = cw % WN;
         const int swz = (li >> 2) & 3;
         const int aoff = (wm * 128 + li) * 64;                          // + t * 2048 + p * BM * 64
-        const int boff = P * BM * 64 + (wn * 32 + li) * 64;             // + p * BN * 64
         const int ch0 = ((0 + hi) ^ swz) << 4, ch1 = ((2 + hi) ^ swz) << 4;   // chunk of k half 0 / 1
+        const char* __restrict__ Bb = reinterpret_cast<const char*>(Bp);
+        const unsigned bplane = (unsigned)N * 32u;                      // bytes of one plane of one k half-step
+        const unsigned bhalf = (unsigned)P * bplane;                    // bytes of one k half-step
 
-        bf16x8 a[4][P], b[P];
+        bf16x8 a[3][P], a3x[P], a3y[P], bx[P], by[P];     // A tiles 0-2; A tile 3 and B in two alternating sets (x: k half 0)
         f32x16 acc[4];
         auto ldf = [](const unsigned char* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p)); };
+        auto ldb = [&](const char* Bh, unsigned bl, int p) {           // Bh: wave-uniform base of the k half-step, bl: this lane's row
+            return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bh + (unsigned)p * bplane + bl));
+        };
         // One 16-deep k step from registers, hand-scheduled (sched_barrier pins the groups): the fragments of the NEXT step
-        // (stage buffer Sn, chunk chn) are read between the MFMA groups into registers that are free by then -- B and the
-        // last A tile into a second set, the other A tiles into their own registers once their products are issued -- so
-        // only 3 reads trail the last 3 MFMAs and the step after the barrier starts from registers.
-        auto kstep = [&](const unsigned char* Sn, int chn, auto pf_tag) {
-            constexpr bool PF = decltype(pf_tag)::value;              // false: the last step of a tile (its fragments die in the epilogue)
-            bf16x8 bn[P], a3n[P];
-            if constexpr (PF) {
+        // (A: LDS stage Sn, chunk chn; B: half-step base Bn, lane row bln) are fetched between the MFMA groups into
+        // registers that are free by then -- B and the last A tile into a second set, the other A tiles into their own
+        // registers once their products are issued -- so only 3 reads trail the last 3 MFMAs.
+        // (bc, a3c): B and last-A-tile fragments of the step being multiplied; (bnx, a3nx): where the next step's go.  The two
+        // k halves of a stage call it with the two sets swapped, so no register copies are needed.
+        auto kstep = [&](const unsigned char* Sn, int chn, const char* Bn, unsigned bln, bool pfa,
+                         bf16x8 (&bc)[P], bf16x8 (&a3c)[P], bf16x8 (&bnx)[P], bf16x8 (&a3nx)[P]) {
+            // pfa (wave-uniform): fetch the next A fragments too -- false in the last step of a tile (its A fragments would only
+            // sit in registers across the epilogue; B, one L2 round trip away, does ride over it)
+            if constexpr ((ABL & 2048) != 0) return;       // ablation: idle consumers (the producers' own pace)
+            if constexpr (!(ABL & 256)) {
 #pragma unroll
-                for (int p = 0; p < P; ++p) bn[p] = ldf(Sn + boff + p * (BN * 64) + chn);
+                for (int p = 0; p < P; ++p) bnx[p] = ldb(Bn, bln, p);
+            }
+            if (pfa && !(ABL & 16)) {
 #pragma unroll
-                for (int p = 0; p < P; ++p) a3n[p] = ldf(Sn + aoff + 3 * 2048 + p * (BM * 64) + chn);
+                for (int p = 0; p < P; ++p) a3nx[p] = ldf(Sn + aoff + 3 * 2048 + p * (BM * 64) + chn);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < PRODUCTS; ++q) {
                 const int pa = SplitTerm<PRODUCTS>::pa(q), pb = SplitTerm<PRODUCTS>::pb(q);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][pa], b[pb], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][pa], b[pb], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][pa], bc[pb], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][pa], bc[pb], acc[1], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PF) {
+            if (pfa && !(ABL & 16)) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -255,99 +258,149 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_pc_kernel(const float* __restr
 #pragma unroll
             for (int q = 0; q < QH; ++q) {
                 const int pa = SplitTerm<PRODUCTS>::pa(q), pb = SplitTerm<PRODUCTS>::pb(q);
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][pa], b[pb], acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[3][pa], b[pb], acc[3], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][pa], bc[pb], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3c[pa], bc[pb], acc[3], 0, 0, 0);
             }
 #pragma unroll
             for (int q = QH; q < PRODUCTS; ++q)
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][SplitTerm<PRODUCTS>::pa(q)], b[SplitTerm<PRODUCTS>::pb(q)], acc[2], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][SplitTerm<PRODUCTS>::pa(q)], bc[SplitTerm<PRODUCTS>::pb(q)], acc[2], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PF) {
+            if (pfa && !(ABL & 16)) {
 #pragma unroll
                 for (int p = 0; p < P; ++p) a[2][p] = ldf(Sn + aoff + 2 * 2048 + p * (BM * 64) + chn);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = QH; q < PRODUCTS; ++q)
-                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[3][SplitTerm<PRODUCTS>::pa(q)], b[SplitTerm<PRODUCTS>::pb(q)], acc[3], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3c[SplitTerm<PRODUCTS>::pa(q)], bc[SplitTerm<PRODUCTS>::pb(q)], acc[3], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PF) {
-#pragma unroll
-                for (int p = 0; p < P; ++p) { b[p] = bn[p]; a[3][p] = a3n[p]; }
-            }
         };
-        auto load_frags = [&](const unsigned char* Sn, int chn) {
+        auto load_a_frags = [&](const unsigned char* Sn, int chn) {
 #pragma unroll
-            for (int p = 0; p < P; ++p) b[p] = ldf(Sn + boff + p * (BN * 64) + chn);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 3; ++t)
 #pragma unroll
                 for (int p = 0; p < P; ++p) a[t][p] = ldf(Sn + aoff + t * 2048 + p * (BM * 64) + chn);
+#pragma unroll
+            for (int p = 0; p < P; ++p) a3x[p] = ldf(Sn + aoff + 3 * 2048 + p * (BM * 64) + chn);
+        };
+        auto lane_row = [&](unsigned tile) {                            // byte offset of this lane's B row inside a plane
+            int n = (int)(tile % ntn) * BN + wn * 32 + li;
+            n = n < N ? n : N - 1;
+            return (unsigned)n * 32u + (unsigned)hi * 16u;
         };
 
-        __syncthreads();                                                // stage 0 and the first half of stage 1 are in LDS
-
-        // Per tile: fragments of its first k step (complete since the last barrier), the k loop, the epilogue.  Nothing but
-        // the accumulators lives across the epilogue, and the fragment registers are carried by the inner loop only (with
-        // the prefetch carried across tiles the allocator spilled fragments inside the k loop).
-        unsigned g = 0;                                                 // stage counter of the block
+        unsigned long long t_wait = 0, t_begin = 0;
+        if constexpr ((ABL & 32768) != 0) t_begin = __builtin_amdgcn_s_memtime();
+        unsigned slot = 0, gen1 = 4;                                    // LDS slot of the current stage; full[slot] value that means "written"
+        unsigned bl = lane_row(t0);
+#pragma unroll
+        for (int p = 0; p < P; ++p) { bx[p] = ldb(Bb, bl, p); by[p] = bx[p]; a3y[p] = bx[p]; }      // k half-step 0 of the first tile
         for (unsigned tile = t0; tile < t1; ++tile) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-            load_frags(smem + (g & 1u) * STAGE, ch0);
-            for (int ks = 0; ks < nst; ++ks, ++g) {
-                const unsigned char* S0 = smem + (g & 1u) * STAGE;
-                const unsigned char* S1 = smem + ((g + 1u) & 1u) * STAGE;
-                kstep(S0, ch1, PfYes());                                // k half 0 of stage g; fetch its half 1
-                __syncthreads();
-                kstep(S1, ch0, PfYes());                                // k half 1; fetch half 0 of stage g + 1 (unused after the tile's last stage)
-                __syncthreads();
+            int colc = (int)(tile % ntn) * BN + wn * 32 + li;
+            colc = colc < N ? colc : N - 1;
+            const float bias = ep.bias != nullptr ? ep.bias[colc] : 0.f;                 // needed in the epilogue only: its latency is free here
+            const unsigned bl_next = lane_row(tile + 1 < t1 ? tile + 1 : tile);
+            pc_wait_flag(&full[slot], gen1);                            // first stage of the tile
+            load_a_frags(smem + slot * ASTAGE, ch0);
+            for (int ks = 0; ks < nst; ++ks) {
+                const unsigned char* S0 = smem + slot * ASTAGE;
+                const unsigned nslot = slot + 1 < (unsigned)R ? slot + 1 : 0u;
+                const unsigned ngen1 = slot + 1 < (unsigned)R ? gen1 : gen1 + 4u;
+                const char* Bh = Bb + (unsigned)(2 * ks) * bhalf;      // k half-step (ks, 0) of this tile
+                const bool last = ks + 1 == nst;
+                kstep(S0, ch1, Bh + bhalf, bl, true, bx, a3x, by, a3y);  // k half 0 of the stage from registers; fetch its half 1
+                // every fragment read of this stage has been issued: the release below orders them before the counter
+                if (lane == 0) pc_bump_flag(&empty[slot]);
+                if constexpr ((ABL & 32768) != 0) {
+                    const unsigned long long t0w = __builtin_amdgcn_s_memtime();
+                    if (!last) pc_wait_flag(&full[nslot], ngen1);
+                    t_wait += __builtin_amdgcn_s_memtime() - t0w;
+                } else
+                if (!last) pc_wait_flag(&full[nslot], ngen1);
+                // k half 1; fetch half 0 of the next stage, or (last) only the B fragments of the next tile's first step
+                kstep(smem + nslot * ASTAGE, ch0, last ? Bb : Bh + 2 * bhalf, last ? bl_next : bl, !last, by, a3y, bx, a3x);
+                slot = nslot; gen1 = ngen1;
             }
-            const int64_t m0 = (int64_t)(tile / ntn) * BM;
-            const int n0 = (int)(tile % ntn) * BN;
-            const float* sx = side + (tile & 1u) * (2 * BM) + wm * 128;
-            pc_epilogue<BNB>(acc, C, ldc, M, N, ep, m0 + wm * 128, n0 + wn * 32, li, hi, sx, sx + BM, use_cs);
+            if constexpr (!(ABL & 128)) {
+                const int64_t m0 = (int64_t)(tile / ntn) * BM;
+                const int n0 = (int)(tile % ntn) * BN;
+                const float* sx = side + (tile % SLOTS) * (2 * BM) + wm * 128;
+                if (n0 + wn * 32 < N) pc_epilogue<EPI>(acc, C, ldc, N, ep, m0 + wm * 128, n0 + wn * 32, li, hi, sx, sx + BM, bias);
+            } else if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.f) {
+                C[tid] = bias;
+            }
+            if constexpr ((ABL & 32768) != 0) {
+                if (tile + 1 == t1 && lane == 0) {
+                    const unsigned long long t_all = __builtin_amdgcn_s_memtime() - t_begin;
+                    C[(blockIdx.x * 8 + cw) * 2 + 0] = (float)t_wait;
+                    C[(blockIdx.x * 8 + cw) * 2 + 1] = (float)t_all;
+                }
+            }
+            bl = bl_next;
         }
     } else {
         // ------------------------------------------------ producers ------------------------------------------------
-        const int ptid = tid - 512;
+        if (((opt >> 2) & 3) == 1) __builtin_amdgcn_s_setprio(1);
+        else if (((opt >> 2) & 3) == 2) __builtin_amdgcn_s_setprio(2);
+        else if (((opt >> 2) & 3) == 3) __builtin_amdgcn_s_setprio(3);
+        const int ptid = tid - 512, plane_lane = ptid & 63;
         const int prow = ptid >> 2, pch = ptid & 3;                     // item i: row prow + 64 i of the tile, chunk pch
         const unsigned tlast = t1 - 1;
-        PcCursor la, lb, wc;                                            // A loads, B loads, LDS writes
+        PcCursor la, wc;                                                // A loads (DA stages ahead), LDS writes
         pc_locate<BM, BN>(la, t0, ntn); la.ks = 0;
-        lb = la; wc = la;
+        wc = la;
 
-        float4 ra[DA][NA][2];
-        float sa0[DA][NA], sa1[DA][NA];
-        u32x4 rb[P * NBP];
+        f32x4 ra[DA][NA][2];
+        float sa0[DA][NA], sa1[DA][NA], sdx[DA], sdy[DA];
         const bool has_r0 = as.r0 != nullptr, has_r1 = as.r1 != nullptr;
         const float* r0p = has_r0 ? as.r0 : A;                          // branch-free: a dummy (valid) address when absent
         const float* r1p = has_r1 ? as.r1 : r0p;
+        // epilogue row factors: FWD (denom, keep) / DX (cs.r0, cs.r1); absent ones read a dummy address and become 1.0
+        const float* sxp = use_cs ? (ep.cs.r0 != nullptr ? ep.cs.r0 : A) : (ep.denom != nullptr ? ep.denom : A);
+        const float* syp = use_cs ? (ep.cs.r1 != nullptr ? ep.cs.r1 : A) : (ep.keep != nullptr ? ep.keep : A);
+        const bool has_sx = use_cs ? ep.cs.r0 != nullptr : ep.denom != nullptr, has_sy = use_cs ? ep.cs.r1 != nullptr : ep.keep != nullptr;
+        const int srow = ptid < BM ? ptid : BM - 1;
 
-        auto load_a = [&](const PcCursor& c, int slot, int i) {
-            const int64_t rowl = c.m0 + prow + 64 * i;
-            const int64_t row = rowl < M ? rowl : M - 1;
-            int k = c.ks * 32 + pch * 8;
-            k = k < K - 8 ? k : K - 8;                                  // K % 8 == 0: the stage-tiled B holds zeros past K
-            const float* p = A + row * lda + k;
-            ra[slot][i][0] = *reinterpret_cast<const float4*>(p);
-            ra[slot][i][1] = *reinterpret_cast<const float4*>(p + 4);
-            const float x0 = r0p[has_r0 ? row : 0], x1 = r1p[(has_r0 || has_r1) ? row : 0];
-            sa0[slot][i] = has_r0 ? x0 : 1.f;
-            sa1[slot][i] = has_r1 ? x1 : 1.f;
+        // Addresses = wave-uniform base of the tile's rows (scalar unit) + per-lane byte offsets that never change: tiles are
+        // full in M, so only the k position of the stage moves the base (a k tail re-reads the row's last 8 floats; the
+        // tiled B holds zeros there).
+        unsigned aoffv[NA], roffv[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            aoffv[i] = (unsigned)(((prow + 64 * i) * (int)lda + pch * 8) * 4);
+            if constexpr ((ABL & 4096) != 0) aoffv[i] = (unsigned)((((ptid >> 3) + 64 * i) * (int)lda + (ptid & 7) * 4) * 4);   // timing probe: full 128-byte lines per 8 lanes (wrong data)
+            roffv[i] = (unsigned)((prow + 64 * i) * 4);
+        }
+        const unsigned soffv = (unsigned)(srow * 4);
+        // the LT counted loads of one stage, always in this order: per item 2 x 16 bytes of A + 2 row scales, then the 2 row factors
+        auto load_item = [&](const PcCursor& c, int slotr, int i) {
+            if constexpr ((ABL & 64) != 0) { ra[slotr][i][0] = ra[slotr][i][1] = f32x4{1.f, 2.f, 3.f, 4.f}; sa0[slotr][i] = sa1[slotr][i] = 1.f; return; }
+            const float* base = (ABL & 8192) ? A + (int64_t)(t0 / ntn) * BM * lda : A + c.m0 * lda + c.ks * 32;   // (8192: timing probe, every stage re-reads the first one)
+            unsigned off = aoffv[i];
+            if (c.ks * 32 + 32 > K) {                                   // wave-uniform: the stage holding the k tail
+                const int k = c.ks * 32 + pch * 8;
+                if (k > K - 8) off -= (unsigned)((k - (K - 8)) * 4);
+            }
+            async_load16(ra[slotr][i][0], base, off);
+            async_load16(ra[slotr][i][1], base, (ABL & 4096) ? off + 32u * (unsigned)lda * 4u : off + 16u);
+            if constexpr ((ABL & 512) != 0) { sa0[slotr][i] = sa1[slotr][i] = 1.f; return; }
+            async_load4(sa0[slotr][i], r0p + (has_r0 ? c.m0 : 0), has_r0 ? roffv[i] : 0u);
+            async_load4(sa1[slotr][i], r1p + ((has_r0 || has_r1) ? c.m0 : 0), (has_r0 || has_r1) ? roffv[i] : 0u);
         };
-        auto load_b = [&](const PcCursor& c, int e) {                   // piece e = p * NBP + ii
-            const int p = e / NBP, ii = e % NBP;
-            int nrow = c.n0 + prow + 64 * ii;
-            nrow = nrow < N ? nrow : N - 1;
-            const unsigned off = (unsigned)((((c.ks * P + p) * N + nrow) * 32 + pch * 8) * 2);
-            rb[e] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(Bp) + off);
+        auto load_side = [&](const PcCursor& c, int slotr) {
+            if constexpr ((ABL & (64 | 512)) != 0) { sdx[slotr] = sdy[slotr] = 1.f; return; }
+            async_load4(sdx[slotr], sxp + (has_sx ? c.m0 : 0), has_sx ? soffv : 0u);
+            async_load4(sdy[slotr], syp + (has_sy ? c.m0 : 0), has_sy ? soffv : 0u);
         };
-        auto store_a = [&](const PcCursor& c, unsigned char* S, int slot, int i) {
-            float v[8] = {ra[slot][i][0].x, ra[slot][i][0].y, ra[slot][i][0].z, ra[slot][i][0].w,
-                          ra[slot][i][1].x, ra[slot][i][1].y, ra[slot][i][1].z, ra[slot][i][1].w};
+        auto store_item = [&](const PcCursor& c, unsigned char* S, int slotr, int i) {
+            if constexpr ((ABL & 512) != 0 && !(ABL & 1024)) async_wait<DA * LT - 2>(ra[slotr][i][0], ra[slotr][i][1]);
+            if constexpr (!(ABL & (64 | 512 | 1024))) async_wait<DA * LT - 4>(ra[slotr][i][0], ra[slotr][i][1], sa0[slotr][i], sa1[slotr][i]);
+            float v[8] = {ra[slotr][i][0][0], ra[slotr][i][0][1], ra[slotr][i][0][2], ra[slotr][i][0][3],
+                          ra[slotr][i][1][0], ra[slotr][i][1][1], ra[slotr][i][1][2], ra[slotr][i][1][3]};
             int k = c.ks * 32 + pch * 8;
             k = k < K - 8 ? k : K - 8;
             if constexpr (BNIN) {
@@ -355,119 +408,107 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_pc_kernel(const float* __restr
                 const float4 h0 = *reinterpret_cast<const float4*>(bnv + 1024 + k), h1 = *reinterpret_cast<const float4*>(bnv + 1024 + k + 4);
                 const float sc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
                 const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                if (ib.hi < __builtin_huge_valf()) {                     // ReLU6 (wave-uniform): the upper clamp
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = bn_act_load(v[e], sc[e], sh[e], ib.neg, ib.hi);
+                    for (int e = 0; e < 8; ++e) v[e] = bn_act_load(v[e], sc[e], sh[e], ib.neg, ib.hi);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float z = fmaf(v[e], sc[e], sh[e]); v[e] = fmaxf(z, ib.neg * z); }
+                }
             }
-            if (has_r0) {
+            if (has_r0) {                                               // as.split % 8 == 0 (launcher): one factor per chunk
+                const float sc8 = (k < as.split) ? sa0[slotr][i] : (has_r1 ? sa1[slotr][i] : 1.f);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= (k + e < as.split) ? sa0[slot][i] : sa1[slot][i];
+                for (int e = 0; e < 8; ++e) v[e] *= sc8;
             }
             u32x4 pl[P];
             split8<P>(v, pl);
             const int off = split_off(prow + 64 * i, pch);
+            if constexpr ((ABL & 32) != 0) { if (pl[0][0] + pl[P - 1][3] == 0x12345u) S[0] = 1; return; }      // ablation: no LDS stores
 #pragma unroll
             for (int p = 0; p < P; ++p) *reinterpret_cast<u32x4*>(S + p * (BM * 64) + off) = pl[p];
         };
-        auto store_b = [&](unsigned char* S, int e) {
-            const int p = e / NBP, ii = e % NBP;
-            *reinterpret_cast<u32x4*>(S + P * BM * 64 + p * (BN * 64) + split_off(prow + 64 * ii, pch)) = rb[e];
-        };
-        // per-row epilogue factors of the tile at c (c.ks == 0): loads first, LDS stores when the interval's other work is done
-        float sdx = 1.f, sdy = 1.f;
-        int srow = 0;
-        auto side_load = [&](const PcCursor& c, int rr) {
-            const int64_t rowl = c.m0 + rr;
-            const int64_t row = rowl < M ? rowl : M - 1;
-            sdx = 1.f; sdy = 1.f;
-            if (use_cs) { sdx = ep.cs.r0[row]; if (ep.cs.r1 != nullptr) sdy = ep.cs.r1[row]; }
-            else {
-                if (ep.denom != nullptr) sdx = ep.denom[row];
-                if (ep.keep != nullptr) sdy = ep.keep[row];
+        auto store_side = [&](const PcCursor& c, int slotr) {
+            if constexpr (!(ABL & (64 | 512 | 1024))) async_wait<DA * LT - 2>(sdx[slotr], sdy[slotr]);
+            if (c.ks == 0 && ptid < BM) {
+                float* sx = side + (c.tile % SLOTS) * (2 * BM);
+                const float x = has_sx ? sdx[slotr] : 1.f;
+                sx[ptid] = (!use_cs && has_sx) ? 1.0f / x : x;          // one IEEE division per row
+                sx[BM + ptid] = has_sy ? sdy[slotr] : 1.f;
             }
-            srow = rr;
-        };
-        auto side_store = [&](const PcCursor& c) {
-            float* sx = side + (c.tile & 1u) * (2 * BM);
-            sx[srow] = (!use_cs && ep.denom != nullptr) ? 1.0f / sdx : sdx;     // one IEEE division per row
-            sx[BM + srow] = sdy;
         };
 
-        // ---- prologue: loads of stages 0 .. DA-1 (A) and 0 (B); stage 0 and the first half of stage 1 into LDS ----
+        // requests of stages 0 .. DA-1 (the same order the loop re-issues them in: the wait counts hold from the first stage on)
 #pragma unroll
         for (int u = 0; u < DA; ++u) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) load_a(la, u, i);
+            for (int i = 0; i < NA; ++i) load_item(la, u, i);
+            load_side(la, u);
             pc_advance<BM, BN>(la, nst, ntn, tlast);
         }
-#pragma unroll
-        for (int e = 0; e < P * NBP; ++e) load_b(lb, e);
-        pc_advance<BM, BN>(lb, nst, ntn, tlast);
-        for (int rr = ptid; rr < BM; rr += 256) { side_load(wc, rr); side_store(wc); }
-#pragma unroll
-        for (int i = 0; i < NA; ++i) { store_a(wc, smem, 0, i); load_a(la, 0, i); }
-        pc_advance<BM, BN>(la, nst, ntn, tlast);
-#pragma unroll
-        for (int e = 0; e < P * NBP; ++e) { store_b(smem, e); load_b(lb, e); }
-        pc_advance<BM, BN>(lb, nst, ntn, tlast);
-        pc_advance<BM, BN>(wc, nst, ntn, tlast);                        // wc = stage 1
-        if (stages > 1) {
-#pragma unroll
-            for (int i = 0; i < NA / 2; ++i) { store_a(wc, smem + STAGE, 1 % DA, i); load_a(la, 1 % DA, i); }
-#pragma unroll
-            for (int e = 0; e < P * NBP / 2; ++e) { store_b(smem + STAGE, e); load_b(lb, e); }
-        }
-        __syncthreads();
-
-        // ---- main loop: interval 2s-2 = second half of stage s, interval 2s-1 = first half of stage s+1 ----
-        for (unsigned sb = 1; sb <= stages; sb += DA) {
+        unsigned long long tp_empty = 0, tp_store = 0, tp_begin = 0, tp_wait = 0, tp_issue = 0;
+        if constexpr ((ABL & 32768) != 0) tp_begin = __builtin_amdgcn_s_memtime();
+        unsigned slot = 0, gen8 = 0;                                    // LDS slot of the stage being written; empty[slot] value that frees it
+        for (unsigned gb = 0; gb < stages; gb += DA) {
 #pragma unroll
             for (int u = 0; u < DA; ++u) {
-                const unsigned s = sb + u;
-                if (s > stages) break;
-                const int slot = (1 + u) % DA, slot1 = (2 + u) % DA;
-                if (s < stages) {
-                    unsigned char* S = smem + (s & 1u) * STAGE;
-                    const bool newtile = wc.ks == 0;
-                    if (newtile) side_load(wc, ptid);                   // (BM == 128: the upper half loads clamped rows it never stores)
+                if (gb + u >= stages) break;
+                unsigned char* S = smem + slot * ASTAGE;
+                unsigned long long tq0 = 0, tq1 = 0;
+                if constexpr ((ABL & 32768) != 0) tq0 = __builtin_amdgcn_s_memtime();
+                if (gen8 != 0u) pc_wait_flag_lazy(&empty[slot], gen8);       // all 8 consumer waves are done with the slot's previous stage
+                if constexpr ((ABL & 32768) != 0) { tq1 = __builtin_amdgcn_s_memtime(); tp_empty += tq1 - tq0; }
+                if constexpr ((ABL & 32768) != 0) {       // finer timers: [vmcnt wait] [split + LDS stores] [load issue]
 #pragma unroll
-                    for (int i = NA / 2; i < NA; ++i) { store_a(wc, S, slot, i); load_a(la, slot, i); }
-                    pc_advance<BM, BN>(la, nst, ntn, tlast);
+                    for (int i = 0; i < NA; ++i) {
+                        const unsigned long long ta = __builtin_amdgcn_s_memtime();
+                        if constexpr (!(ABL & (64 | 1024))) async_wait<DA * LT - 2>(ra[u][i][0], ra[u][i][1]);
+                        const unsigned long long tb = __builtin_amdgcn_s_memtime();
+                        store_item(wc, S, u, i);
+                        const unsigned long long tc = __builtin_amdgcn_s_memtime();
+                        load_item(la, u, i);
+                        const unsigned long long td = __builtin_amdgcn_s_memtime();
+                        tp_wait += tb - ta; tp_store += tc - tb; tp_issue += td - tc;
+                    }
+                } else {
 #pragma unroll
-                    for (int e = P * NBP / 2; e < P * NBP; ++e) { store_b(S, e); load_b(lb, e); }
-                    pc_advance<BM, BN>(lb, nst, ntn, tlast);
-                    if (newtile && ptid < BM) side_store(wc);
-                    pc_advance<BM, BN>(wc, nst, ntn, tlast);
+                for (int i = 0; i < NA; ++i) { store_item(wc, S, u, i); load_item(la, u, i); }
                 }
-                __syncthreads();
-                if (s + 1 < stages) {
-                    unsigned char* S = smem + ((s + 1u) & 1u) * STAGE;
-#pragma unroll
-                    for (int i = 0; i < NA / 2; ++i) { store_a(wc, S, slot1, i); load_a(la, slot1, i); }
-#pragma unroll
-                    for (int e = 0; e < P * NBP / 2; ++e) { store_b(S, e); load_b(lb, e); }
-                }
-                __syncthreads();
+                store_side(wc, u);
+                load_side(la, u);
+                if (plane_lane == 0) pc_bump_flag(&full[slot]);         // release: this wave's LDS stores precede it
+                pc_advance<BM, BN>(la, nst, ntn, tlast);
+                pc_advance<BM, BN>(wc, nst, ntn, tlast);
+                if (++slot == (unsigned)R) { slot = 0; gen8 += 8u; }
+            }
+        }
+        async_wait<0>(sdx[0]);                                          // nothing in flight when the wave ends
+        if constexpr ((ABL & 32768) != 0) {
+            if (plane_lane == 0) {
+                float* d = C + 8192 + (blockIdx.x * 4 + (ptid >> 6)) * 8;
+                d[0] = (float)tp_empty; d[1] = (float)tp_store; d[2] = (float)(__builtin_amdgcn_s_memtime() - tp_begin); d[3] = (float)stages;
+                d[4] = (float)tp_wait; d[5] = (float)tp_issue;
             }
         }
     }
 }
 
-// ---- weights: fp32 [N,K] (or its transpose) -> P bf16 planes in the stage-tiled layout [k stage][plane][n][32] ------
+// ---- weights: fp32 [N,K] (or its transpose) -> P bf16 planes tiled as [k half-step][plane][n][16 k], zeros past K ----
 template <int P>
-__global__ void split_w_tiled_kernel(const float* __restrict__ w, int cols_in, int transpose, int N, int K, int nst,
+__global__ void split_w_tiled_kernel(const float* __restrict__ w, int cols_in, int transpose, int N, int K, int nhalf,
                                      unsigned short* __restrict__ planes) {
-    const int64_t total = (int64_t)nst * N * 32;
+    const int64_t total = (int64_t)nhalf * N * 16;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int kk = (int)(i & 31);
-        const int n = (int)((i >> 5) % N), s = (int)((i >> 5) / N);
-        const int k = s * 32 + kk;
+        const int kk = (int)(i & 15);
+        const int n = (int)((i >> 4) % N), s = (int)((i >> 4) / N);
+        const int k = s * 16 + kk;
         float x = 0.f;
         if (k < K) x = transpose ? w[(int64_t)k * cols_in + n] : w[(int64_t)n * cols_in + k];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const __bf16 h = (__bf16)x;                               // RNE
             const unsigned short u = __builtin_bit_cast(unsigned short, h);
-            planes[(((int64_t)s * P + p) * N + n) * 32 + kk] = u;
+            planes[(((int64_t)s * P + p) * N + n) * 16 + kk] = u;
             x -= __builtin_bit_cast(float, (unsigned)u << 16);
         }
     }
@@ -484,14 +525,22 @@ static int pc_cus() {            // read-only device-properties cache
 }
 
 static int g_pc = getenv("TSII_GEMM_PC") ? atoi(getenv("TSII_GEMM_PC")) : 1;              // A/B knob: 0 = 4-wave kernels only
-static int g_pc_min_n = getenv("TSII_GEMM_PC_MIN_N") ? atoi(getenv("TSII_GEMM_PC_MIN_N")) : 64;
+static int g_pc_opt = getenv("TSII_GEMM_PC_OPT") ? atoi(getenv("TSII_GEMM_PC_OPT")) : 0;   // wave priorities (kernel comment)
+static int g_pc_abl = getenv("TSII_GEMM_PC_ABL") ? atoi(getenv("TSII_GEMM_PC_ABL")) : 0;   // tools/pc_probe.py ablations only
+static int g_pc_min_n = getenv("TSII_GEMM_PC_MIN_N") ? atoi(getenv("TSII_GEMM_PC_MIN_N")) : 128;   // measured: 64-column outputs stay faster on the 4-wave kernel
 
 size_t nt_pc_ws_bytes(int n, int k) { return (size_t)3 * n * ((k + 31) & ~31) * sizeof(unsigned short) + 16; }
 
-bool nt_pc_ok(const float* A, int64_t lda, int N, int K, const Epilogue& ep, const InBN& ib) {
+// plain 1x1 layers in the 6-product mode whose tiles are full: M a multiple of the tile height, N of 32 (everything else
+// stays on the 4-wave kernels of gemm_split.hip)
+static bool pc_wide(int N) { return cdiv(N, 256) * 256 == cdiv(N, 128) * 128; }      // 256-column tiles waste no more columns than 128-column ones
+bool nt_pc_ok(const float* A, int64_t lda, const RowScale& as, int64_t M, int N, int K, const Epilogue& ep, const InBN& ib) {
     if (!g_pc || gemm_products() != 6) return false;
-    if (N < g_pc_min_n || K % 8 != 0 || lda % 4 != 0 || !aligned16(A)) return false;
-    if (ep.cs.r0 != nullptr && (ep.denom != nullptr || ep.keep != nullptr || ep.bias != nullptr)) return false;   // one epilogue mode at a time
+    if (N < g_pc_min_n || N % 32 != 0 || M % (pc_wide(N) ? 128 : 256) != 0 || K % 8 != 0 || lda % 4 != 0 || !aligned16(A)) return false;
+    const bool dx = ep.cs.r0 != nullptr || ep.bn_y != nullptr;
+    if (as.r0 != nullptr && as.r1 != nullptr && as.split % 8 != 0) return false;                                   // one row-scale factor per 8-k chunk
+    if (dx && (ep.denom != nullptr || ep.keep != nullptr || ep.bias != nullptr || ep.stats != nullptr || ib.sc != nullptr)) return false;   // one epilogue mode at a time
+    if (ep.bn_y != nullptr && K < 64) return false;                                                               // one-stage tiles + the K6c epilogue: measured slower
     if (ib.sc != nullptr && K > 1024) return false;                                                               // (scale, shift) live in LDS
     if ((int64_t)3 * N * ((K + 31) & ~31) * 2 >= (1ll << 31)) return false;
     return true;
@@ -504,15 +553,39 @@ static int launch_nt_pc_cfg(const float* A, int64_t lda, RowScale as, const unsi
     const unsigned ntn = (unsigned)cdiv(N, BN);
     const int64_t tiles = cdiv64(M, BM) * ntn;
     TSII_REQUIRE(tiles < (1ll << 31), "gemm_nt_pc: too many tiles");
+    TSII_REQUIRE(ldc * 128 * 4 < (1ll << 31) && (int64_t)N * 128 * 4 < (1ll << 31), "gemm_nt_pc: row pitch too large");
     const unsigned grid = (unsigned)(tiles < pc_cus() ? tiles : pc_cus());
-    if (ep.bn_y != nullptr) {
-        TSII_REQUIRE(ib.sc == nullptr, "gemm_nt_pc: no input BatchNorm together with the BatchNorm-backward epilogue");
-        hipLaunchKernelGGL((gemm_nt_pc_kernel<WM, WN, 6, false, true>), dim3(grid), dim3(768), 0, stream, A, lda, as, Bp, C, ldc, M, N, K, ep, ib, ntn, (unsigned)tiles);
-    } else if (ib.sc != nullptr) {
-        hipLaunchKernelGGL((gemm_nt_pc_kernel<WM, WN, 6, true, false>), dim3(grid), dim3(768), 0, stream, A, lda, as, Bp, C, ldc, M, N, K, ep, ib, ntn, (unsigned)tiles);
-    } else {
-        hipLaunchKernelGGL((gemm_nt_pc_kernel<WM, WN, 6, false, false>), dim3(grid), dim3(768), 0, stream, A, lda, as, Bp, C, ldc, M, N, K, ep, ib, ntn, (unsigned)tiles);
+#define TSII_PC_LAUNCH(BNINV, EPIV, ABLV) hipLaunchKernelGGL((gemm_nt_pc_kernel<WM, WN, 6, BNINV, EPIV, ABLV>), dim3(grid), dim3(768), 0, stream, \
+                                                             A, lda, as, Bp, C, ldc, M, N, K, ep, ib, ntn, (unsigned)tiles, g_pc_opt)
+    if (ep.bn_y != nullptr) TSII_PC_LAUNCH(false, 3, 0);
+    else if (ep.cs.r0 != nullptr) TSII_PC_LAUNCH(false, 2, 0);
+    else if (ib.sc != nullptr) { if (ep.stats != nullptr) TSII_PC_LAUNCH(true, 1, 0); else TSII_PC_LAUNCH(true, 0, 0); }
+    else if (ep.stats != nullptr) TSII_PC_LAUNCH(false, 1, 0);
+    else {
+        if (WM == 1 && g_pc_abl == 16) TSII_PC_LAUNCH(false, 0, 16);
+        else if (WM == 1 && g_pc_abl == 32) TSII_PC_LAUNCH(false, 0, 32);
+        else if (WM == 1 && g_pc_abl == 128) TSII_PC_LAUNCH(false, 0, 128);
+        else if (WM == 1 && g_pc_abl == 256) TSII_PC_LAUNCH(false, 0, 256);
+        else if (WM == 1 && g_pc_abl == 272) TSII_PC_LAUNCH(false, 0, 272);
+        else if (WM == 1 && g_pc_abl == 400) TSII_PC_LAUNCH(false, 0, 400);
+        else if (WM == 1 && g_pc_abl == 432) TSII_PC_LAUNCH(false, 0, 432);
+        else if (WM == 1 && g_pc_abl == 464) TSII_PC_LAUNCH(false, 0, 464);
+        else if (WM == 1 && g_pc_abl == 496) TSII_PC_LAUNCH(false, 0, 496);
+        else if (WM == 1 && g_pc_abl == 96) TSII_PC_LAUNCH(false, 0, 96);
+        else if (WM == 1 && g_pc_abl == 912) TSII_PC_LAUNCH(false, 0, 912);
+        else if (WM == 1 && g_pc_abl == 1424) TSII_PC_LAUNCH(false, 0, 1424);
+        else if (WM == 1 && g_pc_abl == 512) TSII_PC_LAUNCH(false, 0, 512);
+        else if (WM == 1 && g_pc_abl == 2448) TSII_PC_LAUNCH(false, 0, 2448);
+        else if (WM == 1 && g_pc_abl == 5008) TSII_PC_LAUNCH(false, 0, 5008);
+        else if (WM == 1 && g_pc_abl == 9104) TSII_PC_LAUNCH(false, 0, 9104);
+        else if (WM == 1 && g_pc_abl == 33680) TSII_PC_LAUNCH(false, 0, 33680);
+        else if (WM == 1 && g_pc_abl == 33232) TSII_PC_LAUNCH(false, 0, 33232);
+        else if (WM == 1 && g_pc_abl == 17296) TSII_PC_LAUNCH(false, 0, 17296);
+        else if (WM == 1 && g_pc_abl == 4096) TSII_PC_LAUNCH(false, 0, 4096);
+        else if (WM == 1 && g_pc_abl == 2512) TSII_PC_LAUNCH(false, 0, 2512);
+        else TSII_PC_LAUNCH(false, 0, 0);
     }
+#undef TSII_PC_LAUNCH
     return check_launch("gemm_nt_pc");
 }
 
@@ -520,12 +593,11 @@ static int launch_nt_pc_cfg(const float* A, int64_t lda, RowScale as, const unsi
 int launch_nt_pc(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, bool b_transposed, float* C, int64_t ldc,
                  int64_t M, int N, int K, Epilogue ep, InBN ib, void* wsplit, hipStream_t stream) {
     unsigned short* planes = reinterpret_cast<unsigned short*>((reinterpret_cast<uintptr_t>(wsplit) + 15) & ~(uintptr_t)15);
-    const int nst = (K + 31) >> 5;
-    hipLaunchKernelGGL(split_w_tiled_kernel<3>, dim3(stream_grid((int64_t)nst * N * 32, 256)), dim3(256), 0, stream, B, (int)ldb, b_transposed ? 1 : 0, N, K, nst, planes);
+    const int nhalf = ((K + 31) >> 5) * 2;
+    hipLaunchKernelGGL(split_w_tiled_kernel<3>, dim3(stream_grid((int64_t)nhalf * N * 16, 256)), dim3(256), 0, stream, B, (int)ldb, b_transposed ? 1 : 0, N, K, nhalf, planes);
     int rc = check_launch("split_w_tiled");
     if (rc) return rc;
-    // 256-column tiles when they waste no more columns than 128-column ones
-    if (cdiv(N, 256) * 256 == cdiv(N, 128) * 128) return launch_nt_pc_cfg<1, 8>(A, lda, as, planes, C, ldc, M, N, K, ep, ib, stream);
+    if (pc_wide(N)) return launch_nt_pc_cfg<1, 8>(A, lda, as, planes, C, ldc, M, N, K, ep, ib, stream);
     return launch_nt_pc_cfg<2, 4>(A, lda, as, planes, C, ldc, M, N, K, ep, ib, stream);
 }
 

@@ -240,7 +240,7 @@ int launch_nt_split(const float* A, int64_t lda, RowScale as, const float* B, in
                     int64_t M, int N, int K, Epilogue ep, InBN ib, void* wsplit, hipStream_t stream);
 
 // producer / consumer form of the NT split kernel (gemm_pc.hip): plain 1x1 layers in the 6-product mode
-bool nt_pc_ok(const float* A, int64_t lda, int N, int K, const Epilogue& ep, const InBN& ib);
+bool nt_pc_ok(const float* A, int64_t lda, const RowScale& as, int64_t M, int N, int K, const Epilogue& ep, const InBN& ib);
 size_t nt_pc_ws_bytes(int n, int k);
 int launch_nt_pc(const float* A, int64_t lda, RowScale as, const float* B, int64_t ldb, bool b_transposed, float* C, int64_t ldc,
                  int64_t M, int N, int K, Epilogue ep, InBN ib, void* wsplit, hipStream_t stream);

@@ -180,6 +180,33 @@ __device__ __forceinline__ void vstore(float* __restrict__ p, const VecF<W>& r) 
 #define TSII_OPAQUE_U32(x) asm volatile("" : "+v"(x))
 #endif
 
+// Counted asynchronous global loads.  hipcc's own s_waitcnt insertion is conservative across loop iterations: in a
+// software-pipelined loop it waits for loads issued one iteration ago however far ahead they were requested (measured
+// in gemm_pc.hip: the producer waves ran at one memory latency per stage).  These loads are invisible to that pass; the
+// caller waits with an explicit count = the number of loads it issued after the one it needs, and passes the destination
+// registers through the wait so that no use can be scheduled above it.  (tests/emu supplies synchronous host forms.)
+#ifndef TSII_ASYNC_LOADS
+namespace tsii {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void async_load16(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void async_load16(u32x4v& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void async_load4(float& d, const void* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+// wave-uniform 64-bit base (SGPR pair) + 32-bit byte offset per lane: no address arithmetic on the vector pipe
+__device__ __forceinline__ void async_load16(f32x4& d, const void* base, unsigned off) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void async_load4(float& d, const void* base, unsigned off) { asm volatile("global_load_dword %0, %1, %2" : "=v"(d) : "v"(off), "s"(base) : "memory"); }
+template <int N, class A> __device__ __forceinline__ void async_wait(A& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
+template <int N, class A, class B> __device__ __forceinline__ void async_wait(A& a, B& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
+template <int N, class A, class B, class C, class D>
+__device__ __forceinline__ void async_wait(A& a, B& b, C& c, D& d) { asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory"); }
+}  // namespace tsii
+#else
+namespace tsii {
+typedef f32x4_emu2 f32x4;
+typedef u32x4_emu2 u32x4v;
+}
+#endif
+
 #define TSII_REQUIRE(cond, ...)                 \
     do {                                        \
         if (!(cond)) {                          \

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 SHAPES = [(65536, 192, 384), (32768, 64, 256), (16384, 384, 768), (8192, 256, 1024), (8192, 1024, 256), (4099, 40, 200),
-          (20000, 128, 512), (16384, 512, 128), (16384, 384, 64), (70000, 96, 192)]
+          (20480, 128, 512), (16384, 512, 128), (16384, 384, 64), (69632, 96, 192), (131072, 32, 128)]
 
 
 def main():
