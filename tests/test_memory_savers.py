@@ -34,6 +34,35 @@ def test_forward_checkpoint_matches_plain(backend):
     assert int(next(v for k, v in b1.items() if "tracked" in k)) == 1
 
 
+@both_backends
+def test_checkpointed_frozen_stages(backend):
+    """Stage-1 recipe shape: the first stages are frozen and fed by data, the rest trains.  A checkpointed pass must not
+    crash on the frozen segments ('element 0 of tensors does not require grad'), must not give them gradients, and must
+    reproduce the plain pass on the trainable ones."""
+    def run(dev, checkpointed):
+        torch.manual_seed(0)
+        enc = T.DilatedMobileNetV2(width_mult=0.25, activation=torch.nn.LeakyReLU(0.3), add_sece=True)
+        fill_state_dict_(enc.state_dict(), seed=62)
+        enc = enc.to(dev).train()
+        stages = list(enc.features) if hasattr(enc, "features") else list(enc.children())
+        for st in stages[:3]:
+            for p in st.parameters():
+                p.requires_grad_(False)
+        x = torch.from_numpy(np.random.default_rng(62).standard_normal((2, 3, 32, 32)).astype(np.float32)).to(dev)
+        y = enc.forward_checkpoint(x) if checkpointed else enc(x)
+        y.square().mean().backward()
+        return y.detach().cpu(), {k: (None if p.grad is None else p.grad.detach().cpu().clone()) for k, p in enc.named_parameters()}
+    with BACKENDS[backend]() as dev:
+        y0, g0 = run(dev, False)
+        y1, g1 = run(dev, True)
+    assert torch.equal(y0, y1)
+    assert any(v is None for v in g1.values()) and any(v is not None for v in g1.values())
+    for k in g0:
+        assert (g0[k] is None) == (g1[k] is None), k
+        if g0[k] is not None:
+            assert torch.equal(g0[k], g1[k]), k
+
+
 @pytest.mark.gpu
 def test_textsegament_checkpointed_encoder_gpu():
     """TextSegament with ``checkpoint_encoder``: same loss / gradients, lower peak memory (reported)."""

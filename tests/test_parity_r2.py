@@ -77,12 +77,19 @@ def test_depthwise_large_dilation_taps_in_range(backend):
             assert_close(m.feature_conv.weight.grad, w.grad, TOL, f"pconv dw d={d} dw")
 
 
-def _rfb_case(dev, hw, cin, cout, seed, report=False):
+def _rfb_case(dev, hw, cin, cout, seed, report=False, smooth=False):
     """RFB forward / dX / every parameter gradient vs the oracle.  Train-mode BatchNorm over few samples makes some of
     these gradients ill-conditioned (at TextSegament's channel counts the oracle's own fp32 run is 1.3e-2 away from its
     fp64 run in dX), so the target is the fp64 oracle and the tolerance per tensor is max(floor, 4x the oracle's
-    fp32-vs-fp64 discrepancy)."""
-    act = torch.nn.LeakyReLU(0.3)
+    fp32-vs-fp64 discrepancy).
+
+    Two forms.  ``smooth`` (no activation: every kernel of the block, nothing piecewise): EVERY tensor within the bar --
+    this is the check of the kernels.  LeakyReLU (the form the nets use): two fp32 implementations put about one
+    activation in a million on different sides of the kink and one flip moves the gradients of the layers around it by
+    several 1e-3 (tests/util.py: assert_gradients_close; seen here as 6.4e-3 on one (k,1) weight after the 1x1 GEMMs moved
+    to another -- equally exact, 1e-6 vs fp64 per call -- kernel), so that form allows a few tensors up to 5x the bar and
+    holds the median to a tenth of it."""
+    act = None if smooth else torch.nn.LeakyReLU(0.3)
     m = T.RFB(cin, cout, activation=act, add_sece=True)
     fill_state_dict_(m.state_dict(), seed=seed)
     rng = np.random.default_rng(seed)
@@ -95,7 +102,7 @@ def _rfb_case(dev, hw, cin, cout, seed, report=False):
             if v.dtype.is_floating_point and "running" not in k:
                 v.requires_grad_(True)
         xo = x.to(dtype).clone().requires_grad_(True)
-        yo = S.rfb(sd, "", xo, cout, O.leaky(0.3), True)
+        yo = S.rfb(sd, "", xo, cout, (lambda t: t) if smooth else O.leaky(0.3), True)
         yo.backward(gy.to(dtype))
         return yo.detach(), xo.grad, {k: v.grad for k, v in sd.items() if v.grad is not None}
 
@@ -120,8 +127,15 @@ def _rfb_case(dev, hw, cin, cout, seed, report=False):
         print(f"\n[RFB {cin}->{cout} {hw}x{hw}] dx err {rel_err(xd.grad, dx64):.2e} (oracle fp32-vs-fp64 {rel_err(dx32, dx64):.2e}); worst gradient tensors:")
         for r in rows[:6]:
             print(f"   ratio {r[0]:6.2f}  {r[1]:40s} err {r[2]:.2e}  oracle fp32 noise {r[3]:.2e}")
-    for ratio, k, e, noise in rows:
-        assert e <= max(3e-3, 4 * noise), f"RFB {hw}x{hw} grad {k}: {e:.2e} vs fp32 noise {noise:.2e}"
+    over = [(e, k) for ratio, k, e, noise in rows if e > max(3e-3, 4 * noise)]
+    if smooth:
+        assert not over, f"RFB {hw}x{hw} (no activation): {over[:5]}"
+    else:
+        for ratio, k, e, noise in rows:
+            assert e <= 5 * max(3e-3, 4 * noise), f"RFB {hw}x{hw} grad {k}: {e:.2e} vs fp32 noise {noise:.2e}"
+        assert len(over) <= max(4, len(rows) // 25), f"RFB {hw}x{hw}: {len(over)} tensors beyond the bar: {over[:8]}"
+        errs = sorted(e for _, _, e, _ in rows)
+        assert errs[len(errs) // 2] <= 3e-4, f"RFB {hw}x{hw}: median gradient error {errs[len(errs) // 2]:.2e}"
     assert len(rows) >= 20
 
 
@@ -129,6 +143,7 @@ def test_rfb_32x32_emu():
     """RFB with the d = 5 / 17 taps in range (32x32 map = cfg 1's 1/8 map), small channel counts, through the emulator."""
     with BACKENDS["emu"]() as dev:
         _rfb_case(dev, 32, 16, 8, seed=1400)
+        _rfb_case(dev, 32, 16, 8, seed=1400, smooth=True)
 
 
 @pytest.mark.gpu
@@ -138,6 +153,8 @@ def test_rfb_64x64_gpu(capsys):
         _rfb_case(dev, 64, 64, 32, seed=1401)
         _rfb_case(dev, 32, 48, 16, seed=1402)
         _rfb_case(dev, 32, 1344, 256, seed=1403, report=True)      # TextSegament's own RFB (in 1344, out 256) on cfg 1's 32x32 map
+        _rfb_case(dev, 32, 1344, 256, seed=1403, report=True, smooth=True)
+        _rfb_case(dev, 64, 64, 32, seed=1401, smooth=True)
 
 
 @pytest.mark.gpu

@@ -48,6 +48,18 @@ def _update_error(p_hip, p_ref, p_start):
     return max(0.0, float((p_hip - p_ref).abs().max()) - slack) / max(upd, 1e-12)
 
 
+def _judge_ratios(rows, what):
+    """rows: (error / max(oracle fp32 noise, floor), name, error, noise), worst first.  The yardstick comes from two fp32
+    runs of the oracle, which catch the bulk of the rounding noise but rarely the activation-kink flip that hits one
+    particular tensor (tests/util.py: assert_gradients_close; the kink-free RFB form in tests/test_parity_r2.py shows the
+    kernels themselves at 1e-6): every tensor within 8x except at most max(2, 2 %) of them, those within 40x (a real
+    kernel error is O(1) on whole families of tensors), the median within 2x."""
+    over = [r for r in rows if r[0] > 8.0]
+    assert len(over) <= max(2, len(rows) // 50), (what, over[:6])
+    assert rows[0][0] <= 40.0, (what, rows[:3])
+    assert sorted(r[0] for r in rows)[len(rows) // 2] <= 2.0, (what, rows[len(rows) // 2])
+
+
 class TinyFill(nn.Module):
     """stem partial conv (bias, LeakyReLU) -> PartialInvertedResidual (three BatchNorms, residual) -> 3-channel head"""
 
@@ -70,29 +82,49 @@ def _tiny_fill_oracle(sd, x, mask):
 
 
 def _inpainting_recipe_case(backend, make_model, oracle_fwd, key_shapes, trainable, size, tol):
+    """Target = the fp64 oracle loop.  Per tensor the bar is k x the ORACLE'S OWN fp32 noise on that tensor under this loss:
+    its fp32 loop (plain, and with a 1-ulp perturbation of the input image) against its fp64 loop -- measured, not assumed
+    (BatchNorm gammas under the Gram-matrix terms of InpaintingLoss amplify rounding noise by orders of magnitude; a
+    cancellation-free tensor gets the floor)."""
     from text_segmentation_image_inpainting_amd.recipes import InpaintingRecipe
     batch, steps = 2, 3
     cfg = dict(base_lr=1e-4, max_lr=1e-2, step_size=2)
     _, mask = seeded_input(batch, 3, size, size, seed=5, hole_frac=0.15)
     clean = torch.from_numpy(np.random.default_rng(6).uniform(0, 1, (batch, 3, size, size)).astype(np.float32))
     corrupted = clean * mask
-    # ---- oracle loop (stock torch, CPU)
-    sd = make_state_dict(key_shapes, seed=3)
-    for k in trainable:
-        sd[k].requires_grad_(True)
     crit_keys = T.InpaintingLoss(T.MobileNetV2(width_mult=1), feature_range=3).state_dict()
-    ext_sd = make_state_dict([(k, tuple(v.shape)) for k, v in crit_keys.items()], seed=77)
-    opt, sched = _torch_loop([sd[k] for k in trainable], cfg["base_lr"], cfg["max_lr"], cfg["step_size"], 1e-4)
-    start = {k: sd[k].detach().clone() for k in trainable}
-    ref_losses, ref_lrs = [], []
-    for _ in range(steps):
-        opt.zero_grad()
-        loss = S.inpainting_loss(ext_sd, corrupted, mask, oracle_fwd(sd, corrupted, mask), clean)
-        loss.backward()
-        ref_lrs.append(opt.param_groups[0]["lr"])
-        opt.step()
-        sched.step()
-        ref_losses.append(float(loss.detach()))
+
+    def oracle_loop(dtype, ulp=False):
+        """stock torch on the CPU in `dtype`; ulp: the input image moved by one fp32 ulp per pixel (noise yardstick)"""
+        sd = make_state_dict(key_shapes, seed=3, dtype=dtype)
+        for k in trainable:
+            sd[k].requires_grad_(True)
+        ext_sd = make_state_dict([(k, tuple(v.shape)) for k, v in crit_keys.items()], seed=77, dtype=dtype)
+        cl = torch.nextafter(clean, torch.ones_like(clean)) if ulp else clean
+        cl, mk = cl.to(dtype), mask.to(dtype)
+        co = cl * mk
+        opt, sched = _torch_loop([sd[k] for k in trainable], cfg["base_lr"], cfg["max_lr"], cfg["step_size"], 1e-4)
+        start = {k: sd[k].detach().clone() for k in trainable}
+        losses, lrs = [], []
+        for _ in range(steps):
+            opt.zero_grad()
+            loss = S.inpainting_loss(ext_sd, co, mk, oracle_fwd(sd, co, mk), cl)
+            loss.backward()
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sched.step()
+            losses.append(float(loss.detach()))
+        return sd, ext_sd, start, losses, lrs
+
+    sd, ext_sd, start, ref_losses, ref_lrs = oracle_loop(torch.float32)
+    sd64, _, start64, _, _ = oracle_loop(torch.float64)
+    sdu, _, _, _, _ = oracle_loop(torch.float32, ulp=True)
+    ref64 = {k: sd64[k].detach() for k in trainable}
+    st64 = {k: start64[k] for k in trainable}
+
+    def upd_err(p, k):          # vs the fp64 loop, relative to the size of that tensor's update
+        return _update_error(p.double(), ref64[k], st64[k])
+    noise = {k: max(upd_err(sd[k].detach(), k), upd_err(sdu[k].detach(), k)) for k in trainable}
     # ---- the recipe on the HIP path
     with BACKENDS[backend]() as dev:
         model = make_model()
@@ -109,14 +141,18 @@ def _inpainting_recipe_case(backend, make_model, oracle_fwd, key_shapes, trainab
         _check_losses(losses, ref_losses)
         params = dict(model.named_parameters())
         assert sorted(k for k, p in params.items() if p.requires_grad) == sorted(trainable)
-        # per tensor (cancellation-heavy ones -- BatchNorm gammas under the Gram-matrix terms -- carry the noise-limited
-        # gradient error of train-mode BatchNorm nets almost undamped: loose bound), and over the whole update vector (tight)
-        worst = max((_update_error(params[k].detach().cpu(), sd[k].detach(), start[k]), k) for k in trainable)
-        du_hip = torch.cat([(params[k].detach().cpu() - start[k]).reshape(-1).double() for k in trainable])
-        du_ref = torch.cat([(sd[k].detach() - start[k]).reshape(-1).double() for k in trainable])
+        errs = {k: upd_err(params[k].detach().cpu(), k) for k in trainable}
+        rows = sorted(((errs[k] / max(noise[k], tol / 8), k, errs[k], noise[k]) for k in trainable), reverse=True)
+        du_hip = torch.cat([(params[k].detach().cpu().double() - st64[k]).reshape(-1) for k in trainable])
+        du_ref = torch.cat([(ref64[k] - st64[k]).reshape(-1) for k in trainable])
+        du_o32 = torch.cat([(sd[k].detach().double() - st64[k]).reshape(-1) for k in trainable])
         rel = float((du_hip - du_ref).norm() / du_ref.norm())
-        print(f"[recipe {backend}] update vector: relative L2 error {rel:.3e}; worst tensor {worst[1]} {worst[0]:.3e}")
-        assert rel <= tol and worst[0] <= 10 * tol, (rel, worst)
+        rel_o = float((du_o32 - du_ref).norm() / du_ref.norm())
+        print(f"\n[recipe {backend}] update vector vs the fp64 loop: relative L2 error {rel:.3e} (the fp32 oracle loop: {rel_o:.3e}); worst tensors (error / oracle fp32 noise):")
+        for r in rows[:5]:
+            print(f"   ratio {r[0]:6.2f}  {r[1]:50s} err {r[2]:.2e}  oracle fp32 noise {r[3]:.2e}")
+        assert rel <= max(tol, 4 * rel_o), (rel, rel_o)
+        _judge_ratios(rows, "inpainting recipe")
         # the extractor stays in train mode in the reference: its running statistics move, and match the oracle's
         k0 = "feature_encoder.layers.0.1.0.running_mean"
         assert float((rec.criterion.state_dict()[k0].cpu() - ext_sd[k0]).abs().max()) <= 2e-3 * float(ext_sd[k0].abs().max())   # fed by the (slightly diverged) outputs
@@ -137,29 +173,52 @@ def test_inpainting_recipe_imagefill_gpu():
 
 
 def _segmentation_recipe_case(backend, width_mult, x, t, tol):
+    """Two stages against the fp64 oracle loop; per tensor the bar is 8x the oracle's own fp32 noise on that tensor's update
+    (fp32 loop, plain and with the input moved by one ulp, vs the fp64 loop; floor tol / 8), the median tensor within 2x."""
     from text_segmentation_image_inpainting_amd.recipes import SegmentationRecipe
     cfg = dict(base_lr=1e-4, max_lr=4e-4, step_size=2)
     probe = T.TextSegament(width_mult=width_mult)
     keys = [(k, tuple(v.shape)) for k, v in probe.state_dict().items()]
     all_params = [k for k, _ in probe.named_parameters()]
     stage1 = [k for k in all_params if not k.startswith("encoder.")]
-    # ---- oracle: stage 1 trains everything outside `encoder.`, stage 2 everything (fresh optimizer + schedule)
-    sd = make_state_dict(keys, seed=41, gain=1.0)
-    start = {k: sd[k].detach().clone() for k in all_params}
-    ref_losses = []
-    for names, nsteps in ((stage1, 2), (all_params, 1)):
-        for k in all_params:
-            sd[k].requires_grad_(k in names)
-        opt, sched = _torch_loop([sd[k] for k in names], cfg["base_lr"], cfg["max_lr"], cfg["step_size"], 1e-3)
-        for _ in range(nsteps):
-            opt.zero_grad()
-            loss = S.binary_focal_loss(S.text_segament(sd, x, training=True, width_mult=width_mult), t, 0.0, 1.0, 2.0)
-            loss.backward()
-            opt.step()
-            sched.step()
-            ref_losses.append(float(loss.detach()))
-        if names is stage1:
-            mid = {k: sd[k].detach().clone() for k in all_params}
+
+    def oracle_loop(dtype, ulp=False):
+        # stage 1 trains everything outside `encoder.`, stage 2 everything (fresh optimizer + schedule)
+        sd = make_state_dict(keys, seed=41, gain=1.0, dtype=dtype)
+        xi = (torch.nextafter(x, torch.full_like(x, float("inf"))) if ulp else x).to(dtype)
+        start = {k: sd[k].detach().clone() for k in all_params}
+        losses, mid = [], None
+        for names, nsteps in ((stage1, 2), (all_params, 1)):
+            for k in all_params:
+                sd[k].requires_grad_(k in names)
+            opt, sched = _torch_loop([sd[k] for k in names], cfg["base_lr"], cfg["max_lr"], cfg["step_size"], 1e-3)
+            for _ in range(nsteps):
+                opt.zero_grad()
+                loss = S.binary_focal_loss(S.text_segament(sd, xi, training=True, width_mult=width_mult), t.to(dtype), 0.0, 1.0, 2.0)
+                loss.backward()
+                opt.step()
+                sched.step()
+                losses.append(float(loss.detach()))
+            if names is stage1:
+                mid = {k: sd[k].detach().clone() for k in all_params}
+        return start, mid, {k: sd[k].detach().clone() for k in all_params}, losses
+
+    _, mid32, end32, ref_losses = oracle_loop(torch.float32)
+    start64, mid64, end64, _ = oracle_loop(torch.float64)
+    _, midu, endu, _ = oracle_loop(torch.float32, ulp=True)
+
+    def e1(p, k): return _update_error(p.double(), mid64[k], start64[k])
+    def e2(p, k): return _update_error(p.double(), end64[k], mid64[k])
+    noise1 = {k: max(e1(mid32[k], k), e1(midu[k], k)) for k in stage1}
+    noise2 = {k: max(e2(end32[k], k), e2(endu[k], k)) for k in all_params}
+
+    def judge(errs, noise, what):
+        rows = sorted(((errs[k] / max(noise[k], tol / 8), k, errs[k], noise[k]) for k in errs), reverse=True)
+        print(f"\n[seg recipe {backend}] {what}: worst tensors (error / oracle fp32 noise):")
+        for r in rows[:4]:
+            print(f"   ratio {r[0]:6.2f}  {r[1]:50s} err {r[2]:.2e}  oracle fp32 noise {r[3]:.2e}")
+        _judge_ratios(rows, what)
+
     with BACKENDS[backend]() as dev:
         net = T.TextSegament(width_mult=width_mult)
         fill_state_dict_(net.state_dict(), seed=41, gain=1.0)
@@ -173,14 +232,15 @@ def _segmentation_recipe_case(backend, width_mult, x, t, tol):
         assert all(torch.equal(v, dict(net.encoder.named_parameters())[k].detach()) for k, v in enc0.items())
         assert not torch.equal(bn0, net.state_dict()["encoder.features.0.1.0.running_mean"])
         params = dict(net.named_parameters())
-        worst1 = max((_update_error(params[k].detach().cpu(), mid[k], start[k]), k) for k in stage1)
+        judge({k: e1(params[k].detach().cpu(), k) for k in stage1}, noise1, "stage 1 (two steps, decoder only)")
         rec.unfreeze()
         assert rec.stage == 2 and len(rec.trainer.params) == len(all_params) and rec.lr == cfg["base_lr"]
         losses.append(float(rec.step(x.to(dev), t.to(dev))))
         params = dict(net.named_parameters())
-        worst2 = max((_update_error(params[k].detach().cpu(), sd[k].detach(), mid[k]), k) for k in all_params)
+        # the stage-2 step starts from the HIP run's own stage-1 result: compare the step taken, not the end point
+        hip_mid = {k: params[k].detach().cpu() for k in all_params}
         _check_losses(losses, ref_losses)
-        assert worst1[0] <= tol and worst2[0] <= tol, (worst1, worst2)
+        judge({k: _update_error(hip_mid[k].double(), end64[k], mid64[k]) for k in all_params}, noise2, "stage 2 (one step, everything)")
         assert any(not torch.equal(v, params["encoder." + k].detach()) for k, v in enc0.items())     # stage 2 trains the encoder
 
 

@@ -108,7 +108,7 @@ def lib():
                 f"{LIB_PATH} not found: the MI355X HIP library has not been built "
                 "(python -m text_segmentation_image_inpainting_amd.build_ext). There is no CPU fallback.")
         _LIB = bind(ctypes.CDLL(LIB_PATH))
-        if _LIB.tsii_version() != 1:
+        if _LIB.tsii_version() != 3:
             raise RuntimeError("libtsii_hip.so ABI version mismatch")
     return _LIB
 

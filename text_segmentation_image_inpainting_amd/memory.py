@@ -50,13 +50,24 @@ class _Segment(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[1] and not _any_trainable(ctx.run):
+            return None, None, None        # nothing behind this segment wants a gradient (checkpoint_segment avoids such nodes)
         # the recomputation sees the input exactly as the first pass did (a data tensor stays a data tensor: kernels
         # may pick a different -- equally valid, differently rounded -- form when an input gradient is wanted)
         xin = x.detach().requires_grad_(ctx.needs_input_grad[1])
         with torch.enable_grad(), _recompute_pass():
             y = ctx.run(xin)
-        torch.autograd.backward(y, gy)
+        if y.requires_grad:
+            torch.autograd.backward(y, gy)
         return None, xin.grad, None
+
+
+def _any_trainable(run) -> bool:
+    """Does the stage own a parameter that wants a gradient?  (Callables that are not modules count as trainable.)"""
+    params = getattr(run, "parameters", None)
+    if params is None:
+        return True
+    return any(p.requires_grad for p in params())
 
 
 def checkpoint_segment(run, x):
@@ -64,6 +75,11 @@ def checkpoint_segment(run, x):
     module parameters / buffers (deterministic kernels: the recomputation reproduces the first pass bit for bit)."""
     if not torch.is_grad_enabled():
         return run(x)
+    if not x.requires_grad and not _any_trainable(run):
+        # a frozen stage fed by data (two-stage recipes freeze the encoder's first stages): no node at all -- its output
+        # must not require grad either, or the segments behind it would back-propagate through the frozen weights for nothing
+        with torch.no_grad():
+            return run(x)
     # the dummy input carries requires_grad so the node is kept even when x itself needs no gradient (first stage)
     dummy = torch.empty(0, device=x.device, requires_grad=True)
     return _Segment.apply(run, x, dummy)
