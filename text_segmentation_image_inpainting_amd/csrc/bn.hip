@@ -197,7 +197,7 @@ __global__ void bn_scale_shift_kernel(const float* __restrict__ mean, const floa
     }
 }
 
-// launched with chan_grid(): (gridDim*blockDim) % CG == 0, so each thread's channel group is fixed
+// launched with flat_grid(): one vector per thread (tsii_common.h); with any other grid (gridDim*blockDim) % CG == 0 must hold
 template <int W>
 __global__ void bn_act_fwd_kernel(const float* __restrict__ y, int64_t M, int C, const float* __restrict__ mean,
                                   const float* __restrict__ var, const float* __restrict__ gamma,
@@ -205,21 +205,24 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ y, int64_t M, int C,
                                   const float* __restrict__ residual, float* __restrict__ out) {
     const unsigned CG = (unsigned)(C / W);
     const int64_t total = M * CG;
-    const unsigned gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int c = (int)(gt % CG) * W;
     float mu[W], sc[W], be[W];
+    {   // per-channel constants as vector loads (the kernel runs one vector per thread)
+        const VecF<W> m4 = vload<W>(mean + c), v4 = vload<W>(var + c), g4 = vload<W>(gamma + c), b4 = vload<W>(beta + c);
 #pragma unroll
-    for (int i = 0; i < W; ++i) {
-        mu[i] = mean[c + i];
-        sc[i] = (1.0f / sqrtf(var[c + i] + eps)) * gamma[c + i];
-        be[i] = beta[c + i];
+        for (int i = 0; i < W; ++i) {
+            mu[i] = m4.v[i];
+            sc[i] = (1.0f / sqrtf(v4.v[i] + eps)) * g4.v[i];
+            be[i] = b4.v[i];
+        }
     }
     for (int64_t idx = gt; idx < total; idx += stride) {
         const int64_t off = idx * W;
-        VecF<W> v = vload<W>(y + off);
+        VecF<W> v = vload_nt<W>(y + off);
         VecF<W> res;
-        if (residual != nullptr) res = vload<W>(residual + off);
+        if (residual != nullptr) res = vload_nt<W>(residual + off);
 #pragma unroll
         for (int i = 0; i < W; ++i) {
             float z = (v.v[i] - mu[i]) * sc[i] + be[i];
@@ -227,7 +230,7 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ y, int64_t M, int C,
             if (residual != nullptr) z += res.v[i];
             v.v[i] = z;
         }
-        vstore<W>(out + off, v);
+        vstore_nt<W>(out + off, v);
     }
 }
 
@@ -268,7 +271,11 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ dout, const floa
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const T* __restrict__ part, int R, int C,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           // the backward apply's table of per-channel constants (coef[6][C]; see bn_bwd_apply_kernel)
+                                                           int64_t M, const float* __restrict__ mean, const float* __restrict__ var,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int training,
+                                                           float* __restrict__ coef) {
     __shared__ double sh[2][8][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + tx;
@@ -281,69 +288,77 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const T* __restrict__
         for (int j = 0; j < 8; ++j) { s1 += sh[0][j][tx]; s2 += sh[1][j][tx]; }
         dbeta[c] = (float)s1;
         dgamma[c] = (float)s2;
+        const float invM = 1.0f / (float)M;
+        coef[c] = mean[c];
+        coef[C + c] = 1.0f / sqrtf(var[c] + eps);
+        coef[2 * C + c] = gamma[c];
+        coef[3 * C + c] = beta[c];
+        coef[4 * C + c] = training ? (float)s1 * invM : 0.f;
+        coef[5 * C + c] = training ? (float)s2 * invM : 0.f;
     }
 }
 
 // backward pass 2: dy = gamma*istd*(dz - s1/M - xhat*s2/M)   (training)  |  gamma*istd*dz  (eval)
+// One vector per thread (flat_grid): the six per-channel constants come from the table bn_bwd_final_kernel leaves behind
+// (coef[j][C], j = mean, 1/std, gamma, beta, dbeta/M, dgamma/M) -- re-deriving them per thread (24 scalar loads + 4
+// rsqrt) made the pass 2.3x slower than the grid-stride form it replaced.
 template <int W>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y, int64_t M, int C,
-                                    const float* __restrict__ mean, const float* __restrict__ var,
-                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                    int act, float slope, int training, const float* __restrict__ dgamma,
-                                    const float* __restrict__ dbeta, float* __restrict__ dy) {
+                                    const float* __restrict__ coef, int act, float slope, float* __restrict__ dy) {
     const unsigned CG = (unsigned)(C / W);
     const int64_t total = M * CG;
-    const unsigned gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int c = (int)(gt % CG) * W;
-    const float invM = 1.0f / (float)M;
-    float mu[W], istd[W], ga[W], be[W], k1[W], k2[W];
-#pragma unroll
-    for (int i = 0; i < W; ++i) {
-        mu[i] = mean[c + i];
-        istd[i] = 1.0f / sqrtf(var[c + i] + eps);
-        ga[i] = gamma[c + i];
-        be[i] = beta[c + i];
-        k1[i] = training ? dbeta[c + i] * invM : 0.f;
-        k2[i] = training ? dgamma[c + i] * invM : 0.f;
-    }
+    const VecF<W> mu = vload<W>(coef + c), istd = vload<W>(coef + C + c), ga = vload<W>(coef + 2 * C + c), be = vload<W>(coef + 3 * C + c),
+                  k1 = vload<W>(coef + 4 * C + c), k2 = vload<W>(coef + 5 * C + c);
     for (int64_t idx = gt; idx < total; idx += stride) {
         const int64_t off = idx * W;
-        const VecF<W> yv = vload<W>(y + off);
-        VecF<W> dv = vload<W>(dout + off);
+        const VecF<W> yv = vload_nt<W>(y + off);
+        VecF<W> dv = vload_nt<W>(dout + off);
 #pragma unroll
         for (int i = 0; i < W; ++i) {
-            const float xh = (yv.v[i] - mu[i]) * istd[i];
-            const float z = xh * ga[i] + be[i];
+            const float xh = (yv.v[i] - mu.v[i]) * istd.v[i];
+            const float z = xh * ga.v[i] + be.v[i];
             float dz = dv.v[i] * act_grad(z, act, slope);
-            dz = dz - k1[i] - xh * k2[i];
-            dv.v[i] = dz * ga[i] * istd[i];
+            dz = dz - k1.v[i] - xh * k2.v[i];
+            dv.v[i] = dz * ga.v[i] * istd.v[i];
         }
-        vstore<W>(dy + off, dv);
+        vstore_nt<W>(dy + off, dv);
     }
+}
+
+static int launch_bn_bwd_apply(const float* dout, const float* y, int64_t m, int c, int act, float slope, float* dy, const float* coef, hipStream_t st) {
+    const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(dout) && aligned16(dy) && aligned16(coef);
+    const int64_t total = m * (vec ? c / 4 : c);
+    const unsigned grid = flat_grid(total, 256);
+    if (vec) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(grid), dim3(256), 0, st, dout, y, m, c, coef, act, slope, dy);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(grid), dim3(256), 0, st, dout, y, m, c, coef, act, slope, dy);
+    return check_launch("bn_bwd_apply");
 }
 
 template <int W>
 __global__ void act_fwd_kernel(const float* __restrict__ x, int64_t n4, int act, float slope, float* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        VecF<W> v = vload<W>(x + i * W);
+        VecF<W> v = vload_nt<W>(x + i * W);
 #pragma unroll
         for (int e = 0; e < W; ++e) v.v[e] = apply_act(v.v[e], act, slope);
-        vstore<W>(out + i * W, v);
+        vstore_nt<W>(out + i * W, v);
     }
 }
 template <int W>
 __global__ void act_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x, int64_t n4, int act,
                                float slope, float* __restrict__ dx) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const VecF<W> xv = vload<W>(x + i * W);
-        VecF<W> dv = vload<W>(dout + i * W);
+        const VecF<W> xv = vload_nt<W>(x + i * W);
+        VecF<W> dv = vload_nt<W>(dout + i * W);
 #pragma unroll
         for (int e = 0; e < W; ++e) dv.v[e] *= act_grad(xv.v[e], act, slope);
-        vstore<W>(dx + i * W, dv);
+        vstore_nt<W>(dx + i * W, dv);
     }
 }
 
+static inline size_t bn_coef_bytes(int c) { return (size_t)6 * c * sizeof(float) + 32; }
 static inline int bn_rows(int64_t m, int c) { return partial_rows(m, (c % 4 == 0) ? c / 4 : c); }
 
 }  // namespace tsii
@@ -353,7 +368,14 @@ using namespace tsii;
 extern "C" size_t tsii_bn_ws_bytes(int64_t m, int c) {
     if (m <= 0 || c <= 0) return 0;
     const size_t rows = (size_t)bn_rows(m, c);
-    return rows * 2 * c * sizeof(float) + (size_t)cdiv64((int64_t)rows, BN_L1_ROWS) * 2 * c * sizeof(double) + 16;
+    // partial rows + level-1 sums + the backward apply's table of 6 per-channel constants (at the end)
+    return rows * 2 * c * sizeof(float) + (size_t)cdiv64((int64_t)rows, BN_L1_ROWS) * 2 * c * sizeof(double) + 16 + bn_coef_bytes(c);
+}
+
+// the constants' table sits at the end of the workspace (16-byte aligned)
+static inline float* bn_coef_buffer(void* ws, size_t ws_bytes, int c) {
+    uintptr_t p = (uintptr_t)ws + ws_bytes - bn_coef_bytes(c);
+    return (float*)((p + 15) & ~(uintptr_t)15);
 }
 
 // doubles live after the float partial rows (8-byte aligned)
@@ -432,9 +454,10 @@ extern "C" int tsii_bn_act_fwd(const float* y, int64_t m, int c, const float* me
     TSII_REQUIRE(m > 0 && c > 0, "bn_act_fwd: bad shape");
     TSII_REQUIRE(act >= 0 && act <= 4, "bn_act_fwd: unknown activation %d", act);
     hipStream_t st = (hipStream_t)stream;
-    const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(out) && (residual == nullptr || aligned16(residual));
+    const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(out) && (residual == nullptr || aligned16(residual)) &&
+                     aligned16(mean) && aligned16(var) && aligned16(gamma) && aligned16(beta);
     const int64_t total = m * (vec ? c / 4 : c);
-    const unsigned grid = chan_grid(total, vec ? c / 4 : c, 256);
+    const unsigned grid = flat_grid(total, 256);
     if (vec) hipLaunchKernelGGL((bn_act_fwd_kernel<4>), dim3(grid), dim3(256), 0, st, y, m, c, mean, var, gamma, beta, eps, act, slope, residual, out);
     else hipLaunchKernelGGL((bn_act_fwd_kernel<1>), dim3(grid), dim3(256), 0, st, y, m, c, mean, var, gamma, beta, eps, act, slope, residual, out);
     return check_launch("bn_act_fwd");
@@ -452,6 +475,7 @@ extern "C" int tsii_bn_act_bwd(const float* dout, const float* y, int64_t m, int
     const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(dout) && aligned16(dy);
     const int64_t tasks = (int64_t)R * (vec ? c / 4 : c);
     float* part = (float*)ws;
+    float* coef = bn_coef_buffer(ws, ws_bytes, c);
     if (vec) hipLaunchKernelGGL((bn_bwd_partial_kernel<4>), dim3(stream_grid(tasks, 256)), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta, eps, act, slope, R, part);
     else hipLaunchKernelGGL((bn_bwd_partial_kernel<1>), dim3(stream_grid(tasks, 256)), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta, eps, act, slope, R, part);
     int rc = check_launch("bn_bwd_partial");
@@ -462,17 +486,15 @@ extern "C" int tsii_bn_act_bwd(const float* dout, const float* y, int64_t m, int
         hipLaunchKernelGGL(part2_l1_kernel, dim3(cdiv(c, 32), chunks), dim3(256), 0, st, part, R, c, l1);
         rc = check_launch("bn_part_l1");
         if (rc) return rc;
-        hipLaunchKernelGGL((bn_bwd_final_kernel<double>), dim3(cdiv(c, 32)), dim3(256), 0, st, (const double*)l1, chunks, c, dgamma, dbeta);
+        hipLaunchKernelGGL((bn_bwd_final_kernel<double>), dim3(cdiv(c, 32)), dim3(256), 0, st, (const double*)l1, chunks, c, dgamma, dbeta,
+                           m, mean, var, gamma, beta, eps, training, coef);
     } else {
-        hipLaunchKernelGGL((bn_bwd_final_kernel<float>), dim3(cdiv(c, 32)), dim3(256), 0, st, (const float*)part, R, c, dgamma, dbeta);
+        hipLaunchKernelGGL((bn_bwd_final_kernel<float>), dim3(cdiv(c, 32)), dim3(256), 0, st, (const float*)part, R, c, dgamma, dbeta,
+                           m, mean, var, gamma, beta, eps, training, coef);
     }
     rc = check_launch("bn_bwd_final");
     if (rc) return rc;
-    const int64_t total = m * (vec ? c / 4 : c);
-    const unsigned grid = chan_grid(total, vec ? c / 4 : c, 256);
-    if (vec) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(grid), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta, eps, act, slope, training, dgamma, dbeta, dy);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(grid), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta, eps, act, slope, training, dgamma, dbeta, dy);
-    return check_launch("bn_bwd_apply");
+    return launch_bn_bwd_apply(dout, y, m, c, act, slope, dy, coef, st);
 }
 
 extern "C" int tsii_bn_act_bwd_pre(const float* dout, const float* y, int64_t m, int c, const float* mean,
@@ -481,8 +503,10 @@ extern "C" int tsii_bn_act_bwd_pre(const float* dout, const float* y, int64_t m,
                                    float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
     TSII_REQUIRE(dout && y && mean && var && gamma && beta && dy && dgamma && dbeta && bwd_part && ws, "bn_act_bwd_pre: null pointer");
     TSII_REQUIRE(m > 0 && c > 0 && rows > 0 && rows < (1ll << 31), "bn_act_bwd_pre: bad shape");
-    TSII_REQUIRE(ws_bytes >= (size_t)cdiv64(rows, BN_L1_ROWS) * 2 * c * sizeof(double) + 16, "bn_act_bwd_pre: workspace too small");
+    TSII_REQUIRE(ws_bytes >= (size_t)cdiv64(rows, BN_L1_ROWS) * 2 * c * sizeof(double) + 16 + bn_coef_bytes(c),
+                 "bn_act_bwd_pre: workspace too small (tsii_bn_ws_bytes)");
     hipStream_t st = (hipStream_t)stream;
+    float* coef = bn_coef_buffer(ws, ws_bytes, c);
     const int R = (int)rows;
     int rc;
     if (R > BN_L1_ROWS) {
@@ -491,18 +515,15 @@ extern "C" int tsii_bn_act_bwd_pre(const float* dout, const float* y, int64_t m,
         hipLaunchKernelGGL(part2_l1_kernel, dim3(cdiv(c, 32), chunks), dim3(256), 0, st, bwd_part, R, c, l1);
         rc = check_launch("bn_part_l1");
         if (rc) return rc;
-        hipLaunchKernelGGL((bn_bwd_final_kernel<double>), dim3(cdiv(c, 32)), dim3(256), 0, st, (const double*)l1, chunks, c, dgamma, dbeta);
+        hipLaunchKernelGGL((bn_bwd_final_kernel<double>), dim3(cdiv(c, 32)), dim3(256), 0, st, (const double*)l1, chunks, c, dgamma, dbeta,
+                           m, mean, var, gamma, beta, eps, training, coef);
     } else {
-        hipLaunchKernelGGL((bn_bwd_final_kernel<float>), dim3(cdiv(c, 32)), dim3(256), 0, st, bwd_part, R, c, dgamma, dbeta);
+        hipLaunchKernelGGL((bn_bwd_final_kernel<float>), dim3(cdiv(c, 32)), dim3(256), 0, st, bwd_part, R, c, dgamma, dbeta,
+                           m, mean, var, gamma, beta, eps, training, coef);
     }
     rc = check_launch("bn_bwd_final");
     if (rc) return rc;
-    const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(dout) && aligned16(dy);
-    const int64_t total = m * (vec ? c / 4 : c);
-    const unsigned grid = chan_grid(total, vec ? c / 4 : c, 256);
-    if (vec) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(grid), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta, eps, act, slope, training, dgamma, dbeta, dy);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(grid), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta, eps, act, slope, training, dgamma, dbeta, dy);
-    return check_launch("bn_bwd_apply");
+    return launch_bn_bwd_apply(dout, y, m, c, act, slope, dy, coef, st);
 }
 
 extern "C" int tsii_act_fwd(const float* x, int64_t numel, int act, float slope, float* out, void* stream) {
@@ -510,9 +531,9 @@ extern "C" int tsii_act_fwd(const float* x, int64_t numel, int act, float slope,
     TSII_REQUIRE(act >= 0 && act <= 4, "act_fwd: unknown activation %d", act);
     hipStream_t st = (hipStream_t)stream;
     if (numel % 4 == 0 && aligned16(x) && aligned16(out))
-        hipLaunchKernelGGL((act_fwd_kernel<4>), dim3(stream_grid(numel / 4, 256)), dim3(256), 0, st, x, numel / 4, act, slope, out);
+        hipLaunchKernelGGL((act_fwd_kernel<4>), dim3(flat_grid(numel / 4, 256)), dim3(256), 0, st, x, numel / 4, act, slope, out);
     else
-        hipLaunchKernelGGL((act_fwd_kernel<1>), dim3(stream_grid(numel, 256)), dim3(256), 0, st, x, numel, act, slope, out);
+        hipLaunchKernelGGL((act_fwd_kernel<1>), dim3(flat_grid(numel, 256)), dim3(256), 0, st, x, numel, act, slope, out);
     return check_launch("act_fwd");
 }
 
@@ -521,8 +542,8 @@ extern "C" int tsii_act_bwd(const float* dout, const float* x, int64_t numel, in
     TSII_REQUIRE(dout && x && dx && numel > 0, "act_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (numel % 4 == 0 && aligned16(x) && aligned16(dout) && aligned16(dx))
-        hipLaunchKernelGGL((act_bwd_kernel<4>), dim3(stream_grid(numel / 4, 256)), dim3(256), 0, st, dout, x, numel / 4, act, slope, dx);
+        hipLaunchKernelGGL((act_bwd_kernel<4>), dim3(flat_grid(numel / 4, 256)), dim3(256), 0, st, dout, x, numel / 4, act, slope, dx);
     else
-        hipLaunchKernelGGL((act_bwd_kernel<1>), dim3(stream_grid(numel, 256)), dim3(256), 0, st, dout, x, numel, act, slope, dx);
+        hipLaunchKernelGGL((act_bwd_kernel<1>), dim3(flat_grid(numel, 256)), dim3(256), 0, st, dout, x, numel, act, slope, dx);
     return check_launch("act_bwd");
 }

@@ -159,27 +159,27 @@ extern "C" int tsii_l1_mean_fwd(const float* a, const float* b, int64_t numel, f
 extern "C" int tsii_l1_mean_bwd(const float* a, const float* b, int64_t numel, const float* gscale, float* da,
                                 void* stream) {
     TSII_REQUIRE(a && b && gscale && da && numel > 0, "l1_mean_bwd: bad arguments");
-    hipLaunchKernelGGL(l1_bwd_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, (hipStream_t)stream, a, b, numel, gscale, da);
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3(flat_grid(numel, 256)), dim3(256), 0, (hipStream_t)stream, a, b, numel, gscale, da);
     return check_launch("l1_bwd");
 }
 
 extern "C" int tsii_sgd_nesterov(float* p, const float* g, float* buf, int64_t numel, float lr, float momentum,
                                  float weight_decay, void* stream) {
     TSII_REQUIRE(p && g && buf && numel > 0, "sgd_nesterov: bad arguments");
-    hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, (hipStream_t)stream, p, g, buf,
+    hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(flat_grid(numel, 256)), dim3(256), 0, (hipStream_t)stream, p, g, buf,
                        numel, lr, momentum, weight_decay);
     return check_launch("sgd_nesterov");
 }
 
 extern "C" int tsii_compose_fwd(const float* raw, const float* mask, const float* out, int64_t numel, float* comp, void* stream) {
     TSII_REQUIRE(raw && mask && out && comp && numel > 0, "compose_fwd: bad arguments");
-    hipLaunchKernelGGL(compose_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, (hipStream_t)stream, raw, mask, out, numel, comp);
+    hipLaunchKernelGGL(compose_kernel, dim3(flat_grid(numel, 256)), dim3(256), 0, (hipStream_t)stream, raw, mask, out, numel, comp);
     return check_launch("compose_fwd");
 }
 
 extern "C" int tsii_compose_bwd(const float* dcomp, const float* mask, int64_t numel, float* dout, void* stream) {
     TSII_REQUIRE(dcomp && mask && dout && numel > 0, "compose_bwd: bad arguments");
-    hipLaunchKernelGGL(compose_bwd_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, (hipStream_t)stream, dcomp, mask, numel, dout);
+    hipLaunchKernelGGL(compose_bwd_kernel, dim3(flat_grid(numel, 256)), dim3(256), 0, (hipStream_t)stream, dcomp, mask, numel, dout);
     return check_launch("compose_bwd");
 }
 
@@ -200,7 +200,7 @@ extern "C" int tsii_masked_l1_fwd(const float* out, const float* gt, const float
 extern "C" int tsii_masked_l1_bwd(const float* out, const float* gt, const float* mask, int64_t numel, float w_valid,
                                   float w_hole, const float* gscale, float* dout, void* stream) {
     TSII_REQUIRE(out && gt && mask && gscale && dout && numel > 0, "masked_l1_bwd: bad arguments");
-    hipLaunchKernelGGL(masked_l1_bwd_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, (hipStream_t)stream, out, gt, mask,
+    hipLaunchKernelGGL(masked_l1_bwd_kernel, dim3(flat_grid(numel, 256)), dim3(256), 0, (hipStream_t)stream, out, gt, mask,
                        numel, w_valid, w_hole, gscale, dout);
     return check_launch("masked_l1_bwd");
 }
@@ -224,7 +224,7 @@ extern "C" int tsii_tv_bwd(const float* x, int n, int h, int w, int c, const flo
     TSII_REQUIRE(x && gscale && dx && n > 0 && h > 1 && w > 1 && c > 0, "tv_bwd: bad arguments");
     const int64_t numel = (int64_t)n * h * w * c;
     const float gw = (float)(1.0 / ((double)n * c * h * (w - 1))), gh = (float)(1.0 / ((double)n * c * (h - 1) * w));
-    hipLaunchKernelGGL(tv_bwd_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, (hipStream_t)stream, x, numel, h, w, c, gw, gh,
+    hipLaunchKernelGGL(tv_bwd_kernel, dim3(flat_grid(numel, 256)), dim3(256), 0, (hipStream_t)stream, x, numel, h, w, c, gw, gh,
                        gscale, dx);
     return check_launch("tv_bwd");
 }

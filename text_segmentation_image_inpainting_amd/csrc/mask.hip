@@ -80,7 +80,7 @@ extern "C" int tsii_mask_channel_sum(const float* mask, int n, int h, int w, int
     TSII_REQUIRE(mask && plane, "mask_channel_sum: null pointer");
     TSII_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0, "mask_channel_sum: bad shape %d %d %d %d", n, h, w, c);
     const int64_t total = (int64_t)n * h * w;
-    hipLaunchKernelGGL(mask_channel_sum_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(mask_channel_sum_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        mask, total, h, w, c, sn, sh, sw, sc, plane);
     return check_launch("mask_channel_sum");
 }
@@ -95,7 +95,7 @@ extern "C" int tsii_mask_update(const float* p0, float a0, const float* p1, floa
     TSII_REQUIRE(ho == (h + 2 * ph - dh * (kh - 1) - 1) / sh + 1 && wo == (w + 2 * pw - dw * (kw - 1) - 1) / sw + 1,
                  "mask_update: output size %dx%d inconsistent with conv geometry", ho, wo);
     const int64_t total = (int64_t)n * ho * wo;
-    hipLaunchKernelGGL(mask_update_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(mask_update_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        p0, a0, p1, a1, total, h, w, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo, post_scale, fill_holes,
                        denom, new_mask, inv);
     return check_launch("mask_update");
@@ -104,14 +104,14 @@ extern "C" int tsii_mask_update(const float* p0, float a0, const float* p1, floa
 extern "C" int tsii_plane_upsample2x(const float* in, int n, int h, int w, float* out, void* stream) {
     TSII_REQUIRE(in && out && n > 0 && h > 0 && w > 0, "plane_upsample2x: bad arguments");
     const int64_t total = (int64_t)n * h * w * 4;
-    hipLaunchKernelGGL(plane_upsample2x_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(plane_upsample2x_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        in, total, h, w, out);
     return check_launch("plane_upsample2x");
 }
 
 extern "C" int tsii_mul_mask(const float* x, const float* mask, int64_t numel, float* out, void* stream) {
     TSII_REQUIRE(x && mask && out && numel > 0, "mul_mask: bad arguments");
-    hipLaunchKernelGGL(mul_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(mul_kernel, dim3(flat_grid(numel, 256)), dim3(256), 0, (hipStream_t)stream,
                        x, mask, numel, out);
     return check_launch("mul_mask");
 }

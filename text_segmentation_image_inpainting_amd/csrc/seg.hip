@@ -272,7 +272,7 @@ using namespace tsii;
 extern "C" int tsii_pixel_shuffle(const float* src, int n, int h, int w, int c, int r, int inverse, float* dst, void* stream) {
     TSII_REQUIRE(src && dst && n > 0 && h > 0 && w > 0 && c > 0 && r >= 1, "pixel_shuffle: bad arguments");
     const int64_t total = (int64_t)n * h * r * w * r * c;
-    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, src, total, h, w, c, r,
+    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, src, total, h, w, c, r,
                        inverse, dst);
     return check_launch("pixel_shuffle");
 }
@@ -282,9 +282,9 @@ extern "C" int tsii_add_act_fwd(const float* a, const float* b, int64_t numel, i
     TSII_REQUIRE(act >= 0 && act <= 4, "add_act_fwd: unknown activation %d", act);
     hipStream_t st = (hipStream_t)stream;
     if (numel % 4 == 0 && aligned16(a) && aligned16(b) && aligned16(out))
-        hipLaunchKernelGGL((add_act_kernel<4>), dim3(stream_grid(numel / 4, 256)), dim3(256), 0, st, a, b, numel / 4, act, slope, out);
+        hipLaunchKernelGGL((add_act_kernel<4>), dim3(flat_grid(numel / 4, 256)), dim3(256), 0, st, a, b, numel / 4, act, slope, out);
     else
-        hipLaunchKernelGGL((add_act_kernel<1>), dim3(stream_grid(numel, 256)), dim3(256), 0, st, a, b, numel, act, slope, out);
+        hipLaunchKernelGGL((add_act_kernel<1>), dim3(flat_grid(numel, 256)), dim3(256), 0, st, a, b, numel, act, slope, out);
     return check_launch("add_act_fwd");
 }
 
@@ -292,7 +292,7 @@ extern "C" int tsii_copy_channels(float* big, int64_t m, int cbig, int coff, flo
     TSII_REQUIRE(big && small_ && m > 0 && cbig > 0 && csmall > 0 && coff >= 0 && coff + csmall <= cbig, "copy_channels: bad arguments");
     const bool vec = (cbig % 4 == 0) && (csmall % 4 == 0) && (coff % 4 == 0) && aligned16(big) && aligned16(small_);
     const int CG = vec ? csmall / 4 : csmall;
-    const unsigned grid = chan_grid(m * CG, CG, 256);
+    const unsigned grid = flat_grid(m * CG, 256);
     if (vec) hipLaunchKernelGGL((copy_channels_kernel<4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, big, m, cbig, coff, small_, csmall, to_dst);
     else hipLaunchKernelGGL((copy_channels_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, big, m, cbig, coff, small_, csmall, to_dst);
     return check_launch("copy_channels");
@@ -302,8 +302,8 @@ extern "C" int tsii_bilinear_up_fwd(const float* x, int n, int h, int w, int c, 
     TSII_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && scale >= 1, "bilinear_up_fwd: bad arguments");
     const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(y);
     const int64_t total = (int64_t)n * h * scale * w * scale * (vec ? c / 4 : c);
-    if (vec) hipLaunchKernelGGL((bilinear_up_fwd_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, n, h, w, c, scale, y);
-    else hipLaunchKernelGGL((bilinear_up_fwd_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, n, h, w, c, scale, y);
+    if (vec) hipLaunchKernelGGL((bilinear_up_fwd_kernel<4>), dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, n, h, w, c, scale, y);
+    else hipLaunchKernelGGL((bilinear_up_fwd_kernel<1>), dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, n, h, w, c, scale, y);
     return check_launch("bilinear_up_fwd");
 }
 
@@ -311,8 +311,8 @@ extern "C" int tsii_bilinear_up_bwd(const float* dy, int n, int h, int w, int c,
     TSII_REQUIRE(dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && scale >= 1, "bilinear_up_bwd: bad arguments");
     const bool vec = (c % 4 == 0) && aligned16(dx) && aligned16(dy);
     const int64_t total = (int64_t)n * h * w * (vec ? c / 4 : c);
-    if (vec) hipLaunchKernelGGL((bilinear_up_bwd_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, n, h, w, c, scale, dx);
-    else hipLaunchKernelGGL((bilinear_up_bwd_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, n, h, w, c, scale, dx);
+    if (vec) hipLaunchKernelGGL((bilinear_up_bwd_kernel<4>), dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, n, h, w, c, scale, dx);
+    else hipLaunchKernelGGL((bilinear_up_bwd_kernel<1>), dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, n, h, w, c, scale, dx);
     return check_launch("bilinear_up_bwd");
 }
 
@@ -331,8 +331,8 @@ extern "C" int tsii_gap_bwd(const float* dgap, int n, int hw, int c, float* dx, 
     TSII_REQUIRE(dgap && dx && n > 0 && hw > 0 && c > 0, "gap_bwd: bad arguments");
     const bool vec = (c % 4 == 0) && aligned16(dgap) && aligned16(dx);
     const int64_t total = (int64_t)n * hw * (vec ? c / 4 : c);
-    if (vec) hipLaunchKernelGGL((gap_bwd_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dgap, n, hw, c, dx);
-    else hipLaunchKernelGGL((gap_bwd_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dgap, n, hw, c, dx);
+    if (vec) hipLaunchKernelGGL((gap_bwd_kernel<4>), dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dgap, n, hw, c, dx);
+    else hipLaunchKernelGGL((gap_bwd_kernel<1>), dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dgap, n, hw, c, dx);
     return check_launch("gap_bwd");
 }
 
@@ -340,8 +340,8 @@ extern "C" int tsii_scse_fwd(const float* x, const float* cse, const float* sse,
     TSII_REQUIRE(x && cse && sse && out && n > 0 && hw > 0 && c > 0, "scse_fwd: bad arguments");
     const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(cse) && aligned16(out);
     const int64_t total = (int64_t)n * hw * (vec ? c / 4 : c);
-    if (vec) hipLaunchKernelGGL((scse_scale_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, cse, sse, n, hw, c, out);
-    else hipLaunchKernelGGL((scse_scale_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, cse, sse, n, hw, c, out);
+    if (vec) hipLaunchKernelGGL((scse_scale_kernel<4>), dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, cse, sse, n, hw, c, out);
+    else hipLaunchKernelGGL((scse_scale_kernel<1>), dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, cse, sse, n, hw, c, out);
     return check_launch("scse_fwd");
 }
 
@@ -376,7 +376,7 @@ extern "C" int tsii_bce_focal_fwd(const float* x, const float* t, int64_t numel,
 extern "C" int tsii_bce_focal_bwd(const float* x, const float* t, int64_t numel, float gamma, float background_w,
                                   float words_w, const float* gscale, float* dx, void* stream) {
     TSII_REQUIRE(x && t && gscale && dx && numel > 0, "bce_focal_bwd: bad arguments");
-    hipLaunchKernelGGL(bce_focal_bwd_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, (hipStream_t)stream, x, t, numel,
+    hipLaunchKernelGGL(bce_focal_bwd_kernel, dim3(flat_grid(numel, 256)), dim3(256), 0, (hipStream_t)stream, x, t, numel,
                        gamma, background_w, words_w, gscale, dx);
     return check_launch("bce_focal_bwd");
 }

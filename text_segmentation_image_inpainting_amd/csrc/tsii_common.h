@@ -25,6 +25,18 @@ static inline unsigned stream_grid(int64_t work_items, int block) {
     return (unsigned)g;
 }
 
+// Element-wise streaming kernels: ONE vector per thread, as many blocks as that takes.  Measured on the MI355X
+// (tools/probes/stream_copy.hip, 3.2 GB in + 3.2 GB out): a capped grid of 2048 blocks walking the tensor with a
+// grid-stride loop copies at 4.7 TB/s whatever the unroll depth, one float4 per thread at 6.1 TB/s, 6.5 TB/s with
+// non-temporal loads and stores (the dispatcher's block order sweeps the address range once, front to back).  The
+// kernels keep their grid-stride loop (any grid is correct); this grid makes it run once.
+static inline unsigned flat_grid(int64_t work_items, int block) {
+    int64_t g = cdiv64(work_items, block);
+    if (g > 0x7fffffffll) g = 0x7fffffffll;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     if (act == TSII_ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == TSII_ACT_LEAKY) return v > 0.f ? v : v * slope;
@@ -161,6 +173,30 @@ __device__ __forceinline__ VecF<W> vload(const float* __restrict__ p) {
         for (int i = 0; i < W; ++i) r.v[i] = p[i];
     }
     return r;
+}
+// non-temporal forms for tensors that are streamed once (activations far larger than the caches)
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+template <int W>
+__device__ __forceinline__ VecF<W> vload_nt(const float* __restrict__ p) {
+    VecF<W> r;
+    if constexpr (W == 4) {
+        const f32x4s t = __builtin_nontemporal_load(reinterpret_cast<const f32x4s*>(p));
+        r.v[0] = t[0]; r.v[1] = t[1]; r.v[2] = t[2]; r.v[3] = t[3];
+    } else {
+#pragma unroll
+        for (int i = 0; i < W; ++i) r.v[i] = __builtin_nontemporal_load(p + i);
+    }
+    return r;
+}
+template <int W>
+__device__ __forceinline__ void vstore_nt(float* __restrict__ p, const VecF<W>& r) {
+    if constexpr (W == 4) {
+        const f32x4s t = {r.v[0], r.v[1], r.v[2], r.v[3]};
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x4s*>(p));
+    } else {
+#pragma unroll
+        for (int i = 0; i < W; ++i) __builtin_nontemporal_store(r.v[i], p + i);
+    }
 }
 template <int W>
 __device__ __forceinline__ void vstore(float* __restrict__ p, const VecF<W>& r) {

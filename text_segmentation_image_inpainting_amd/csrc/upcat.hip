@@ -19,9 +19,9 @@ __global__ void upcat_fwd_kernel(const float* __restrict__ low, const float* __r
         const int y = (int)((pix / w2) % h2);
         const int64_t b = pix / ((int64_t)w2 * h2);
         VecF<W> v;
-        if (c < c1) v = vload<W>(low + ((b * h + (y >> 1)) * w + (x >> 1)) * c1 + c);
-        else v = vload<W>(skip + pix * c2 + (c - c1));
-        vstore<W>(out + pix * C + c, v);
+        if (c < c1) v = vload<W>(low + ((b * h + (y >> 1)) * w + (x >> 1)) * c1 + c);      // read 4 times: stays cached
+        else v = vload_nt<W>(skip + pix * c2 + (c - c1));
+        vstore_nt<W>(out + pix * C + c, v);
     }
 }
 
@@ -62,10 +62,10 @@ __global__ void upcat_bwd_low_kernel(const float* __restrict__ dout, int n, int 
         const int y = (int)((pix / w) % h);
         const int64_t b = pix / ((int64_t)w * h);
         const int64_t p00 = (b * 2 * h + 2 * y) * w2 + 2 * x;
-        const VecF<W> a0 = vload<W>(dout + p00 * C + c);
-        const VecF<W> a1 = vload<W>(dout + (p00 + 1) * C + c);
-        const VecF<W> a2 = vload<W>(dout + (p00 + w2) * C + c);
-        const VecF<W> a3 = vload<W>(dout + (p00 + w2 + 1) * C + c);
+        const VecF<W> a0 = vload_nt<W>(dout + p00 * C + c);
+        const VecF<W> a1 = vload_nt<W>(dout + (p00 + 1) * C + c);
+        const VecF<W> a2 = vload_nt<W>(dout + (p00 + w2) * C + c);
+        const VecF<W> a3 = vload_nt<W>(dout + (p00 + w2 + 1) * C + c);
         VecF<W> s;
 #pragma unroll
         for (int i = 0; i < W; ++i) s.v[i] = (a0.v[i] + a1.v[i]) + (a2.v[i] + a3.v[i]);
@@ -81,7 +81,7 @@ __global__ void upcat_bwd_skip_kernel(const float* __restrict__ dout, int64_t np
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(idx % CG) * W;
         const int64_t pix = idx / CG;
-        vstore<W>(dskip + pix * c2 + c, vload<W>(dout + pix * C + c1 + c));
+        vstore_nt<W>(dskip + pix * c2 + c, vload_nt<W>(dout + pix * C + c1 + c));
     }
 }
 
@@ -96,10 +96,10 @@ extern "C" int tsii_upcat_fwd(const float* low, const float* skip, int n, int h,
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (c1 % 4 == 0) && (c2 % 4 == 0) && aligned16(low) && (c2 == 0 || aligned16(skip)) && aligned16(out);
     const int64_t total = (int64_t)n * 4 * h * w * (vec ? (c1 + c2) / 4 : (c1 + c2));
-    if (vec) hipLaunchKernelGGL((upcat_fwd_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, st, low, skip, n, h, w, c1, c2, out);
+    if (vec) hipLaunchKernelGGL((upcat_fwd_kernel<4>), dim3(flat_grid(total, 256)), dim3(256), 0, st, low, skip, n, h, w, c1, c2, out);
     else if (c2 > 0 && (int64_t)2 * w * (c1 + c2) < (1 << 24) && (int64_t)n * 2 * h <= 65535)
         hipLaunchKernelGGL(upcat_fwd_row_kernel, dim3(cdiv(2 * w * (c1 + c2), 1024), n * 2 * h), dim3(256), 0, st, low, skip, h, w, c1, c2, out);
-    else hipLaunchKernelGGL((upcat_fwd_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, st, low, skip, n, h, w, c1, c2, out);
+    else hipLaunchKernelGGL((upcat_fwd_kernel<1>), dim3(flat_grid(total, 256)), dim3(256), 0, st, low, skip, n, h, w, c1, c2, out);
     return check_launch("upcat_fwd");
 }
 
@@ -112,16 +112,16 @@ extern "C" int tsii_upcat_bwd(const float* dout, int n, int h, int w, int c1, in
     int rc = 0;
     if (dlow != nullptr) {
         const int64_t total = (int64_t)n * h * w * (vec ? c1 / 4 : c1);
-        if (vec) hipLaunchKernelGGL((upcat_bwd_low_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, st, dout, n, h, w, c1, c2, dlow);
-        else hipLaunchKernelGGL((upcat_bwd_low_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, st, dout, n, h, w, c1, c2, dlow);
+        if (vec) hipLaunchKernelGGL((upcat_bwd_low_kernel<4>), dim3(flat_grid(total, 256)), dim3(256), 0, st, dout, n, h, w, c1, c2, dlow);
+        else hipLaunchKernelGGL((upcat_bwd_low_kernel<1>), dim3(flat_grid(total, 256)), dim3(256), 0, st, dout, n, h, w, c1, c2, dlow);
         rc = check_launch("upcat_bwd_low");
         if (rc) return rc;
     }
     if (dskip != nullptr && c2 > 0) {
         const int64_t npix = (int64_t)n * 4 * h * w;
         const int64_t total = npix * (vec ? c2 / 4 : c2);
-        if (vec) hipLaunchKernelGGL((upcat_bwd_skip_kernel<4>), dim3(stream_grid(total, 256)), dim3(256), 0, st, dout, npix, c1, c2, dskip);
-        else hipLaunchKernelGGL((upcat_bwd_skip_kernel<1>), dim3(stream_grid(total, 256)), dim3(256), 0, st, dout, npix, c1, c2, dskip);
+        if (vec) hipLaunchKernelGGL((upcat_bwd_skip_kernel<4>), dim3(flat_grid(total, 256)), dim3(256), 0, st, dout, npix, c1, c2, dskip);
+        else hipLaunchKernelGGL((upcat_bwd_skip_kernel<1>), dim3(flat_grid(total, 256)), dim3(256), 0, st, dout, npix, c1, c2, dskip);
         rc = check_launch("upcat_bwd_skip");
     }
     return rc;

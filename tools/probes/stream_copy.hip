@@ -43,6 +43,48 @@ __global__ void copy_chunk_kernel(const f32x4* __restrict__ x, f32x4* __restrict
     for (; i < b1; i += blockDim.x) { f32x4 r = x[i]; y[i] = r > 0.f ? r : r * 0.3f; }
 }
 
+// BatchNorm-backward-apply shaped kernels (2 streams in, 1 out, 6 per-channel constants):
+//  FORM 0: the library's form (grid-stride, constants in registers, grid*block % CG == 0)
+//  FORM 1: one float4 per thread, constants re-loaded per thread (L1 hits), non-temporal streams
+//  FORM 2: as 1, constants packed as [CG][6] float4 rows
+template <int FORM>
+__global__ void bnapply_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ y, long n4, unsigned CG,
+                               const f32x4* __restrict__ tab) {
+    const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (FORM == 0) {
+        const unsigned cg = (unsigned)(gt % CG);
+        const f32x4 mu = tab[cg], is = tab[CG + cg], ga = tab[2 * CG + cg], be = tab[3 * CG + cg], k1 = tab[4 * CG + cg], k2 = tab[5 * CG + cg];
+        for (long i = gt; i < n4; i += (long)gridDim.x * blockDim.x) {
+            const f32x4 xh = (b[i] - mu) * is, z = xh * ga + be;
+            f32x4 dz = a[i] * (z > 0.f ? 1.f : 0.3f);
+            dz = dz - k1 - xh * k2;
+            y[i] = dz * ga * is;
+        }
+    } else {
+        if (gt >= n4) return;
+        const unsigned cg = (unsigned)(gt % CG);
+        f32x4 mu, is, ga, be, k1, k2;
+        if (FORM == 1) { mu = tab[cg]; is = tab[CG + cg]; ga = tab[2 * CG + cg]; be = tab[3 * CG + cg]; k1 = tab[4 * CG + cg]; k2 = tab[5 * CG + cg]; }
+        else { const f32x4* t = tab + cg * 6; mu = t[0]; is = t[1]; ga = t[2]; be = t[3]; k1 = t[4]; k2 = t[5]; }
+        const f32x4 bv = __builtin_nontemporal_load(b + gt), av = __builtin_nontemporal_load(a + gt);
+        const f32x4 xh = (bv - mu) * is, z = xh * ga + be;
+        f32x4 dz = av * (z > 0.f ? 1.f : 0.3f);
+        dz = dz - k1 - xh * k2;
+        __builtin_nontemporal_store(dz * ga * is, y + gt);
+    }
+}
+template <int FORM>
+static void run_bn(const char* name, int grid, const f32x4* a, const f32x4* b, f32x4* y, long n4, unsigned CG, const f32x4* tab) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(bnapply_kernel<FORM>, dim3(grid), dim3(256), 0, 0, a, b, y, n4, CG, tab);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(bnapply_kernel<FORM>, dim3(grid), dim3(256), 0, 0, a, b, y, n4, CG, tab);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    printf("%-44s grid %6d x  256 : %.3f ms  %.2f TB/s\n", name, grid, ms, 3.0 * n4 * 16 / ms / 1e9);
+}
+
 template <class K>
 static void run(const char* name, K kern, int grid, int block, const f32x4* x, f32x4* y, long n4) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -79,6 +121,13 @@ int main() {
         run("chunk U=4", copy_chunk_kernel<4, false>, g, 256, x, y, n4);
         run("chunk U=4 nontemporal", copy_chunk_kernel<4, true>, g, 256, x, y, n4);
         run("chunk U=8 nontemporal", copy_chunk_kernel<8, true>, g, 256, x, y, n4);
+    }
+    {
+        f32x4 *b2, *tab; hipMalloc(&b2, n4 * 16); hipMemset(b2, 0x3e, n4 * 16); hipMalloc(&tab, 4096 * 16); hipMemset(tab, 0x3d, 4096 * 16);
+        const unsigned CG = 96;          // C = 384
+        run_bn<0>("bn apply: library form (grid-stride)", 2016, x, b2, y, n4, CG, tab);      // multiple of CG / gcd
+        run_bn<1>("bn apply: one float4 per thread, nt", (int)((n4 + 255) / 256), x, b2, y, n4, CG, tab);
+        run_bn<2>("bn apply: one per thread, packed consts", (int)((n4 + 255) / 256), x, b2, y, n4, CG, tab);
     }
     // one float4 per thread, no loop at all
     run("one element per thread", copy_kernel<1, false>, (int)((n4 + 255) / 256), 256, x, y, n4);
