@@ -129,7 +129,8 @@ def pmc_traffic(kernel_prefix):
         js = json.load(open(path))
         if js.get("csrc_sha") != csrc_sha():
             return None, f"profiles/{PMC_SUMMARY} was measured at csrc {js.get('csrc_sha')}, sources are now {csrc_sha()}: stale, not reported"
-        recs = [r for k, r in js["kernels"].items() if k.startswith(kernel_prefix)]
+        prefixes = (kernel_prefix,) if isinstance(kernel_prefix, str) else tuple(kernel_prefix)
+        recs = [r for k, r in js["kernels"].items() if k.startswith(prefixes)]
         launches = sum(r["launches"] for r in recs)
         return sum(r["bytes_per_launch"] * r["launches"] for r in recs) / launches, f"profiles/{PMC_SUMMARY} (csrc {js['csrc_sha']})"
     except Exception as exc:  # noqa: BLE001 - no summary committed for this kernel/config
@@ -233,8 +234,8 @@ def main():
 
     L = _lib.lib()
     if args.products >= 0:
-        assert L.tsii_set_gemm_products(args.products) == 0, "--products: 0, 1, 3, 6 or 8"
-    products = int(L.tsii_get_gemm_products())
+        _lib.set_gemm_products(args.products)
+    products = _lib.get_gemm_products()
     torch.manual_seed(0)  # identical random-init weights on every rank
     seg = args.model in ("TextSegament", "XceptionTextSegment")
     if seg:
@@ -277,6 +278,7 @@ def main():
         loss = trainer.step(corrupted, mask, clean_nhwc)
     sync()
     _lib.start_timing(gemm_calls)      # HIP events (launch stream) around the GEMM entry points inside the timed region
+    trainer.measure_exposed = world > 1    # N > 1: how long each step stalls for all-reduces backward did not hide (2 events / step)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.step(corrupted, mask, clean_nhwc)
@@ -284,6 +286,9 @@ def main():
     elapsed = time.perf_counter() - t0
     timed = _lib.stop_timing()
     eager_ms = elapsed / args.steps * 1e3
+    trainer.measure_exposed = False
+    # "comm": bucket layout, stand-alone all-reduce time / bus bandwidth of the whole gradient buffer, and (N > 1) the exposed
+    # vs overlapped split of it measured in the timed steps above
     comm = trainer.comm_stats() if hasattr(trainer, "comm_stats") else None
     graphed = False
     if args.graph:
@@ -322,7 +327,7 @@ def main():
     # the same step in the other arithmetic modes, short runs, for reference: 0 = bit-exact f32-MFMA (fp32 FMA chain),
     # 3 = 2-piece split / 3 partial products (opt-in: ~8x the rounding error of the fp32 chain, still 3 orders inside the 1e-3 bar)
     def mode_leg(mode, what):
-        L.tsii_set_gemm_products(mode)
+        _lib.set_gemm_products(mode)
         for _ in range(3):
             trainer.step(corrupted, mask, clean_nhwc)
         sync()
@@ -338,7 +343,7 @@ def main():
                 trainer.loss_fn(model((corrupted, mask)), clean_nhwc)
             sync()
             e3 = time.perf_counter() - t3
-        L.tsii_set_gemm_products(products)
+        _lib.set_gemm_products(products)
         return {"value": round(world * args.batch * n2 / e2, 2), "unit": "imgs/s (rank 0 clock)", "ms_per_step": round(e2 / n2 * 1e3, 3), "steps": n2,
                 "forward_ms_per_step": round(e3 / n2 * 1e3, 3), "arithmetic": what}
     f32_leg = split3_leg = None
@@ -360,13 +365,17 @@ def main():
         roofline = None
         if dom:
             k, d = dom
-            kern = {"gemm_nt": ("tsii::gemm_nt_split_kernel<2, 2, 2, 2" if products else "tsii::gemm_nt_kernel<2, 2, 2, 2"),
+            # the kernels behind the class: the persistent producer/consumer kernel takes every 6-product layer with N >= 128 that
+            # tiles evenly (csrc/gemm_pc.hip nt_pc_ok), the block-synchronous split kernel the rest
+            kern = {"gemm_nt": (("tsii::gemm_nt_pc_kernel<", "tsii::gemm_nt_split_kernel<") if products else "tsii::gemm_nt_kernel<2, 2, 2, 2"),
                     "gemm_tn": ("tsii::gemm_tn_split_kernel<2, 2, 2, 2" if products else "tsii::gemm_tn_kernel<2, 2, 2, 2")}.get(k, "tsii::" + k)
+            kname = kern if isinstance(kern, str) else " + ".join(x.split("::")[1] + "...>" for x in kern)
+            kname = kname.split("::")[1] + "...>" if "::" in kname else kname
             t_hbm = d["alg_gb_per_step"] / (PEAK_HBM_TBS * 1e3)            # seconds per step at the HBM peak
             t_mfma = d["ms_per_step"] * 1e-3 * d.get("mfma_frac", 0.0)      # seconds per step at the MFMA peak of the mode
             hbm_bound = t_hbm >= t_mfma
             traffic, traffic_src = pmc_traffic(kern) if (args.batch == 32 and args.size == 512 and args.model == "ImageFill") else (None, "not the profiled configuration")
-            roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": kern.split("::")[1] + "...> (class " + k + ": 1x1-conv forward + dX GEMMs)" if k == "gemm_nt" else kern.split("::")[1] + "...> (class " + k + ")",
+            roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": kname + " (class " + k + (": 1x1-conv forward + dX GEMMs)" if k == "gemm_nt" else ")"),
                         "achieved": d["tb_per_s"] * 1e3 if hbm_bound else d["fp32_equiv_tflops"],
                         "peak": PEAK_HBM_TBS * 1e3 if hbm_bound else d["mfma_peak_fp32_equiv"],
                         "unit": "GB/s" if hbm_bound else "TFLOP/s (fp32-equivalent)",

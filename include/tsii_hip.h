@@ -43,7 +43,10 @@ extern "C" {
 int tsii_version(void);
 const char* tsii_last_error(void);
 
-/* Arithmetic of the point-wise / implicit-GEMM matrix products (process-wide switch, read by every later call):
+/* Arithmetic of the point-wise / implicit-GEMM matrix products.  The switch is THREAD-LOCAL: it applies to the entry points
+ * the calling thread calls afterwards and nothing another thread does can change it (the only other state the library keeps is
+ * the thread-local error string and a read-only device-properties cache).  A host that runs forward and backward on
+ * different threads (PyTorch autograd does) sets it on each of them -- the package's `_lib.call` does so before every call.
  *   6 (default) split-bf16: each fp32 operand is split exactly into 3 bf16 pieces while it is staged, the 6 partial
  *               products of weight >= 2^-16 go through v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- dropped terms
  *               <= 2^-23 |a*b|, i.e. fp32-class results at 2.7x the matrix-core rate of the f32-input MFMA;
@@ -52,7 +55,9 @@ const char* tsii_last_error(void);
  *   1           operands rounded to bf16, one product (fp32 accumulation, fp32 storage everywhere else): the "mixed bf16"
  *               arithmetic of BASELINE config 5, tolerance 1e-2 class, opt-in;
  *   0           v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chain).
- * The environment variable TSII_GEMM_PRODUCTS sets the initial value.  inputs/outputs are fp32 in every mode. */
+ * The environment variable TSII_GEMM_PRODUCTS sets every thread's initial value.  inputs/outputs are fp32 in every mode.
+ * Range caveat of the split modes: an operand that is inf, or finite but beyond the largest bf16 (3.39e38), splits into
+ * (inf, NaN, NaN) -- where the f32 MFMA mode gives +-inf for that row, these give NaN; both rows are lost either way. */
 int tsii_set_gemm_products(int products);
 int tsii_get_gemm_products(void);
 

@@ -32,7 +32,9 @@ def test_library_exports_every_symbol():
     for name in _header_symbols():
         assert hasattr(cdll, name), f"{name} declared in include/tsii_hip.h but not exported"
     _lib.bind(cdll)
-    assert cdll.tsii_version() == 1
+    assert cdll.tsii_version() == _lib.ABI_VERSION
+    header = open(os.path.join(ROOT, "include", "tsii_hip.h")).read()
+    assert int(re.search(r"#define\s+TSII_ABI_VERSION\s+(\d+)", header).group(1)) == _lib.ABI_VERSION
 
 
 def test_state_dict_layout_matches_reference(golden_dir):

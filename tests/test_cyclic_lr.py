@@ -45,3 +45,23 @@ def test_cyclic_lr_closed_form_and_resume():
         CyclicLR(opt, mode="nope")
     with pytest.raises(ValueError):
         CyclicLR(opt, base_lr=[1e-3, 2e-3])
+
+
+def test_cyclic_lr_vs_reference_fixture():
+    """Learning-rate sequences of the reference's own scheduler (tests/golden/cyclic_lr.json, produced by
+    tests/golden/make_golden_misc.py from /root/reference/models/utils/cls.py:74-157): three policies, per-group bounds, a restart
+    from last_batch_iteration=10.  Entry 0 is the rate the constructor leaves behind, entry i the rate after the i-th batch_step()."""
+    import json
+    import os
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cyclic_lr.json")))
+    assert len(cases) >= 4
+    for case in cases:
+        n = len(case["lrs"][0])
+        opt = torch.optim.SGD([{"params": [torch.nn.Parameter(torch.zeros(1))]} for _ in range(n)], lr=0.1)
+        s = CyclicLR(opt, **case["cfg"])
+        got = [[g["lr"] for g in opt.param_groups]]
+        for _ in range(len(case["lrs"]) - 1):
+            s.batch_step()
+            got.append([g["lr"] for g in opt.param_groups])
+        for it, (a, b) in enumerate(zip(got, case["lrs"])):
+            assert a == pytest.approx(b, rel=1e-12, abs=1e-18), (case["cfg"], it)

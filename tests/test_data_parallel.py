@@ -14,10 +14,44 @@ import torch.multiprocessing as mp
 from torch import nn
 
 
-def _make_model(seed=21):
+def _make_model(seed=21, variant="plain"):
+    """variant "reordered": modules registered in the opposite order of their use, so gradients become ready in the reverse of
+    the flat layout and the LAST bucket completes first; "shared": one block applied in two recomputed segments, so its
+    parameters are accumulated into twice per backward (two post_accumulate_grad firings)."""
     import text_segmentation_image_inpainting_amd as T
+    from text_segmentation_image_inpainting_amd.memory import checkpoint_segment
+    from text_segmentation_image_inpainting_amd.BaseModels import DSConvBlock
     from oracle.filler import fill_state_dict_
     act = nn.LeakyReLU(0.3)
+
+    class Reordered(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.unused = nn.Parameter(torch.ones(5))
+            self.body = T.PartialInvertedResidual(8, 8, 3, 1, 1, 1, 2, BN=True, activation=act, use_1_conv=True, same_holes=True)
+            self.stem = T.partial_convolution_block(3, 8, 3, 1, 1, 1, bias=True, BN=False, activation=act)
+
+        def forward(self, args):
+            return self.body(self.stem(args))[0]
+
+    class Shared(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.stem = T.partial_convolution_block(3, 8, 3, 1, 1, 1, bias=True, BN=False, activation=act)
+            self.block = DSConvBlock(8, 8, 3, 1, 1, BN=True, activation_dep=act, activation_point=act)
+            self.tail = DSConvBlock(8, 8, 3, 1, 1, BN=True, activation_dep=act, activation_point=None)
+            self.unused = nn.Parameter(torch.ones(5))
+
+        def forward(self, args):
+            h = self.stem(args)[0]
+            h = checkpoint_segment(self.block, h)
+            h = checkpoint_segment(self.block, h)
+            return self.tail(h)
+
+    if variant != "plain":
+        net = {"reordered": Reordered, "shared": Shared}[variant]()
+        fill_state_dict_(net.state_dict(), seed=seed)
+        return net
 
     class Net(nn.Module):
         """stem partial conv + a PartialInvertedResidual with three BatchNorms + a head that ignores one parameter"""
@@ -42,51 +76,78 @@ def _data():
     return x, mask, tgt
 
 
-def _trainer(model):
+def _trainer(model, overlap=True):
     from text_segmentation_image_inpainting_amd.train_step import FlatSGDTrainer
-    return FlatSGDTrainer(model, lr=0.1, momentum=0.9, weight_decay=1e-3, bucket_mb=0.0005)   # ~130 floats: several buckets
+    return FlatSGDTrainer(model, lr=0.1, momentum=0.9, weight_decay=1e-3, bucket_mb=0.0005, overlap=overlap)   # ~130 floats: several buckets
 
 
-def _worker(rank, world, initfile, out):
+def _worker(rank, world, initfile, out, variant="plain", overlap=True):
     from tests.backends import emu_backend
     from text_segmentation_image_inpainting_amd.BaseModels import to_nhwc
     dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
     with emu_backend():
         x, mask, tgt = _data()
         sl = slice(rank * 2, rank * 2 + 2)
-        model = _make_model(seed=21 if rank == 0 else 99)         # rank 1 starts from different weights AND buffers ...
+        model = _make_model(seed=21 if rank == 0 else 99, variant=variant)     # rank 1 starts from different weights AND buffers ...
         if rank == 1:
             for b in model.buffers():
                 if b.dtype.is_floating_point:
                     b.add_(0.5)
-        tr = _trainer(model)
-        assert tr.overlap and len(tr.buckets) >= 3
+        tr = _trainer(model, overlap)
+        assert tr.overlap == overlap and len(tr.buckets) >= 3
         tr.broadcast_parameters()                                  # ... until rank 0's are broadcast
         start_bufs = {k: v.clone() for k, v in model.state_dict().items() if "running" in k}
+        unused0 = model.unused.detach().clone()
+        order = []                                                 # the order in which buckets went out
+        launch = tr._launch_bucket
+        tr._launch_bucket = lambda b: (order.append(b), launch(b))[1]
+        tr.measure_exposed = True
         losses = [float(tr.step(x[sl], mask[sl], to_nhwc(tgt[sl]))) for _ in range(2)]
         stats = tr.comm_stats(iters=2)
     torch.save({"p": tr.flat_param.clone(), "g": tr.flat_grad.clone(), "loss": losses, "start_bufs": start_bufs,
                 "bufs": {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "tracked" in k},
-                "stats": stats}, f"{out}.{rank}")
+                "stats": stats, "order": order, "unused": model.unused.detach().clone(), "unused0": unused0,
+                "hooks": len(tr._hooks)}, f"{out}.{rank}")
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_dp2_bucketed_overlap_matches_sequential_shards():
+@pytest.mark.parametrize("variant,overlap", [("plain", True), ("plain", False), ("reordered", True), ("shared", True)])
+def test_dp2_bucketed_overlap_matches_sequential_shards(variant, overlap):
+    """plain: buckets complete in layout order and go out from the hooks; overlap=False: everything is reduced after
+    backward; reordered: buckets complete out of layout order (same order on every rank: the graph decides); shared: a block
+    whose parameters accumulate twice per backward -- its buckets fall back to the post-backward exchange instead of being
+    reduced half-summed.  All four must equal the sequential oracle."""
     from tests.backends import emu_backend
     from text_segmentation_image_inpainting_amd.BaseModels import to_nhwc
     from text_segmentation_image_inpainting_amd import ops
     with tempfile.TemporaryDirectory() as d:
         initfile, out = os.path.join(d, "init"), os.path.join(d, "out")
-        mp.spawn(_worker, args=(2, initfile, out), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, initfile, out, variant, overlap), nprocs=2, join=True)
         r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    nb = r0["stats"]["buckets"]
+    assert r0["order"] == r1["order"] and set(r0["order"]) == set(range(nb))
+    if variant != "shared":                                        # (a deferred bucket may have gone out twice)
+        assert sorted(r0["order"][:nb]) == list(range(nb)) and len(r0["order"]) == 2 * nb
+    first = r0["order"][:nb]
+    if variant == "plain":
+        assert first == list(range(nb)) and r0["stats"]["overlap_with_backward"] == overlap
+    if variant == "reordered":
+        assert first != list(range(nb)) and first[0] != 0          # a later bucket went out before bucket 0
+    if variant == "shared":
+        assert r0["stats"]["deferred_buckets"] >= 2                # once per step at least
+    else:
+        assert r0["stats"]["deferred_buckets"] == 0
+    assert r0["hooks"] == (r0["stats"]["world"] > 1 and overlap) * sum(1 for _ in _make_model(variant=variant).parameters() if _.requires_grad)
+    assert r0["stats"]["exposed_ms_per_step"] >= 0 and "overlapped_ms_per_step" in r0["stats"]
+    assert torch.equal(r0["unused"], r0["unused0"])                # no gradient -> no weight decay, no momentum (torch.optim.SGD)
     assert torch.equal(r0["p"], r1["p"]) and torch.equal(r0["g"], r1["g"])      # replicas stay in lock-step
     assert all(torch.equal(r0["start_bufs"][k], r1["start_bufs"][k]) for k in r0["start_bufs"])   # buffers were broadcast
     assert r0["stats"]["world"] == 2 and r0["stats"]["buckets"] >= 3 and r0["stats"]["allreduce_ms"] > 0
     # oracle: one process, the two shards one after the other on replicas of the broadcast state
     with emu_backend():
         x, mask, tgt = _data()
-        reps = [_trainer(_make_model(seed=21)) for _ in range(2)]
+        reps = [_trainer(_make_model(seed=21, variant=variant)) for _ in range(2)]
         for step in range(2):
             grads = []
             for r, tr in enumerate(reps):
@@ -108,8 +169,9 @@ def test_dp2_bucketed_overlap_matches_sequential_shards():
         for k, v in rec["bufs"].items():
             assert torch.allclose(v.float(), sd[k].float(), rtol=1e-5, atol=1e-6), (r, k)
     assert any(not torch.equal(r0["bufs"][k], r1["bufs"][k]) for k in r0["bufs"] if "running_mean" in k)
-    # the unused parameter: zero gradient slice, weight decay only
-    assert int(r0["bufs"][next(k for k in r0["bufs"] if "tracked" in k)]) == 2
+    # batch counters: one per application and step -- the shared block runs twice per step, and its recomputation in backward
+    # does not count again
+    assert int(r0["bufs"][next(k for k in r0["bufs"] if "tracked" in k)]) == (4 if variant == "shared" else 2)
 
 
 @pytest.mark.gpu

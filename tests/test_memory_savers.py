@@ -88,3 +88,13 @@ def test_textsegament_checkpointed_encoder_gpu():
         print(f"\n[memory] TextSegament 256x256 bs 8 train step: peak {m0:.0f} MiB plain, {m1:.0f} MiB with checkpointed encoder")
         assert l0 == l1 and torch.equal(g0, g1)
         assert m1 < m0
+
+
+@pytest.mark.gpu
+def test_checkpointed_textsegament_vs_reference_fixture_gpu():
+    """Row n4 against the ORACLE side, not against this package's own plain pass: TextSegament with the recomputing
+    encoder reproduces the fixture the reference generated (outputs, focal loss, every recorded gradient; the same bars
+    as the plain network in tests/test_parity_seg.py)."""
+    from tests.test_parity_seg import golden_seg_net_case
+    golden_seg_net_case("TextSegament", checkpoint_encoder=True)
+

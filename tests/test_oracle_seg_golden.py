@@ -104,3 +104,21 @@ def test_inpainting_loss(golden_dir):
     assert abs(l.item() - float(G["loss"])) < 1e-5 * abs(float(G["loss"]))
     l.backward()
     assert_close(out.grad, G["dout"], 1e-4, "InpaintingLoss d/d(output)")
+
+
+@pytest.mark.parametrize("name", ["TextSegament", "XceptionTextSegment"])
+def test_seg_oracle_256_vs_reference_fixture(name, golden_dir):
+    """cfg 1 size: the oracle's eval / train outputs and focal loss against the reference's own 256 x 256 run
+    (tests/golden/make_golden_misc.py).  Forward only here (the backward at this size is the GPU suite's reference run)."""
+    keys = json.load(open(os.path.join(golden_dir, "seg_state_dict_keys.json")))[name]
+    G = np.load(os.path.join(golden_dir, name.lower() + "_256.npz"))
+    x = torch.from_numpy(np.random.default_rng(int(G["seed_x"])).standard_normal((2, 3, 256, 256)).astype(np.float32))
+    t = (torch.from_numpy(np.random.default_rng(int(G["seed_t"])).uniform(size=(2, 1, 256, 256))) > 0.8).float()
+    sd = make_state_dict([(k, s) for k, s in keys], seed=43, gain=1.0)
+    with torch.no_grad():
+        ye = S.SEG_MODELS[name](sd, x, training=False)
+        y = S.SEG_MODELS[name](sd, x, training=True)
+        loss = S.binary_focal_loss(y, t, 0.0, 1.0, 2.0)
+    assert_close(ye, G["y_eval"], 1e-4, name + " 256 eval")
+    assert_close(y, G["y_train"], 1e-4, name + " 256 train")
+    assert abs(float(loss) - float(G["loss"])) < 1e-5

@@ -169,7 +169,7 @@ def test_seg_nets_256_vs_oracle_gpu(name, capsys):
     of 1.3e-2 in dX on the CPU -- the HIP RFB is at 4e-4 of the fp64 result, see test_rfb_64x64_gpu).  A kernel bug
     gives O(1) errors on the affected tensors; rounding chaos gives a heavy-tailed few-percent scatter.  The yardstick is
     therefore the oracle's own fp32 noise per tensor (largest deviation from the fp64 gradient over its plain fp32 run and
-    three 1-ulp input perturbation runs), and the bars are: every tensor within 64x (max error) / 16x (RMS) of that noise (floors 3e-3 / 1e-3), and the
+    three 1-ulp input perturbation runs), and the bars are: every tensor within 16x (max error) / 4x (RMS) of that noise (floors 3e-3 / 1e-3; observed worst 8.2x / 2.3x), and the
     MEDIAN tensor within 2x -- i.e. the bulk agrees at noise level and nothing is off by more than the heavy tail
     allows.  The worst tensors are printed with their ratios."""
     keys = json.load(open(os.path.join(GOLD, "seg_state_dict_keys.json")))[name]
@@ -228,7 +228,7 @@ def test_seg_nets_256_vs_oracle_gpu(name, capsys):
             e_max = float((ours - ref64).abs().max()) / scale
             e_rms = float((ours - ref64).pow(2).mean().sqrt()) / rscale
             rows.append((e_max / max(n_max, 3e-4), e_rms / max(n_rms, 2.5e-4), k, e_max, n_max, e_rms, n_rms))
-            if e_max > max(3e-3, 64 * n_max) or e_rms > max(1e-3, 16 * n_rms):
+            if e_max > max(3e-3, 16 * n_max) or e_rms > max(1e-3, 4 * n_rms):
                 bad.append((k, e_max, n_max, e_rms, n_rms))
         rows.sort(reverse=True)
         median_ratio = float(np.median([r[0] for r in rows]))
@@ -241,6 +241,55 @@ def test_seg_nets_256_vs_oracle_gpu(name, capsys):
         assert not bad, bad[:5]
         assert median_ratio <= 2.0
         assert len(g64) >= 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["TextSegament", "XceptionTextSegment"])
+def test_seg_nets_256_vs_reference_fixture_gpu(name, capsys):
+    """cfg 1 size against what the REFERENCE ITSELF produced (tests/golden/<name>_256.npz, written by
+    tests/golden/make_golden_misc.py from /root/reference/models/text_segmentation.py + loss.py in fp32 and fp64; the inputs are
+    rebuilt from the recorded seeds): eval output and train output at 1e-3 / noise level, focal loss at 1e-4, and the recorded
+    sample of 24 gradient tensors.  The gradient yardstick is the reference's own fp32-vs-fp64 discrepancy; the fixture holds ONE
+    fp32 run, i.e. one sample of a heavy-tailed noise (see test_seg_nets_256_vs_oracle_gpu), so a tensor's noise is taken no
+    smaller than the median over the recorded tensors.  Bars: 16x that noise per tensor (floor 3e-3), median tensor within 3x."""
+    G = np.load(os.path.join(GOLD, name.lower() + "_256.npz"))
+    x = torch.from_numpy(np.random.default_rng(int(G["seed_x"])).standard_normal((2, 3, 256, 256)).astype(np.float32))
+    t = (torch.from_numpy(np.random.default_rng(int(G["seed_t"])).uniform(size=(2, 1, 256, 256))) > 0.8).float()
+    with BACKENDS["gpu"]() as dev:
+        m = getattr(T, name)()
+        fill_state_dict_(m.state_dict(), seed=43, gain=1.0)
+        m = m.to(dev)
+        m.eval()
+        with torch.no_grad():
+            ye = m(x.to(dev))
+        assert_close(ye, G["y_eval_f64"], TOL, name + " 256 eval vs the reference's fp64 run")
+        assert_close(ye, G["y_eval"], TOL, name + " 256 eval vs the reference's fp32 run")
+        m.train()
+        y = m(x.to(dev))
+        noise_y = float(np.abs(G["y_train"] - G["y_train_f64"]).max() / np.abs(G["y_train_f64"]).max())
+        assert_close(y, G["y_train_f64"], max(TOL, 4 * noise_y), name + " 256 train vs the reference's fp64 run")
+        loss = T.BinaryFocalLoss(0, 1, 2)(y, t.to(dev))
+        assert abs(loss.item() - float(G["loss_f64"])) < 1e-4
+        loss.backward()
+        params = dict(m.named_parameters())
+        names = [k[5:] for k in G.files if k.startswith("grad.")]
+        assert len(names) >= 20
+        gmax = max(float(np.abs(G["grad64." + k]).max()) for k in names)
+        noise, err = {}, {}
+        for k in names:
+            ref64 = G["grad64." + k].astype(np.float64)
+            scale = max(float(np.abs(ref64).max()), 1e-3 * gmax)
+            noise[k] = float(np.abs(G["grad." + k] - ref64).max()) / scale
+            err[k] = float(np.abs(params[k].grad.detach().cpu().double().numpy() - ref64).max()) / scale
+        pooled = float(np.median(list(noise.values())))
+        rows = sorted(((err[k] / max(noise[k], pooled, 3e-4), k, err[k], noise[k]) for k in names), reverse=True)
+        with capsys.disabled():
+            print(f"\n[{name} 256 vs reference fixture] {len(names)} gradient tensors, pooled fp32 noise of the reference {pooled:.2e}; worst:")
+            for r in rows[:6]:
+                print(f"   ratio {r[0]:6.2f}  {r[1]:60s} err {r[2]:.2e}  reference fp32-vs-fp64 {r[3]:.2e}")
+        for ratio, k, e, n in rows:
+            assert e <= max(3e-3, 16 * max(n, pooled)), (k, e, n, pooled)
+        assert float(np.median([r[0] for r in rows])) <= 3.0
 
 
 @pytest.mark.gpu
@@ -455,32 +504,48 @@ def test_demo_end_to_end_gpu(name, tmp_path):
 
 @pytest.mark.gpu
 def test_mixed_bf16_products_mode_gpu(capsys):
-    """BASELINE config 5's arithmetic ("mixed bf16"): tsii_set_gemm_products(1) rounds the 1x1-convolution operands to bf16
+    """BASELINE config 5's arithmetic ("mixed bf16"): gemm products = 1 rounds the operands of every matrix product to bf16
     (one MFMA product, fp32 accumulation; storage, BatchNorm, stencils stay fp32).  There is no reference code for it
-    (models/ACNN.py is un-importable), so the yardstick is the fp32 reference fixture with the bf16-class tolerance
-    SURVEY.md 8(d) states for this config (1e-2 expected; 3e-2 asserted), eval-mode forward of XceptionTextSegment."""
+    (models/ACNN.py is un-importable), so the yardstick is the fp32 / fp64 reference fixture of XceptionTextSegment with
+    bf16-class tolerances (1e-2 expected): eval forward (3e-2), and -- the part a training run uses --
+    the train-mode forward with batch statistics (5e-2), the focal loss (2e-2) and every recorded gradient: the median
+    tensor within 5e-2 of its fp64 value, none beyond 0.5 (bf16 operand rounding is ~4e-3 per product and the train-mode
+    BatchNorm chains amplify it; a broken backward in this mode is O(1) everywhere)."""
     from text_segmentation_image_inpainting_amd import _lib
     G = np.load(os.path.join(GOLD, "xceptiontextsegment_64.npz"))
     with BACKENDS["gpu"]() as dev:
-        L = _lib.lib()
-        saved = L.tsii_get_gemm_products()
+        saved = _lib._GEMM_PRODUCTS
         try:
             m = T.XceptionTextSegment()
             fill_state_dict_(m.state_dict(), seed=41, gain=1.0)
             m = m.to(dev).eval()
-            x = torch.from_numpy(G["x"]).to(dev)
+            x, t = torch.from_numpy(G["x"]).to(dev), torch.from_numpy(G["t"]).to(dev)
             errs = {}
             for mode in (6, 3, 1):
-                assert L.tsii_set_gemm_products(mode) == 0
+                _lib.set_gemm_products(mode)          # kept by the package and applied on every calling thread (autograd's too)
                 with torch.no_grad():
                     y = m(x)
                 errs[mode] = float((y.cpu().double() - torch.from_numpy(G["y_eval_f64"]).double()).abs().max() / np.abs(G["y_eval_f64"]).max())
+            # train mode, forward + backward in the bf16-operand arithmetic
+            m.train()
+            y = m(x)
+            e_train = rel_err(y, G["y_train"])
+            loss = T.BinaryFocalLoss(0, 1, 2)(y, t)
+            e_loss = abs(loss.item() - float(G["loss"])) / abs(float(G["loss"]))
+            loss.backward()
+            params = dict(m.named_parameters())
+            gmax = max(float(np.abs(G[k]).max()) for k in G.files if k.startswith("grad64."))
+            gerr = sorted((rel_err(params[k[7:]].grad, G[k].astype(np.float32), 1e-3 * gmax), k[7:]) for k in G.files if k.startswith("grad64."))
         finally:
-            L.tsii_set_gemm_products(saved)
+            _lib.set_gemm_products(saved)
         with capsys.disabled():
             print("\n[mixed bf16] XceptionTextSegment 64x64 eval, max-normalised error vs the reference's fp64 run: " +
                   ", ".join(f"products={k}: {v:.2e}" for k, v in errs.items()))
+            print(f"[mixed bf16] train mode, products=1: output {e_train:.2e}, focal loss {e_loss:.2e}, gradients vs fp64: median "
+                  f"{gerr[len(gerr) // 2][0]:.2e}, worst {gerr[-1][0]:.2e} ({gerr[-1][1]}) over {len(gerr)} tensors")
         assert errs[6] <= 1e-3 and errs[3] <= 1e-3 and errs[1] <= 3e-2
+        assert e_train <= 5e-2 and e_loss <= 2e-2
+        assert len(gerr) >= 12 and gerr[len(gerr) // 2][0] <= 5e-2 and gerr[-1][0] <= 0.5
 
 
 @both_backends

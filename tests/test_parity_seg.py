@@ -75,6 +75,13 @@ def test_golden_focal_loss(backend):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["TextSegament", "XceptionTextSegment"])
 def test_golden_seg_nets_64_gpu(name):
+    golden_seg_net_case(name)
+
+
+def golden_seg_net_case(name, checkpoint_encoder=False):
+    """A segmentation net against the fixture the REFERENCE produced (tests/golden/make_golden_seg.py): eval / train outputs, focal
+    loss and every recorded gradient.  checkpoint_encoder: the same through the stage-recomputing encoder (SURVEY.md n4;
+    tests/test_memory_savers.py)."""
     keys = json.load(open(os.path.join(GOLD, "seg_state_dict_keys.json")))[name]
     G = np.load(os.path.join(GOLD, name.lower() + "_64.npz"))
     with BACKENDS["gpu"]() as dev:
@@ -82,6 +89,8 @@ def test_golden_seg_nets_64_gpu(name):
         assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == keys
         fill_state_dict_(m.state_dict(), seed=41, gain=1.0)
         m = m.to(dev)
+        if checkpoint_encoder:
+            m.checkpoint_encoder = True
         x, t = torch.from_numpy(G["x"]).to(dev), torch.from_numpy(G["t"]).to(dev)
         m.eval()
         with torch.no_grad():
@@ -152,3 +161,45 @@ def test_pixel_shuffle_vs_torch(backend):
             assert torch.equal(y.detach().cpu(), yo.detach())
             y.backward(gy.to(dev))
             assert torch.equal(xd.grad.cpu(), xo.grad)
+
+
+@both_backends
+def test_textsegament_pixel_shuffle_head_vs_stock(backend):
+    """cfg 3's head variant, ``TextSegament(pixel_shuffle_head=True)``: Conv2d(128, 16, 3) -> PixelShuffle(4).  The reference
+    ships no code for it, so the oracle is stock torch on the CPU in fp64: (a) the head alone, forward and
+    every gradient, on a random feature map; (b) the whole network's output = stock head applied to the features the
+    network itself produced (wiring), at width 0.25 so the emulator run stays short."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(77)
+    with BACKENDS[backend]() as dev:
+        m = T.TextSegament(width_mult=0.25 if backend == "emu" else 2, pixel_shuffle_head=True)
+        fill_state_dict_(m.state_dict(), seed=43, gain=1.0)
+        m = m.to(dev).train()
+        w = m.out_conv[0].weight.detach().cpu().double().requires_grad_(True)
+        b = m.out_conv[0].bias.detach().cpu().double().requires_grad_(True)
+        assert tuple(w.shape) == (16, 128, 3, 3)
+        # (a) the head alone
+        feat = torch.from_numpy(rng.standard_normal((2, 128, 12, 10)).astype(np.float32))
+        fo = feat.double().requires_grad_(True)
+        yo = F.pixel_shuffle(F.conv2d(fo, w, b, padding=1), 4)
+        gy = torch.from_numpy(rng.standard_normal(tuple(yo.shape)).astype(np.float32))
+        yo.backward(gy.double())
+        fd = feat.to(dev).requires_grad_(True)
+        y = m.out_conv(fd)
+        assert tuple(y.shape) == (2, 1, 48, 40)
+        assert_close(y, yo.detach(), TOL, "pixel-shuffle head y")
+        y.backward(gy.to(dev))
+        assert_close(fd.grad, fo.grad, TOL, "pixel-shuffle head d/d(features)")
+        assert_close(m.out_conv[0].weight.grad, w.grad, TOL, "pixel-shuffle head dW")
+        assert_close(m.out_conv[0].bias.grad, b.grad, TOL, "pixel-shuffle head db")
+        # (b) wiring of the whole net: x4 logits of the features it computed
+        grabbed = []
+        h = m.smooth_feature_4x_conv.register_forward_hook(lambda mod, inp, out: grabbed.append(out.detach().cpu().double()))
+        x = torch.from_numpy(rng.standard_normal((2, 3, 32, 32)).astype(np.float32)).to(dev)
+        with torch.no_grad():
+            out = m(x)
+        h.remove()
+        assert tuple(out.shape) == (2, 1, 32, 32) and len(grabbed) == 1
+        ref = F.pixel_shuffle(F.conv2d(grabbed[0], w.detach(), b.detach(), padding=1), 4)
+        assert_close(out, ref, TOL, "TextSegament(pixel_shuffle_head=True) output")
+

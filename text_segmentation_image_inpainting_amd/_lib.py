@@ -10,6 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtsii_hip.so")
+ABI_VERSION = 3           # TSII_ABI_VERSION of include/tsii_hip.h this binding was written against
 
 _p, _i, _l, _f, _z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 _GEOM = [_i] * 8  # kh kw sh sw ph pw dh dw
@@ -108,8 +109,9 @@ def lib():
                 f"{LIB_PATH} not found: the MI355X HIP library has not been built "
                 "(python -m text_segmentation_image_inpainting_amd.build_ext). There is no CPU fallback.")
         _LIB = bind(ctypes.CDLL(LIB_PATH))
-        if _LIB.tsii_version() != 3:
-            raise RuntimeError("libtsii_hip.so ABI version mismatch")
+        if _LIB.tsii_version() != ABI_VERSION:
+            raise RuntimeError("libtsii_hip.so ABI version mismatch: library %d, binding %d -- rebuild with "
+                               "python -m text_segmentation_image_inpainting_amd.build_ext" % (_LIB.tsii_version(), ABI_VERSION))
     return _LIB
 
 
@@ -150,8 +152,31 @@ def stop_timing():
     return {n: [(a.elapsed_time(b), args) for a, b, args in lst] for n, lst in (rec or {}).items()}
 
 
+# Arithmetic mode of the matrix products (include/tsii_hip.h: tsii_set_gemm_products).  The library's switch is
+# thread-local and autograd runs backward on its own threads, so the mode is kept HERE and handed to the library on
+# whichever thread makes a call.  None = the library default (6, or TSII_GEMM_PRODUCTS).
+_GEMM_PRODUCTS = None
+
+
+def set_gemm_products(products):
+    """0 (f32 MFMA), 1 (bf16 operands), 3, 6 (default, fp32 class) or 8; None = library default.  Applies to every
+    later call made through this module, on any thread."""
+    global _GEMM_PRODUCTS
+    if products is not None and products not in (0, 1, 3, 6, 8):
+        raise ValueError("gemm products: 0, 1, 3, 6 or 8")
+    _GEMM_PRODUCTS = products
+    if products is not None:
+        lib().tsii_set_gemm_products(int(products))
+
+
+def get_gemm_products():
+    return int(lib().tsii_get_gemm_products()) if _GEMM_PRODUCTS is None else int(_GEMM_PRODUCTS)
+
+
 def call(name, *args):
     L = lib()
+    if _GEMM_PRODUCTS is not None:
+        L.tsii_set_gemm_products(_GEMM_PRODUCTS)        # this thread's switch
     timed = _TIMED is not None and name in _TIMED
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -693,7 +693,7 @@ static int env_products() {
     const int v = atoi(e);
     return (v == 0 || v == 1 || v == 3 || v == 6 || v == 8) ? v : 6;
 }
-static int g_products = env_products();
+static thread_local int g_products = env_products();      // per calling thread (tsii_set_gemm_products)
 static int g_abl = getenv("TSII_GEMM_ABL") ? atoi(getenv("TSII_GEMM_ABL")) : 0;     // tools/gemm_bench.py ablations only
 
 int gemm_products() { return g_products; }

@@ -96,6 +96,7 @@ class SegmentationRecipe(_Recipe):
         for p in self._trainable:
             p.requires_grad_(True)
         self.stage = 2
+        self.trainer.close()        # stage 1's gradient hooks and flat buffers go before stage 2's trainer is built
         self._build()
         return self
 

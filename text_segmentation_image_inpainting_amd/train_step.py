@@ -66,10 +66,21 @@ class FlatSGDTrainer:
             for i in bk["params"]:
                 self._bucket_of[i] = b
         self.overlap = bool(overlap) and self.world > 1
-        self._pending, self._works, self._launched = None, [], None
+        self._pending, self._works, self._launched, self._fired = None, {}, None, None
+        self._skipped = []              # parameters without a gradient in the current step (torch.optim.SGD leaves those alone)
+        self.deferred_buckets = 0       # buckets taken off the overlapped path because a gradient was accumulated twice
+        self.measure_exposed, self._exposed = False, []
+        self._hooks = []
         if self.overlap:
             for i, p in enumerate(self.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    def close(self):
+        """Detach from the model: remove the gradient hooks (their closures keep the flat buffers alive and would keep running
+        on every backward).  The parameters stay views of ``flat_param``; build the next trainer from the model as usual."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self.overlap, self._pending = [], False, None
 
     # ---- replication ---------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src=0):
@@ -102,10 +113,28 @@ class FlatSGDTrainer:
             if self._pending is None:          # outside forward_backward (e.g. a user's own backward): nothing to do
                 return
             b = self._bucket_of[i]
+            if self._fired[i] or self._pending[b] < 0:
+                # a second accumulation into the same parameter (e.g. one shared by two checkpoint segments, each with its
+                # own autograd.backward): the one-firing-per-parameter count no longer says when the bucket is complete
+                self._defer_bucket(b)
+                return
+            self._fired[i] = True
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._launch_bucket(b)
         return hook
+
+    def _defer_bucket(self, b):
+        """Take bucket b off the overlapped path for this step: an all-reduce already started on an incomplete gradient is
+        waited for and discarded, and reduce_gradients() packs and reduces the bucket after backward.  Every rank runs the
+        same graph, hence takes the same decision at the same point of the collective sequence."""
+        if self._pending[b] >= 0:
+            self.deferred_buckets += 1
+        self._pending[b] = -1
+        work = self._works.pop(b, None)
+        if work is not None:
+            work.wait()
+        self._launched[b] = False
 
     def _pack_bucket(self, b):
         dst, src = [], []
@@ -113,6 +142,7 @@ class FlatSGDTrainer:
             p, v = self.params[i], self.grad_views[i]
             if p.grad is None:          # parameter not reached by this step's graph (unused / frozen branch)
                 v.zero_()
+                self._skipped.append(i)
             elif p.grad.data_ptr() != v.data_ptr():
                 dst.append(v)
                 src.append(p.grad)
@@ -126,14 +156,15 @@ class FlatSGDTrainer:
         self._launched[b] = True
         if self.distributed:
             bk = self.buckets[b]
-            self._works.append(dist.all_reduce(self.flat_grad[bk["lo"]:bk["hi"]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self._works[b] = dist.all_reduce(self.flat_grad[bk["lo"]:bk["hi"]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def forward_backward(self, corrupted, mask, clean_nhwc):
         for p in self.params:
             p.grad = None
-        self._works = []
+        self._works, self._skipped = {}, []
         self._launched = [False] * len(self.buckets)
         self._pending = [len(bk["params"]) for bk in self.buckets] if self.overlap else None
+        self._fired = [False] * len(self.params)
         with deferred_batch_counters():      # the BatchNorm batch counters: one multi-tensor add instead of one kernel each
             out = self.model((corrupted, mask))
         loss = self.loss_fn(out, clean_nhwc)
@@ -143,6 +174,7 @@ class FlatSGDTrainer:
         return loss.detach()    # do not hand the autograd graph (and its AccumulateGrad nodes) to the caller
 
     def _pack_gradients(self):
+        self._skipped = []
         for b in range(len(self.buckets)):
             self._pack_bucket(b)
 
@@ -153,14 +185,61 @@ class FlatSGDTrainer:
         for b in range(len(self.buckets)):
             if not launched[b]:
                 self._launch_bucket(b) if self.distributed else self._pack_bucket(b)
-        for w in self._works:
-            w.wait()
-        self._works, self._launched = [], None
-        for p, v in zip(self.params, self.grad_views):
+        t0 = self._exposed_begin()
+        for b in sorted(self._works):
+            self._works[b].wait()
+        self._exposed_end(t0)
+        self._works, self._launched = {}, None
+        self._skipped = sorted(set(self._skipped))
+        for i, (p, v) in enumerate(zip(self.params, self.grad_views)):
             p.grad = v
 
+    # exposed communication = how long the compute stream stalls in reduce_gradients() for collectives that backward did not
+    # hide (HIP events on the current stream around the waits: nothing else is enqueued between them; host clock on CPU / gloo)
+    def _exposed_begin(self):
+        if not (self.measure_exposed and self.distributed):
+            return None
+        if self.flat_grad.is_cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        import time
+        return time.perf_counter()
+
+    def _exposed_end(self, t0):
+        if t0 is None:
+            return
+        if self.flat_grad.is_cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._exposed.append((t0, e))
+        else:
+            import time
+            self._exposed.append((time.perf_counter() - t0) * 1e3)
+
+    def exposed_ms(self):
+        """Mean stall per step recorded while ``measure_exposed`` was set (synchronises); None when nothing was recorded."""
+        if not self._exposed:
+            return None
+        if self.flat_grad.is_cuda:
+            torch.cuda.synchronize(self.flat_grad.device)
+            vals = [a.elapsed_time(b) for a, b in self._exposed]
+        else:
+            vals = list(self._exposed)
+        self._exposed = []
+        return sum(vals) / len(vals)
+
     def update(self):
+        """Fused SGD-Nesterov over the flat buffers.  Parameters that received no gradient in this step keep their value AND
+        their momentum buffer, as with torch.optim.SGD (which skips ``p.grad is None``; the reference's optimizer) -- their
+        slices are saved around the fused kernel instead of breaking it up.  Ranks must agree on which parameters those are
+        (same graph on every rank, the DistributedDataParallel ``find_unused_parameters=False`` contract)."""
+        keep = [(self.slices[i][0], self.slices[i][1]) for i in self._skipped]
+        saved = [(self.flat_param[o:o + n].clone(), self.flat_buf[o:o + n].clone()) for o, n in keep]
         ops.sgd_nesterov_(self.flat_param, self.flat_grad, self.flat_buf, self.lr, self.momentum, self.weight_decay)
+        for (o, n), (p0, b0) in zip(keep, saved):
+            self.flat_param[o:o + n].copy_(p0)
+            self.flat_buf[o:o + n].copy_(b0)
 
     def step(self, corrupted, mask, clean_nhwc):
         loss = self.forward_backward(corrupted, mask, clean_nhwc)
@@ -174,7 +253,8 @@ class FlatSGDTrainer:
         2 (n-1)/n x bytes / time)."""
         info = {"world": self.world, "backend": dist.get_backend(self.pg) if self.distributed else None,
                 "buckets": len(self.buckets), "bucket_mb": [round((bk["hi"] - bk["lo"]) * 4 / 2**20, 2) for bk in self.buckets],
-                "grad_mb": round(self.flat_grad.numel() * 4 / 2**20, 2), "overlap_with_backward": self.overlap}
+                "grad_mb": round(self.flat_grad.numel() * 4 / 2**20, 2), "overlap_with_backward": self.overlap,
+                "deferred_buckets": self.deferred_buckets}
         if not self.distributed or self.world < 2:
             return info
         import time
@@ -193,6 +273,11 @@ class FlatSGDTrainer:
         nbytes = scratch.numel() * 4
         info.update({"allreduce_ms": round(dt * 1e3, 3), "alg_gb_s": round(nbytes / dt / 1e9, 2),
                      "bus_gb_s": round(2 * (self.world - 1) / self.world * nbytes / dt / 1e9, 2)})
+        exposed = self.exposed_ms()
+        if exposed is not None:
+            # exposed: what the step actually waited for; overlapped: the rest of the stand-alone all-reduce time, hidden
+            # behind backward
+            info.update({"exposed_ms_per_step": round(exposed, 3), "overlapped_ms_per_step": round(max(0.0, dt * 1e3 - exposed), 3)})
         return info
 
     # ---- HIP-graph replay of the step --------------------------------------------------------------------------

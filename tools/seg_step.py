@@ -27,7 +27,7 @@ def main():
     torch.manual_seed(0)
     from text_segmentation_image_inpainting_amd import _lib
     if args.products >= 0:
-        _lib.lib().tsii_set_gemm_products(args.products)
+        _lib.set_gemm_products(args.products)
     kw = {"pixel_shuffle_head": True} if (args.pixel_shuffle and args.model == "TextSegament") else {}
     m = getattr(T, args.model)(**kw).to(dev).train()
     if args.checkpoint and hasattr(m, "checkpoint_encoder"):
@@ -44,7 +44,7 @@ def main():
         loss.backward()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print(f"{args.model}{' +pixel-shuffle head' if kw else ''}{' +checkpointed encoder' if args.checkpoint else ''} products={_lib.lib().tsii_get_gemm_products()} "
+    print(f"{args.model}{' +pixel-shuffle head' if kw else ''}{' +checkpointed encoder' if args.checkpoint else ''} products={_lib.get_gemm_products()} "
           f"{args.size}x{args.size} bs{args.batch}: {dt * 1e3:.1f} ms/step, {args.batch / dt:.1f} img/s, "
           f"loss {loss.item():.4f}, peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 
