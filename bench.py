@@ -101,8 +101,12 @@ def class_table(timed, steps, products):
                 by, macs = fn(a)
             except (IndexError, TypeError):
                 continue
-            d = agg.setdefault(cls, {"ms": 0.0, "bytes": 0.0, "macs": 0.0, "launches": 0})
+            d = agg.setdefault(cls, {"ms": 0.0, "bytes": 0.0, "macs": 0.0, "launches": 0, "floor": 0.0})
             d["ms"] += ms; d["bytes"] += by; d["macs"] += macs; d["launches"] += 1
+            # this launch's own roofline: the larger of its HBM time and (matrix kernels) its MFMA time in the arithmetic mode --
+            # a class mixes HBM-bound layers (few channels) and MFMA-bound ones, so the class-level fractions under-state both
+            mfma_peak = (PEAK_BF16_TFLOPS / products if products else PEAK_FP32_TFLOPS) * 1e12
+            d["floor"] += max(by / (PEAK_HBM_TBS * 1e12), (2.0 * macs / mfma_peak) if cls.startswith(("gemm", "dense")) else 0.0) * 1e3
     out = {}
     for cls, d in agg.items():
         if d["ms"] <= 0:
@@ -110,7 +114,8 @@ def class_table(timed, steps, products):
         t = d["ms"] * 1e-3
         tbs = d["bytes"] / t / 1e12
         rec = {"ms_per_step": round(d["ms"] / steps, 3), "launches_per_step": d["launches"] // steps,
-               "alg_gb_per_step": round(d["bytes"] / steps / 1e9, 3), "tb_per_s": round(tbs, 3), "hbm_frac": round(tbs / PEAK_HBM_TBS, 4)}
+               "alg_gb_per_step": round(d["bytes"] / steps / 1e9, 3), "tb_per_s": round(tbs, 3), "hbm_frac": round(tbs / PEAK_HBM_TBS, 4),
+               "per_launch_roofline_ms": round(d["floor"] / steps, 3), "per_launch_roofline_frac": round(d["floor"] / d["ms"], 4)}
         if d["macs"] > 0 and cls.startswith(("gemm", "dense")):
             tf = 2.0 * d["macs"] / t / 1e12
             split = products != 0      # point-wise GEMMs and the implicit-GEMM dense convolutions both run on the split kernels
@@ -381,6 +386,8 @@ def main():
                         "unit": "GB/s" if hbm_bound else "TFLOP/s (fp32-equivalent)",
                         "frac": d["hbm_frac"] if hbm_bound else d["mfma_frac"],
                         "hbm_frac": d["hbm_frac"], "mfma_frac": d.get("mfma_frac"),
+                        # sum over the class's launches of max(HBM time, MFMA time) / measured: each layer against its own bound
+                        "per_launch_roofline_frac": d["per_launch_roofline_frac"],
                         "traffic": traffic, "traffic_source": traffic_src,
                         "alg_bytes_per_launch": round(d["alg_gb_per_step"] * 1e9 / max(1, d["launches_per_step"])),
                         "launches_per_step": d["launches_per_step"],

@@ -55,7 +55,8 @@ const char* tsii_last_error(void);
  *   1           operands rounded to bf16, one product (fp32 accumulation, fp32 storage everywhere else): the "mixed bf16"
  *               arithmetic of BASELINE config 5, tolerance 1e-2 class, opt-in;
  *   0           v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chain).
- * The environment variable TSII_GEMM_PRODUCTS sets every thread's initial value.  inputs/outputs are fp32 in every mode.
+ * The environment variable TSII_GEMM_PRODUCTS sets every thread's initial value; -1 puts the calling thread back to it.
+ * inputs/outputs are fp32 in every mode.
  * Range caveat of the split modes: an operand that is inf, or finite but beyond the largest bf16 (3.39e38), splits into
  * (inf, NaN, NaN) -- where the f32 MFMA mode gives +-inf for that row, these give NaN; both rows are lost either way. */
 int tsii_set_gemm_products(int products);

@@ -2,6 +2,7 @@
 arithmetic modes (tsii_set_gemm_products: 0 = f32-input MFMA, 6 = split-bf16 fp32 class, 3 = split-bf16 2 planes)
 -- fragment layouts, LDS swizzle, tile tails, row scales, LDS-staged epilogue -- against float64 numpy."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -270,7 +271,13 @@ def test_dense_conv_gather_gemms(emu, mode, cin, cout, k, s, p, d, h):
     assert np.abs(dx - rdx).max() <= tol * np.abs(rdx).max()
 
 
-@pytest.mark.parametrize("M,K,N", [(768, 64, 256), (512, 40, 128), (512, 96, 384), (256, 32, 128), (1152, 160, 192), (1664, 72, 224), (2560, 128, 128)])
+# threads per block of the persistent split-bf16 NT kernel in use: 512 = wave-symmetric K3w, 768 = producer / consumer K3p
+# (csrc/gemm_pc.hip; TSII_GEMM_WS picks, read when the library loads -- run this file under both values to cover both)
+PC_THREADS = 512 if os.environ.get("TSII_GEMM_WS", "0") != "0" else 768
+
+
+@pytest.mark.parametrize("M,K,N", [(768, 64, 256), (512, 40, 128), (512, 96, 384), (256, 32, 128), (1152, 160, 192), (1664, 72, 224), (2560, 128, 128),
+                                   (1280, 32, 256), (640, 224, 512)])
 def test_producer_consumer_gemm(emu, M, K, N):
     """K3p (gemm_pc.hip) at kernel level on the emulator (3 'CUs': several tiles per persistent block, more stages than
     LDS slots, k tails, column blocks past N, both tile shapes): forward with BatchNorm-on-load + statistics, dX with
@@ -283,7 +290,7 @@ def test_producer_consumer_gemm(emu, M, K, N):
     from tests.emu import build_emu
     raw = ctypes.CDLL(build_emu.build())
     raw.hipemu_launches.restype = ctypes.c_long
-    before = raw.hipemu_launches(768)
+    before = raw.hipemu_launches(PC_THREADS)
     x = (rng.standard_normal((M, K)) * 2 + 0.5).astype(np.float32)
     w = rng.standard_normal((N, K)).astype(np.float32)
     b = rng.standard_normal(N).astype(np.float32)
@@ -307,7 +314,7 @@ def test_producer_consumer_gemm(emu, M, K, N):
                             P(part), P(y), P(wws), wws.nbytes, None) == 0, L.tsii_last_error()
     ref = (am @ w.T.astype(np.float64) / denom[:, None] + b) * keep[:, None]
     assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max()
-    assert raw.hipemu_launches(768) == before + 1
+    assert raw.hipemu_launches(PC_THREADS) == before + 1
     # the statistics partials: per 128-row block (count, pivot, sum(y - pivot), sum((y - pivot)^2))
     y64 = y.astype(np.float64)
     for rb in range(rows):
@@ -330,9 +337,9 @@ def test_producer_consumer_gemm(emu, M, K, N):
     rdx[:, split:] *= r1[:, None]
     dx = np.zeros((M, K), np.float32)
     wt = np.zeros(L.tsii_pw_ws_bytes(N, K) // 4 + 4, np.float32)
-    before = raw.hipemu_launches(768)
+    before = raw.hipemu_launches(PC_THREADS)
     assert L.tsii_pw_bwd_dx(P(dy), M, N, P(w), K, P(inv), P(r0), split, P(r1), P(dx), P(wt), None) == 0, L.tsii_last_error()
-    pc_dx = raw.hipemu_launches(768) - before          # dX has K output columns: whole 32-blocks, at least 128
+    pc_dx = raw.hipemu_launches(PC_THREADS) - before          # dX has K output columns: whole 32-blocks, at least 128
     assert pc_dx == (1 if (K >= 128 and K % 32 == 0) else 0)
     assert np.abs(dx - rdx).max() <= 1e-5 * np.abs(rdx).max()
     if K % 4 == 0:

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtsii_hip.so")
+LIB_PATH = os.environ.get("TSII_LIBRARY") or os.path.join(_HERE, "libtsii_hip.so")   # TSII_LIBRARY: another BUILD of csrc/ (A/B measurements)
 ABI_VERSION = 3           # TSII_ABI_VERSION of include/tsii_hip.h this binding was written against
 
 _p, _i, _l, _f, _z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
@@ -156,6 +156,7 @@ def stop_timing():
 # thread-local and autograd runs backward on its own threads, so the mode is kept HERE and handed to the library on
 # whichever thread makes a call.  None = the library default (6, or TSII_GEMM_PRODUCTS).
 _GEMM_PRODUCTS = None
+_GEMM_TOUCHED = False      # set_gemm_products() was called at least once: from then on every call re-applies the selection
 
 
 def set_gemm_products(products):
@@ -164,19 +165,21 @@ def set_gemm_products(products):
     global _GEMM_PRODUCTS
     if products is not None and products not in (0, 1, 3, 6, 8):
         raise ValueError("gemm products: 0, 1, 3, 6 or 8")
-    _GEMM_PRODUCTS = products
-    if products is not None:
-        lib().tsii_set_gemm_products(int(products))
+    global _GEMM_TOUCHED
+    _GEMM_PRODUCTS, _GEMM_TOUCHED = products, True
+    lib().tsii_set_gemm_products(-1 if products is None else int(products))
 
 
 def get_gemm_products():
-    return int(lib().tsii_get_gemm_products()) if _GEMM_PRODUCTS is None else int(_GEMM_PRODUCTS)
+    if _GEMM_TOUCHED:
+        lib().tsii_set_gemm_products(-1 if _GEMM_PRODUCTS is None else int(_GEMM_PRODUCTS))
+    return int(lib().tsii_get_gemm_products())
 
 
 def call(name, *args):
     L = lib()
-    if _GEMM_PRODUCTS is not None:
-        L.tsii_set_gemm_products(_GEMM_PRODUCTS)        # this thread's switch
+    if _GEMM_TOUCHED:       # the library's switch is per thread: bring the calling thread (autograd's workers too) in line
+        L.tsii_set_gemm_products(-1 if _GEMM_PRODUCTS is None else _GEMM_PRODUCTS)
     timed = _TIMED is not None and name in _TIMED
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

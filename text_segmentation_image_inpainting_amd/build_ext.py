@@ -18,6 +18,15 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libtsii_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
+# The MFMA kernels are built without v_pk_{add,mul,fma}_f32 (-packed-fp32-ops): next to a busy matrix pipe the packed forms issue
+# at ~1/15 of the scalar rate (measured on MI355X, tools/probes/valu_rates.hip: 9 vs 100-180 cycles per instruction beside a
+# v_mfma_f32_32x32x16_bf16 stream).  The stencil / streaming kernels keep them: without MFMAs around they are two flops per slot.
+NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+MFMA_SOURCES = ("gemm.hip", "gemm_split.hip", "gemm_pc.hip")
+
+
+def flags_for(src):
+    return FLAGS + (NO_PACKED_F32 if os.path.basename(src) in MFMA_SOURCES else [])
 
 
 def _hipcc():
@@ -36,7 +45,7 @@ def _digest(paths):
     for p in paths:
         with open(p, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(flags_for(paths[0])).encode())
     return h.hexdigest()
 
 
@@ -44,12 +53,14 @@ def _compile_one(args):
     hipcc, src, obj, stamp, dig = args
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return src, 0, "cached"
-    cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+    cmd = [hipcc] + flags_for(src) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode == 0:
         with open(stamp, "w") as f:
             f.write(dig)
-    return src, r.returncode, r.stdout + r.stderr
+    # the HOST pass of a .hip file does not know the device feature named in FLAGS and says so once per pass: not a diagnostic
+    out = "\n".join(ln for ln in (r.stdout + r.stderr).splitlines() if "'-packed-fp32-ops' is not a recognized feature" not in ln).strip()
+    return src, r.returncode, out
 
 
 def build(force=False, verbose=True):

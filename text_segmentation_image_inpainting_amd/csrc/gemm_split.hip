@@ -855,8 +855,9 @@ int launch_tn_split_conv(const float* A, int64_t lda, const float* sa, const flo
 }  // namespace tsii
 
 extern "C" int tsii_set_gemm_products(int products) {
-    TSII_REQUIRE(products == 0 || products == 1 || products == 3 || products == 6 || products == 8, "set_gemm_products: 0 (f32 MFMA), 1 (bf16 operands), 3, 6 or 8 (split bf16)");
-    tsii::g_products = products;
+    TSII_REQUIRE(products == -1 || products == 0 || products == 1 || products == 3 || products == 6 || products == 8,
+                 "set_gemm_products: 0 (f32 MFMA), 1 (bf16 operands), 3, 6 or 8 (split bf16), -1 (back to the process default)");
+    tsii::g_products = products < 0 ? tsii::env_products() : products;
     return 0;
 }
 

@@ -11,6 +11,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int SPLIT_BK = 32;          // K elements per tile; one LDS row = 32 bf16 = 64 bytes = 4 chunks of 8
 
+// a - b as ONE v_sub_f32 the vectorizer cannot pair into a packed-fp32 instruction
+__device__ __forceinline__ float scalar_sub(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a - b;
+#endif
+}
+
 // 8 consecutive fp32 values -> P planes of 8 bf16 (element i of a plane in bits [16*(i&1), +16) of dword i >> 1)
 template <int P>
 __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&pl)[P]) {
@@ -23,8 +34,11 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&pl)[P]) {
             const unsigned u = __builtin_bit_cast(unsigned, h);
             pl[p][j] = u;
             if (p + 1 < P) {
-                const f32x2 back = {__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
-                x = x - back;                                          // exact: the low significand bits
+                // exact: the low significand bits.  Two scalar v_sub_f32 ON PURPOSE: the packed form (v_pk_add_f32) issues at
+                // ~1/15 of the scalar rate while the SIMD's matrix pipe is busy (tools/probes/valu_rates.hip, measured on MI355X:
+                // 9 vs 100-180 cycles per instruction next to a v_mfma_f32_32x32x16_bf16 stream)
+                x[0] = scalar_sub(x[0], __builtin_bit_cast(float, u << 16));
+                x[1] = scalar_sub(x[1], __builtin_bit_cast(float, u & 0xffff0000u));
             }
         }
     }

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Is a second forward + backward of the same network on the same input bit-identical to the first (no state may leak from one
+step into the next: workspaces, partial-sum buffers, cached operand planes)?  TextSegament(width_mult=2) on the 64x64 fixture input,
+decoder-side parameters trainable as in the recipe's stage 1; then the same with the weights nudged in between (what an optimizer
+step does) against a fresh model holding the nudged weights.
+    python tools/repeat_probe.py            (GPU box)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def grads(net, x, t, T):
+    for p in net.parameters():
+        p.grad = None
+    loss = T.BinaryFocalLoss(0, 1, 2)(net(x), t)
+    loss.backward()
+    return float(loss), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+
+def main():
+    import text_segmentation_image_inpainting_amd as T
+    from oracle.filler import fill_state_dict_
+    G = np.load(os.path.join(ROOT, "tests", "golden", "textsegament_64.npz"))
+    dev = torch.device("cuda:0")
+    x, t = torch.from_numpy(G["x"]).to(dev), torch.from_numpy(G["t"]).to(dev)
+
+    def make():
+        net = T.TextSegament(width_mult=2)
+        fill_state_dict_(net.state_dict(), seed=41, gain=1.0)
+        net = net.to(dev).train()
+        for p in net.encoder.parameters():
+            p.requires_grad_(False)
+        return net
+    net = make()
+    l1, g1 = grads(net, x, t, T)
+    l2, g2 = grads(net, x, t, T)
+    worst = max((float((g1[k] - g2[k]).abs().max() / (g1[k].abs().max() + 1e-30)), k) for k in g1)
+    print(f"same weights, pass 2 vs pass 1: loss {l1:.9f} / {l2:.9f}; worst relative gradient difference {worst[0]:.3e} ({worst[1]})")
+    # nudge the trainable weights in place (as the fused SGD kernel does: through the storage, no autograd version bump)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    deltas = {}
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if p.requires_grad:
+                d = (torch.randn(p.shape, generator=gen) * 1e-4 * float(p.abs().max())).to(dev)
+                deltas[k] = d
+                p.data.add_(d)
+    l3, g3 = grads(net, x, t, T)
+    fresh = make()
+    with torch.no_grad():
+        for k, p in fresh.named_parameters():
+            if k in deltas:
+                p.data.add_(deltas[k])
+        for (k, b), (_, b0) in zip(fresh.named_buffers(), net.named_buffers()):
+            b.copy_(b0)
+    l4, g4 = grads(fresh, x, t, T)
+    rows = sorted(((float((g3[k] - g4[k]).abs().max() / (g4[k].abs().max() + 1e-30)), k) for k in g3), reverse=True)
+    print(f"nudged weights, third pass of the used model vs first pass of a fresh one: loss {l3:.9f} / {l4:.9f}; worst gradient differences:")
+    for e, k in rows[:6]:
+        print(f"   {e:.3e}  {k}")
+
+
+if __name__ == "__main__":
+    main()

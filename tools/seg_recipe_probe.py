@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Diagnostic behind tests/test_training_recipe.py::test_segmentation_two_stage_recipe_gpu: the stage-1 loop step by step, the
+HIP recipe against the fp64 oracle loop -- per step the gradient error and the parameter error (relative to that step's update) of
+the tensors the test flags, so a deviation can be pinned to a step and to gradient vs optimizer.
+    python tools/seg_recipe_probe.py            (GPU box; the oracle runs on the host cores)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    import text_segmentation_image_inpainting_amd as T
+    from text_segmentation_image_inpainting_amd.recipes import SegmentationRecipe
+    from oracle import seg_oracle as S
+    from oracle.filler import fill_state_dict_, make_state_dict
+    from tests.test_training_recipe import _torch_loop
+    G = np.load(os.path.join(ROOT, "tests", "golden", "textsegament_64.npz"))
+    x, t = torch.from_numpy(G["x"]), torch.from_numpy(G["t"])
+    cfg = dict(base_lr=1e-4, max_lr=4e-4, step_size=2)
+    probe = T.TextSegament(width_mult=2)
+    keys = [(k, tuple(v.shape)) for k, v in probe.state_dict().items()]
+    names = [k for k, _ in probe.named_parameters() if not k.startswith("encoder.")]
+    watch = ["feature_pooling.rfb_linear_conv.0.weight", "feature_pooling.input_down_channel.0.weight", "feature_pooling.rfb.2.4.weight",
+             "feature_pooling.rfb_linear_conv.1.0.weight", "out_conv.1.0.weight"]
+    watch = [k for k in watch if k in names]
+    dev = torch.device("cuda:0")
+
+    def oracle(dtype):
+        sd = make_state_dict(keys, seed=41, gain=1.0, dtype=dtype)
+        for k, _ in probe.named_parameters():
+            sd[k].requires_grad_(k in names)
+        opt, sched = _torch_loop([sd[k] for k in names], cfg["base_lr"], cfg["max_lr"], cfg["step_size"], 1e-3)
+        out = []
+        for _ in range(2):
+            opt.zero_grad()
+            loss = S.binary_focal_loss(S.text_segament(sd, x.to(dtype), training=True, width_mult=2), t.to(dtype), 0.0, 1.0, 2.0)
+            loss.backward()
+            g = {k: sd[k].grad.detach().clone().double() for k in watch}
+            p0 = {k: sd[k].detach().clone().double() for k in watch}
+            opt.step(); sched.step()
+            out.append((g, p0, {k: sd[k].detach().clone().double() for k in watch}, float(loss)))
+        return out
+    o64, o32 = oracle(torch.float64), oracle(torch.float32)
+    net = T.TextSegament(width_mult=2)
+    fill_state_dict_(net.state_dict(), seed=41, gain=1.0)
+    net = net.to(dev).train()
+    rec = SegmentationRecipe(net, free_last_blocks=0, weight_decay=1e-3, **cfg)
+    params = dict(net.named_parameters())
+    for step in range(2):
+        before = {k: params[k].detach().cpu().double() for k in watch}
+        loss = float(rec.step(x.to(dev), t.to(dev)))
+        g64, p064, p164, l64 = o64[step]
+        g32, _, p132, _ = o32[step]
+        print(f"step {step}: lr {rec.lr:.3e}  loss {loss:.7f} (fp64 oracle {l64:.7f})")
+        for k in watch:
+            g = params[k].grad.detach().cpu().double()
+            p1 = params[k].detach().cpu().double()
+            upd = float((p164[k] - p064[k]).abs().max())
+            from tests.util import low_rank_error
+            lr_g = low_rank_error(g, g64[k])[1]
+            lr_p = low_rank_error(p1, p164[k])[1]
+            print(f"   {k:48s} grad err {float((g - g64[k]).abs().max() / g64[k].abs().max()):.2e} (oracle fp32 {float((g32[k] - g64[k]).abs().max() / g64[k].abs().max()):.2e})"
+                  f"  start err/upd {float((before[k] - p064[k]).abs().max()) / upd:.2e}  end err/upd {float((p1 - p164[k]).abs().max()) / upd:.2e}"
+                  f" (oracle fp32 {float((p132[k] - p164[k]).abs().max()) / upd:.2e})  step err/upd {float(((p1 - before[k]) - (p164[k] - p064[k])).abs().max()) / upd:.2e}"
+                  f"  max|p| {float(p164[k].abs().max()):.2e} max|g| {float(g64[k].abs().max()):.2e} upd {upd:.2e}"
+                  f"  error carried by <= 3 singular values: gradient {100 * lr_g:.1f} %, parameter {100 * lr_p:.1f} %")
+
+
+if __name__ == "__main__":
+    main()
