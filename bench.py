@@ -194,7 +194,7 @@ def cpu_baseline(size: int, threads: int):
     return {"value": round(bs / t, 4), "unit": "imgs/s", "cores": threads, "kind": "port",
             "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
             "sample": f"ImageFill {size}x{size} bs {bs} fwd+bwd (train-mode BN, L1 loss), 1 warm-up + 3 timed steps, median; "
-                      f"{threads} torch threads (a 4-image batch does not scale past ~32: more threads ran slower)"}
+                      f"{threads} torch threads"}
 
 
 def main():
@@ -212,7 +212,7 @@ def main():
     ap.add_argument("--products", type=int, default=-1, help="tsii_set_gemm_products for this run (1 = the 'mixed bf16' arithmetic of cfg 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the short run in the bit-exact f32-MFMA arithmetic mode")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU-baseline leg (default: min(physical cores, 32))")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU-baseline leg (default: both min(physical cores, 32) and all physical cores, the better one reported)")
     ap.add_argument("--bernoulli-masks", action="store_true", help="stress variant: i.i.d. per-channel masks")
     ap.add_argument("--graph", action="store_true", help="also replay the step from a HIP graph (measured: no gain; off by default)")
     args = ap.parse_args()
@@ -435,7 +435,14 @@ def main():
         line["peak_mem_gib"] = round(torch.cuda.max_memory_allocated() / 2**30, 1)
         if not args.no_cpu_baseline and world == 1 and not seg:
             _, phys, logical = host_cpu()
-            line["cpu_baseline"] = cpu_baseline(args.size, args.cpu_threads or min(phys or logical or 1, 32))
+            if args.cpu_threads:
+                line["cpu_baseline"] = cpu_baseline(args.size, args.cpu_threads)
+            else:
+                # two thread counts: 32 (where a 4-image batch stops scaling) and every physical core; the better one is the baseline
+                runs = [cpu_baseline(args.size, t) for t in sorted({min(phys or logical or 1, 32), phys or logical or 1})]
+                best = max(runs, key=lambda r: r["value"])
+                best["all_runs"] = [{"cores": r["cores"], "value": r["value"]} for r in runs]
+                line["cpu_baseline"] = best
         elif world == 1:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -398,6 +398,8 @@ __global__ __launch_bounds__(256, MODE != 0 ? 2 : 3) void dw_strip_kernel(
     float vals[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int cnt = 0;
     // one step: fetch slab `fstep` into the (fpf, fpm) set, compute step s, commit slab s + 1 from the (cpf, cpm) set
+    // The two barriers of a step guard the LDS ring only and are lds_barrier()s: __syncthreads() also waits for vmcnt(0), i.e. for
+    // the slab(s) just requested and for this step's stores -- the prefetch would be over before the compute had begun.
     auto do_step = [&](int s, int fstep, float4 (&fpf)[PF], float (&fpm)[PF], const float4 (&cpf)[PF], const float (&cpm)[PF]) {
         const bool more = s + 1 < nsteps;
         if (fstep < nsteps) fetch(PRO + NEW * fstep, NEW, fpf, fpm);          // in flight during the compute below
@@ -463,9 +465,9 @@ __global__ __launch_bounds__(256, MODE != 0 ? 2 : 3) void dw_strip_kernel(
                 vals[6] = fmaf(dz, dz, vals[6]); vals[7] = fmaf(dw, dw, vals[7]);
             }
         }
-        __syncthreads();                                    // every read of this step's rows is done
+        lds_barrier();                                       // every read of this step's rows is done
         if (more) { commit(PRO + NEW * (s + 1), NEW, cpf, cpm); commit_planes(s + 1); }   // into the slots this step no longer needs
-        __syncthreads();
+        lds_barrier();   
     };
     if constexpr (DEEP) {
         if (nsteps > 1) fetch(PRO + NEW, NEW, pf, pm);
@@ -690,9 +692,9 @@ __global__ __launch_bounds__(256, 3) void dw_strip_dx2_kernel(const float* __res
                 vals[6] = fmaf(gz, hz, vals[6]); vals[7] = fmaf(gw, hw, vals[7]);
             }
         }
-        __syncthreads();
+        lds_barrier();   
         if (more) { commit(PRO + NEW * (s + 1), NEW); commit_planes(s + 1); }
-        __syncthreads();
+        lds_barrier();   
     }
     if constexpr (BNB) {
         // lanes of a wave with the same channel group sit 8 threads apart: butterfly over them, then 4 wave rows through LDS
@@ -924,9 +926,9 @@ __global__ __launch_bounds__(256, 2) void dw_strip_dw_kernel(const float* __rest
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();   
         if (more) { commit(PRO + NEW * (s + 1), NEW); commit_planes(s + 1); }
-        __syncthreads();
+        lds_barrier();   
     }
     // combine the 32 pixel lanes through the (free) ring: [10 taps][256 threads] float4, then 80 threads per ... sum
     float4* red4 = reinterpret_cast<float4*>(ring);
