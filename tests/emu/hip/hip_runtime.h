@@ -109,8 +109,6 @@ static inline void async_load4(float& d, const void* p) { std::memcpy(&d, p, 4);
 static inline void async_load16(f32x4_emu2& d, const void* base, unsigned off) { std::memcpy(&d, (const char*)base + off, 16); }
 static inline void async_load4(float& d, const void* base, unsigned off) { std::memcpy(&d, (const char*)base + off, 4); }
 template <int N, class... T> static inline void async_wait(T&...) {}
-template <int N> static inline void async_wait_count() {}
-template <class A> static inline void async_pin(A&) {}
 static inline void lds_barrier() { hipemu::syncthreads(); }
 }
 static inline f32x16_emu __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16_emu c, int, int, int) {

@@ -271,9 +271,7 @@ def test_dense_conv_gather_gemms(emu, mode, cin, cout, k, s, p, d, h):
     assert np.abs(dx - rdx).max() <= tol * np.abs(rdx).max()
 
 
-# threads per block of the persistent split-bf16 NT kernel in use: 512 = wave-symmetric K3w, 768 = producer / consumer K3p
-# (csrc/gemm_pc.hip; TSII_GEMM_WS picks, read when the library loads -- run this file under both values to cover both)
-PC_THREADS = 512 if os.environ.get("TSII_GEMM_WS", "0") != "0" else 768
+PC_THREADS = 768      # threads per block of the persistent producer / consumer NT kernel (csrc/gemm_pc.hip)
 
 
 @pytest.mark.parametrize("M,K,N", [(768, 64, 256), (512, 40, 128), (512, 96, 384), (256, 32, 128), (1152, 160, 192), (1664, 72, 224), (2560, 128, 128),

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, MODE != 0 ? 2 : 3) void dw_strip_kernel(
         }
         lds_barrier();                                       // every read of this step's rows is done
         if (more) { commit(PRO + NEW * (s + 1), NEW, cpf, cpm); commit_planes(s + 1); }   // into the slots this step no longer needs
-        lds_barrier();   
+        lds_barrier();
     };
     if constexpr (DEEP) {
         if (nsteps > 1) fetch(PRO + NEW, NEW, pf, pm);
@@ -692,9 +692,9 @@ __global__ __launch_bounds__(256, 3) void dw_strip_dx2_kernel(const float* __res
                 vals[6] = fmaf(gz, hz, vals[6]); vals[7] = fmaf(gw, hw, vals[7]);
             }
         }
-        lds_barrier();   
+        lds_barrier();
         if (more) { commit(PRO + NEW * (s + 1), NEW); commit_planes(s + 1); }
-        lds_barrier();   
+        lds_barrier();
     }
     if constexpr (BNB) {
         // lanes of a wave with the same channel group sit 8 threads apart: butterfly over them, then 4 wave rows through LDS
@@ -926,9 +926,9 @@ __global__ __launch_bounds__(256, 2) void dw_strip_dw_kernel(const float* __rest
                 }
             }
         }
-        lds_barrier();   
+        lds_barrier();
         if (more) { commit(PRO + NEW * (s + 1), NEW); commit_planes(s + 1); }
-        lds_barrier();   
+        lds_barrier();
     }
     // combine the 32 pixel lanes through the (free) ring: [10 taps][256 threads] float4, then 80 threads per ... sum
     float4* red4 = reinterpret_cast<float4*>(ring);

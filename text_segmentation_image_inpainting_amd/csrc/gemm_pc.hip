@@ -31,8 +31,6 @@
 // row block are consecutive on one CU (A re-reads hit L2) and every block streams B in the same order.
 #include <stdlib.h>
 
-#include <type_traits>
-
 #include "split_bf16.h"
 
 namespace tsii {
@@ -501,372 +499,18 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_pc_kernel(const float* __restr
     }
 }
 
-// ---- K3w: the same tiles, WAVE-SYMMETRIC ------------------------------------------------------------------------------
-// Measured on MI355X (tools/probes/valu_rates.hip, mfma_valu_mix.hip): a wave whose instructions are all vector-ALU is
-// STARVED next to two waves of the same SIMD that always have an MFMA ready (one instruction per ~10^7 cycles at equal priority;
-// with s_setprio it runs, and the matrix pipe drops to 41-57 % busy) -- while a wave that issues its own vector-ALU instructions
-// between its own MFMAs pays almost nothing for them (6 per MFMA: pipe 88 % busy).  So the split of A does not belong in separate
-// producer waves: here 8 identical waves (2 per SIMD, <= 256 VGPRs) each own a 128 x 32 accumulator block AND 1/8 of the
-// staging, with the staging instructions placed one small slice after every second MFMA:
-//   iteration g (one 32-deep k stage):  MFMAs of stage g from LDS buffer g % 3 (A) and registers (B);
-//                                       split + ds_write of stage g+2 (requested two iterations ago) into buffer (g+2) % 3;
-//                                       global loads of B for stage g+1 and of A for stage g+4; one LDS-only barrier.
-// Three LDS buffers take the barrier off the critical path (the fragments of stage g+1 are fetched before it).  Every global load
-// is a counted asynchronous one (tsii_common.h) and a single s_waitcnt vmcnt(LT) at the top of an iteration releases B(g) and
-// A(g+2) while A(g+3) stays in flight: B is requested BEFORE A within an iteration precisely so that this works (loads complete in
-// order).  Per-row factors, the bias and the input BatchNorm constants reach their users through LDS, so no compiler-tracked
-// global load (whose wait would drain everything) sits in the loop.
-// WABL (compile time; TSII_GEMM_PC_ABL with TSII_GEMM_WS=1, tools/pc_probe.py only, results are garbage): 1 no split arithmetic,
-// 2 no LDS stores, 4 no A global loads, 8 no B loads, 16 no A-fragment reads, 32 no per-stage barrier, 64 no epilogue, 128 no MFMAs
-template <int WM, int WN, bool BNIN, int EPI, int WABL = 0>
-__global__ __launch_bounds__(512, 2) void gemm_nt_ws_kernel(const float* __restrict__ A, int64_t lda, RowScale as,
-                                                            const unsigned short* __restrict__ Bp, float* __restrict__ C, int64_t ldc,
-                                                            int64_t M, int N, int K, Epilogue ep, InBN ib, unsigned ntn, unsigned tiles) {
-    static_assert(WM * WN == 8, "8 waves");
-    constexpr int P = 3, PRODUCTS = 6;
-    constexpr int BM = WM * 128, BN = WN * 32;
-    constexpr int ASTAGE = P * BM * 64;                       // bytes of one LDS stage
-    constexpr int NA = BM / 128;                              // A items (row, 8-k chunk) per thread and stage
-    constexpr int LT = NA * 4 + 3;                            // counted loads per thread and stage besides B: per item 2 x 16 B + 2 row scales; 2 row factors + 1 column constant
-    constexpr int SIDE = 2 * BM + BN;                         // floats of one tile's [X rows][Y rows][bias columns]
-    constexpr int BNV_FLOATS = BNIN ? 2048 : 0;
-    constexpr bool use_cs = EPI >= 2;
-    static_assert(2 * LT + 6 <= 63, "vmcnt is a 6-bit counter");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * ASTAGE + (3 * SIDE + BNV_FLOATS) * 4];
-    float* side = reinterpret_cast<float*>(smem + 3 * ASTAGE);          // ring of 3 tiles
-    float* bnv = side + 3 * SIDE;
-
-    const int tid = threadIdx.x;
-    const unsigned t0 = (unsigned)(((uint64_t)blockIdx.x * tiles) / gridDim.x);
-    const unsigned t1 = (unsigned)(((uint64_t)(blockIdx.x + 1) * tiles) / gridDim.x);
-    const int nst = (K + 31) >> 5;
-    const unsigned stages = (t1 - t0) * (unsigned)nst;
-    const unsigned tlast = t1 - 1;
-
-    if constexpr (BNIN) {
-        for (int i = tid; i < 2048; i += 512) {
-            const int k = i & 1023;
-            bnv[i] = k < K ? (i < 1024 ? ib.sc[k] : ib.sh[k]) : 0.f;
-        }
-    }
-
-    // ---- MFMA side of the wave
-    const int cw = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
-    const int wm = cw / WN, wn = cw % WN;
-    const int swz = (li >> 2) & 3;
-    const int aoff = (wm * 128 + li) * 64;
-    const int ch0 = ((0 + hi) ^ swz) << 4, ch1 = ((2 + hi) ^ swz) << 4;
-    const char* __restrict__ Bb = reinterpret_cast<const char*>(Bp);
-    const unsigned bplane = (unsigned)N * 32u;
-    bf16x8 a[3][P], a3x[P], a3y[P];
-    f32x4 bq[2][2][P];                                       // [stage parity][k half][plane]
-    f32x16 acc[4];
-    auto ldf = [](const unsigned char* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p)); };
-    auto load_a_frags = [&](const unsigned char* Sn, int chn) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int p = 0; p < P; ++p) a[t][p] = ldf(Sn + aoff + t * 2048 + p * (BM * 64) + chn);
-#pragma unroll
-        for (int p = 0; p < P; ++p) a3x[p] = ldf(Sn + aoff + 3 * 2048 + p * (BM * 64) + chn);
-    };
-
-    // ---- staging side of the wave: item i = (row prow + 128 i of the tile, 8-k chunk pch)
-    const int prow = tid >> 2, pch = tid & 3;
-    f32x4 ra[2][NA][2];
-    float sa0[2][NA], sa1[2][NA], sdx[2], sdy[2], sdb[2];
-    const bool has_r0 = as.r0 != nullptr, has_r1 = as.r1 != nullptr;
-    const float* r0p = has_r0 ? as.r0 : A;
-    const float* r1p = has_r1 ? as.r1 : r0p;
-    const float* sxp = use_cs ? (ep.cs.r0 != nullptr ? ep.cs.r0 : A) : (ep.denom != nullptr ? ep.denom : A);
-    const float* syp = use_cs ? (ep.cs.r1 != nullptr ? ep.cs.r1 : A) : (ep.keep != nullptr ? ep.keep : A);
-    const bool has_sx = use_cs ? ep.cs.r0 != nullptr : ep.denom != nullptr, has_sy = use_cs ? ep.cs.r1 != nullptr : ep.keep != nullptr;
-    const bool has_b = !use_cs && ep.bias != nullptr;
-    const float* sbp = has_b ? ep.bias : A;
-    const int srow = tid < BM ? tid : BM - 1;
-    unsigned aoffv[NA], roffv[NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        aoffv[i] = (unsigned)(((prow + 128 * i) * (int)lda + pch * 8) * 4);
-        roffv[i] = (unsigned)((prow + 128 * i) * 4);
-    }
-    const unsigned soffv = (unsigned)(srow * 4);
-    const int scol = tid < BN ? tid : BN - 1;
-
-    auto load_item = [&](const PcCursor& c, auto U, int i) {
-        constexpr int u = decltype(U)::value;
-        if constexpr ((WABL & 4) != 0) { ra[u][i][0] = ra[u][i][1] = f32x4{1.f, 2.f, 3.f, 4.f}; sa0[u][i] = sa1[u][i] = 1.f; return; }
-        const float* base = A + c.m0 * lda + c.ks * 32;
-        unsigned off = aoffv[i];
-        if (c.ks * 32 + 32 > K) {                               // the stage holding the k tail re-reads the row's last 8 floats
-            const int k = c.ks * 32 + pch * 8;
-            if (k > K - 8) off -= (unsigned)((k - (K - 8)) * 4);
-        }
-        async_load16(ra[u][i][0], base, off);
-        async_load16(ra[u][i][1], base, off + 16u);
-        async_load4(sa0[u][i], r0p + (has_r0 ? c.m0 : 0), has_r0 ? roffv[i] : 0u);
-        async_load4(sa1[u][i], r1p + ((has_r0 || has_r1) ? c.m0 : 0), (has_r0 || has_r1) ? roffv[i] : 0u);
-    };
-    auto load_side = [&](const PcCursor& c, auto U) {
-        constexpr int u = decltype(U)::value;
-        if constexpr ((WABL & 4) != 0) { sdx[u] = sdy[u] = sdb[u] = 1.f; return; }
-        async_load4(sdx[u], sxp + (has_sx ? c.m0 : 0), has_sx ? soffv : 0u);
-        async_load4(sdy[u], syp + (has_sy ? c.m0 : 0), has_sy ? soffv : 0u);
-        int col = c.n0 + scol;
-        col = col < N ? col : N - 1;
-        async_load4(sdb[u], sbp, has_b ? (unsigned)col * 4u : 0u);
-    };
-    auto load_b = [&](const PcCursor& c, auto U) {             // the 6 B fragments of a stage, straight from the tiled planes
-        constexpr int u = decltype(U)::value;
-        if constexpr ((WABL & 8) != 0) return;
-        int n = c.n0 + wn * 32 + li;
-        n = n < N ? n : N - 1;
-        const unsigned bl = (unsigned)n * 32u + (unsigned)hi * 16u;
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-            for (int p = 0; p < P; ++p) async_load16(bq[u][kh][p], Bb + (size_t)((2 * c.ks + kh) * P + p) * bplane, bl);
-    };
-    auto pin_set = [&](auto U) {
-        constexpr int u = decltype(U)::value;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) { async_pin(ra[u][i][0]); async_pin(ra[u][i][1]); async_pin(sa0[u][i]); async_pin(sa1[u][i]); }
-        async_pin(sdx[u]); async_pin(sdy[u]); async_pin(sdb[u]);
-    };
-    auto pin_b = [&](auto U) {
-        constexpr int u = decltype(U)::value;
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-            for (int p = 0; p < P; ++p) async_pin(bq[u][kh][p]);
-    };
-
-    // the staging of one item in slices (called between MFMA pairs): v = the item's 8 values, pl = its planes
-    float v[NA][8];
-    u32x4 pl[NA][P];
-    auto item_k = [&](const PcCursor& c) { int k = c.ks * 32 + pch * 8; return k < K - 8 ? k : K - 8; };
-    auto st_take = [&](auto U, int i) {
-        constexpr int u = decltype(U)::value;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[i][e] = ra[u][i][0][e]; v[i][4 + e] = ra[u][i][1][e]; }
-    };
-    auto st_bn = [&](const PcCursor& c, int i, int half) {      // input BatchNorm + activation of 4 values
-        if constexpr (BNIN) {
-            const int k = item_k(c) + 4 * half;
-            const float4 c0 = *reinterpret_cast<const float4*>(bnv + k), h0 = *reinterpret_cast<const float4*>(bnv + 1024 + k);
-            const float sc[4] = {c0.x, c0.y, c0.z, c0.w}, sh[4] = {h0.x, h0.y, h0.z, h0.w};
-            if (ib.hi < __builtin_huge_valf()) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[i][4 * half + e] = bn_act_load(v[i][4 * half + e], sc[e], sh[e], ib.neg, ib.hi);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float z = fmaf(v[i][4 * half + e], sc[e], sh[e]); v[i][4 * half + e] = fmaxf(z, ib.neg * z); }
-            }
-        }
-    };
-    auto st_scale = [&](const PcCursor& c, auto U, int i) {
-        constexpr int u = decltype(U)::value;
-        const float s0 = sa0[u][i], s1 = sa1[u][i];              // (values first: a select between the two array slots would pin both arrays to memory)
-        if (has_r0) {
-            const float sc8 = (item_k(c) < as.split) ? s0 : (has_r1 ? s1 : 1.f);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[i][e] *= sc8;
-        }
-    };
-    auto st_split = [&](int i, int j) {                         // pair j of the item -> dword j of its planes
-        if constexpr ((WABL & 1) != 0) { pl[i][0][j] = pl[i][1][j] = pl[i][2][j] = __builtin_bit_cast(unsigned, v[i][2 * j]); return; }
-        float x0 = v[i][2 * j], x1 = v[i][2 * j + 1];
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const f32x2 xx = {x0, x1};
-            const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(xx, bf16x2));
-            pl[i][p][j] = u;
-            if (p + 1 < P) { x0 -= __builtin_bit_cast(float, u << 16); x1 -= __builtin_bit_cast(float, u & 0xffff0000u); }
-        }
-    };
-    auto st_write = [&](unsigned char* S, int i) {
-        if constexpr ((WABL & 2) != 0) { if (pl[i][0][0] + pl[i][P - 1][3] == 0x12345u) S[0] = 1; return; }
-        const int off = split_off(prow + 128 * i, pch);
-#pragma unroll
-        for (int p = 0; p < P; ++p) *reinterpret_cast<u32x4*>(S + p * (BM * 64) + off) = pl[i][p];
-    };
-    auto st_side = [&](const PcCursor& c, auto U) {
-        constexpr int u = decltype(U)::value;
-        const float fx = sdx[u], fy = sdy[u], fb = sdb[u];
-        if (c.ks == 0) {
-            float* sx = side + (c.tile % 3u) * SIDE;
-            if (tid < BM) {
-                const float x = has_sx ? fx : 1.f;
-                sx[tid] = (!use_cs && has_sx) ? 1.0f / x : x;
-                sx[BM + tid] = has_sy ? fy : 1.f;
-            }
-            if (tid < BN) sx[2 * BM + tid] = has_b ? fb : 0.f;
-        }
-    };
-
-    // cursors: cm = the stage being multiplied (g), c1 = g+1 (B loads), cs = g+2 (LDS stores), cl = g+4 (A loads)
-    PcCursor cm, c1, cs, cl;
-    pc_locate<BM, BN>(cm, t0, ntn); cm.ks = 0;
-    c1 = cm; pc_advance<BM, BN>(c1, nst, ntn, tlast);
-    cs = c1; pc_advance<BM, BN>(cs, nst, ntn, tlast);
-    cl = cm;
-
-    // ---- prologue: stages 0 and 1 into LDS; in flight afterwards, in this order: A(2), B(0), A(3)
-    using U0 = std::integral_constant<int, 0>;
-    using U1 = std::integral_constant<int, 1>;
-    {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) load_item(cl, U0{}, i);
-        load_side(cl, U0{});
-        PcCursor c0 = cl;
-        pc_advance<BM, BN>(cl, nst, ntn, tlast);
-#pragma unroll
-        for (int i = 0; i < NA; ++i) load_item(cl, U1{}, i);
-        load_side(cl, U1{});
-        PcCursor c1s = cl;
-        pc_advance<BM, BN>(cl, nst, ntn, tlast);
-        async_wait_count<0>();
-        pin_set(U0{}); pin_set(U1{});
-        __syncthreads();                                        // bnv written
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            st_take(U0{}, i); st_bn(c0, i, 0); st_bn(c0, i, 1); st_scale(c0, U0{}, i);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) st_split(i, j);
-            st_write(smem, i);
-        }
-        st_side(c0, U0{});
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            st_take(U1{}, i); st_bn(c1s, i, 0); st_bn(c1s, i, 1); st_scale(c1s, U1{}, i);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) st_split(i, j);
-            st_write(smem + ASTAGE, i);
-        }
-        st_side(c1s, U1{});
-#pragma unroll
-        for (int i = 0; i < NA; ++i) load_item(cl, U0{}, i);     // A(2)
-        load_side(cl, U0{});
-        pc_advance<BM, BN>(cl, nst, ntn, tlast);
-        load_b(cm, U0{});                                        // B(0)
-#pragma unroll
-        for (int i = 0; i < NA; ++i) load_item(cl, U1{}, i);     // A(3)
-        load_side(cl, U1{});
-        pc_advance<BM, BN>(cl, nst, ntn, tlast);
-        lds_barrier();
-        load_a_frags(smem, ch0);
-    }
-
-    unsigned sm = 0;                                             // LDS buffer of stage g
-    bool waited = false;
-    // One stage.  U = g & 1 selects the register sets: A set U holds stage g+2 (then receives g+4), B set U holds stage g.
-    auto body = [&](auto U) {
-        constexpr int u = decltype(U)::value;
-        using UN = std::integral_constant<int, u ^ 1>;
-        const unsigned sn = sm + 1 < 3u ? sm + 1 : 0u, sw = sn + 1 < 3u ? sn + 1 : 0u;
-        const unsigned char* S0 = smem + sm * ASTAGE;
-        const unsigned char* S1 = smem + sn * ASTAGE;
-        unsigned char* SW = smem + sw * ASTAGE;
-        const bool first = cm.ks == 0, last = cm.ks + 1 == nst;
-        if (first) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        }
-        // B(g) and A(g+2) have landed, A(g+3) may still be in flight.  After an epilogue the same wait was already made BEFORE its
-        // stores (they count in vmcnt too: here it would mean waiting for the last of them to retire)
-        if (!waited) async_wait_count<LT>();
-        waited = false;
-        pin_b(U); pin_set(U);
-#pragma unroll
-        for (int i = 0; i < NA; ++i) st_take(U, i);
-        // staging slices, one after every MFMA pair (24 per stage): B(g+1) first, then per item [BN, BN, scale, split x 4, write,
-        // load A(g+4)], then the row factors
-        auto slice = [&](auto SI) {
-            constexpr int sidx = decltype(SI)::value;
-            if constexpr (sidx == 0) load_b(c1, UN{});
-            else if constexpr (sidx >= 1 && sidx < 1 + 9 * NA) {
-                constexpr int i = (sidx - 1) / 9, w = (sidx - 1) % 9;
-                if constexpr (w == 0) st_bn(cs, i, 0);
-                else if constexpr (w == 1) st_bn(cs, i, 1);
-                else if constexpr (w == 2) st_scale(cs, U, i);
-                else if constexpr (w < 7) st_split(i, w - 3);
-                else if constexpr (w == 7) st_write(SW, i);
-                else load_item(cl, U, i);
-            } else if constexpr (sidx == 1 + 9 * NA) { st_side(cs, U); load_side(cl, U); }
-        };
-        auto mm = [&](int t, const bf16x8& af, const f32x4& bf) {
-            if constexpr ((WABL & 128) != 0) { acc[t][0] += af[0] == bf[0] ? 1.f : 0.f; return; }
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bf), acc[t], 0, 0, 0);
-        };
-        // one 16-deep k step: 12 MFMA pairs, a staging slice after each; the A fragments of the next step are fetched into
-        // registers as they fall free (kstep of the producer / consumer kernel above)
-        auto kstep = [&](auto KH, const unsigned char* Sn, int chn, bool pfa, bf16x8 (&a3c)[P], bf16x8 (&a3nx)[P]) {
-            constexpr int kh = decltype(KH)::value;
-            f32x4 (&bc)[P] = bq[u][kh];
-            if constexpr ((WABL & 16) != 0) pfa = false;
-            if (pfa) {
-#pragma unroll
-                for (int p = 0; p < P; ++p) a3nx[p] = ldf(Sn + aoff + 3 * 2048 + p * (BM * 64) + chn);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#define TSII_WS_SLICE(J) __builtin_amdgcn_sched_barrier(0); slice(std::integral_constant<int, kh * 12 + (J)>{}); __builtin_amdgcn_sched_barrier(0)
-#define TSII_WS_Q(T, AF, Q) mm(T, AF[SplitTerm<PRODUCTS>::pa(Q)], bc[SplitTerm<PRODUCTS>::pb(Q)])
-            TSII_WS_Q(0, a[0], 0); TSII_WS_Q(1, a[1], 0); TSII_WS_SLICE(0);
-            TSII_WS_Q(0, a[0], 1); TSII_WS_Q(1, a[1], 1); TSII_WS_SLICE(1);
-            TSII_WS_Q(0, a[0], 2); TSII_WS_Q(1, a[1], 2); TSII_WS_SLICE(2);
-            TSII_WS_Q(0, a[0], 3); TSII_WS_Q(1, a[1], 3); TSII_WS_SLICE(3);
-            TSII_WS_Q(0, a[0], 4); TSII_WS_Q(1, a[1], 4); TSII_WS_SLICE(4);
-            TSII_WS_Q(0, a[0], 5); TSII_WS_Q(1, a[1], 5);
-            __builtin_amdgcn_sched_barrier(0);
-            if (pfa) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int p = 0; p < P; ++p) a[t][p] = ldf(Sn + aoff + t * 2048 + p * (BM * 64) + chn);
-            }
-            TSII_WS_SLICE(5);
-            TSII_WS_Q(2, a[2], 0); TSII_WS_Q(3, a3c, 0); TSII_WS_SLICE(6);
-            TSII_WS_Q(2, a[2], 1); TSII_WS_Q(3, a3c, 1); TSII_WS_SLICE(7);
-            TSII_WS_Q(2, a[2], 2); TSII_WS_Q(3, a3c, 2); TSII_WS_SLICE(8);
-            TSII_WS_Q(2, a[2], 3); TSII_WS_Q(3, a3c, 3); TSII_WS_SLICE(9);
-            TSII_WS_Q(2, a[2], 4); TSII_WS_Q(2, a[2], 5);
-            __builtin_amdgcn_sched_barrier(0);
-            if (pfa) {
-#pragma unroll
-                for (int p = 0; p < P; ++p) a[2][p] = ldf(Sn + aoff + 2 * 2048 + p * (BM * 64) + chn);
-            }
-            TSII_WS_SLICE(10);
-            TSII_WS_Q(3, a3c, 4); TSII_WS_Q(3, a3c, 5); TSII_WS_SLICE(11);
-#undef TSII_WS_Q
-#undef TSII_WS_SLICE
-        };
-        kstep(std::integral_constant<int, 0>{}, S0, ch1, true, a3x, a3y);       // k half 0; fetch half 1 of this stage
-        kstep(std::integral_constant<int, 1>{}, S1, ch0, !last, a3y, a3x);      // k half 1; fetch half 0 of the next stage (not over an epilogue)
-        if (last) {
-            async_wait_count<LT>();                              // what the next stage needs (B(g+1), A(g+3)); A(g+4) stays in flight
-            waited = true;
-            const float* sx = side + (cm.tile % 3u) * SIDE;
-            const float bias = sx[2 * BM + wn * 32 + li];
-            if constexpr (!(WABL & 64)) {
-                if (cm.n0 + wn * 32 < N) pc_epilogue<EPI>(acc, C, ldc, N, ep, cm.m0 + wm * 128, cm.n0 + wn * 32, li, hi, sx + wm * 128, sx + BM + wm * 128, bias);
-            } else if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.f) C[tid] = bias;
-        }
-        if constexpr (!(WABL & 32)) lds_barrier();               // stage g+2 is in LDS; everyone is done reading stage g
-        if (last && !(WABL & 16)) load_a_frags(S1, ch0);
-        pc_advance<BM, BN>(cm, nst, ntn, tlast);
-        pc_advance<BM, BN>(c1, nst, ntn, tlast);
-        pc_advance<BM, BN>(cs, nst, ntn, tlast);
-        pc_advance<BM, BN>(cl, nst, ntn, tlast);
-        sm = sn;
-    };
-    for (unsigned gidx = 0; gidx < stages; gidx += 2) {
-        body(U0{});
-        if (gidx + 1 < stages) body(U1{});
-    }
-    async_wait_count<0>();                                       // nothing in flight when the wave ends
-}
+// ---- what was measured instead of this design (round 3; code at commit e9fb585) --------------------------------------------
+// tools/probes/valu_rates.hip, mfma_valu_mix.hip on MI355X: a wave that only issues vector-ALU instructions is starved next to
+// two waves of its SIMD that always have an MFMA ready (one instruction per ~10^7 cycles at equal priority; with s_setprio 3 it
+// runs and the matrix pipe drops to 41-57 % busy), v_pk_{add,mul,fma}_f32 issue ~15x slower beside a busy matrix pipe (these
+// files are built without them), and a wave's OWN vector-ALU instructions between its MFMAs are nearly free (6 per MFMA: pipe
+// 88 % busy).  That argued for a wave-symmetric kernel (gemm_nt_ws_kernel: 8 identical waves, staging slices after every MFMA
+// pair, 3 LDS stages, one LDS-only barrier per stage, every global load counted).  Built, exact (1.2e-6 vs fp64, bitwise
+// repeatable), and 3-8 % SLOWER than this kernel on 11 of 14 shapes (0.69 vs 0.63 ms on 65536 x 1024 x 1024).  Its ablations
+// (profiles/r03_ws_ablations.log) show why neither form gets past ~50 % of the nominal MFMA peak: the split arithmetic is free
+// (0.708 -> 0.703 ms without it), and with EVERYTHING but the MFMAs removed the loop still takes 0.446 ms -- the chip is at its
+// 1400 W cap (tools/clock_watch.py, profiles/r03_clock_watch.log): 2.30 GHz in the MFMA-only loop, 1.57-1.67 GHz under the full
+// kernel.  Loads, LDS traffic and the epilogue cost time by costing power.
 
 // ---- weights: fp32 [N,K] (or its transpose) -> P bf16 planes tiled as [k half-step][plane][n][16 k], zeros past K ----
 template <int P>
@@ -900,7 +544,6 @@ static int pc_cus() {            // read-only device-properties cache
 }
 
 static int g_pc = getenv("TSII_GEMM_PC") ? atoi(getenv("TSII_GEMM_PC")) : 1;              // A/B knob: 0 = 4-wave kernels only
-static int g_ws = getenv("TSII_GEMM_WS") ? atoi(getenv("TSII_GEMM_WS")) : 0;              // A/B knob: 1 = the wave-symmetric kernel (K3w) instead of producer / consumer
 static int g_pc_opt = getenv("TSII_GEMM_PC_OPT") ? atoi(getenv("TSII_GEMM_PC_OPT")) : 0;   // wave priorities (kernel comment)
 static int g_pc_abl = getenv("TSII_GEMM_PC_ABL") ? atoi(getenv("TSII_GEMM_PC_ABL")) : 0;   // tools/pc_probe.py ablations only
 static int g_pc_min_n = getenv("TSII_GEMM_PC_MIN_N") ? atoi(getenv("TSII_GEMM_PC_MIN_N")) : 128;   // measured: 64-column outputs stay faster on the 4-wave kernel
@@ -931,23 +574,6 @@ static int launch_nt_pc_cfg(const float* A, int64_t lda, RowScale as, const unsi
     TSII_REQUIRE(tiles < (1ll << 31), "gemm_nt_pc: too many tiles");
     TSII_REQUIRE(ldc * 128 * 4 < (1ll << 31) && (int64_t)N * 128 * 4 < (1ll << 31), "gemm_nt_pc: row pitch too large");
     const unsigned grid = (unsigned)(tiles < pc_cus() ? tiles : pc_cus());
-    if (g_ws) {          // wave-symmetric form (K3w)
-#define TSII_WS_LAUNCH(BNINV, EPIV) hipLaunchKernelGGL((gemm_nt_ws_kernel<WM, WN, BNINV, EPIV>), dim3(grid), dim3(512), 0, stream, \
-                                                       A, lda, as, Bp, C, ldc, M, N, K, ep, ib, ntn, (unsigned)tiles)
-        if (ep.bn_y != nullptr) TSII_WS_LAUNCH(false, 3);
-        else if (ep.cs.r0 != nullptr) TSII_WS_LAUNCH(false, 2);
-        else if (ib.sc != nullptr) { if (ep.stats != nullptr) TSII_WS_LAUNCH(true, 1); else TSII_WS_LAUNCH(true, 0); }
-        else if (ep.stats != nullptr) TSII_WS_LAUNCH(false, 1);
-        else if (WM == 1 && g_pc_abl != 0) {
-#define TSII_WS_ABL(V) if (g_pc_abl == (V)) hipLaunchKernelGGL((gemm_nt_ws_kernel<WM, WN, false, 0, (V)>), dim3(grid), dim3(512), 0, stream, A, lda, as, Bp, C, ldc, M, N, K, ep, ib, ntn, (unsigned)tiles)
-            TSII_WS_ABL(1); TSII_WS_ABL(2); TSII_WS_ABL(3); TSII_WS_ABL(4); TSII_WS_ABL(7); TSII_WS_ABL(8); TSII_WS_ABL(15); TSII_WS_ABL(16); TSII_WS_ABL(31);
-            TSII_WS_ABL(32); TSII_WS_ABL(63); TSII_WS_ABL(64); TSII_WS_ABL(127); TSII_WS_ABL(128); TSII_WS_ABL(135); TSII_WS_ABL(71); TSII_WS_ABL(79); TSII_WS_ABL(95);
-#undef TSII_WS_ABL
-        }
-        else TSII_WS_LAUNCH(false, 0);
-#undef TSII_WS_LAUNCH
-        return check_launch("gemm_nt_ws");
-    }
 #define TSII_PC_LAUNCH(BNINV, EPIV, ABLV) hipLaunchKernelGGL((gemm_nt_pc_kernel<WM, WN, 6, BNINV, EPIV, ABLV>), dim3(grid), dim3(768), 0, stream, \
                                                              A, lda, as, Bp, C, ldc, M, N, K, ep, ib, ntn, (unsigned)tiles, g_pc_opt)
     if (ep.bn_y != nullptr) TSII_PC_LAUNCH(false, 3, 0);

@@ -22,8 +22,6 @@
 #include <stdlib.h>
 
 #include "gemm_tiles.h"
-#include <type_traits>
-
 #include "split_bf16.h"
 
 namespace tsii {
@@ -559,6 +557,10 @@ __device__ __forceinline__ void tn_conv_factors(const ConvGather& cg, const int 
     }
 }
 
+// (Round 3 measured a software-pipelined form of this kernel -- one block per CU, two LDS buffers, the staging of stage s+1 in
+// slices between the MFMA pairs of stage s, one LDS-only barrier per stage; commit e9fb585, gemm_tn_pipe_kernel: exact, and
+// 135 vs 175 TF/s on the 65536 x 1024 x 1024 dW, slower on every shape of tools/gemm_bench.py.  With one wave per SIMD every
+// fragment-read or wait stall idles the matrix pipe; three co-resident blocks in alternating phases hide more.)
 template <int WM, int WN, int TM, int TN, int PRODUCTS, bool BNIN, bool BCONV = false>
 __global__ __launch_bounds__(256, 3) void gemm_tn_split_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ sa,
                                                             const float* __restrict__ B, int64_t ldb, RowScale sb,
@@ -702,175 +704,6 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_split_kernel(const float* __re
         }
 }
 
-// ---- TN, software-pipelined (K3t) --------------------------------------------------------------------------------------
-// The kernel above alternates a matrix phase and a staging phase (split + transposed LDS stores) per 32-row stage and relies on
-// three co-resident blocks to overlap them.  Measured on MI355X (tools/probes/valu_rates.hip, mfma_valu_mix.hip): waves that only
-// issue vector-ALU work are starved by waves of the same SIMD that always have an MFMA ready, whereas a wave's OWN vector-ALU
-// instructions between its MFMAs cost almost nothing (6 per MFMA: matrix pipe 80-88 % busy).  Here one block per CU (4 waves,
-// one per SIMD, the whole register file) keeps TWO LDS buffers: while the MFMAs of stage s run out of one, the same waves split
-// stage s+1 (already in registers) into the other, and the global loads of stage s+2 are in flight; one LDS-only barrier per
-// stage (lds_barrier: __syncthreads would also wait for those loads).
-template <int TM, int TN, int PRODUCTS, bool BNIN>
-__global__ __launch_bounds__(256, 1) void gemm_tn_pipe_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ sa,
-                                                              const float* __restrict__ B, int64_t ldb, RowScale sb,
-                                                              float* __restrict__ Cws, int64_t M, int Pn, int Q, int64_t chunk, InBN ib,
-                                                              unsigned qtiles, unsigned ptiles) {
-    constexpr int WM = 2, WN = 2;
-    constexpr int P = SplitPlanes<PRODUCTS>::value;
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int STAGE = P * (BM + BN) * 64;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
-
-    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-    const unsigned zsplit = bid / (qtiles * ptiles), rem = bid % (qtiles * ptiles);
-    const int q0 = (int)(rem % qtiles) * BN, p0 = (int)(rem / qtiles) * BM;
-    const int64_t mbeg = (int64_t)zsplit * chunk;
-    const int64_t mend = (mbeg + chunk < M) ? mbeg + chunk : M;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int li = lane & 31, hi = lane >> 5;
-    const int cq = (lane & 7) | ((lane >> 4) << 3), mq = ((lane >> 3) & 1) | (wave << 1);
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int t = 0; t < TM; ++t)
-#pragma unroll
-        for (int u = 0; u < TN; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
-
-    float4 ra[2][4], rb[2][4];                       // two register sets: stage s+1 (being split) and s+2 (in flight)
-    float fa0[2][4], fa1[2][4], fb0[2][4], fb1[2][4];    // per-row factors of the same two stages (fetched with them: a factor load issued
-                                                          // after the next stage's data would be waited for together with that data)
-    const RowScale none = {nullptr, nullptr, 0};
-    const bool sb_active = sb.r0 != nullptr;
-    float4 bsc = make_float4(0.f, 0.f, 0.f, 0.f), bsh = bsc;
-    if constexpr (BNIN) {
-        const int q = q0 + cq * 4;
-        if ((BN == 128 || cq < BN / 4) && q < Q) { bsc = *reinterpret_cast<const float4*>(ib.sc + q); bsh = *reinterpret_cast<const float4*>(ib.sh + q); }
-    }
-    auto rows_left = [&](int64_t mt) { const int64_t l = mend - mt; return (int)(l < 0 ? 0 : (l < 32 ? l : 32)); };
-    auto clampm = [&](int64_t mt) { return mt < mend ? mt : mend - 1; };     // stages past the chunk re-read its last row (stored as zeros)
-    auto load_stage = [&](int64_t mt, int set) {
-        tn_split_load<BM>(A, lda, clampm(mt), mend, p0, Pn, cq, mq, ra[set]);
-        tn_split_load<BN>(B, ldb, clampm(mt), mend, q0, Q, cq, mq, rb[set]);
-        tn_split_factors(clampm(mt), mend, sa, none, mq, fa0[set], fa1[set]);
-        tn_split_factors(clampm(mt), mend, nullptr, sb, mq, fb0[set], fb1[set]);
-    };
-    auto store_stage = [&](unsigned char* S, int64_t mt, int set) {
-        const int left = rows_left(mt);
-        tn_split_store<BM, P, false>(S, ra[set], p0, 0, false, fa0[set], fa1[set], cq, mq, bsc, bsh, 1.f, 0.f, left, Pn);
-        tn_split_store<BN, P, BNIN>(S + P * BM * 64, rb[set], q0, sb.split, sb_active, fb0[set], fb1[set], cq, mq, bsc, bsh, ib.neg, ib.hi, left, Q);
-    };
-
-    int foA[TM][2], foB[TN][2];
-#pragma unroll
-    for (int t = 0; t < TM; ++t)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) foA[t][s] = tn_atom<BM>(2 * s + hi, (wm * TM + t) * 32 + li) * 16;
-#pragma unroll
-    for (int u = 0; u < TN; ++u)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) foB[u][s] = tn_atom<BN>(2 * s + hi, (wn * TN + u) * 32 + li) * 16;
-
-    // prologue: stage 0 into buffer 0; stage 1 in registers (set 0)
-    load_stage(mbeg, 0);
-    store_stage(smem, mbeg, 0);
-    load_stage(mbeg + SPLIT_BK, 0);
-    lds_barrier();
-
-    // one stage: MFMAs of stage (mt) from `cur`, split of stage mt+32 (set x) into `nxt`, loads of stage mt+64 into set x^1.
-    // The staging runs in 24 slices of ~10 vector-ALU instructions (8 channel quads x prepare / split / write), one after every
-    // MFMA pair (2 x TM x TN x 6 / 2 pairs), pinned by sched_barrier: left to the scheduler the whole staging sank below the MFMAs.
-    auto step = [&](int64_t mt, const unsigned char* cur, unsigned char* nxt, auto X) {
-        constexpr int x = decltype(X)::value;
-        load_stage(mt + 2 * SPLIT_BK, x ^ 1);
-        const unsigned char* As = cur;
-        const unsigned char* Bs = cur + P * BM * 64;
-        const int left = rows_left(mt + SPLIT_BK);
-        const bool a_col_ok = p0 + cq * 4 < Pn, b_col_ok = q0 + cq * 4 < Q;
-        const float scv[4] = {bsc.x, bsc.y, bsc.z, bsc.w}, shv[4] = {bsh.x, bsh.y, bsh.z, bsh.w};
-        float xq[4];
-        unsigned w0[P], w1[P];
-        auto slice = [&](auto SI) {
-            constexpr int si = decltype(SI)::value;
-            constexpr int NSL = 24;
-            if constexpr (si < NSL) {
-                constexpr int quad = si / 3, part = si % 3, opb = quad / 4, e = quad % 4;      // quads 0-3: A, 4-7: B
-                if constexpr (opb == 0) {
-                    if constexpr (part == 0) tn_quad_prepare<false>(xq, ra[x], e, p0 + cq * 4, 0, false, fa0[x], fa1[x], mq, 1.f, 0.f, 1.f, 0.f, left, a_col_ok, -1, 0u);
-                    else if constexpr (part == 1) tn_quad_split<P>(xq, w0, w1);
-                    else tn_quad_write<BM, P>(nxt, e, cq, mq, w0, w1);
-                } else if (BN == 128 || cq < BN / 4) {
-                    if constexpr (part == 0) tn_quad_prepare<BNIN>(xq, rb[x], e, q0 + cq * 4, sb.split, sb_active, fb0[x], fb1[x], mq, scv[e], shv[e], ib.neg, ib.hi, left, b_col_ok, -1, 0u);
-                    else if constexpr (part == 1) tn_quad_split<P>(xq, w0, w1);
-                    else tn_quad_write<BN, P>(nxt + P * BM * 64, e, cq, mq, w0, w1);
-                }
-            }
-        };
-        constexpr int PAIRS = 2 * TM * PRODUCTS * TN / 2;     // MFMA pairs of the stage: 24 (TN = 2) or 12 (TN = 1)
-        constexpr int SPP = 24 / PAIRS;                        // slices per pair
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 b[TN][P];
-#pragma unroll
-            for (int u = 0; u < TN; ++u)
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    b[u][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + p * (BN * 64) + foB[u][s]));
-#pragma unroll
-            for (int t = 0; t < TM; ++t) {
-                bf16x8 a[P];
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    a[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * (BM * 64) + foA[t][s]));
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < PRODUCTS; q += (TN == 2 ? 1 : 2)) {
-                    // one pair: (q, u = 0, 1) for 2-column-block waves, (q, q + 1) for single-block ones
-                    if constexpr (TN == 2) {
-                        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[SplitTerm<PRODUCTS>::pa(q)], b[0][SplitTerm<PRODUCTS>::pb(q)], acc[t][0], 0, 0, 0);
-                        acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[SplitTerm<PRODUCTS>::pa(q)], b[1][SplitTerm<PRODUCTS>::pb(q)], acc[t][1], 0, 0, 0);
-                    } else {
-                        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[SplitTerm<PRODUCTS>::pa(q)], b[0][SplitTerm<PRODUCTS>::pb(q)], acc[t][0], 0, 0, 0);
-                        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[SplitTerm<PRODUCTS>::pa(q + 1)], b[0][SplitTerm<PRODUCTS>::pb(q + 1)], acc[t][0], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int pair = ((s * TM + t) * PRODUCTS + q) / (TN == 2 ? 1 : 2);
-                    // `pair` is a compile-time value after unrolling; dispatch the slices through a constant switch
-#define TSII_TN_SL(V) if (pair * SPP + 0 == (V)) slice(std::integral_constant<int, (V)>{}); if (SPP == 2 && pair * SPP + 1 == (V)) slice(std::integral_constant<int, (V)>{})
-                    TSII_TN_SL(0); TSII_TN_SL(1); TSII_TN_SL(2); TSII_TN_SL(3); TSII_TN_SL(4); TSII_TN_SL(5); TSII_TN_SL(6); TSII_TN_SL(7);
-                    TSII_TN_SL(8); TSII_TN_SL(9); TSII_TN_SL(10); TSII_TN_SL(11); TSII_TN_SL(12); TSII_TN_SL(13); TSII_TN_SL(14); TSII_TN_SL(15);
-                    TSII_TN_SL(16); TSII_TN_SL(17); TSII_TN_SL(18); TSII_TN_SL(19); TSII_TN_SL(20); TSII_TN_SL(21); TSII_TN_SL(22); TSII_TN_SL(23);
-#undef TSII_TN_SL
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        lds_barrier();
-    };
-    int64_t mt = mbeg;
-    for (; mt < mend; mt += 2 * SPLIT_BK) {
-        step(mt, smem, smem + STAGE, std::integral_constant<int, 0>{});
-        if (mt + SPLIT_BK < mend) step(mt + SPLIT_BK, smem + STAGE, smem, std::integral_constant<int, 1>{});
-    }
-
-    float* Cz = Cws + (int64_t)zsplit * Pn * Q;
-#pragma unroll
-    for (int t = 0; t < TM; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int pp = p0 + (wm * TM + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (pp >= Pn) continue;
-#pragma unroll
-            for (int u = 0; u < TN; ++u) {
-                const int q = q0 + (wn * TN + u) * 32 + li;
-                if (q < Q) Cz[(int64_t)pp * Q + q] = acc[t][u][r];
-            }
-        }
-}
-
 // ---- mode switch --------------------------------------------------------------------------------------------
 // 0: f32-input MFMA (gemm.hip) | 6 (default): split-bf16, fp32 class | 3: split-bf16, 2 planes (opt-in)
 static int env_products() {
@@ -880,7 +713,6 @@ static int env_products() {
     return (v == 0 || v == 1 || v == 3 || v == 6 || v == 8) ? v : 6;
 }
 static thread_local int g_products = env_products();      // per calling thread (tsii_set_gemm_products)
-static int g_tn_pipe = getenv("TSII_GEMM_TN_PIPE") ? atoi(getenv("TSII_GEMM_TN_PIPE")) : 0;    // A/B knob: 1 = the software-pipelined TN kernel (K3t)
 static int g_abl = getenv("TSII_GEMM_ABL") ? atoi(getenv("TSII_GEMM_ABL")) : 0;     // tools/gemm_bench.py ablations only
 
 int gemm_products() { return g_products; }
@@ -1005,13 +837,6 @@ int launch_tn_split(const float* A, int64_t lda, const float* sa, const float* B
     TSII_REQUIRE(nblocks < (1ll << 31), "gemm_tn_split: grid too large");
     const dim3 grid((unsigned)nblocks);
     if (ib.sc != nullptr) TSII_REQUIRE(aligned16(ib.sc) && aligned16(ib.sh), "gemm_tn_split: input BatchNorm needs 16-byte aligned scale / shift");
-    if (g_tn_pipe && g_products == 6 && tile != 2) {      // software-pipelined form (K3t), 128-row tiles in the default arithmetic
-#define TSII_TN_PIPE(TNV, BNV) hipLaunchKernelGGL((gemm_tn_pipe_kernel<2, TNV, 6, BNV>), grid, dim3(256), 0, stream, A, lda, sa, B, ldb, sb, Cws, M, Pn, Q, chunk, ib, qt, pt)
-        if (ib.sc != nullptr) { if (tile == 0) TSII_TN_PIPE(2, true); else TSII_TN_PIPE(1, true); }
-        else { if (tile == 0) TSII_TN_PIPE(2, false); else TSII_TN_PIPE(1, false); }
-#undef TSII_TN_PIPE
-        return check_launch("gemm_tn_pipe");
-    }
 #define TSII_TN_SPLIT(TMV, TNV, PR, BNV) hipLaunchKernelGGL((gemm_tn_split_kernel<2, 2, TMV, TNV, PR, BNV>), grid, dim3(256), 0, stream, A, lda, sa, B, ldb, sb, Cws, M, Pn, Q, chunk, ib, qt, pt, kNoGather)
 #define TSII_TN_SPLIT_T(PR, BNV) do { if (tile == 0) TSII_TN_SPLIT(2, 2, PR, BNV); else if (tile == 1) TSII_TN_SPLIT(2, 1, PR, BNV); else TSII_TN_SPLIT(1, 1, PR, BNV); } while (0)
     if (ib.sc != nullptr) { if (g_products == 1) TSII_TN_SPLIT_T(1, true); else if (g_products == 8) TSII_TN_SPLIT_T(8, true); else if (g_products == 3) TSII_TN_SPLIT_T(3, true); else TSII_TN_SPLIT_T(6, true); }

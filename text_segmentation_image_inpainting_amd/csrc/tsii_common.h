@@ -235,10 +235,6 @@ template <int N, class A> __device__ __forceinline__ void async_wait(A& a) { asm
 template <int N, class A, class B> __device__ __forceinline__ void async_wait(A& a, B& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
 template <int N, class A, class B, class C, class D>
 __device__ __forceinline__ void async_wait(A& a, B& b, C& c, D& d) { asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory"); }
-// the same in two pieces, for a wait that releases many registers: one counted wait, then a zero-instruction pin per destination
-// (asm volatile statements keep their order; the pin makes every later use of the register depend on it)
-template <int N> __device__ __forceinline__ void async_wait_count() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-template <class A> __device__ __forceinline__ void async_pin(A& a) { asm volatile("" : "+v"(a)); }
 // block barrier for LDS traffic only: __syncthreads() also drains vmcnt, i.e. every load in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
 }  // namespace tsii

@@ -8,7 +8,7 @@
 # 4. per-entry-point / per-shape timing of one step              -> gpurun_out/<tag>_per_shape.log
 # Copy the outputs into profiles/ and commit them.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"; mkdir -p gpurun_out
 timeout 900 python bench.py > gpurun_out/${TAG}_bench_bs32.log 2>&1; tail -1 gpurun_out/${TAG}_bench_bs32.log | cut -c1-200
@@ -18,6 +18,13 @@ timeout 600 python bench.py --model TextSegament --batch 64 --pixel-shuffle --st
 timeout 600 python bench.py --model XceptionTextSegment --size 1024 --batch 8 --products 1 --steps 8 --warmup 2 --no-f32-leg 2>&1 | tail -1 > gpurun_out/${TAG}_bench_cfg5_xception1024_bf16.log
 timeout 600 python bench.py --model XceptionTextSegment --size 1024 --batch 8 --steps 8 --warmup 2 --no-f32-leg 2>&1 | tail -1 > gpurun_out/${TAG}_bench_cfg5_xception1024_fp32class.log
 timeout 300 python tools/microbench.py > gpurun_out/${TAG}_microbench.log 2>&1
+# evidence lines: the two Origin nets, the Bernoulli-mask stress variant, the step with the reference's full InpaintingLoss
+timeout 600 python bench.py --model ImageFillOrigin --batch 16 --steps 8 --warmup 2 --no-f32-leg --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${TAG}_bench_imagefillorigin_bs16.log
+timeout 600 python bench.py --model ImageFillOriginV2 --batch 16 --steps 8 --warmup 2 --no-f32-leg --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${TAG}_bench_imagefilloriginv2_bs16.log
+timeout 600 python bench.py --bernoulli-masks --steps 10 --warmup 3 --no-f32-leg --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${TAG}_bench_bernoulli_masks.log
+timeout 600 python tools/full_loss_step.py --batch 32 --size 512 --steps 5 2>&1 | tail -1 > gpurun_out/${TAG}_full_loss_step.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${TAG}_smoke.log 2>&1; tail -1 gpurun_out/${TAG}_smoke.log
+timeout 1800 python -m pytest tests -m gpu -q -s > gpurun_out/${TAG}_gputests.log 2>&1; tail -1 gpurun_out/${TAG}_gputests.log
 export TMPDIR=/tmp; cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof -o b32 --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-f32-leg > $R/gpurun_out/${TAG}_rocprof.log 2>&1; echo "rocprof stats rc=$?"
 cp $R/gpurun_out/${TAG}_prof/b32_kernel_stats.csv $R/gpurun_out/${TAG}_kernel_stats_bs32.csv
