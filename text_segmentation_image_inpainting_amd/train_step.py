@@ -1,13 +1,20 @@
-"""Single-node data-parallel training step for the inpainting nets.
+"""Single-node data-parallel training step for the inpainting and segmentation nets.
 
-One process per GPU.  Images of a minibatch are independent except for BatchNorm batch
-statistics, which the reference computes per process-local batch (no SyncBN), so the batch is
-sharded across ranks with replicated weights and ONE exchange per iteration: a sum all-reduce of
-the trainable gradients (RCCL over xGMI through ``torch.distributed``, backend "nccl"), packed in
-a single flat fp32 buffer (ImageFill: 6.5 M grads = 26 MB -- far below one xGMI link-second, so
-one large collective beats bucketing here).  The mean over ranks is folded into the loss scale.
-Frozen parameters (``mask_conv.weight``) never enter the buffer.  The update is the SGD-Nesterov
-the reference trained with (checkpoints/ReadME.md:4) as one fused HIP kernel over flat buffers.
+One process per GPU.  Images of a minibatch are independent except for BatchNorm batch statistics, which the reference computes
+per process-local batch (no SyncBN), so the batch is sharded across ranks with replicated weights and ONE kind of exchange per
+iteration: a sum all-reduce of the trainable gradients (RCCL over xGMI through ``torch.distributed``, backend "nccl").
+
+* All trainable parameters, their gradients and momentum buffers live in three flat fp32 buffers laid out in the order gradients
+  become ready in backward (reverse registration order), every slice on a 256-byte boundary.  Frozen parameters
+  (``mask_conv.weight``, a frozen encoder) never enter them.
+* The gradient buffer is cut into buckets (default 16 MB: ImageFill's 26 MB = 2, ImageFillOrigin / V2's 131 / 149 MB = 9 / 10).
+  With more than one rank a bucket's all-reduce starts asynchronously from ``post_accumulate_grad`` hooks as soon as its last
+  gradient exists, so the exchange overlaps the rest of backward; ``step()`` waits for what is outstanding (``exposed_ms`` measures
+  that wait) before the update.  A parameter that accumulates twice in one backward (shared across recomputed segments) takes its
+  bucket off the overlapped path for that step.  The mean over ranks is folded into the backward seed.
+* The update is the SGD-Nesterov the reference trained with (checkpoints/ReadME.md:4) as one fused HIP kernel over the flat
+  buffers; parameters without a gradient keep value and momentum, as under ``torch.optim.SGD``.
+* ``capture`` / ``step_graph`` replay forward + backward + packing (+ update on one GPU) from a HIP graph.
 """
 import torch
 import torch.distributed as dist
