@@ -2,12 +2,12 @@
 """Diagnostic behind tests/util.py:assert_gradients_close: for the ImageFill 64^2 train step, list the gradient tensors
 furthest from the oracle and test whether their error is (near) rank-1 = the contribution of single pixels whose activation
 sits on the other side of a LeakyReLU kink, as opposed to the dense error pattern of an inaccurate kernel.
-    python tools/kink_probe.py            (GPU box; the oracle runs on the host cores)
+    python tests/diag/kink_probe.py            (GPU box; the oracle runs on the host cores)
 """
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

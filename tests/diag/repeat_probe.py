@@ -3,11 +3,11 @@
 step into the next: workspaces, partial-sum buffers, cached operand planes)?  TextSegament(width_mult=2) on the 64x64 fixture input,
 decoder-side parameters trainable as in the recipe's stage 1; then the same with the weights nudged in between (what an optimizer
 step does) against a fresh model holding the nudged weights.
-    python tools/repeat_probe.py            (GPU box)"""
+    python tests/diag/repeat_probe.py            (GPU box)"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

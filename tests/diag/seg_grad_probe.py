@@ -3,13 +3,13 @@
 ONE forward + backward, every decoder-side gradient against the fp64 oracle in each arithmetic mode (6 = split bf16, 0 = f32
 MFMA): error relative to the tensor's largest entry AND relative to what decides an SGD update at lr 1e-4 (the recipe test's
 yardstick), with the rank structure of the error for the worst tensors.
-    python tools/seg_grad_probe.py            (GPU box; the oracle runs on the host cores)
+    python tests/diag/seg_grad_probe.py            (GPU box; the oracle runs on the host cores)
 """
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

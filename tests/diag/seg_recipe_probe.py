@@ -2,12 +2,12 @@
 """Diagnostic behind tests/test_training_recipe.py::test_segmentation_two_stage_recipe_gpu: the stage-1 loop step by step, the
 HIP recipe against the fp64 oracle loop -- per step the gradient error and the parameter error (relative to that step's update) of
 the tensors the test flags, so a deviation can be pinned to a step and to gradient vs optimizer.
-    python tools/seg_recipe_probe.py            (GPU box; the oracle runs on the host cores)
+    python tests/diag/seg_recipe_probe.py            (GPU box; the oracle runs on the host cores)
 """
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

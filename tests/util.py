@@ -50,7 +50,7 @@ def assert_gradients_close(errs, tol=2e-3, what="", pairs=None):
     layers around it by 1e-3 .. 1e-2 of their largest entry at test sizes (a few hundred pixels per channel), whereas a wrong
     kernel moves whole families of tensors.  Measured on ImageFill 64^2: every tensor within 7e-4 on the emulator; on the chip
     the same build had one tensor at 2.5e-3 .. 3.1e-3 -- a different tensor after unrelated upstream changes -- where the
-    oracle's own fp32-vs-fp64 distance was 3e-6 (no flip between its two runs).  ``tools/kink_probe.py`` on the chip
+    oracle's own fp32-vs-fp64 distance was 3e-6 (no flip between its two runs).  ``tests/diag/kink_probe.py`` on the chip
     (profiles/r02r_kink_probe.log): the three tensors beyond 2e-3 (6.3e-3, 3.1e-3, 2.5e-3: the 1x1 weight of one decoder block,
     the BatchNorm bias behind it, the stem bias) have an error matrix of rank 1 / a single-entry error vector -- 100.0 % of the
     Frobenius norm in the top singular value -- i.e. one pixel's contribution; the median over all 139 tensors is 5e-7.

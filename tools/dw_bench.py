@@ -27,4 +27,22 @@ for (n, h, w, c, s, d) in [(32, 256, 256, 384, 1, 1), (32, 128, 128, 768, 1, 1),
     nb = L.tsii_dw_bwd_dw_ws_bytes(n, ho, wo, c, 3, 3); w2 = torch.empty(nb // 4 + 4, device=dev); dwg = torch.empty_like(wt)
     tw = timeit(lambda: call("tsii_dw_bwd_dw", ptr(dy), ptr(inv), ptr(keep), ptr(x), ptr(m), n, h, w, c, *g, ho, wo, ptr(dwg), None, ptr(w2), nb, st))
     gb = (x.numel() + y.numel()) * 4 / 1e9
-    print(f"dw n{n} {h}x{w} c{c} s{s} d{d}: fwd {tf:6.3f} ms {gb / tf:5.2f} TB/s | dx {tb:6.3f} ms {gb / tb:5.2f} TB/s | dw {tw:6.3f} ms {gb / tw:5.2f} TB/s", flush=True)
+    # the BatchNorm-fused forms (K6b forward: BatchNorm + LeakyReLU on load and statistics partials; K6c dX: reductions of the
+    # BatchNorm backward of the tensor it feeds)
+    sc = torch.rand(c, device=dev) + 0.5; sh = torch.randn(c, device=dev)
+    rows = L.tsii_dw_stat_rows(n, ho, wo, c, 3, 3, s, s, d, d)
+    line = f"dw n{n} {h}x{w} c{c} s{s} d{d}: fwd {tf:6.3f} ms {gb / tf:5.2f} TB/s | dx {tb:6.3f} ms {gb / tb:5.2f} TB/s | dw {tw:6.3f} ms {gb / tw:5.2f} TB/s"
+    if rows > 0:
+        part = torch.empty(rows * 4 * c, device=dev)
+        tfb = timeit(lambda: call("tsii_dw_fwd_bn", ptr(x), ptr(m), ptr(wt), None, ptr(den), ptr(keep), n, h, w, c, *g, ho, wo, ptr(sc), ptr(sh), 2, 0.3,
+                                  ptr(part), ptr(y), ptr(ws), st))
+        line += f" | fwd_bn {tfb:6.3f} ms {gb / tfb:5.2f} TB/s"
+    brows = L.tsii_dw_bwd_stat_rows(n, h, w, c, 3, 3, s, s, d, d, d, d)
+    if brows > 0:
+        bpart = torch.empty(brows * 2 * c, device=dev)
+        mean = torch.randn(c, device=dev); var = torch.rand(c, device=dev) + 0.5; gam = torch.rand(c, device=dev) + 0.5; bet = torch.randn(c, device=dev)
+        tdb = timeit(lambda: call("tsii_dw_bwd_dx_bn", ptr(dy), ptr(inv), ptr(wt), ptr(m), n, h, w, c, *g, ho, wo, ptr(x), ptr(mean), ptr(var), ptr(gam), ptr(bet),
+                                  1e-5, 2, 0.3, ptr(dx), ptr(bpart), ptr(ws), st))
+        gb3 = gb + x.numel() * 4 / 1e9
+        line += f" | dx_bn {tdb:6.3f} ms {gb3 / tdb:5.2f} TB/s"
+    print(line, flush=True)
