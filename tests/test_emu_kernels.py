@@ -275,7 +275,7 @@ PC_THREADS = 768      # threads per block of the persistent producer / consumer 
 
 
 @pytest.mark.parametrize("M,K,N", [(768, 64, 256), (512, 40, 128), (512, 96, 384), (256, 32, 128), (1152, 160, 192), (1664, 72, 224), (2560, 128, 128),
-                                   (1280, 32, 256), (640, 224, 512)])
+                                   (1280, 32, 256), (640, 224, 512), (512, 256, 32)])
 def test_producer_consumer_gemm(emu, M, K, N):
     """K3p (gemm_pc.hip) at kernel level on the emulator (3 'CUs': several tiles per persistent block, more stages than
     LDS slots, k tails, column blocks past N, both tile shapes): forward with BatchNorm-on-load + statistics, dX with
@@ -312,7 +312,8 @@ def test_producer_consumer_gemm(emu, M, K, N):
                             P(part), P(y), P(wws), wws.nbytes, None) == 0, L.tsii_last_error()
     ref = (am @ w.T.astype(np.float64) / denom[:, None] + b) * keep[:, None]
     assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max()
-    assert raw.hipemu_launches(PC_THREADS) == before + 1
+    assert raw.hipemu_launches(PC_THREADS) == before + (1 if N >= 128 else 0)      # (512, 256, 32): forward on the 4-wave kernel, dX + K6c
+                                                                                   # = one-stage tiles of the persistent one
     # the statistics partials: per 128-row block (count, pivot, sum(y - pivot), sum((y - pivot)^2))
     y64 = y.astype(np.float64)
     for rb in range(rows):

@@ -99,6 +99,11 @@ __device__ __forceinline__ void pc_epilogue(f32x16 (&acc)[4], float* __restrict_
     // the row factors of a band are fetched from LDS one band ahead (read where they are used, each band started with a full LDS
     // round trip: 16 of them per tile and wave)
     float4 xq = *reinterpret_cast<const float4*>(sideX + 4 * hi), yq = *reinterpret_cast<const float4*>(sideY + 4 * hi);
+    float ynext[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BNB) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ynext[j] = *reinterpret_cast<const float*>(Yb + yoff + (unsigned)j * n4);
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -108,9 +113,14 @@ __device__ __forceinline__ void pc_epilogue(f32x16 (&acc)[4], float* __restrict_
             TSII_OPAQUE_U32(yoff);
             const int rb4 = t * 32 + 8 * g + 4 * hi;
             float yv[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (BNB) {     // raw BatchNorm input at the positions this lane stores
+            if constexpr (BNB) {     // raw BatchNorm input at the positions this lane stores, requested one band ahead (these
+                                     // layers are HBM-bound: 4 loads in flight per wave left the epilogue waiting on each band)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) yv[j] = *reinterpret_cast<const float*>(Yb + yoff + (unsigned)j * n4);
+                for (int j = 0; j < 4; ++j) yv[j] = ynext[j];
+                if (t * 4 + g < 15) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ynext[j] = *reinterpret_cast<const float*>(Yb + yoff + 8u * n4 + (unsigned)j * n4);
+                }
             }
             const float4 x4 = xq, y4 = yq;
             if (t * 4 + g < 15) {
@@ -546,6 +556,7 @@ static int pc_cus() {            // read-only device-properties cache
 static int g_pc = getenv("TSII_GEMM_PC") ? atoi(getenv("TSII_GEMM_PC")) : 1;              // A/B knob: 0 = 4-wave kernels only
 static int g_pc_opt = getenv("TSII_GEMM_PC_OPT") ? atoi(getenv("TSII_GEMM_PC_OPT")) : 0;   // wave priorities (kernel comment)
 static int g_pc_abl = getenv("TSII_GEMM_PC_ABL") ? atoi(getenv("TSII_GEMM_PC_ABL")) : 0;   // tools/pc_probe.py ablations only
+static int g_pc_bnb_min_k = getenv("TSII_GEMM_PC_BNB_MIN_K") ? atoi(getenv("TSII_GEMM_PC_BNB_MIN_K")) : 32;   // dX + K6c: shortest reduction the persistent kernel takes (one-stage tiles: 1.57 -> 1.45 ms on 2M x 32 -> 384 since the epilogue prefetches the BatchNorm input; 64 before)
 static int g_pc_min_n = getenv("TSII_GEMM_PC_MIN_N") ? atoi(getenv("TSII_GEMM_PC_MIN_N")) : 128;   // measured: 64-column outputs stay faster on the 4-wave kernel
 
 size_t nt_pc_ws_bytes(int n, int k) { return (size_t)3 * n * ((k + 31) & ~31) * sizeof(unsigned short) + 16; }
@@ -559,7 +570,7 @@ bool nt_pc_ok(const float* A, int64_t lda, const RowScale& as, int64_t M, int N,
     const bool dx = ep.cs.r0 != nullptr || ep.bn_y != nullptr;
     if (as.r0 != nullptr && as.r1 != nullptr && as.split % 8 != 0) return false;                                   // one row-scale factor per 8-k chunk
     if (dx && (ep.denom != nullptr || ep.keep != nullptr || ep.bias != nullptr || ep.stats != nullptr || ib.sc != nullptr)) return false;   // one epilogue mode at a time
-    if (ep.bn_y != nullptr && K < 64) return false;                                                               // one-stage tiles + the K6c epilogue: measured slower
+    if (ep.bn_y != nullptr && K < g_pc_bnb_min_k) return false;                                                   // (A/B knob)
     if (ib.sc != nullptr && K > 1024) return false;                                                               // (scale, shift) live in LDS
     if ((int64_t)3 * N * ((K + 31) & ~31) * 2 >= (1ll << 31)) return false;
     return true;
