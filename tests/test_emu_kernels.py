@@ -275,7 +275,7 @@ PC_THREADS = 768      # threads per block of the persistent producer / consumer 
 
 
 @pytest.mark.parametrize("M,K,N", [(768, 64, 256), (512, 40, 128), (512, 96, 384), (256, 32, 128), (1152, 160, 192), (1664, 72, 224), (2560, 128, 128),
-                                   (1280, 32, 256), (640, 224, 512), (512, 256, 32)])
+                                   (1280, 32, 256), (640, 224, 512), (512, 256, 32), (512, 256, 48)])
 def test_producer_consumer_gemm(emu, M, K, N):
     """K3p (gemm_pc.hip) at kernel level on the emulator (3 'CUs': several tiles per persistent block, more stages than
     LDS slots, k tails, column blocks past N, both tile shapes): forward with BatchNorm-on-load + statistics, dX with
@@ -336,11 +336,15 @@ def test_producer_consumer_gemm(emu, M, K, N):
     rdx[:, split:] *= r1[:, None]
     dx = np.zeros((M, K), np.float32)
     wt = np.zeros(L.tsii_pw_ws_bytes(N, K) // 4 + 4, np.float32)
+    # dX runs on W^T: its tiled planes pad the reduction (N here) to 32 -- (512, 256, 48) is the shape that once overran this buffer
+    assert wt.nbytes >= 3 * K * ((N + 31) // 32 * 32) * 2
+    guard = wt[-2:].copy()
     before = raw.hipemu_launches(PC_THREADS)
     assert L.tsii_pw_bwd_dx(P(dy), M, N, P(w), K, P(inv), P(r0), split, P(r1), P(dx), P(wt), None) == 0, L.tsii_last_error()
     pc_dx = raw.hipemu_launches(PC_THREADS) - before          # dX has K output columns: whole 32-blocks, at least 128
     assert pc_dx == (1 if (K >= 128 and K % 32 == 0) else 0)
     assert np.abs(dx - rdx).max() <= 1e-5 * np.abs(rdx).max()
+    assert np.array_equal(wt[-2:], guard)              # nothing written past the size tsii_pw_ws_bytes asked for
     if K % 4 == 0:
         mean = x.astype(np.float64).mean(0).astype(np.float32)
         var = x.astype(np.float64).var(0).astype(np.float32)
@@ -358,3 +362,33 @@ def test_producer_consumer_gemm(emu, M, K, N):
         s2 = bpart[:, 1].astype(np.float64).sum(0)
         assert np.abs(s1 - dz.sum(0)).max() <= 2e-5 * np.abs(dz).sum(0).max()
         assert np.abs(s2 - (dz * xh).sum(0)).max() <= 2e-5 * np.abs(dz * xh).sum(0).max()
+
+
+def test_split_modes_non_finite_operands(emu):
+    """Range caveat of the split-bf16 arithmetic (include/tsii_hip.h): an operand that is inf, or finite but beyond the largest
+    bf16, splits into (inf, NaN, NaN), so the affected output row is NaN where the f32 MFMA mode gives +-inf (or NaN from
+    inf * 0).  Either way the row is lost and every OTHER row is untouched -- that is what this pins."""
+    L = emu
+    rng = np.random.default_rng(77)
+    M, K, N = 256, 64, 128
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = rng.standard_normal((N, K)).astype(np.float32)
+    x[5, 3] = np.inf
+    x[9, 7] = 3.4e38                  # finite in fp32, rounds to inf in bf16
+    ref = np.delete(x, [5, 9], axis=0).astype(np.float64) @ w.T.astype(np.float64)
+    try:
+        for mode in (0, 6):
+            assert L.tsii_set_gemm_products(mode) == 0
+            y = np.zeros((M, N), np.float32)
+            wws = np.zeros(L.tsii_pw_ws_bytes(N, K) // 4 + 4, np.float32)
+            assert L.tsii_pw_fwd(P(x), M, K, P(w), N, None, None, 0, None, None, None, P(y), P(wws), wws.nbytes, None) == 0, L.tsii_last_error()
+            assert not np.isfinite(y[5]).any(), mode                         # the row holding inf: inf or NaN everywhere
+            if mode == 6:
+                assert not np.isfinite(y[9]).any()                           # beyond the bf16 range: lost in the split modes only
+            else:
+                assert np.isfinite(y[9]).all() or np.isinf(y[9]).any()
+            rest = np.delete(y, [5, 9], axis=0)
+            assert np.isfinite(rest).all()
+            assert np.abs(rest - ref).max() <= 1e-5 * np.abs(ref).max()
+    finally:
+        L.tsii_set_gemm_products(6)

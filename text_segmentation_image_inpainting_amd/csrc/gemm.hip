@@ -625,8 +625,11 @@ extern "C" int tsii_pw_fwd(const float* x, int64_t m, int k, const float* w, int
 
 extern "C" size_t tsii_pw_ws_bytes(int n, int k) {   // weight workspace of pw_fwd[_bn] (optional) and pw_bwd_dx[_bn] (wt_ws)
     if (n <= 0 || k <= 0) return 0;
-    const size_t a = (size_t)n * k * sizeof(float), b = nt_split_ws_bytes(n, k), c = nt_pc_ws_bytes(n, k);
-    return a > b ? (a > c ? a : c) : (b > c ? b : c);
+    // forward: planes of W as [n][k]; dX: of W^T as [k][n] -- the tiled planes of the persistent kernel pad the REDUCTION dimension
+    // to 32, so the two orientations differ whenever n or k is not a multiple of 32 (found on TextSegament: 48-channel layers)
+    const size_t a = (size_t)n * k * sizeof(float), b = nt_split_ws_bytes(n, k), c = nt_pc_ws_bytes(n, k), d = nt_pc_ws_bytes(k, n);
+    const size_t ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
 }
 
 extern "C" int64_t tsii_pw_stat_rows(int64_t m) { return m > 0 ? cdiv64(m, 128) : 0; }   // every NT tile variant has BM = 128
