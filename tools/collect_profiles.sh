@@ -8,6 +8,7 @@
 # 4. per-entry-point / per-shape timing of one step              -> gpurun_out/<tag>_per_shape.log
 # Copy the outputs into profiles/ and commit them.
 set -u
+ulimit -c 0      # a faulting 70 GiB process must not fill the box with its core file
 TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"; mkdir -p gpurun_out
