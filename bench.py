@@ -69,6 +69,11 @@ def _upcat(a, bwd):  # (n, h, w, c1, c2): low [n,h,w,c1] + skip [n,2h,2w,c2] <->
     return 4.0 * n * h * w * (c1 + 4 * c2 + 4 * (c1 + c2)), 0.0
 
 
+def _headcat(a, io_in, io_out):
+    c1, c2, n, h, w, cout = a[:6]
+    return 4.0 * n * (io_in * (h * w // 4 * c1 + h * w * c2) + io_out * h * w * cout), float(n) * h * w * cout * (c1 + c2) * 9
+
+
 CALLS = {
     "tsii_pw_fwd": ("gemm_nt", _pw), "tsii_pw_fwd_bn": ("gemm_nt", _pw),
     "tsii_pw_bwd_dx": ("gemm_nt", lambda a: _pw((a[0], a[1], a[2]))),
@@ -84,6 +89,9 @@ CALLS = {
     "tsii_dense_fwd": ("dense_conv", lambda a: _dense(a[1:], 1, 0, 0, 1)), "tsii_dense_fwd_bn": ("dense_conv", lambda a: _dense(a[1:], 1, 0, 0, 1)),
     "tsii_dense_bwd_dx": ("dense_conv", lambda a: _dense(a[1:], 0, 1, 1, 0)),
     "tsii_dense_bwd_dw": ("dense_conv", lambda a: _dense(a[1:], 1, 1, 0, 0)),
+    # K4c head over the virtual concatenation: (c1, c2, n, h, w, cout, ...): low [n,h/2,w/2,c1] + skip [n,h,w,c2] <-> y [n,h,w,cout]
+    "tsii_head_cat_fwd": ("dense_conv", lambda a: _headcat(a, 1, 1)), "tsii_head_cat_bwd_dx": ("dense_conv", lambda a: _headcat(a, 1, 1)),
+    "tsii_head_cat_bwd_dw": ("dense_conv", lambda a: _headcat(a, 1, 1)),
     "tsii_upcat_fwd": ("upcat", lambda a: _upcat(a, False)), "tsii_upcat_bwd": ("upcat", lambda a: _upcat(a, True)),
 }
 BOUND = {"gemm_nt": None, "gemm_tn": None, "dense_conv": "mfma", "dw_stencil": "hbm", "bn_act": "hbm", "bn_bwd": "hbm", "upcat": "hbm"}

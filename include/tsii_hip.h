@@ -149,6 +149,24 @@ int tsii_dense_bwd_dw(const float* dy, const float* inv, const float* keep, cons
                       int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo,
                       float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- K4c: the decoder's last level without its concatenated tensor: 3x3 / stride 1 / pad 1 PartialConv with <= 4 output
+ * channels over cat(nearest-x2(low [n,h/2,wd/2,c1]), skip [n,h,wd,c2])  (DoubleUpSample + torch.cat + the 35 -> 3 output layer,
+ * models/partial_convolution.py:224-231, models/image_inpainting.py:82-86).  r0 / r1: mask planes [n,h,wd] of the two parts
+ * (NULL = ones; the x*mask split is the concat boundary c1), denom / keep / inv as for tsii_dense_*.  Equal to
+ * tsii_upcat_fwd + tsii_dense_fwd (and tsii_dense_bwd_dx + tsii_upcat_bwd, tsii_dense_bwd_dw) to rounding.
+ * tsii_head_cat_ok() != 0: this geometry has the fused kernels (h, wd even, c1 % 4 == 0, 20 < c1 + c2 <= 68, cout <= 4).
+ * ws: tsii_dense_ws_bytes(c1 + c2, cout, 3, 3) (fwd, bwd_dx) / tsii_dense_bwd_dw_ws_bytes(n, h, wd, c1 + c2, cout, 3, 3) (bwd_dw).
+ * dskip may be NULL (the skip is a data tensor). */
+int tsii_head_cat_ok(int n, int h, int wd, int c1, int c2, int cout);
+int tsii_head_cat_fwd(const float* low, const float* skip, int c1, int c2, const float* r0, const float* r1,
+                      const float* w, const float* bias, const float* denom, const float* keep,
+                      int n, int h, int wd, int cout, float* y, void* ws, size_t ws_bytes, void* stream);
+int tsii_head_cat_bwd_dx(const float* dy, const float* inv, const float* w, int c1, int c2, const float* r0, const float* r1,
+                         int n, int h, int wd, int cout, float* dlow, float* dskip, void* ws, size_t ws_bytes, void* stream);
+int tsii_head_cat_bwd_dw(const float* dy, const float* inv, const float* keep, const float* low, const float* skip,
+                         int c1, int c2, const float* r0, const float* r1, int n, int h, int wd, int cout,
+                         float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- K4b: stems (odd k, stride 2, pad (k-1)/2, very few input channels; models/image_inpainting.py:23) as a stride-1
  * valid convolution over the space-to-depth image, so they run on the vector-gather implicit GEMM:
  *   tsii_stem_s2d:   x [n,h,w,c] * mask (mfull, or the r0/split/r1 planes, or none) zero-padded by `pad`

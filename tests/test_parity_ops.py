@@ -471,3 +471,39 @@ def test_imagefill_full_size_properties_gpu():
             tr.reduce_gradients()
             grads.append(tr.flat_grad.clone())
         assert torch.equal(grads[0], grads[1])
+
+
+@both_backends
+@pytest.mark.parametrize("n,h,w,c1,c2,cout,premult", [(2, 12, 40, 32, 3, 3, False), (1, 18, 34, 24, 4, 4, True), (2, 16, 16, 64, 3, 3, True),
+                                                       (1, 8, 66, 32, 3, 2, False)])
+def test_head_over_virtual_concat(backend, n, h, w, c1, c2, cout, premult):
+    """K4c: the 3x3 output head over cat(nearest-x2(low), skip) WITHOUT the concatenated tensor (tsii_head_cat_*) against the
+    same head over the materialised concatenation (tsii_upcat_fwd + tsii_dense_*): output, d low, d skip, dW, dbias; two mask
+    planes with holes (or a pre-multiplied skip part, as at ImageFill's input level), maps that are not tile multiples."""
+    from text_segmentation_image_inpainting_amd import ops
+    rng = np.random.default_rng(n * 1000 + h * 10 + w + c1)
+    with BACKENDS[backend]() as dev:
+        low = torch.from_numpy(rng.standard_normal((n, h // 2, w // 2, c1)).astype(np.float32)).to(dev)
+        skip = torch.from_numpy(rng.standard_normal((n, h, w, c2)).astype(np.float32)).to(dev)
+        wt = torch.from_numpy((rng.standard_normal((cout, c1 + c2, 3, 3)) * 0.2).astype(np.float32)).to(dev)
+        bias = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(dev)
+        r0 = torch.from_numpy((rng.uniform(size=(n, h, w)) > 0.3).astype(np.float32)).to(dev)
+        r1 = None if premult else torch.from_numpy((rng.uniform(size=(n, h, w)) > 0.3).astype(np.float32)).to(dev)
+        g = ops.make_geom((3, 3), (1, 1), (1, 1), (1, 1))
+        p1 = r1 if r1 is not None else torch.ones_like(r0)
+        denom, new_mask, inv = ops.mask_update(r0, float(c1), p1, float(c2), g, 1.0, True)
+        gy = torch.from_numpy(rng.standard_normal((n, h, w, cout)).astype(np.float32)).to(dev)
+        res = []
+        for fused in (True, False):
+            a, b = low.clone().requires_grad_(True), skip.clone().requires_grad_(True)
+            ww, bb = wt.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+            if fused:
+                vc = ops.VirtualCat(a, b)
+                assert ops.head_cat_ok(vc, cout, g)
+                y = ops.pconv_head_cat(vc, ww, bb, r0, r1, denom, new_mask, inv)
+            else:
+                y = ops.pconv_dense(ops.upcat(a, b), ww, bb, None, r0, c1, r1, denom, new_mask, inv, g)
+            y.backward(gy)
+            res.append((y.detach(), a.grad, b.grad, ww.grad, bb.grad))
+        for name, u, v in zip(("y", "d low", "d skip", "dW", "dbias"), *res):
+            assert_close(u, v, 2e-6, f"head over virtual concat: {name}", floor=1e-6)

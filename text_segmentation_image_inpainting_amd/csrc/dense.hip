@@ -426,9 +426,19 @@ __device__ __forceinline__ int fdiv_small(int e, int d, float inv_d) {
     return q;
 }
 
+// K4c: the head's input as a VIRTUAL concatenation cat(nearest-x2(low [n,h/2,w/2,c1]), skip [n,h,w,c2]) -- the decoder's last
+// DoubleUpSample + torch.cat (models/image_inpainting.py:82-85) is never written: the patch is staged straight from the two
+// tensors (16-byte loads for the c1 % 4 == 0 up-sampled channels, 4x fewer bytes than the concatenated tensor), the mask split
+// is the concat boundary.  low == nullptr: plain input x.
+struct HeadCat {
+    const float* low;
+    const float* skip;
+    int c1, c2;
+};
+
 template <int CG>
 __device__ __forceinline__ void head_stage(float* __restrict__ tile, float* __restrict__ side, const float* __restrict__ x,
-                                           const RowScale& rs, const ConvGeom& g, int64_t n, int iy0, int ix0) {
+                                           const HeadCat& cat, const RowScale& rs, const ConvGeom& g, int64_t n, int iy0, int ix0) {
     using H = Head<CG>;
     const int tid = threadIdx.x, nt = blockDim.x;
     // 1. the two mask planes of the patch; pad channels of every pixel are zero
@@ -446,6 +456,59 @@ __device__ __forceinline__ void head_stage(float* __restrict__ tile, float* __re
         for (int c = g.cin; c < H::CP; ++c) tile[p * H::CP + c] = 0.f;
     }
     __syncthreads();
+    if (cat.low != nullptr) {
+        // 2a. up-sampled part: element e = (patch pixel p, channel quad q) <- low pixel (iy >> 1, ix >> 1), times plane 0
+        const int q1 = cat.c1 >> 2, h2 = g.h >> 1, w2 = g.w >> 1;
+        const float inv_q1 = 1.0f / (float)q1;
+        const int tot1 = H::NPIX * q1;
+        for (int e0 = tid; e0 < tot1; e0 += nt * 4) {
+            float4 v[4];
+            int dst[4], pp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * nt;
+                const int p = fdiv_small(e, q1, inv_q1);
+                const int q = e - p * q1;
+                const int py = p / H::PW, px = p - py * H::PW;
+                const int iy = iy0 + py, ix = ix0 + px;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                dst[u] = p * H::CP + q * 4;
+                pp[u] = p;
+                if (e < tot1 && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w)
+                    v[u] = *reinterpret_cast<const float4*>(cat.low + ((n * h2 + (iy >> 1)) * w2 + (ix >> 1)) * cat.c1 + q * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + u * nt < tot1) {
+                    const float m = side[pp[u]];
+                    *reinterpret_cast<float4*>(tile + dst[u]) = make_float4(v[u].x * m, v[u].y * m, v[u].z * m, v[u].w * m);
+                }
+        }
+        // 2b. skip part: element e = (patch pixel p, channel ci of c2), times plane 1
+        const int tot2 = H::NPIX * cat.c2;
+        const float inv_c2 = 1.0f / (float)cat.c2;
+        for (int e0 = tid; e0 < tot2; e0 += nt * 4) {
+            float v[4];
+            int dst[4], pp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * nt;
+                const int p = fdiv_small(e, cat.c2, inv_c2);
+                const int ci = e - p * cat.c2;
+                const int py = p / H::PW, px = p - py * H::PW;
+                const int iy = iy0 + py, ix = ix0 + px;
+                v[u] = 0.f;
+                dst[u] = p * H::CP + cat.c1 + ci;
+                pp[u] = p;
+                if (e < tot2 && iy >= 0 && iy < g.h && ix >= 0 && ix < g.w)
+                    v[u] = cat.skip[((n * g.h + iy) * g.w + ix) * cat.c2 + ci];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + u * nt < tot2) tile[dst[u]] = v[u] * side[H::NPIX + pp[u]];
+        }
+        return;
+    }
     // 2. x * mask: element e = (patch pixel p, channel ci); a patch row is one contiguous run of the NHWC tensor
     const int total = H::NPIX * g.cin;
     const float inv_cin = 1.0f / (float)g.cin;
@@ -492,7 +555,7 @@ __global__ void head_prep_dx_kernel(const float* __restrict__ w, int cin, int co
 }
 
 template <int CG, int NCO>
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, RowScale rs, const float* __restrict__ w4,
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, HeadCat cat, RowScale rs, const float* __restrict__ w4,
                                                        const float* __restrict__ bias, const float* __restrict__ denom,
                                                        const float* __restrict__ keep, ConvGeom g, float* __restrict__ y) {
     using H = Head<CG>;
@@ -500,7 +563,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     __shared__ __attribute__((aligned(16))) float side[H::SIDE];
     const int64_t n = blockIdx.z;
     const int oy0 = blockIdx.y * H::TH, ox0 = blockIdx.x * H::TW;
-    head_stage<CG>(tile, side, x, rs, g, n, oy0 - g.ph, ox0 - g.pw);
+    head_stage<CG>(tile, side, x, cat, rs, g, n, oy0 - g.ph, ox0 - g.pw);
     __syncthreads();
     constexpr int SPLIT = 256 / H::NPX;             // waves sharing a pixel (TW 16): each takes every SPLIT-th group
     const int pixl = threadIdx.x % H::NPX;
@@ -562,7 +625,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 // FMAs -- LDS-issue bound at 9 % of the HBM roofline, 2.4 ms for ImageFill's 35 -> 3 head.)
 template <int CG, int NCO>
 __global__ __launch_bounds__(320) void head_dw_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
-                                                      const float* __restrict__ x, RowScale rs, ConvGeom g,
+                                                      const float* __restrict__ x, HeadCat cat, RowScale rs, ConvGeom g,
                                                       int tiles_per_block, float* __restrict__ part) {
     using H = Head<CG>;
     __shared__ __attribute__((aligned(16))) float tile[H::TILE];
@@ -597,7 +660,7 @@ __global__ __launch_bounds__(320) void head_dw_kernel(const float* __restrict__ 
             }
         }
         __syncthreads();                               // previous tile fully consumed
-        head_stage<CG>(tile, side, x, rs, g, n, oy0 - g.ph, ox0 - g.pw);
+        head_stage<CG>(tile, side, x, cat, rs, g, n, oy0 - g.ph, ox0 - g.pw);
         __syncthreads();                               // patch ready, mask planes dead
         if (threadIdx.x < H::NPX) *reinterpret_cast<float4*>(side + threadIdx.x * 4) = make_float4(gv[0], gv[1], gv[2], gv[3]);
         __syncthreads();
@@ -652,7 +715,7 @@ __global__ __launch_bounds__(320) void head_dw_kernel(const float* __restrict__ 
 template <int CG, int NCO>
 __global__ __launch_bounds__(256) void head_dx_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
                                                       const float* __restrict__ wd, RowScale rs, ConvGeom g,
-                                                      float* __restrict__ dx) {
+                                                      float* __restrict__ dx, float* __restrict__ dlow, float* __restrict__ dskip, int c1) {
     using H = Head<CG>;
     constexpr int SPLIT = 256 / H::NPX;
     constexpr int CGT = (CG + SPLIT - 1) / SPLIT;     // channel groups per thread
@@ -713,6 +776,36 @@ __global__ __launch_bounds__(256) void head_dx_kernel(const float* __restrict__ 
         if (cg0 + j < CG)
             *reinterpret_cast<float4*>(outt + pixl * H::CP + (cg0 + j) * 4) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
     __syncthreads();
+    if (dx == nullptr) {
+        // K4c: the gradient of the virtual concatenation leaves as its two pieces -- d skip [n,h,w,c2] (if wanted) and
+        // d low [n,h/2,w/2,c1] = the sum over the 2x2 pixels a low-resolution pixel was copied to (tiles start on even rows / columns)
+        const int c2 = g.cin - c1;
+        if (dskip != nullptr) {
+            for (int e = threadIdx.x; e < H::NPX * c2; e += 256) {
+                const int p = e / c2, ci = e - p * c2;
+                const int iy = iy0 + p / H::TW, ix = ix0 + p % H::TW;
+                if (iy < g.h && ix < g.w) dskip[((n * g.h + iy) * g.w + ix) * c2 + ci] = outt[p * H::CP + c1 + ci] * mk[H::NPX + p];
+            }
+        }
+        const int h2 = g.h >> 1, w2 = g.w >> 1, q1 = c1 >> 2;
+        constexpr int LW = H::TW / 2, LH = H::TH / 2;
+        for (int e = threadIdx.x; e < LH * LW * q1; e += 256) {
+            const int q = e % q1, lp = e / q1;
+            const int lx = lp % LW, ly = lp / LW;
+            const int gy = (iy0 >> 1) + ly, gx = (ix0 >> 1) + lx;
+            if (gy >= h2 || gx >= w2) continue;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int p = (2 * ly + (d >> 1)) * H::TW + 2 * lx + (d & 1);
+                const float4 v = *reinterpret_cast<const float4*>(outt + p * H::CP + q * 4);
+                const float m = mk[p];
+                a.x = fmaf(v.x, m, a.x); a.y = fmaf(v.y, m, a.y); a.z = fmaf(v.z, m, a.z); a.w = fmaf(v.w, m, a.w);
+            }
+            *reinterpret_cast<float4*>(dlow + ((n * h2 + gy) * w2 + gx) * c1 + q * 4) = a;
+        }
+        return;
+    }
     // write-out: tile row ty = one contiguous run of min(TW, w - ix0) * cin floats
     const int vw = g.w - ix0 < H::TW ? g.w - ix0 : H::TW;
     const int run = vw * g.cin;
@@ -800,6 +893,50 @@ static DdPlan plan_dd(const ConvGeom& g) {
     return p;
 }
 
+// the three head launches, shared by the dense entry points (plain input x) and the K4c ones (virtual concatenation)
+static int launch_head_fwd(const float* x, const HeadCat& cat, const RowScale& rsh, const float* w, const float* bias, const float* denom,
+                           const float* keep, const ConvGeom& g, int hcg, float* wf, float* y, hipStream_t st) {
+    hipLaunchKernelGGL(head_prep_fwd_kernel, dim3(cdiv(9 * hcg * 16, 256)), dim3(256), 0, st, w, g.cin, g.cout, hcg, wf);
+    int rch = check_launch("head_prep_fwd");
+    if (rch) return rch;
+    const dim3 grid(cdiv(g.wo, hcg == 9 ? 32 : 16), cdiv(g.ho, 8), g.n);
+    if (hcg == 9 && g.cout <= 3) hipLaunchKernelGGL((head_fwd_kernel<9, 3>), grid, dim3(256), 0, st, x, cat, rsh, wf, bias, denom, keep, g, y);
+    else if (hcg == 9) hipLaunchKernelGGL((head_fwd_kernel<9, 4>), grid, dim3(256), 0, st, x, cat, rsh, wf, bias, denom, keep, g, y);
+    else if (g.cout <= 3) hipLaunchKernelGGL((head_fwd_kernel<17, 3>), grid, dim3(256), 0, st, x, cat, rsh, wf, bias, denom, keep, g, y);
+    else hipLaunchKernelGGL((head_fwd_kernel<17, 4>), grid, dim3(256), 0, st, x, cat, rsh, wf, bias, denom, keep, g, y);
+    return check_launch("head_fwd");
+}
+static int launch_head_dx(const float* dy, const float* inv, const float* w, const RowScale& rsh, const ConvGeom& g, int hcg, float* wb,
+                          float* dx, float* dlow, float* dskip, int c1, hipStream_t st) {
+    hipLaunchKernelGGL(head_prep_dx_kernel, dim3(cdiv(9 * 4 * hcg * 4, 256)), dim3(256), 0, st, w, g.cin, g.cout, hcg * 4, wb);
+    int rch = check_launch("head_prep_dx");
+    if (rch) return rch;
+    const dim3 grid(cdiv(g.w, hcg == 9 ? 32 : 16), cdiv(g.h, 8), g.n);
+    if (hcg == 9 && g.cout <= 3) hipLaunchKernelGGL((head_dx_kernel<9, 3>), grid, dim3(256), 0, st, dy, inv, wb, rsh, g, dx, dlow, dskip, c1);
+    else if (hcg == 9) hipLaunchKernelGGL((head_dx_kernel<9, 4>), grid, dim3(256), 0, st, dy, inv, wb, rsh, g, dx, dlow, dskip, c1);
+    else if (g.cout <= 3) hipLaunchKernelGGL((head_dx_kernel<17, 3>), grid, dim3(256), 0, st, dy, inv, wb, rsh, g, dx, dlow, dskip, c1);
+    else hipLaunchKernelGGL((head_dx_kernel<17, 4>), grid, dim3(256), 0, st, dy, inv, wb, rsh, g, dx, dlow, dskip, c1);
+    return check_launch("head_dx");
+}
+static int launch_head_dw(const float* dy, const float* inv, const float* keep, const float* x, const HeadCat& cat, const RowScale& rs,
+                          const ConvGeom& g, int hcg, float* part, float* dwgt, float* dbias, hipStream_t st) {
+    int tpb = 0;
+    const int blocks = head_dw_blocks(g, hcg == 9 ? 32 : 16, &tpb);
+    if (hcg == 9 && g.cout <= 3) hipLaunchKernelGGL((head_dw_kernel<9, 3>), dim3(blocks), dim3(320), 0, st, dy, inv, x, cat, rs, g, tpb, part);
+    else if (hcg == 9) hipLaunchKernelGGL((head_dw_kernel<9, 4>), dim3(blocks), dim3(320), 0, st, dy, inv, x, cat, rs, g, tpb, part);
+    else if (g.cout <= 3) hipLaunchKernelGGL((head_dw_kernel<17, 3>), dim3(blocks), dim3(320), 0, st, dy, inv, x, cat, rs, g, tpb, part);
+    else hipLaunchKernelGGL((head_dw_kernel<17, 4>), dim3(blocks), dim3(320), 0, st, dy, inv, x, cat, rs, g, tpb, part);
+    int rch = check_launch("head_dw");
+    if (rch) return rch;
+    const int64_t lenh = (int64_t)g.cout * g.cin * 9;
+    rch = launch_reduce_rows(part, blocks, lenh, dwgt, st);
+    if (rch) return rch;
+    if (dbias != nullptr)
+        rch = launch_colsum_scaled(dy, keep, (int64_t)g.n * g.ho * g.wo, g.cout, dbias, part + (size_t)blocks * lenh, st);
+    return rch;
+}
+static const HeadCat kNoCat = {nullptr, nullptr, 0, 0};
+
 }  // namespace tsii
 
 using namespace tsii;
@@ -831,16 +968,8 @@ static int dense_fwd_impl(const float* x, const float* mfull, const float* r0, i
     TSII_REQUIRE(stats == nullptr || (head_cg(g, mfull) == 0 && !plan_small(g).ok && use_conv_gemm(g, mfull, x, y, ws)),
                  "dense_fwd_bn: statistics partials need the implicit-GEMM path (tsii_dense_stat_rows() > 0, aligned operands)");
     if (const int hcg = head_cg(g, mfull)) {       // 3x3 few-output-channel head
-        hipLaunchKernelGGL(head_prep_fwd_kernel, dim3(cdiv(9 * hcg * 16, 256)), dim3(256), 0, st, w, cin, cout, hcg, wf);
-        int rch = check_launch("head_prep_fwd");
-        if (rch) return rch;
         const RowScale rsh = {r0, r1, split};
-        const dim3 grid(cdiv(wo, hcg == 9 ? 32 : 16), cdiv(ho, 8), n);
-        if (hcg == 9 && cout <= 3) hipLaunchKernelGGL((head_fwd_kernel<9, 3>), grid, dim3(256), 0, st, x, rsh, wf, bias, denom, keep, g, y);
-        else if (hcg == 9) hipLaunchKernelGGL((head_fwd_kernel<9, 4>), grid, dim3(256), 0, st, x, rsh, wf, bias, denom, keep, g, y);
-        else if (cout <= 3) hipLaunchKernelGGL((head_fwd_kernel<17, 3>), grid, dim3(256), 0, st, x, rsh, wf, bias, denom, keep, g, y);
-        else hipLaunchKernelGGL((head_fwd_kernel<17, 4>), grid, dim3(256), 0, st, x, rsh, wf, bias, denom, keep, g, y);
-        return check_launch("head_fwd");
+        return launch_head_fwd(x, kNoCat, rsh, w, bias, denom, keep, g, hcg, wf, y, st);
     }
     const SmallPlan sp = plan_small(g);
     if (sp.ok && cdiv(ho, DS_TH) <= 65535 && n <= 65535) {
@@ -919,16 +1048,8 @@ extern "C" int tsii_dense_bwd_dx(const float* dy, const float* inv, const float*
     const int cinp = pad4(cin), T = kh * kw;
     float* wb = (float*)ws;
     if (const int hcg = head_cg(g, mfull)) {       // 3x3 few-output-channel head
-        hipLaunchKernelGGL(head_prep_dx_kernel, dim3(cdiv(9 * 4 * hcg * 4, 256)), dim3(256), 0, st, w, cin, cout, hcg * 4, wb);
-        int rch = check_launch("head_prep_dx");
-        if (rch) return rch;
         const RowScale rsh = {r0, r1, split};
-        const dim3 grid(cdiv(wd, hcg == 9 ? 32 : 16), cdiv(h, 8), n);
-        if (hcg == 9 && cout <= 3) hipLaunchKernelGGL((head_dx_kernel<9, 3>), grid, dim3(256), 0, st, dy, inv, wb, rsh, g, dx);
-        else if (hcg == 9) hipLaunchKernelGGL((head_dx_kernel<9, 4>), grid, dim3(256), 0, st, dy, inv, wb, rsh, g, dx);
-        else if (cout <= 3) hipLaunchKernelGGL((head_dx_kernel<17, 3>), grid, dim3(256), 0, st, dy, inv, wb, rsh, g, dx);
-        else hipLaunchKernelGGL((head_dx_kernel<17, 4>), grid, dim3(256), 0, st, dy, inv, wb, rsh, g, dx);
-        return check_launch("head_dx");
+        return launch_head_dx(dy, inv, w, rsh, g, hcg, wb, dx, nullptr, nullptr, 0, st);
     }
     if (use_conv_gemm_dx(g, mfull, dy, dx, ws)) {
         const ConvGemmGeom cgp = {n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo};
@@ -980,20 +1101,7 @@ extern "C" int tsii_dense_bwd_dw(const float* dy, const float* inv, const float*
     RowScale rs = {r0, r1, split};
     float* part = (float*)ws;
     if (const int hcg = head_cg(g, mfull)) {       // 3x3 few-output-channel head
-        int tpb = 0;
-        const int blocks = head_dw_blocks(g, hcg == 9 ? 32 : 16, &tpb);
-        if (hcg == 9 && cout <= 3) hipLaunchKernelGGL((head_dw_kernel<9, 3>), dim3(blocks), dim3(320), 0, st, dy, inv, x, rs, g, tpb, part);
-        else if (hcg == 9) hipLaunchKernelGGL((head_dw_kernel<9, 4>), dim3(blocks), dim3(320), 0, st, dy, inv, x, rs, g, tpb, part);
-        else if (cout <= 3) hipLaunchKernelGGL((head_dw_kernel<17, 3>), dim3(blocks), dim3(320), 0, st, dy, inv, x, rs, g, tpb, part);
-        else hipLaunchKernelGGL((head_dw_kernel<17, 4>), dim3(blocks), dim3(320), 0, st, dy, inv, x, rs, g, tpb, part);
-        int rch = check_launch("head_dw");
-        if (rch) return rch;
-        const int64_t lenh = (int64_t)cout * cin * 9;
-        rch = launch_reduce_rows(part, blocks, lenh, dwgt, st);
-        if (rch) return rch;
-        if (dbias != nullptr)
-            rch = launch_colsum_scaled(dy, keep, (int64_t)n * ho * wo, cout, dbias, part + (size_t)blocks * lenh, st);
-        return rch;
+        return launch_head_dw(dy, inv, keep, x, kNoCat, rs, g, hcg, part, dwgt, dbias, st);
     }
     if (use_conv_gemm(g, mfull, dy, x, ws)) {
         const ConvGemmGeom cgg = {n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo};
@@ -1030,4 +1138,48 @@ extern "C" int tsii_dense_bwd_dw(const float* dy, const float* inv, const float*
     if (dbias != nullptr)
         rc = launch_colsum_scaled(dy, keep, (int64_t)n * ho * wo, cout, dbias, part + (size_t)p.chunks * len, st);
     return rc;
+}
+
+
+// ---- K4c: 3x3 / stride 1 / pad 1 head over the virtual concatenation cat(nearest-x2(low), skip) -----------------------------
+// (models/image_inpainting.py:82-86: DoubleUpSample + torch.cat + the 35 -> 3 output PartialConv; here the concatenated tensor and
+// its gradient never exist).  r0 / r1: the mask planes of the two parts at full resolution (NULL = all ones); the split is c1.
+extern "C" int tsii_head_cat_ok(int n, int h, int wd, int c1, int c2, int cout) {
+    if (n <= 0 || h <= 0 || wd <= 0 || c1 <= 0 || c2 <= 0 || cout <= 0 || (h & 1) || (wd & 1) || (c1 & 3)) return 0;
+    const ConvGeom g = {n, h, wd, c1 + c2, cout, 3, 3, 1, 1, 1, 1, 1, 1, h, wd};
+    return head_cg(g, nullptr) != 0 ? 1 : 0;
+}
+
+extern "C" int tsii_head_cat_fwd(const float* low, const float* skip, int c1, int c2, const float* r0, const float* r1,
+                                 const float* w, const float* bias, const float* denom, const float* keep,
+                                 int n, int h, int wd, int cout, float* y, void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(low && skip && w && y && ws, "head_cat_fwd: null pointer");
+    TSII_REQUIRE(tsii_head_cat_ok(n, h, wd, c1, c2, cout), "head_cat_fwd: geometry has no fused head (tsii_head_cat_ok)");
+    TSII_REQUIRE(aligned16(low) && aligned16(ws) && ws_bytes >= tsii_dense_ws_bytes(c1 + c2, cout, 3, 3), "head_cat_fwd: workspace / alignment");
+    const ConvGeom g = {n, h, wd, c1 + c2, cout, 3, 3, 1, 1, 1, 1, 1, 1, h, wd};
+    const HeadCat cat = {low, skip, c1, c2};
+    const RowScale rsh = {r0, r1, c1};
+    return launch_head_fwd(nullptr, cat, rsh, w, bias, denom, keep, g, head_cg(g, nullptr), (float*)ws, y, (hipStream_t)stream);
+}
+
+extern "C" int tsii_head_cat_bwd_dx(const float* dy, const float* inv, const float* w, int c1, int c2, const float* r0, const float* r1,
+                                    int n, int h, int wd, int cout, float* dlow, float* dskip, void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(dy && w && dlow && ws, "head_cat_bwd_dx: null pointer");
+    TSII_REQUIRE(tsii_head_cat_ok(n, h, wd, c1, c2, cout), "head_cat_bwd_dx: geometry has no fused head (tsii_head_cat_ok)");
+    TSII_REQUIRE(aligned16(dlow) && aligned16(ws) && ws_bytes >= tsii_dense_ws_bytes(c1 + c2, cout, 3, 3), "head_cat_bwd_dx: workspace / alignment");
+    const ConvGeom g = {n, h, wd, c1 + c2, cout, 3, 3, 1, 1, 1, 1, 1, 1, h, wd};
+    const RowScale rsh = {r0, r1, c1};
+    return launch_head_dx(dy, inv, w, rsh, g, head_cg(g, nullptr), (float*)ws, nullptr, dlow, dskip, c1, (hipStream_t)stream);
+}
+
+extern "C" int tsii_head_cat_bwd_dw(const float* dy, const float* inv, const float* keep, const float* low, const float* skip,
+                                    int c1, int c2, const float* r0, const float* r1, int n, int h, int wd, int cout,
+                                    float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(dy && low && skip && dwgt && ws, "head_cat_bwd_dw: null pointer");
+    TSII_REQUIRE(tsii_head_cat_ok(n, h, wd, c1, c2, cout), "head_cat_bwd_dw: geometry has no fused head (tsii_head_cat_ok)");
+    TSII_REQUIRE(aligned16(low) && ws_bytes >= tsii_dense_bwd_dw_ws_bytes(n, h, wd, c1 + c2, cout, 3, 3), "head_cat_bwd_dw: workspace / alignment");
+    const ConvGeom g = {n, h, wd, c1 + c2, cout, 3, 3, 1, 1, 1, 1, 1, 1, h, wd};
+    const HeadCat cat = {low, skip, c1, c2};
+    const RowScale rs = {r0, r1, c1};
+    return launch_head_dw(dy, inv, keep, nullptr, cat, rs, g, head_cg(g, nullptr), (float*)ws, dwgt, dbias, (hipStream_t)stream);
 }

@@ -13,23 +13,25 @@ from . import ops
 from .BaseModels import BaseModule, run_nhwc, to_nchw, to_nhwc
 from .MobileNetV2 import PartialInvertedResidual
 from .masks import MaskParts, Part, as_parts
-from .partial_convolution import DoubleUpSample, partial_convolution_block
+from .partial_convolution import DoubleUpSample, PartialConv, partial_convolution_block
 
 
-def _upcat_with_mask(x, mp, skip_x, skip_m):
-    """DoubleUpSample + torch.cat on features and masks (models/image_inpainting.py:82-84)."""
+def _upcat_with_mask(x, mp, skip_x, skip_m, virtual=False):
+    """DoubleUpSample + torch.cat on features and masks (models/image_inpainting.py:82-84).  ``virtual``: the consumer is the
+    output head, which can read the two tensors directly (ops.VirtualCat, K4c) -- the concatenation is not written."""
     up_m = mp.upsample2x()
     sp = skip_m.parts[0]
     if len(skip_m.parts) != 1 or len(up_m.parts) != 1:
         raise NotImplementedError("decoder concat expects single-part masks on both sides")
+    cat = (lambda a, b: ops.VirtualCat(a, b)) if virtual else ops.upcat
     if sp.planar:
-        return ops.upcat(x, skip_x), up_m.cat(skip_m)
+        return cat(x, skip_x), up_m.cat(skip_m)
     # general per-channel skip mask (the raw input level): multiply the skip features once here, so
     # the conv sees a row scale on the up-sampled half only; the count still uses the true mask.
     skip_pre = ops.mul_mask(skip_x, sp.full)
     part = Part(sp.channels, full=sp.full, premultiplied=True)
     part._sum = sp._sum
-    return ops.upcat(x, skip_pre), MaskParts([up_m.parts[0], part])
+    return cat(x, skip_pre), MaskParts([up_m.parts[0], part])
 
 
 class _UNetBase(BaseModule):
@@ -42,8 +44,11 @@ class _UNetBase(BaseModule):
         return x, mp, fx[:-1], fm[:-1]
 
     def _decode(self, x, mp, fx, fm):
-        for layer in self.decoder:
-            x, mp = _upcat_with_mask(x, mp, fx.pop(-1), fm.pop(-1))
+        last = len(self.decoder) - 1
+        for i, layer in enumerate(self.decoder):
+            # the last level feeds a bare PartialConv (the output head): hand it the concatenation unwritten
+            head = i == last and isinstance(layer, nn.Sequential) and len(layer) == 1 and type(layer[0]) is PartialConv
+            x, mp = _upcat_with_mask(x, mp, fx.pop(-1), fm.pop(-1), virtual=head)
             x, mp = run_nhwc(layer, x, mp)
         return x
 

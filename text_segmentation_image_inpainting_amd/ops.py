@@ -690,6 +690,81 @@ def upcat(low, skip):
     return _UpCat.apply(low, skip)
 
 
+class VirtualCat:
+    """cat(nearest-x2(low), skip) along channels, NOT written (K4c): the decoder's last DoubleUpSample + torch.cat, consumed by
+    the few-output-channel head kernels straight from the two tensors.  Anything else calls ``materialize()`` (= upcat)."""
+
+    __slots__ = ("low", "skip")
+
+    def __init__(self, low, skip):
+        n, h, w, _ = low.shape
+        assert skip.shape[0] == n and skip.shape[1] == 2 * h and skip.shape[2] == 2 * w, "upcat: shape mismatch"
+        self.low, self.skip = low, skip
+
+    @property
+    def shape(self):
+        n, h, w, c2 = self.skip.shape
+        return torch.Size((n, h, w, self.low.shape[3] + c2))
+
+    def materialize(self):
+        return upcat(self.low, self.skip)
+
+
+def head_cat_ok(vc: "VirtualCat", cout: int, g) -> bool:
+    """Does the fused head (3x3, stride 1, pad 1, <= 4 output channels) exist for this virtual concatenation?"""
+    n, h, w, c = vc.shape
+    c1 = vc.low.shape[3]
+    return tuple(g) == (3, 3, 1, 1, 1, 1, 1, 1) and bool(_lib.lib().tsii_head_cat_ok(n, h, w, c1, c - c1, int(cout)))
+
+
+class _HeadCat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, low, skip, w, bias, r0, r1, denom, keep, inv):
+        _lib.check_device(low)
+        low, skip, w = low.contiguous(), skip.contiguous(), w.contiguous()
+        n, h, wd, c2 = skip.shape
+        c1, cout = low.shape[3], w.shape[0]
+        y = torch.empty((n, h, wd, cout), dtype=torch.float32, device=low.device)
+        nbytes = _lib.lib().tsii_dense_ws_bytes(c1 + c2, cout, 3, 3)
+        ws = _ws(nbytes, low)
+        call("tsii_head_cat_fwd", ptr(low), ptr(skip), c1, c2, ptr(r0), ptr(r1), ptr(w), ptr(bias), ptr(denom), ptr(keep),
+             n, h, wd, cout, ptr(y), ptr(ws), nbytes, _lib.stream())
+        ctx.save_for_backward(low, skip, w, r0, r1, inv, keep)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        low, skip, w, r0, r1, inv, keep = ctx.saved_tensors
+        gy = gy.contiguous()
+        n, h, wd, c2 = skip.shape
+        c1, cout = low.shape[3], w.shape[0]
+        L, st = _lib.lib(), _lib.stream()
+        dlow = dskip = dw = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dlow = torch.empty_like(low)
+            dskip = torch.empty_like(skip) if ctx.needs_input_grad[1] else None
+            nbytes = L.tsii_dense_ws_bytes(c1 + c2, cout, 3, 3)
+            ws = _ws(nbytes, low)
+            call("tsii_head_cat_bwd_dx", ptr(gy), ptr(inv), ptr(w), c1, c2, ptr(r0), ptr(r1), n, h, wd, cout,
+                 ptr(dlow), ptr(dskip), ptr(ws), nbytes, st)
+            if not ctx.needs_input_grad[0]:
+                dlow = None
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            dw = torch.empty_like(w)
+            db = torch.empty(cout, dtype=torch.float32, device=low.device) if ctx.has_bias else None
+            nbytes = L.tsii_dense_bwd_dw_ws_bytes(n, h, wd, c1 + c2, cout, 3, 3)
+            ws = _ws(nbytes, low)
+            call("tsii_head_cat_bwd_dw", ptr(gy), ptr(inv), ptr(keep), ptr(low), ptr(skip), c1, c2, ptr(r0), ptr(r1),
+                 n, h, wd, cout, ptr(dw), ptr(db), ptr(ws), nbytes, st)
+        return dlow, dskip, dw, db, None, None, None, None, None
+
+
+def pconv_head_cat(vc: VirtualCat, w, bias, r0, r1, denom, keep, inv):
+    """PartialConv 3x3 head over a VirtualCat (K4c): y = keep ? conv(cat * mask) / denom + bias : 0."""
+    return _HeadCat.apply(vc.low, vc.skip, w, bias, r0, r1, denom, keep, inv)
+
+
 class _Up2x(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

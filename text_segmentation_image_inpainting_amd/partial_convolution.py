@@ -80,6 +80,14 @@ class PartialConv(BaseModule):
         pointwise = tuple(g) == (1, 1, 1, 1, 0, 0, 1, 1)
         part = None
         real = lambda t: t.materialize() if isinstance(t, ops.LazyBN) else t
+        if isinstance(x, ops.VirtualCat):
+            if (groups == 1 and mp.fusable and not want_stats and len(mp.parts) == 2 and mp.parts[0].channels == x.low.shape[3]
+                    and ops.head_cat_ok(x, cout, g)):
+                # K4c: the decoder's up-sample + concat is consumed by the head without being written
+                r0, _, r1 = mp.row_scale()
+                y = ops.pconv_head_cat(x, w, b, r0, r1, denom, keep, inv)
+                return y, MaskParts.from_plane(new_mask, cout)
+            x = x.materialize()
         if groups == 1:
             if mp.fusable:
                 r0, split, r1 = mp.row_scale()
