@@ -20,13 +20,26 @@ def emu_backend():
     from tests.emu import build_emu
     if not build_emu.available():
         pytest.skip("host clang++ for the emulator build is not available")
+    from text_segmentation_image_inpainting_amd import ops
     cdll = _lib.bind(ctypes.CDLL(build_emu.build()))
-    saved = (_lib._LIB, _lib.stream, _lib.check_device)
-    _lib._LIB, _lib.stream, _lib.check_device = cdll, (lambda: None), (lambda t: None)
+    saved = (_lib._LIB, _lib.stream, _lib.check_device, ops._ws)
+    # every kernel workspace the package allocates gets a canary tail right behind the size the library asked for, checked on the
+    # way out: on the host an overrun lands in the heap silently
+    canary, guarded = -12345.678, []
+
+    def guarded_ws(nbytes, like):
+        n = max(4, (int(nbytes) + 3) // 4)
+        buf = torch.empty(n + 64, dtype=torch.float32)
+        buf[n:] = canary
+        guarded.append((buf, n))
+        return buf[:n]
+    _lib._LIB, _lib.stream, _lib.check_device, ops._ws = cdll, (lambda: None), (lambda t: None), guarded_ws
     try:
         yield torch.device("cpu")
+        for buf, n in guarded:
+            assert bool((buf[n:] == canary).all()), f"a kernel wrote past its {4 * n}-byte workspace"
     finally:
-        _lib._LIB, _lib.stream, _lib.check_device = saved
+        _lib._LIB, _lib.stream, _lib.check_device, ops._ws = saved
 
 
 @contextlib.contextmanager
