@@ -118,6 +118,18 @@ def test_bench_class_table_and_traffic_gate(tmp_path, monkeypatch):
     assert abs(bench.class_table(timed, 2, 0)["gemm_nt"]["mfma_peak_fp32_equiv"] - bench.PEAK_FP32_TFLOPS) < 0.1
     b = tab["bn_act"]
     assert abs(b["tb_per_s"] - 8.0 * m * n / 0.5e-3 / 1e12) < 0.05 and "mfma_frac" not in b
+    # per-launch roofline: every launch against the larger of ITS HBM time and (matrix kernels) ITS MFMA time
+    t_hbm = 4.0 * m * (k + n) / (bench.PEAK_HBM_TBS * 1e12) * 1e3
+    t_mfma = 2.0 * m * k * n / (bench.PEAK_BF16_TFLOPS / 6 * 1e12) * 1e3
+    assert abs(g["per_launch_roofline_ms"] - max(t_hbm, t_mfma)) < 2e-3 and abs(g["per_launch_roofline_frac"] - max(t_hbm, t_mfma) / 1.0) < 2e-3
+    assert abs(b["per_launch_roofline_frac"] - b["hbm_frac"]) < 1e-3              # a streaming class: the two coincide
+    # a class mixing an HBM-bound and an MFMA-bound layer: the blended fraction exceeds both class-level fractions
+    mix = bench.class_table({"tsii_pw_fwd": [(1.0, (m, 1024, 1024)), (1.0, (8 * m, 64, 32))]}, 1, 6)["gemm_nt"]
+    assert mix["per_launch_roofline_frac"] > max(mix["hbm_frac"], mix["mfma_frac"])
+    # the K4c entry points are accounted for (virtual concatenation: bytes of low + skip + y only)
+    hc = bench.class_table({"tsii_head_cat_fwd": [(0.5, (32, 3, 32, 512, 512, 3, 5184))]}, 1, 6)["dense_conv"]
+    assert abs(hc["alg_gb_per_step"] - 4.0 * 32 * (512 * 512 // 4 * 32 + 512 * 512 * 3 + 512 * 512 * 3) / 1e9) < 1e-2
+    # several kernels behind one class in the traffic lookup
     # traffic gate
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     os.makedirs(tmp_path / "profiles")
@@ -129,3 +141,7 @@ def test_bench_class_table_and_traffic_gate(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "csrc_sha", lambda: "0" * 12)
     val, why = bench.pmc_traffic("tsii::gemm_nt_split_kernel<2, 2, 2, 2")
     assert val == 1e9
+    js["kernels"]["tsii::gemm_nt_pc_kernel<1, 8, 6, false, 0, 0>"] = {"launches": 6, "bytes_per_launch": 2e9}
+    json.dump(js, open(tmp_path / "profiles" / bench.PMC_SUMMARY, "w"))
+    val, why = bench.pmc_traffic(("tsii::gemm_nt_pc_kernel<", "tsii::gemm_nt_split_kernel<"))
+    assert abs(val - (2 * 1e9 + 6 * 2e9) / 8) < 1.0
