@@ -31,6 +31,7 @@
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
 #define TSII_HIP_EMU 1
 #define TSII_OPAQUE_U32(x) asm volatile("" : "+r"(x))
+#define TSII_PIN_F2(x) ((void)0)
 
 struct dim3 {
     unsigned x, y, z;
@@ -123,6 +124,7 @@ static inline f32x16_emu __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf16x8_emu a, b
 }
 
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 
 // ---- runtime API subset -----------------------------------------------------
 typedef void* hipStream_t;

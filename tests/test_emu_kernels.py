@@ -414,3 +414,129 @@ def test_split_modes_non_finite_operands(emu):
             assert np.abs(rest - ref).max() <= 1e-5 * np.abs(ref).max()
     finally:
         L.tsii_set_gemm_products(6)
+
+
+# ---- depth-wise 3x3 marching strips through the C ABI (K2; the stride-1 / dilation-1 geometry runs csrc/dw_lean.h) -------------
+def _dw_ref_fwd(x, rmask, w, bias, denom, keep, s, d, p):
+    """float64: y = keep ? (sum_t w[t] * (x*rmask)[i_t]) / denom + bias : 0 on NHWC arrays."""
+    n, h, wd, c = x.shape
+    xm = x.astype(np.float64) * (1.0 if rmask is None else rmask.astype(np.float64)[..., None])
+    ho, wo = (h + 2 * p - 2 * d - 1) // s + 1, (wd + 2 * p - 2 * d - 1) // s + 1
+    xp = np.zeros((n, h + 2 * p, wd + 2 * p, c))
+    xp[:, p:p + h, p:p + wd] = xm
+    y = np.zeros((n, ho, wo, c))
+    for ky in range(3):
+        for kx in range(3):
+            y += xp[:, ky * d:ky * d + (ho - 1) * s + 1:s, kx * d:kx * d + (wo - 1) * s + 1:s] * w[:, 0, ky, kx].astype(np.float64)
+    if denom is not None:
+        y = y / denom.astype(np.float64)[..., None]
+    if bias is not None:
+        y = y + bias.astype(np.float64)
+    if keep is not None:
+        y = np.where(keep[..., None] != 0, y, 0.0)
+    return y
+
+
+def _act(z, act, slope):
+    if act == 1:
+        return np.maximum(z, 0)
+    if act == 2:
+        return np.where(z > 0, z, z * slope)
+    if act == 3:
+        return np.clip(z, 0, 6)
+    return z
+
+
+@pytest.mark.parametrize("n,h,wd,c,masked,bias,act", [
+    (2, 21, 37, 40, True, True, 2),      # row / column / channel tails, one chunk
+    (1, 8, 16, 32, True, False, 3),      # exactly one step, one strip, ReLU6 (finite upper clamp)
+    (1, 3, 5, 4, False, True, 0),        # smaller than a step and a strip, no mask planes
+    (3, 43, 18, 36, True, True, 1),      # several steps per chunk, strip tail of 2 columns, channel tail
+    (1, 70, 33, 8, False, False, 2),     # many steps: both LDS buffers in turn, no mask planes
+])
+@pytest.mark.parametrize("target", [1536, 1])
+def test_depthwise_strip_entry_points(emu, n, h, wd, c, masked, bias, act, target):
+    """target = 1: one chunk per image (emulator-only hook), i.e. chunks of several marching steps -- with the product's block
+    target small tensors are cut into one-step chunks and the step-to-step hand-over would never run on the CPU."""
+    L = emu
+    L.tsii_emu_set_strip_target(target)
+    try:
+        _strip_entry_points(L, n, h, wd, c, masked, bias, act)
+    finally:
+        L.tsii_emu_set_strip_target(0)
+
+
+def _strip_entry_points(L, n, h, wd, c, masked, bias, act):
+    rng = np.random.default_rng(h * 100 + wd)
+    slope = 0.3
+    x = rng.standard_normal((n, h, wd, c)).astype(np.float32) + 0.5
+    w = rng.standard_normal((c, 1, 3, 3)).astype(np.float32)
+    b = rng.standard_normal(c).astype(np.float32) if bias else None
+    rmask = (rng.uniform(size=(n, h, wd)) > 0.2).astype(np.float32) if masked else None
+    cnt = None
+    if masked:
+        pm = np.zeros((n, h + 2, wd + 2)); pm[:, 1:-1, 1:-1] = rmask
+        cnt = sum(pm[:, ky:ky + h, kx:kx + wd] for ky in range(3) for kx in range(3))
+    keep = (cnt > 0).astype(np.float32) if masked else None
+    denom = (np.where(cnt > 0, cnt, 1.0) * c).astype(np.float32) if masked else None
+    geom = (3, 3, 1, 1, 1, 1, 1, 1)
+    ws = WS(4 * (9 * c + 16))
+    # plain forward
+    y = np.full((n, h, wd, c), np.nan, np.float32)
+    assert L.tsii_dw_fwd(P(x), P(rmask), P(w), P(b), P(denom), P(keep), n, h, wd, c, *geom, h, wd, P(y), P(ws), None) == 0, L.tsii_last_error()
+    yr = _dw_ref_fwd(x, rmask, w, b, denom, keep, 1, 1, 1)
+    assert np.abs(y - yr).max() <= 2e-6 * max(1.0, np.abs(yr).max())
+    # forward with BatchNorm + activation on load and statistics partials
+    sc = (rng.uniform(size=c) + 0.5).astype(np.float32); sh = rng.standard_normal(c).astype(np.float32)
+    rows = L.tsii_dw_stat_rows(n, h, wd, c, 3, 3, 1, 1, 1, 1)
+    assert rows > 0
+    part = WS(4 * rows * 4 * c)
+    y2 = np.full((n, h, wd, c), np.nan, np.float32)
+    assert L.tsii_dw_fwd_bn(P(x), P(rmask), P(w), P(b), P(denom), P(keep), n, h, wd, c, *geom, h, wd, P(sc), P(sh), act, slope,
+                            P(part), P(y2), P(ws), None) == 0, L.tsii_last_error()
+    xa = _act(x.astype(np.float64) * sc + sh, act, slope)
+    y2r = _dw_ref_fwd(xa, rmask, w, b, denom, keep, 1, 1, 1)
+    assert np.abs(y2 - y2r).max() <= 2e-6 * max(1.0, np.abs(y2r).max())
+    pr = part[:rows * 4 * c].reshape(rows, 4, c).astype(np.float64)
+    cnts, piv, s1, s2 = pr[:, 0], pr[:, 1], pr[:, 2], pr[:, 3]
+    m_tot = n * h * wd
+    assert np.all(cnts.sum(0) == m_tot)
+    mean = (cnts * piv + s1).sum(0) / m_tot
+    ex2 = (s2 + 2 * piv * s1 + cnts * piv * piv).sum(0) / m_tot
+    y2d = y2.astype(np.float64).reshape(-1, c)
+    assert np.abs(mean - y2d.mean(0)).max() <= 1e-5 * max(1.0, np.abs(y2d).max())
+    assert np.abs(ex2 - (y2d ** 2).mean(0)).max() <= 1e-5 * max(1.0, (y2d ** 2).max())
+    # statistics only (no producer BatchNorm): the identity transform must be exact
+    y3 = np.full((n, h, wd, c), np.nan, np.float32)
+    assert L.tsii_dw_fwd_bn(P(x), P(rmask), P(w), P(b), P(denom), P(keep), n, h, wd, c, *geom, h, wd, None, None, 0, 0.0,
+                            P(part), P(y3), P(ws), None) == 0, L.tsii_last_error()
+    assert np.array_equal(y3, y)
+    # dX (flipped taps, dy * inv staged, rmask applied to the result) and its K6c form
+    dy = rng.standard_normal((n, h, wd, c)).astype(np.float32)
+    inv = (keep / denom).astype(np.float32) if masked else None
+    dx = np.full((n, h, wd, c), np.nan, np.float32)
+    assert L.tsii_dw_bwd_dx(P(dy), P(inv), P(w), P(rmask), n, h, wd, c, *geom, h, wd, P(dx), P(ws), None) == 0, L.tsii_last_error()
+    wf = w[:, :, ::-1, ::-1]
+    dxr = _dw_ref_fwd(dy, inv, wf, None, None, None, 1, 1, 1)
+    if masked:
+        dxr = dxr * rmask.astype(np.float64)[..., None]
+    assert np.abs(dx - dxr).max() <= 2e-6 * max(1.0, np.abs(dxr).max())
+    brows = L.tsii_dw_bwd_stat_rows(n, h, wd, c, *geom)
+    assert brows > 0
+    bpart = WS(4 * brows * 2 * c)
+    mean_b = rng.standard_normal(c).astype(np.float32); var_b = (rng.uniform(size=c) + 0.5).astype(np.float32)
+    gam = (rng.uniform(size=c) + 0.5).astype(np.float32); bet = rng.standard_normal(c).astype(np.float32)
+    dx2 = np.full((n, h, wd, c), np.nan, np.float32)
+    assert L.tsii_dw_bwd_dx_bn(P(dy), P(inv), P(w), P(rmask), n, h, wd, c, *geom, h, wd, P(x), P(mean_b), P(var_b), P(gam), P(bet),
+                               1e-5, act, slope, P(dx2), P(bpart), P(ws), None) == 0, L.tsii_last_error()
+    assert np.array_equal(dx2, dx)
+    xh = (x.astype(np.float64) - mean_b) / np.sqrt(var_b.astype(np.float64) + 1e-5)
+    z = xh * gam + bet
+    g1 = {0: np.ones_like(z), 1: (z > 0) * 1.0, 2: np.where(z > 0, 1.0, slope), 3: ((z > 0) & (z < 6)) * 1.0}[act]
+    dz = dx.astype(np.float64) * g1
+    bp = bpart[:brows * 2 * c].reshape(brows, 2, c).astype(np.float64).sum(0)
+    # a pre-activation within rounding of a kink may take the other slope: compare with a bound on the flipped mass
+    near = (np.abs(z) < 1e-5) | (np.abs(z - 6) < 1e-5)
+    slack = (np.abs(dx) * near).reshape(-1, c).sum(0) * 2 + 1e-4 * np.abs(dz).reshape(-1, c).sum(0).max()
+    assert np.all(np.abs(bp[0] - dz.reshape(-1, c).sum(0)) <= slack)
+    assert np.all(np.abs(bp[1] - (dz * xh).reshape(-1, c).sum(0)) <= slack * max(1.0, np.abs(xh).max()))

@@ -1,0 +1,422 @@
+// K2 (round 4): the stride-1 / dilation-1 marching strip, rebuilt around the instruction budget.
+//
+// The round-3 strip kernel (dw_strip_kernel<1, 1, *> in dwconv.hip) was ISSUE-bound, not HBM-bound: rocprofv3 put its waves at
+// 45 % active-issue with two waves per SIMD, and its main loop spent ~190 vector instructions per 4-channel output pixel -- ring
+// rows taken `% 10` per tap row, the v_pk_fma_f32 pairs hipcc chose needing two v_mov per LDS read, one IEEE division per pixel
+// in each of the 8 threads sharing it, 64-bit address arithmetic and exec-mask branches around every load.  This kernel does the
+// same arithmetic in the same order (outputs are bit-identical) with a third of that:
+//   * TWO plain LDS buffers of 10 input rows instead of a ring: every LDS address is a per-thread base + an immediate offset.
+//     The two rows a step shares with the next one are copied LDS -> LDS into the other buffer while the step runs, and the next
+//     slab is committed into that other buffer too, so a step needs ONE barrier (nothing ever writes the buffer being read).
+//   * a thread owns 4 vertically adjacent pixels of a column: 6 input rows x 3 columns = 18 ds_read_b128 feed 144 FMAs
+//     (the old mapping read 36), written as explicit float2 pairs on the natural register pairs of the 16-byte reads.
+//   * per-pixel planes are reduced by the threads that fetch them (1 / denom once per pixel, as a (1/denom, keep) pair).
+//   * slab loads are wave-uniform running pointers + 32-bit offsets computed once; interior steps load without bounds arithmetic.
+//   * per-channel constants other than the 9 x 4 weights (BatchNorm scale / shift, bias, the K6c constants) sit in LDS and are
+//     read where they are used: 3 waves per SIMD.
+//   * BatchNorm statistics (K6b) use the thread's first output as pivot without a per-pixel select; the K6c reductions run
+//     after the step's stores, when the BatchNorm-input loads issued at the top of the step have landed.
+// Included by dwconv.hip (after DtGeom / DwBN / DwBnBwd).
+#pragma once
+
+// a value the compiler must have materialised at this point (keeps the FMAs that produce it from being sunk); no-op on the test emulator
+#ifndef TSII_PIN_F2
+#define TSII_PIN_F2(x) asm volatile("" : "+v"(x))
+#endif
+
+namespace tsii {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+static constexpr int LS_R = 8, LS_TW = 16, LS_PW = 18, LS_ROWS = 10, LS_CB = 32, LS_PF = 5;
+static constexpr int LS_PIXB = LS_CB * 4;                    // bytes of one staged pixel
+static constexpr int LS_BUFB = LS_ROWS * LS_PW * LS_PIXB;    // bytes per buffer (23040)
+static constexpr int LS_NPX = LS_R * LS_TW;
+
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 max2(f32x2 a, f32x2 b) { return f32x2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+__device__ __forceinline__ f32x2 min2(f32x2 a, f32x2 b) { return f32x2{fminf(a.x, b.x), fminf(a.y, b.y)}; }
+__device__ __forceinline__ f32x4 cat4(f32x2 a, f32x2 b) { return f32x4{a.x, a.y, b.x, b.y}; }
+
+// MODE 0: plain; 1: forward with BatchNorm on load and / or statistics partials (K6b); 2: dX feeding a BatchNorm backward (K6c).
+// DXE: dX epilogue (out = post_mul != 0 ? acc * post_mul : 0) instead of the forward one (acc / denom + bias, zero where keep == 0).
+// PRE: the staged input is multiplied by a per-pixel plane (mask for forward, 1 / count for dX).
+template <int MODE, bool DXE, bool PRE>
+__global__ __launch_bounds__(256, 3) void dw_lean_kernel(
+    const float* __restrict__ in, const float* __restrict__ pre, const float* __restrict__ wT, const float* __restrict__ bias,
+    const float* __restrict__ denom, const float* __restrict__ keep, const float* __restrict__ post_mul, DtGeom g, int chunk_rows,
+    unsigned strips_x, unsigned chunks_y, unsigned cblocks, DwBN ib, float* __restrict__ stats, DwBnBwd bb,
+    float* __restrict__ out) {
+    constexpr bool FUSED = (MODE == 1), BNB = (MODE == 2);
+    static_assert(!BNB || DXE, "K6c rides on the dX epilogue");
+    static_assert(!FUSED || !DXE, "K6b rides on the forward epilogue");
+    __shared__ __attribute__((aligned(16))) float lbuf[2 * LS_BUFB / 4];
+    __shared__ __attribute__((aligned(8))) float lplanes[2][LS_NPX][2];
+    __shared__ __attribute__((aligned(16))) float lconst[4][LS_CB];   // K6b: scale, shift, bias | K6c: mean, 1/sigma, gamma, beta
+    unsigned b = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned cb = b % cblocks; b /= cblocks;
+    const unsigned sx = b % strips_x; b /= strips_x;
+    const unsigned cy = b % chunks_y;
+    const int64_t n = b / chunks_y;
+    const int t = threadIdx.x;
+    const int cg = t & 7, lane = t >> 3;
+    const int C = g.c;
+    const int c0 = (int)cb * LS_CB + cg * 4;
+    const bool cok = c0 < C;
+    const int oy_beg = (int)cy * chunk_rows;
+    const int oy_end = oy_beg + chunk_rows < g.hout ? oy_beg + chunk_rows : g.hout;
+    const int ox0 = (int)sx * LS_TW;
+    const int iy_base = oy_beg - g.pad_h, ix0 = ox0 - g.pad_w;      // input row of buffer row 0 at step 0 / input column of slab column 0
+    const int nsteps = (oy_end - oy_beg + LS_R - 1) / LS_R;
+    const bool col_interior = ix0 >= 0 && ix0 + LS_PW <= g.win;      // block-uniform
+    const float bn_neg = FUSED && ib.sc != nullptr ? ib.neg : 1.f;   // no producer BatchNorm: the identity (scale 1, shift 0, neg 1), exact
+    const bool hi_finite = FUSED && ib.sc != nullptr && ib.hi < __builtin_huge_valf();
+
+    if (t < LS_CB) {                                          // per-channel constants of this block's 32 channels
+        const int ch = (int)cb * LS_CB + t;
+        const bool ok = ch < C;
+        if (BNB) {
+            lconst[0][t] = ok ? bb.mean[ch] : 0.f;
+            lconst[1][t] = ok ? 1.0f / sqrtf(bb.var[ch] + bb.eps) : 0.f;
+            lconst[2][t] = ok ? bb.gamma[ch] : 0.f;
+            lconst[3][t] = ok ? bb.beta[ch] : 0.f;
+        } else {
+            lconst[0][t] = (FUSED && ib.sc != nullptr && ok) ? ib.sc[ch] : 1.f;
+            lconst[1][t] = (FUSED && ib.sc != nullptr && ok) ? ib.sh[ch] : 0.f;
+            lconst[2][t] = (!DXE && bias != nullptr && ok) ? bias[ch] : 0.f;
+        }
+    }
+    f32x4 w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (cok) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const f32x4*>(wT + (g.flip ? 8 - k : k) * C + c0);
+    }
+
+    // ---- slab staging: 8 rows x 18 pixels per step; slab pixel p = lane + 32 i of thread t sits at byte (t + 256 i) * 16 ----
+    // EVERY global load below is unconditional (threads without a valid item load a clamped, valid address and drop the value)
+    // and so is its first use: a load inside an exec-masked region whose consumer sits in another one leaves hipcc's waitcnt
+    // scoreboard with a pending entry on the skipping path, and the next load into that register then waits vmcnt(0) -- for
+    // the loads issued just before it.
+    unsigned poff[LS_PF];                  // byte offset of the item's pixel in a per-pixel plane, from the slab's first pixel
+    unsigned rowpk = 0, pxpk = 0;
+#pragma unroll
+    for (int i = 0; i < LS_PF; ++i) {
+        const int pr = lane + 32 * i;
+        const int p = pr < LS_R * LS_PW ? pr : LS_R * LS_PW - 1;   // item 4 of the pixel lanes >= 16: a second load of the slab's last pixel
+        const int row = p / LS_PW, px = p - row * LS_PW;
+        poff[i] = (unsigned)(row * g.win + px) * 4u;
+        rowpk |= (unsigned)row << (4 * i);
+        pxpk |= (unsigned)px << (5 * i);
+    }
+    const bool item4 = lane < LS_R * LS_PW - 128;             // item 4 exists for the first 16 pixel lanes only
+    const unsigned c0b = (unsigned)(cok ? c0 : C - 4) * 4u;   // channel offset for loads (clamped: the channel tail of the last block)
+    // Offsets pass through an opaque copy right before their use: the zero-extension then sits next to the access and hipcc
+    // selects the `global_load v, v_off, s[base]` form instead of 64-bit vector address pairs
+    auto opq = [](unsigned o) { TSII_OPAQUE_U32(o); return o; };
+
+    f32x4 pf[LS_PF];
+    float pm[LS_PF];
+    unsigned vmask = 0;                                        // edge steps: bit i = item i lies inside the image
+    const int64_t img_pix = n * g.hin * (int64_t)g.win;
+    const char* const ibase = reinterpret_cast<const char*>(in + img_pix * C);      // pixel (0, 0) of this image
+    const char* const ipre = reinterpret_cast<const char*>(pre + img_pix);
+    // running pointers to the first pixel of the NEXT slab to fetch (may point outside the tensor; only used by interior steps)
+    int iyb = iy_base + 2;
+    const char* sb = reinterpret_cast<const char*>(in + (img_pix + (int64_t)iyb * g.win + ix0) * C);
+    const char* pb = reinterpret_cast<const char*>(pre + (img_pix + (int64_t)iyb * g.win + ix0));
+    const int64_t sb_step = (int64_t)LS_R * g.win * C * 4, pb_step = (int64_t)LS_R * g.win * 4;
+    auto fetch = [&]() {                                      // global -> registers, slab rows iyb .. iyb + 7
+        const bool interior = col_interior && iyb >= 0 && iyb + LS_R <= g.hin;
+        unsigned po[LS_PF];
+        vmask = 31u;
+#pragma unroll
+        for (int i = 0; i < LS_PF; ++i) po[i] = poff[i];
+        if (!interior) {                                       // edge step: offsets of the clamped pixel from the image's first pixel
+            vmask = 0;
+#pragma unroll
+            for (int i = 0; i < LS_PF; ++i) {
+                const int iy = iyb + (int)((rowpk >> (4 * i)) & 15u), ix = ix0 + (int)((pxpk >> (5 * i)) & 31u);
+                if ((unsigned)iy < (unsigned)g.hin && (unsigned)ix < (unsigned)g.win) vmask |= 1u << i;
+                const int iyc = iy < 0 ? 0 : (iy >= g.hin ? g.hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= g.win ? g.win - 1 : ix);
+                po[i] = (unsigned)(iyc * g.win + ixc) * 4u;
+            }
+        }
+        const char* const ab = interior ? sb : ibase;
+        const char* const mb = interior ? pb : ipre;
+#pragma unroll
+        for (int i = 0; i < LS_PF; ++i) {
+            pf[i] = *reinterpret_cast<const f32x4*>(ab + opq(__umul24(po[i], (unsigned)C) + c0b));
+            pm[i] = PRE ? *reinterpret_cast<const float*>(mb + opq(po[i])) : 1.f;
+        }
+        iyb += LS_R; sb += sb_step; pb += pb_step;
+    };
+    // BatchNorm + activation of the producer (K6b), then the per-pixel plane; items outside the image become exact zeros (never
+    // `x * 0`: the clamped address may hold NaN / Inf) -- zero padding pads the ACTIVATED tensor
+    char* const lthr = reinterpret_cast<char*>(lbuf) + t * 16;
+    const char* const cthr = reinterpret_cast<const char*>(&lconst[0][0]) + cg * 16;
+    auto stage = [&](f32x4 v, float m, bool inside, const f32x4& isc, const f32x4& ish) {
+        if (FUSED) {
+            f32x2 z0 = fma2(v.xy, isc.xy, ish.xy), z1 = fma2(v.zw, isc.zw, ish.zw);
+            z0 = max2(z0, z0 * bn_neg); z1 = max2(z1, z1 * bn_neg);
+            if (hi_finite) { z0 = min2(z0, f32x2{ib.hi, ib.hi}); z1 = min2(z1, f32x2{ib.hi, ib.hi}); }
+            v = cat4(z0, z1);
+        }
+        v *= m;
+        if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        return v;
+    };
+    // registers -> buffer `which` rows 2..9 (threads of a channel tail write their never-read slots too)
+    auto commit_slab = [&](int which, const f32x4& isc, const f32x4& ish) {
+        char* const T = lthr + which * LS_BUFB + 2 * LS_PW * LS_PIXB;
+        if (vmask == 31u) {                                    // interior step (wave-uniform in practice; any mix is handled below)
+#pragma unroll
+            for (int i = 0; i < LS_PF; ++i) {
+                const f32x4 v = stage(pf[i], pm[i], true, isc, ish);
+                if (i < 4 || item4) *reinterpret_cast<f32x4*>(T + 256 * i * 16) = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < LS_PF; ++i) {
+                const f32x4 v = stage(pf[i], pm[i], (vmask >> i) & 1u, isc, ish);
+                if (i < 4 || item4) *reinterpret_cast<f32x4*>(T + 256 * i * 16) = v;
+            }
+        }
+    };
+    // rows 0..1 of buffer `which` = rows 8..9 of the other buffer (which nothing writes during this step)
+    auto commit = [&](int which) {
+        char* const T = lthr + which * LS_BUFB;
+        const char* const S = lthr + (which ^ 1) * LS_BUFB + 8 * LS_PW * LS_PIXB;
+        const f32x4 c0v = *reinterpret_cast<const f32x4*>(S);
+        f32x4 c1v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < 2 * LS_PW * 8 - 256) c1v = *reinterpret_cast<const f32x4*>(S + 256 * 16);
+        f32x4 isc = {1.f, 1.f, 1.f, 1.f}, ish = {0.f, 0.f, 0.f, 0.f};
+        if (FUSED) { isc = *reinterpret_cast<const f32x4*>(cthr); ish = *reinterpret_cast<const f32x4*>(cthr + LS_PIXB); }
+        *reinterpret_cast<f32x4*>(T) = c0v;
+        if (t < 2 * LS_PW * 8 - 256) *reinterpret_cast<f32x4*>(T + 256 * 16) = c1v;
+        commit_slab(which, isc, ish);
+    };
+    // per-pixel planes of step s (one output pixel per thread, threads 128.. repeat 0..127), reduced to what the epilogue multiplies by
+    float pl0 = 1.f, pl1 = 1.f;
+    auto fetch_planes = [&](int s) {
+        const int tp = t & (LS_NPX - 1);
+        const int oy = oy_beg + LS_R * s + tp / LS_TW, ox = ox0 + tp % LS_TW;
+        const bool ok = oy < oy_end && ox < g.wout;
+        const int64_t q = (n * g.hout + (ok ? oy : oy_beg)) * (int64_t)g.wout + (ok ? ox : ox0);
+        if (DXE) {
+            pl0 = post_mul != nullptr ? post_mul[q] : 1.f;
+        } else {
+            pl0 = denom != nullptr ? denom[q] : 1.f;
+            pl1 = keep != nullptr ? keep[q] : 1.f;
+        }
+    };
+    auto commit_planes = [&](int s) {
+        // one IEEE division per pixel, then multiplies (<= 1 ulp from the reference's division)
+        const float r0 = DXE ? pl0 : 1.0f / pl0, r1 = pl1;
+        if (t < LS_NPX) {
+            lplanes[s & 1][t][0] = r0;
+            lplanes[s & 1][t][1] = r1;
+        }
+    };
+
+    // ---- prologue: input rows 0..1 of the first step -> buffer 0 rows 0..1, slab 0 -> rows 2..9 ----------------------------
+    fetch_planes(0);
+    __syncthreads();                                           // lconst
+    {
+        const f32x4 isc = *reinterpret_cast<const f32x4*>(cthr), ish = *reinterpret_cast<const f32x4*>(cthr + LS_PIXB);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pr = lane + 32 * i;
+            const int p = pr < 2 * LS_PW ? pr : 2 * LS_PW - 1;
+            const int row = p / LS_PW, px = p - row * LS_PW;
+            const int iy = iy_base + row, ix = ix0 + px;
+            const bool inside = (unsigned)iy < (unsigned)g.hin && (unsigned)ix < (unsigned)g.win;
+            const int iyc = iy < 0 ? 0 : (iy >= g.hin ? g.hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= g.win ? g.win - 1 : ix);
+            const unsigned q = (unsigned)(iyc * g.win + ixc) * 4u;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ibase + opq(__umul24(q, (unsigned)C) + c0b));
+            const float m = PRE ? *reinterpret_cast<const float*>(ipre + opq(q)) : 1.f;
+            const f32x4 sv = stage(v, m, inside, isc, ish);
+            if (pr < 2 * LS_PW) *reinterpret_cast<f32x4*>(lthr + 256 * i * 16) = sv;
+        }
+        fetch();
+        commit_slab(0, isc, ish);
+    }
+    commit_planes(0);
+    __syncthreads();
+
+    // this thread's output pixels: column tx, rows 4 th .. 4 th + 3 of the step
+    const int tx = lane & 15, th = lane >> 4;
+    const bool xok = cok && ox0 + tx < g.wout;
+    const unsigned orow = (unsigned)g.wout * (unsigned)C * 4u;
+    const unsigned ocol = ((unsigned)tx * (unsigned)C + (unsigned)c0) * 4u;
+    const unsigned ocol_ld = ((unsigned)(ox0 + tx < g.wout ? tx : g.wout - 1 - ox0) * (unsigned)C) * 4u + c0b;   // clamped, for loads
+    const char* const rthr = reinterpret_cast<const char*>(lbuf) + ((4 * th) * LS_PW + tx) * LS_PIXB + cg * 16;
+    const int64_t opix0 = (n * g.hout + oy_beg) * (int64_t)g.wout + ox0;
+    char* ob = reinterpret_cast<char*>(out + opix0 * C);                       // running: first output pixel of the step
+    const char* yb = reinterpret_cast<const char*>(bb.y + opix0 * C);
+    const int64_t ob_step = (int64_t)LS_R * g.wout * C * 4;
+
+    f32x4 P = {0.f, 0.f, 0.f, 0.f};                    // K6b: thread-local pivot = its first output
+    f32x2 va[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};   // K6b: s1.xy s1.zw s2.xy s2.zw | K6c: sum dz, sum dz*xhat
+
+    // one step; `more`: another one follows (its slab and planes are fetched before, and committed after, the compute)
+    auto step = [&](int s, bool more) {
+        const int rows_left = oy_end - (oy_beg + LS_R * s);
+        f32x4 yv[4];
+        if (BNB) {                                           // K6c: raw BatchNorm input at this thread's output pixels, used after the stores
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ry = 4 * th + k < rows_left ? 4 * th + k : rows_left - 1;      // clamped: the load is unconditional
+                yv[k] = *reinterpret_cast<const f32x4*>(yb + opq((unsigned)ry * orow + ocol_ld));
+            }
+        }
+        if (more) { fetch(); fetch_planes(s + 1); }          // in flight during the compute below
+
+        const char* const rb = rthr + (s & 1) * LS_BUFB;
+        f32x2 a[4][2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k][0] = f32x2{0.f, 0.f}; a[k][1] = f32x2{0.f, 0.f}; }
+        // two batches of three input rows: 9 reads in flight (the VGPR budget of 3 waves per SIMD).  The accumulators pass through
+        // an opaque copy after the first batch so that its FMAs are issued there and not sunk below the second batch's reads.
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            f32x4 v[3];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) v[kx] = *reinterpret_cast<const f32x4*>(rb + (r * LS_PW + kx) * LS_PIXB);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int k = r - ky;
+                if (k < 0 || k > 3) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    a[k][0] = fma2(v[kx].xy, w[ky * 3 + kx].xy, a[k][0]);
+                    a[k][1] = fma2(v[kx].zw, w[ky * 3 + kx].zw, a[k][1]);
+                }
+            }
+            if (r == 2) {
+                TSII_PIN_F2(a[0][0]); TSII_PIN_F2(a[0][1]); TSII_PIN_F2(a[1][0]); TSII_PIN_F2(a[1][1]); TSII_PIN_F2(a[2][0]); TSII_PIN_F2(a[2][1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const float* pls = &lplanes[s & 1][(4 * th) * LS_TW + tx][0];
+        f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+        if (!DXE) bq = *reinterpret_cast<const f32x4*>(cthr + 2 * LS_PIXB);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f32x2 a0 = a[k][0], a1 = a[k][1];
+            if (DXE) {
+                const float pmk = pls[k * LS_TW * 2];
+                a0 *= pmk; a1 *= pmk;
+                if (pmk == 0.f) { a0 = f32x2{0.f, 0.f}; a1 = a0; }
+            } else {
+                const f32x2 pq = *reinterpret_cast<const f32x2*>(pls + k * LS_TW * 2);
+                a0 *= pq.x; a1 *= pq.x;
+                a0 += bq.xy; a1 += bq.zw;
+                if (pq.y == 0.f) { a0 = f32x2{0.f, 0.f}; a1 = a0; }
+            }
+            a[k][0] = a0; a[k][1] = a1;
+            if (xok && 4 * th + k < rows_left) {
+                *reinterpret_cast<f32x4*>(ob + opq((unsigned)(4 * th + k) * orow + ocol)) = cat4(a0, a1);
+                if (FUSED) {
+                    if (s == 0 && k == 0) P = cat4(a0, a1);  // a thread with any pixel at all has this one
+                    const f32x2 d0 = a0 - P.xy, d1 = a1 - P.zw;
+                    va[0] += d0; va[1] += d1;
+                    va[2] = fma2(d0, d0, va[2]); va[3] = fma2(d1, d1, va[3]);
+                }
+            }
+        }
+        if (BNB) {
+            const f32x4 bmu = *reinterpret_cast<const f32x4*>(cthr), bis = *reinterpret_cast<const f32x4*>(cthr + LS_PIXB);
+            const f32x4 bga = *reinterpret_cast<const f32x4*>(cthr + 2 * LS_PIXB), bbe = *reinterpret_cast<const f32x4*>(cthr + 3 * LS_PIXB);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 yq = yv[k];
+                const f32x2 h0 = (yq.xy - bmu.xy) * bis.xy, h1 = (yq.zw - bmu.zw) * bis.zw;
+                const f32x2 z0 = fma2(h0, bga.xy, bbe.xy), z1 = fma2(h1, bga.zw, bbe.zw);
+                f32x2 d0 = a[k][0], d1 = a[k][1];
+                d0.x *= (z0.x > 0.f && z0.x < bb.hi) ? 1.f : (z0.x > 0.f ? 0.f : bb.neg);
+                d0.y *= (z0.y > 0.f && z0.y < bb.hi) ? 1.f : (z0.y > 0.f ? 0.f : bb.neg);
+                d1.x *= (z1.x > 0.f && z1.x < bb.hi) ? 1.f : (z1.x > 0.f ? 0.f : bb.neg);
+                d1.y *= (z1.y > 0.f && z1.y < bb.hi) ? 1.f : (z1.y > 0.f ? 0.f : bb.neg);
+                if (xok && 4 * th + k < rows_left) {
+                    va[0] += d0; va[1] += d1;
+                    va[2] = fma2(d0, h0, va[2]); va[3] = fma2(d1, h1, va[3]);
+                }
+            }
+        }
+        if (more) { commit((s + 1) & 1); commit_planes(s + 1); }   // into the buffer nobody reads during this step
+        ob += ob_step; yb += ob_step;
+        lds_barrier();
+    };
+    for (int s = 0; s + 1 < nsteps; ++s) step(s, true);
+    step(nsteps - 1, false);
+
+    if (BNB) {
+        float* mrg = lbuf;                               // [256][8]; the loop ended on a barrier: the buffers are free
+        float* mt = mrg + t * 8;
+        mt[0] = va[0].x; mt[1] = va[0].y; mt[2] = va[1].x; mt[3] = va[1].y;
+        mt[4] = va[2].x; mt[5] = va[2].y; mt[6] = va[3].x; mt[7] = va[3].y;
+        __syncthreads();
+        if (t < 2 * LS_CB) {
+            const int which = t / LS_CB, ch = t % LS_CB;
+            if ((int)cb * LS_CB + ch < C) {
+                float sum = 0.f;
+                for (int l = 0; l < 32; ++l) sum += mrg[(l * 8 + ch / 4) * 8 + which * 4 + ch % 4];
+                const int64_t prow = (n * chunks_y + cy) * strips_x + sx;
+                bb.part[(prow * 2 + which) * C + (int)cb * LS_CB + ch] = sum;
+            }
+        }
+    } else if (FUSED) {
+        if (stats != nullptr) {
+            // merge the 32 pixel lanes of every channel: (count, pivot, s1, s2) per thread through the (now free) buffers,
+            // re-based to a common pivot:  s1' = s1 + n dp,  s2' = s2 + 2 dp s1 + n dp^2
+            const int rows = oy_end - oy_beg, full = rows / LS_R, tail = rows % LS_R - 4 * th;
+            const int cnt = xok ? 4 * full + (tail < 0 ? 0 : (tail > 4 ? 4 : tail)) : 0;
+            float* mrg = lbuf;                               // [256][13]
+            static_assert(256 * 13 * 4 <= 2 * LS_BUFB, "merge buffer fits the LDS buffers");
+            float* mt = mrg + t * 13;
+            mt[0] = (float)cnt;
+            mt[1] = P.x; mt[2] = P.y; mt[3] = P.z; mt[4] = P.w;
+            mt[5] = va[0].x; mt[6] = va[0].y; mt[7] = va[1].x; mt[8] = va[1].y;
+            mt[9] = va[2].x; mt[10] = va[2].y; mt[11] = va[3].x; mt[12] = va[3].y;
+            __syncthreads();
+            if (t < LS_CB && (int)cb * LS_CB + t < C) {
+                const int ch = t, mcg = ch / 4, mi = ch % 4;
+                float nn = 0.f, pv = 0.f, s1 = 0.f, s2 = 0.f;
+                bool have = false;
+                {   // common pivot: an interior lane's (lane 17 = rows 4..7, column 1 of the step) when it saw pixels -- the strip's
+                    // first pixel is an image-border pixel, the typical outlier of a channel
+                    const float* qi = mrg + (17 * 8 + mcg) * 13;
+                    if (qi[0] != 0.f) { pv = qi[1 + mi]; have = true; }
+                }
+                for (int l = 0; l < 32; ++l) {
+                    const float* q = mrg + (l * 8 + mcg) * 13;
+                    const float n_t = q[0];
+                    if (n_t == 0.f) continue;
+                    if (!have) { pv = q[1 + mi]; have = true; }
+                    const float dp = q[1 + mi] - pv, a1 = q[5 + mi], a2 = q[9 + mi];
+                    s1 += fmaf(n_t, dp, a1);
+                    s2 += a2 + dp * (2.f * a1 + n_t * dp);
+                    nn += n_t;
+                }
+                const int64_t prow = (n * chunks_y + cy) * strips_x + sx;       // one partial row per strip chunk
+                float* sp = stats + prow * 4 * C + (int)cb * LS_CB + ch;
+                sp[0] = nn;
+                sp[C] = pv;
+                sp[2 * (int64_t)C] = s1;
+                sp[3 * (int64_t)C] = s2;
+            }
+        }
+    }
+}
+
+// the lean kernel addresses a slab / an output step with 32-bit byte offsets from a wave-uniform base (and forms the activation
+// offset with a 24-bit multiply)
+static inline bool dw_lean_ok(const DtGeom& g) {
+    return g.s == 1 && g.d == 1 && g.c < (1 << 24) && (int64_t)(LS_ROWS * (int64_t)g.win + 64) * 4 < (1ll << 24) &&
+           (int64_t)(LS_ROWS * (int64_t)g.win + 64) * g.c * 4 < (1ll << 31) &&
+           (int64_t)(LS_ROWS * (int64_t)g.wout + 64) * g.c * 4 < (1ll << 31);
+}
+
+}  // namespace tsii

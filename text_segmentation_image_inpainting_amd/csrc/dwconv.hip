@@ -722,18 +722,29 @@ __global__ __launch_bounds__(256, 3) void dw_strip_dx2_kernel(const float* __res
     }
 }
 
+}  // namespace tsii
+#include "dw_lean.h"
+namespace tsii {
+
 struct StripPlan {
     bool ok;
     int chunk_rows;
     unsigned strips_x, chunks_y, cblocks;
 };
+#ifdef TSII_HIP_EMU
+// TEST-ONLY (emulator build, tests/emu): the block target of plan_strip, so that small test tensors get chunks of several steps
+static int g_strip_target = 1536;
+extern "C" void tsii_emu_set_strip_target(int v) { g_strip_target = v > 0 ? v : 1536; }
+#else
+static constexpr int g_strip_target = 1536;
+#endif
 static StripPlan plan_strip(int n, int hout, int wout, int c, int s, int d) {
     StripPlan p;
     p.ok = ((s == 1 && (d == 1 || d == 2 || d == 4 || d == 8)) || (s == 2 && d == 1)) && c % 4 == 0;
     p.strips_x = cdiv(wout, ST_TW / (s == 2 ? 2 : 1));
     p.cblocks = cdiv(c, ST_CB);
     const int64_t per_chunk = (int64_t)p.strips_x * p.cblocks * n;
-    int64_t want = cdiv64(1536, per_chunk);                  // ~6 blocks per CU
+    int64_t want = cdiv64(g_strip_target, per_chunk);        // ~6 blocks per CU
     const int max_chunks = cdiv(hout, ST_R);
     if (want > max_chunks) want = max_chunks;
     if (want < 1) want = 1;
@@ -762,6 +773,24 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
     const bool fused = ib.sc != nullptr || stats != nullptr || bb.y != nullptr;
     if (fused && !dw_fused_ok(g.s, g.d)) return 1;
     if (bb.y != nullptr && g.s != 1) return 1;
+    if (dw_lean_ok(g) && !(post_mul != nullptr && (denom != nullptr || keep != nullptr || bias != nullptr))) {
+        const bool dxe = denom == nullptr && keep == nullptr && bias == nullptr;
+#define TSII_DW_LEAN(MODE, DXE) do { \
+            if (pre != nullptr) hipLaunchKernelGGL((dw_lean_kernel<MODE, DXE, true>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, \
+                                                   sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out); \
+            else hipLaunchKernelGGL((dw_lean_kernel<MODE, DXE, false>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, \
+                                    sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out); } while (0)
+        if (bb.y != nullptr) {
+            if (!dxe) return 1;
+            TSII_DW_LEAN(2, true);
+        } else if (fused) {
+            if (post_mul != nullptr) return 1;
+            TSII_DW_LEAN(1, false);
+        } else if (dxe) TSII_DW_LEAN(0, true);
+        else TSII_DW_LEAN(0, false);
+#undef TSII_DW_LEAN
+        return check_launch("dw_lean");
+    }
 #define TSII_DW_STRIP(S, D, MODE) hipLaunchKernelGGL((dw_strip_kernel<S, D, MODE>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, \
                                                      sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out)
 #define TSII_DW_STRIP_D(D) do { if (bb.y != nullptr) TSII_DW_STRIP(1, D, 2); else if (fused) TSII_DW_STRIP(1, D, 1); else TSII_DW_STRIP(1, D, 0); } while (0)
