@@ -24,6 +24,20 @@
 #define TSII_PIN_F2(x) asm volatile("" : "+v"(x))
 #endif
 
+// A/B build knobs (tools/variants/build_variant.py); the defaults are what measured best on the MI355X
+#ifndef LS_NT_STORE
+#define LS_NT_STORE 1          // non-temporal output stores (A/B on the 256^2 x 384 layer: fwd_bn 1.269 -> 1.214 ms)
+#endif
+#ifndef LS_NT_LOAD
+#define LS_NT_LOAD 0           // non-temporal slab loads
+#endif
+#ifndef LS_ORDER
+#define LS_ORDER 1             // block order: 0 channel block fastest, 1 strip fastest, then channel block, chunk, image (fwd 1.227 -> 1.160 ms)
+#endif
+#ifndef LS_WAVES_FUSED
+#define LS_WAVES_FUSED 3       // waves per SIMD the K6b / K6c forms are compiled for
+#endif
+
 namespace tsii {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -42,7 +56,7 @@ __device__ __forceinline__ f32x4 cat4(f32x2 a, f32x2 b) { return f32x4{a.x, a.y,
 // DXE: dX epilogue (out = post_mul != 0 ? acc * post_mul : 0) instead of the forward one (acc / denom + bias, zero where keep == 0).
 // PRE: the staged input is multiplied by a per-pixel plane (mask for forward, 1 / count for dX).
 template <int MODE, bool DXE, bool PRE>
-__global__ __launch_bounds__(256, 3) void dw_lean_kernel(
+__global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_kernel(
     const float* __restrict__ in, const float* __restrict__ pre, const float* __restrict__ wT, const float* __restrict__ bias,
     const float* __restrict__ denom, const float* __restrict__ keep, const float* __restrict__ post_mul, DtGeom g, int chunk_rows,
     unsigned strips_x, unsigned chunks_y, unsigned cblocks, DwBN ib, float* __restrict__ stats, DwBnBwd bb,
@@ -54,8 +68,9 @@ __global__ __launch_bounds__(256, 3) void dw_lean_kernel(
     __shared__ __attribute__((aligned(8))) float lplanes[2][LS_NPX][2];
     __shared__ __attribute__((aligned(16))) float lconst[4][LS_CB];   // K6b: scale, shift, bias | K6c: mean, 1/sigma, gamma, beta
     unsigned b = xcd_remap(blockIdx.x, gridDim.x);
-    const unsigned cb = b % cblocks; b /= cblocks;
-    const unsigned sx = b % strips_x; b /= strips_x;
+    unsigned cb, sx;
+    if (LS_ORDER == 1) { sx = b % strips_x; b /= strips_x; cb = b % cblocks; b /= cblocks; }
+    else { cb = b % cblocks; b /= cblocks; sx = b % strips_x; b /= strips_x; }
     const unsigned cy = b % chunks_y;
     const int64_t n = b / chunks_y;
     const int t = threadIdx.x;
@@ -147,7 +162,8 @@ __global__ __launch_bounds__(256, 3) void dw_lean_kernel(
         const char* const mb = interior ? pb : ipre;
 #pragma unroll
         for (int i = 0; i < LS_PF; ++i) {
-            pf[i] = *reinterpret_cast<const f32x4*>(ab + opq(__umul24(po[i], (unsigned)C) + c0b));
+            pf[i] = LS_NT_LOAD ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ab + opq(__umul24(po[i], (unsigned)C) + c0b)))
+                               : *reinterpret_cast<const f32x4*>(ab + opq(__umul24(po[i], (unsigned)C) + c0b));
             pm[i] = PRE ? *reinterpret_cast<const float*>(mb + opq(po[i])) : 1.f;
         }
         iyb += LS_R; sb += sb_step; pb += pb_step;
@@ -243,6 +259,7 @@ __global__ __launch_bounds__(256, 3) void dw_lean_kernel(
         commit_slab(0, isc, ish);
     }
     commit_planes(0);
+    if (nsteps > 1) { fetch(); fetch_planes(1); }              // slab 1: in flight across the barrier and the first step's compute
     __syncthreads();
 
     // this thread's output pixels: column tx, rows 4 th .. 4 th + 3 of the step
@@ -254,25 +271,30 @@ __global__ __launch_bounds__(256, 3) void dw_lean_kernel(
     const char* const rthr = reinterpret_cast<const char*>(lbuf) + ((4 * th) * LS_PW + tx) * LS_PIXB + cg * 16;
     const int64_t opix0 = (n * g.hout + oy_beg) * (int64_t)g.wout + ox0;
     char* ob = reinterpret_cast<char*>(out + opix0 * C);                       // running: first output pixel of the step
-    const char* yb = reinterpret_cast<const char*>(bb.y + opix0 * C);
+    const char* const yb = reinterpret_cast<const char*>(bb.y + opix0 * C);
     const int64_t ob_step = (int64_t)LS_R * g.wout * C * 4;
 
     f32x4 P = {0.f, 0.f, 0.f, 0.f};                    // K6b: thread-local pivot = its first output
     f32x2 va[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};   // K6b: s1.xy s1.zw s2.xy s2.zw | K6c: sum dz, sum dz*xhat
 
-    // one step; `more`: another one follows (its slab and planes are fetched before, and committed after, the compute)
-    auto step = [&](int s, bool more) {
+    // K6c: raw BatchNorm input at this thread's output pixels of step s (clamped rows / columns: the loads are unconditional),
+    // requested one step ahead like the slab and used after the step's stores
+    f32x4 yv[4];
+    auto fetch_y = [&](int s) {
         const int rows_left = oy_end - (oy_beg + LS_R * s);
-        f32x4 yv[4];
-        if (BNB) {                                           // K6c: raw BatchNorm input at this thread's output pixels, used after the stores
+        const char* const ybs = yb + (int64_t)s * ob_step;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int ry = 4 * th + k < rows_left ? 4 * th + k : rows_left - 1;      // clamped: the load is unconditional
-                yv[k] = *reinterpret_cast<const f32x4*>(yb + opq((unsigned)ry * orow + ocol_ld));
-            }
+        for (int k = 0; k < 4; ++k) {
+            const int ry = 4 * th + k < rows_left ? 4 * th + k : rows_left - 1;
+            yv[k] = *reinterpret_cast<const f32x4*>(ybs + opq((unsigned)ry * orow + ocol_ld));
         }
-        if (more) { fetch(); fetch_planes(s + 1); }          // in flight during the compute below
-
+    };
+    if (BNB) fetch_y(0);
+    // One step.  `more`: another one follows -- its slab and planes were requested at the end of the previous step (right after
+    // the registers they land in were committed: a block always has a slab in flight, also while it waits at the barrier) and
+    // are committed after this step's compute; `more2`: the slab after that is requested then.
+    auto step = [&](int s, bool more, bool more2) {
+        const int rows_left = oy_end - (oy_beg + LS_R * s);
         const char* const rb = rthr + (s & 1) * LS_BUFB;
         f32x2 a[4][2];
 #pragma unroll
@@ -317,7 +339,8 @@ __global__ __launch_bounds__(256, 3) void dw_lean_kernel(
             }
             a[k][0] = a0; a[k][1] = a1;
             if (xok && 4 * th + k < rows_left) {
-                *reinterpret_cast<f32x4*>(ob + opq((unsigned)(4 * th + k) * orow + ocol)) = cat4(a0, a1);
+                if (LS_NT_STORE) __builtin_nontemporal_store(cat4(a0, a1), reinterpret_cast<f32x4*>(ob + opq((unsigned)(4 * th + k) * orow + ocol)));
+                else *reinterpret_cast<f32x4*>(ob + opq((unsigned)(4 * th + k) * orow + ocol)) = cat4(a0, a1);
                 if (FUSED) {
                     if (s == 0 && k == 0) P = cat4(a0, a1);  // a thread with any pixel at all has this one
                     const f32x2 d0 = a0 - P.xy, d1 = a1 - P.zw;
@@ -346,11 +369,14 @@ __global__ __launch_bounds__(256, 3) void dw_lean_kernel(
             }
         }
         if (more) { commit((s + 1) & 1); commit_planes(s + 1); }   // into the buffer nobody reads during this step
-        ob += ob_step; yb += ob_step;
+        if (more2) { fetch(); fetch_planes(s + 2); }
+        if (BNB && more) fetch_y(s + 1);
+        ob += ob_step;
         lds_barrier();
     };
-    for (int s = 0; s + 1 < nsteps; ++s) step(s, true);
-    step(nsteps - 1, false);
+    for (int s = 0; s + 2 < nsteps; ++s) step(s, true, true);
+    if (nsteps > 1) step(nsteps - 2, true, false);
+    step(nsteps - 1, false, false);
 
     if (BNB) {
         float* mrg = lbuf;                               // [256][8]; the loop ended on a barrier: the buffers are free

@@ -736,7 +736,10 @@ struct StripPlan {
 static int g_strip_target = 1536;
 extern "C" void tsii_emu_set_strip_target(int v) { g_strip_target = v > 0 ? v : 1536; }
 #else
-static constexpr int g_strip_target = 1536;
+#ifndef LS_TARGET
+#define LS_TARGET 1536
+#endif
+static constexpr int g_strip_target = LS_TARGET;
 #endif
 static StripPlan plan_strip(int n, int hout, int wout, int c, int s, int d) {
     StripPlan p;
