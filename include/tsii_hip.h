@@ -283,6 +283,23 @@ int tsii_upcat_fwd(const float* low, const float* skip, int n, int h, int w, int
 int tsii_upcat_bwd(const float* dout, int n, int h, int w, int c1, int c2,
                    float* dlow, float* dskip, void* stream);
 
+/* ---- K7b (round 4): the same DoubleUpSample + torch.cat in front of a 1x1 partial convolution, never written --------------
+ * A 1x1 convolution commutes with nearest up-sampling and distributes over the channel concatenation:
+ *   conv1x1(cat(up2(low), skip) * mask) = up2(conv1x1_low(low * mask_low)) + conv1x1_skip(skip * mask_skip)
+ * (models/partial_convolution.py:121-137 over image_inpainting.py:82-85), so the decoder's expand convolutions run their
+ * low-resolution half at LOW resolution -- a quarter of its multiply-adds, and the concatenated tensor never exists:
+ *   z = tsii_pw_fwd(low, ..)                       plain [m/4, n] product at low resolution
+ *   y = tsii_pw_fwd_up(skip, .., up_add = z)       y[row] = keep ? (acc[row] + z[low_row(row)]) / denom + bias : 0
+ * rows of y are the pixels of [.., up_h, up_w] images (up_h even, up_w % 4 == 0, m % (up_h*up_w) == 0, n % 4 == 0, m < 2^31);
+ * stat_part (or NULL) as in tsii_pw_fwd_bn.  Backward: tsii_pw_bwd_dx / tsii_pw_bwd_dw on the skip half as usual, and
+ * dz = tsii_pool2x2_scaled(dy, inv) -- dlow[n,y,x,:] = sum of the 2x2 block of dout[n,2y+dy,2x+dx,:] * scale[n,2y+dy,2x+dx]
+ * (scale NULL = 1; dout is [n,2h,2w,c]) -- is the gradient of z. */
+int tsii_pw_fwd_up(const float* x, int64_t m, int k, const float* w, int n, const float* bias,
+                   const float* r0, int split, const float* r1, const float* denom, const float* keep,
+                   const float* up_add, int up_h, int up_w, float* stat_part, float* y, void* ws, size_t ws_bytes,
+                   void* stream);
+int tsii_pool2x2_scaled(const float* dout, const float* scale, int n, int h, int w, int c, float* dlow, void* stream);
+
 /* ---- K11 (first piece): mean-L1 loss (nn.L1Loss, loss.py:190; bench loss of SURVEY 8d) - */
 size_t tsii_l1_ws_bytes(int64_t numel);
 int tsii_l1_mean_fwd(const float* a, const float* b, int64_t numel, float* loss,

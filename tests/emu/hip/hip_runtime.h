@@ -125,6 +125,7 @@ static inline f32x16_emu __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf16x8_emu a, b
 
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 
 // ---- runtime API subset -----------------------------------------------------
 typedef void* hipStream_t;

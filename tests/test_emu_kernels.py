@@ -540,3 +540,61 @@ def _strip_entry_points(L, n, h, wd, c, masked, bias, act):
     slack = (np.abs(dx) * near).reshape(-1, c).sum(0) * 2 + 1e-4 * np.abs(dz).reshape(-1, c).sum(0).max()
     assert np.all(np.abs(bp[0] - dz.reshape(-1, c).sum(0)) <= slack)
     assert np.all(np.abs(bp[1] - (dz * xh).reshape(-1, c).sum(0)) <= slack * max(1.0, np.abs(xh).max()))
+
+
+# ---- 1x1 convolution over cat(nearest-x2(low), skip) with the low half computed at low resolution (K7b) -------------------------
+@pytest.mark.parametrize("n,h,wd,k,N,stats", [(2, 8, 16, 40, 128, True),      # producer / consumer kernel (256-row tiles)
+                                              (1, 16, 32, 64, 256, False),     # producer / consumer kernel, 128 x 256 tiles
+                                              (1, 6, 12, 20, 36, True),        # 4-wave kernels, row / column tails
+                                              (3, 4, 8, 8, 64, False)])
+def test_pointwise_upsampled_addend(emu, mode, n, h, wd, k, N, stats):
+    L = emu
+    rng = np.random.default_rng(n * 1000 + h * 10 + k)
+    m = n * h * wd
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w = rng.standard_normal((N, k)).astype(np.float32)
+    z = rng.standard_normal((n, h // 2, wd // 2, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    r0 = (rng.uniform(size=m) > 0.2).astype(np.float32)
+    keep = (rng.uniform(size=m) > 0.1).astype(np.float32)
+    denom = rng.integers(1, 9, size=m).astype(np.float32)
+    y = np.full((m, N), np.nan, np.float32)
+    nb = L.tsii_pw_ws_bytes(N, k)
+    ws = WS(nb)
+    rows = L.tsii_pw_stat_rows(m)
+    part = WS(4 * rows * 4 * N) if stats else None
+    before = L.hipemu_launches(768)
+    assert L.tsii_pw_fwd_up(P(x), m, k, P(w), N, P(bias), P(r0), k, None, P(denom), P(keep), P(z), h, wd, P(part), P(y), P(ws), nb, None) == 0, L.tsii_last_error()
+    if mode == 6 and N >= 128:
+        assert L.hipemu_launches(768) == before + 1, "the producer / consumer kernel should have taken this shape"
+    zup = np.repeat(np.repeat(z.astype(np.float64), 2, axis=1), 2, axis=2).reshape(m, N)
+    acc = (x.astype(np.float64) * r0[:, None]) @ w.astype(np.float64).T
+    ref = np.where(keep[:, None] != 0, (acc + zup) / denom[:, None] + bias, 0.0)
+    assert np.abs(y - ref).max() <= MODE_TOL[mode] * np.abs(ref).max(), (np.abs(y - ref).max(), np.abs(ref).max())
+    if stats:
+        pr = part[:rows * 4 * N].reshape(rows, 4, N).astype(np.float64)
+        cnt, piv, s1, s2 = pr[:, 0], pr[:, 1], pr[:, 2], pr[:, 3]
+        assert np.all(cnt.sum(0) == m)
+        mean = (cnt * piv + s1).sum(0) / m
+        yd = y.astype(np.float64)
+        assert np.abs(mean - yd.mean(0)).max() <= 1e-5 * max(1.0, np.abs(yd).max())
+        ex2 = (s2 + 2 * piv * s1 + cnt * piv * piv).sum(0) / m
+        assert np.abs(ex2 - (yd ** 2).mean(0)).max() <= 1e-5 * max(1.0, (yd ** 2).max())
+    # the addend's gradient: 2 x 2 sums of dy * inv
+    dy = rng.standard_normal((n, h, wd, N)).astype(np.float32)
+    inv = (keep / denom).astype(np.float32).reshape(n, h, wd)
+    dz = np.full((n, h // 2, wd // 2, N), np.nan, np.float32)
+    assert L.tsii_pool2x2_scaled(P(dy), P(inv), n, h // 2, wd // 2, N, P(dz), None) == 0, L.tsii_last_error()
+    g = dy.astype(np.float64) * inv[..., None]
+    dzr = g.reshape(n, h // 2, 2, wd // 2, 2, N).sum(axis=(2, 4))
+    assert np.abs(dz - dzr).max() <= 1e-6 * max(1.0, np.abs(dzr).max())
+
+
+def test_pointwise_upsampled_addend_rejects_bad_geometry(emu):
+    L = emu
+    x = np.zeros((48, 8), np.float32); w = np.zeros((8, 8), np.float32); z = np.zeros((12, 8), np.float32); y = np.zeros((48, 8), np.float32)
+    nb = L.tsii_pw_ws_bytes(8, 8); ws = WS(nb)
+    # width 6 is not a multiple of 4; height 3 is odd; rows are not whole images
+    for hh, ww in ((8, 6), (3, 16), (5, 8)):
+        assert L.tsii_pw_fwd_up(P(x), 48, 8, P(w), 8, None, None, 0, None, None, None, P(z), hh, ww, None, P(y), P(ws), nb, None) != 0
+        assert b"pw_fwd_up" in L.tsii_last_error()

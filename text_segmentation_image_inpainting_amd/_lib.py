@@ -50,6 +50,8 @@ SIGNATURES = {
     "tsii_bn_stats": (_i, [_p, _l, _i, _p, _p, _p, _p, _f, _p, _z, _p]),
     "tsii_bn_act_fwd": (_i, [_p, _l, _i, _p, _p, _p, _p, _f, _i, _f, _p, _p, _p]),
     "tsii_bn_act_bwd": (_i, [_p, _p, _l, _i, _p, _p, _p, _p, _f, _i, _f, _i, _p, _p, _p, _p, _z, _p]),
+    "tsii_pw_fwd_up": (_i, [_p, _l, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _z, _p]),
+    "tsii_pool2x2_scaled": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "tsii_pw_stat_rows": (_l, [_l]),
     "tsii_pw_fwd_bn": (_i, [_p, _l, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _p, _z, _p]),
     "tsii_pw_bwd_dw_bn": (_i, [_p, _p, _l, _i, _i, _p, _p, _p, _i, _p, _p, _p, _i, _f, _p, _p, _p, _z, _p]),

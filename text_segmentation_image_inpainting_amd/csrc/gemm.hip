@@ -608,12 +608,21 @@ extern "C" size_t tsii_pw_ws_bytes(int n, int k);
 
 static int pw_fwd_impl(const float* x, int64_t m, int k, const float* w, int n, const float* bias, const float* r0, int split,
                        const float* r1, const float* denom, const float* keep, InBN ib, float* stats, float* y, void* ws, size_t ws_bytes,
-                       void* stream) {
+                       void* stream, const float* up_add = nullptr, int up_h = 0, int up_w = 0) {
     TSII_REQUIRE(x && w && y, "pw_fwd: null pointer");
     TSII_REQUIRE(ws == nullptr || ws_bytes >= tsii_pw_ws_bytes(n, k), "pw_fwd: workspace too small");
     TSII_REQUIRE(m > 0 && k > 0 && n > 0, "pw_fwd: bad shape m=%lld k=%d n=%d", (long long)m, k, n);
     RowScale as = {r0, r1, r0 != nullptr ? split : 0};
     Epilogue ep = {denom, keep, bias, {nullptr, nullptr, 0}, 0, stats};
+    if (up_add != nullptr) {
+        TSII_REQUIRE(up_h > 0 && up_w >= 4 && up_h % 2 == 0 && up_w % 4 == 0 && m % ((int64_t)up_h * up_w) == 0,
+                     "pw_fwd_up: rows must be the pixels of whole images with even height and a width that is a multiple of 4 (got %d x %d, m=%lld)",
+                     up_h, up_w, (long long)m);
+        TSII_REQUIRE(n % 4 == 0 && aligned16(up_add) && m < (1ll << 31), "pw_fwd_up: n %% 4 == 0, a 16-byte aligned addend and m < 2^31 are required");
+        ep.up_add = up_add;
+        ep.up_w = (unsigned)up_w;
+        make_up_div((unsigned)up_w, &ep.up_magic, &ep.up_shift);
+    }
     return launch_nt(x, k, as, w, k, y, n, m, n, k, ep, (hipStream_t)stream, ib, ws);
 }
 
@@ -642,6 +651,14 @@ extern "C" int tsii_pw_fwd_bn(const float* x, int64_t m, int k, const float* w, 
     InBN ib;
     TSII_REQUIRE(make_in_bn(in_scale, in_shift, in_act, in_slope, &ib) == 0, "pw_fwd_bn: activation %d has no load-time form", in_act);
     return pw_fwd_impl(x, m, k, w, n, bias, r0, split, r1, denom, keep, ib, stat_part, y, ws, ws_bytes, stream);
+}
+
+extern "C" int tsii_pw_fwd_up(const float* x, int64_t m, int k, const float* w, int n, const float* bias,
+                              const float* r0, int split, const float* r1, const float* denom, const float* keep,
+                              const float* up_add, int up_h, int up_w, float* stat_part, float* y, void* ws, size_t ws_bytes,
+                              void* stream) {
+    TSII_REQUIRE(up_add != nullptr, "pw_fwd_up: null addend");
+    return pw_fwd_impl(x, m, k, w, n, bias, r0, split, r1, denom, keep, kNoBN, stat_part, y, ws, ws_bytes, stream, up_add, up_h, up_w);
 }
 
 static int pw_bwd_dx_impl(const float* dy, int64_t m, int n, const float* w, int k, const float* inv,

@@ -71,16 +71,23 @@ __device__ __forceinline__ void pc_bump_flag(unsigned* f) { __hip_atomic_fetch_a
 // sideX / sideY: the tile's per-row factors in LDS (always staged, 1.0 when absent).  EPI:
 //   0 / 1 (forward without / with BatchNorm statistics):  y = keep ? acc * (1/denom) + bias : 0      (sideX = 1/denom, sideY = keep)
 //   2 / 3 (dX without / with the K6c reductions):          y = acc * (col < cs.split ? cs.r0 : cs.r1)  (sideX = cs.r0,  sideY = cs.r1)
+//   4 / 5 (forward 0 / 1 with the up-sampled addend, gemm_tiles.h: Epilogue::up_add):  acc + up_add[low row][col] in place of acc;
+//          a 4-row band (rows 4-aligned, up_w % 4 == 0) lies in one image row, so it reads TWO addend rows, one band ahead
 // Addresses: wave-uniform 64-bit bases + RUNNING 32-bit byte offsets (one add per row); written as 64 independent
 // row * ldc products the compiler hoists all of them out of the tile loop and spills them.
 template <int EPI>
 __device__ __forceinline__ void pc_epilogue(f32x16 (&acc)[4], float* __restrict__ C, int64_t ldc, int N, const Epilogue& ep,
                                             int64_t mw0, int col0, int li, int hi, const float* __restrict__ sideX,
                                             const float* __restrict__ sideY, float bias) {
-    constexpr bool DX = EPI >= 2, STATS = EPI == 1, BNB = EPI == 3;
+    constexpr bool UP = EPI >= 4, DX = EPI == 2 || EPI == 3, STATS = EPI == 1 || EPI == 5, BNB = EPI == 3;
     const int col = col0 + li;
     const bool cs_lo = col < ep.cs.split;
     float st1 = 0.f, st2 = 0.f, pvt = 0.f;
+    const char* __restrict__ Zb = UP ? reinterpret_cast<const char*>(ep.up_add) : nullptr;
+    const unsigned mw0u = (unsigned)mw0;
+    auto zoff_of = [&](int rb4) {       // byte offset of the addend row of band rows rb4, rb4 + 1 (rows rb4 + 2, + 3: the next addend row)
+        return up_low_row(mw0u + (unsigned)rb4, ep.up_w, ep.up_magic, ep.up_shift) * ((unsigned)N * 4u) + (unsigned)col * 4u;
+    };
     if constexpr (STATS) {      // pivot of the 128-row block: the value at its middle row, same for both lane halves
         float pv = fmaf(acc[2][0], sideX[64], bias);
         pv = sideY[64] == 0.f ? 0.f : pv;
@@ -104,6 +111,12 @@ __device__ __forceinline__ void pc_epilogue(f32x16 (&acc)[4], float* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) ynext[j] = *reinterpret_cast<const float*>(Yb + yoff + (unsigned)j * n4);
     }
+    float znext[2] = {0.f, 0.f};
+    if constexpr (UP) {
+        const unsigned zo = zoff_of(4 * hi);
+        znext[0] = *reinterpret_cast<const float*>(Zb + zo);
+        znext[1] = *reinterpret_cast<const float*>(Zb + zo + n4);
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -122,6 +135,15 @@ __device__ __forceinline__ void pc_epilogue(f32x16 (&acc)[4], float* __restrict_
                     for (int j = 0; j < 4; ++j) ynext[j] = *reinterpret_cast<const float*>(Yb + yoff + 8u * n4 + (unsigned)j * n4);
                 }
             }
+            float zv[2] = {0.f, 0.f};
+            if constexpr (UP) {
+                zv[0] = znext[0]; zv[1] = znext[1];
+                if (t * 4 + g < 15) {
+                    const unsigned zo = zoff_of(rb4 + 8);
+                    znext[0] = *reinterpret_cast<const float*>(Zb + zo);
+                    znext[1] = *reinterpret_cast<const float*>(Zb + zo + n4);
+                }
+            }
             const float4 x4 = xq, y4 = yq;
             if (t * 4 + g < 15) {
                 xq = *reinterpret_cast<const float4*>(sideX + rb4 + 8);
@@ -133,6 +155,7 @@ __device__ __forceinline__ void pc_epilogue(f32x16 (&acc)[4], float* __restrict_
                 const int r = 4 * g + j;
                 float v;
                 if constexpr (DX) v = acc[t][r] * (cs_lo ? xs[j] : ys[j]);
+                else if constexpr (UP) { v = fmaf(acc[t][r] + zv[j >> 1], xs[j], bias); v = ys[j] == 0.f ? 0.f : v; }
                 else { v = fmaf(acc[t][r], xs[j], bias); v = ys[j] == 0.f ? 0.f : v; }
                 if constexpr (STATS) {
                     const float d = v - pvt;
@@ -205,7 +228,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_pc_kernel(const float* __restr
     const unsigned t1 = (unsigned)(((uint64_t)(blockIdx.x + 1) * tiles) / gridDim.x);
     const int nst = (K + 31) >> 5;
     const unsigned stages = (t1 - t0) * (unsigned)nst;        // >= 1: the launcher never starts more blocks than tiles
-    constexpr bool use_cs = EPI >= 2;                         // dX epilogue: row factors = the two mask planes
+    constexpr bool use_cs = EPI == 2 || EPI == 3;             // dX epilogue: row factors = the two mask planes
 
     if (tid < 16) full[tid] = 0u;
     if constexpr (BNIN) {
@@ -553,11 +576,19 @@ static int pc_cus() {            // read-only device-properties cache
     return cus;
 }
 
-static int g_pc = getenv("TSII_GEMM_PC") ? atoi(getenv("TSII_GEMM_PC")) : 1;              // A/B knob: 0 = 4-wave kernels only
+// Dispatch constants.  They are compile-time in the stock library; an A/B build (-DTSII_GEMM_PC_ABLATIONS, tools/variants) reads
+// them from the environment once at load instead (tools/pc_probe.py, tools/gemm_bench.py).
+#ifdef TSII_GEMM_PC_ABLATIONS
+static int g_pc = getenv("TSII_GEMM_PC") ? atoi(getenv("TSII_GEMM_PC")) : 1;              // 0 = 4-wave kernels only
 static int g_pc_opt = getenv("TSII_GEMM_PC_OPT") ? atoi(getenv("TSII_GEMM_PC_OPT")) : 0;   // wave priorities (kernel comment)
-static int g_pc_abl = getenv("TSII_GEMM_PC_ABL") ? atoi(getenv("TSII_GEMM_PC_ABL")) : 0;   // tools/pc_probe.py ablations only
-static int g_pc_bnb_min_k = getenv("TSII_GEMM_PC_BNB_MIN_K") ? atoi(getenv("TSII_GEMM_PC_BNB_MIN_K")) : 32;   // dX + K6c: shortest reduction the persistent kernel takes (one-stage tiles: 1.57 -> 1.45 ms on 2M x 32 -> 384 since the epilogue prefetches the BatchNorm input; 64 before)
-static int g_pc_min_n = getenv("TSII_GEMM_PC_MIN_N") ? atoi(getenv("TSII_GEMM_PC_MIN_N")) : 128;   // measured: 64-column outputs stay faster on the 4-wave kernel
+static int g_pc_abl = getenv("TSII_GEMM_PC_ABL") ? atoi(getenv("TSII_GEMM_PC_ABL")) : 0;   // tools/pc_probe.py ablations
+static int g_pc_bnb_min_k = getenv("TSII_GEMM_PC_BNB_MIN_K") ? atoi(getenv("TSII_GEMM_PC_BNB_MIN_K")) : 32;
+static int g_pc_min_n = getenv("TSII_GEMM_PC_MIN_N") ? atoi(getenv("TSII_GEMM_PC_MIN_N")) : 128;
+#else
+static constexpr int g_pc = 1, g_pc_opt = 0;
+static constexpr int g_pc_bnb_min_k = 32;   // dX + K6c: shortest reduction the persistent kernel takes (one-stage tiles: 1.57 -> 1.45 ms on 2M x 32 -> 384 since the epilogue prefetches the BatchNorm input; 64 before)
+static constexpr int g_pc_min_n = 128;      // measured: 64-column outputs stay faster on the 4-wave kernel
+#endif
 
 size_t nt_pc_ws_bytes(int n, int k) { return (size_t)3 * n * ((k + 31) & ~31) * sizeof(unsigned short) + 16; }
 
@@ -572,6 +603,7 @@ bool nt_pc_ok(const float* A, int64_t lda, const RowScale& as, int64_t M, int N,
     if (dx && (ep.denom != nullptr || ep.keep != nullptr || ep.bias != nullptr || ep.stats != nullptr || ib.sc != nullptr)) return false;   // one epilogue mode at a time
     if (ep.bn_y != nullptr && K < g_pc_bnb_min_k) return false;                                                   // (A/B knob)
     if (ib.sc != nullptr && K > 1024) return false;                                                               // (scale, shift) live in LDS
+    if (ep.up_add != nullptr && (dx || ib.sc != nullptr || ep.up_w % 4 != 0 || M >= (1ll << 31) || (M / 4) * N * 4 >= (1ll << 32))) return false;   // forward only; 32-bit addend offsets
     if ((int64_t)3 * N * ((K + 31) & ~31) * 2 >= (1ll << 31)) return false;
     return true;
 }
@@ -589,9 +621,11 @@ static int launch_nt_pc_cfg(const float* A, int64_t lda, RowScale as, const unsi
                                                              A, lda, as, Bp, C, ldc, M, N, K, ep, ib, ntn, (unsigned)tiles, g_pc_opt)
     if (ep.bn_y != nullptr) TSII_PC_LAUNCH(false, 3, 0);
     else if (ep.cs.r0 != nullptr) TSII_PC_LAUNCH(false, 2, 0);
+    else if (ep.up_add != nullptr) { if (ep.stats != nullptr) TSII_PC_LAUNCH(false, 5, 0); else TSII_PC_LAUNCH(false, 4, 0); }
     else if (ib.sc != nullptr) { if (ep.stats != nullptr) TSII_PC_LAUNCH(true, 1, 0); else TSII_PC_LAUNCH(true, 0, 0); }
     else if (ep.stats != nullptr) TSII_PC_LAUNCH(false, 1, 0);
     else {
+#ifdef TSII_GEMM_PC_ABLATIONS          // A/B builds only (tools/pc_probe.py): the stock library carries none of these instantiations
         if (WM == 1 && g_pc_abl == 16) TSII_PC_LAUNCH(false, 0, 16);
         else if (WM == 1 && g_pc_abl == 32) TSII_PC_LAUNCH(false, 0, 32);
         else if (WM == 1 && g_pc_abl == 128) TSII_PC_LAUNCH(false, 0, 128);
@@ -613,7 +647,9 @@ static int launch_nt_pc_cfg(const float* A, int64_t lda, RowScale as, const unsi
         else if (WM == 1 && g_pc_abl == 17296) TSII_PC_LAUNCH(false, 0, 17296);
         else if (WM == 1 && g_pc_abl == 4096) TSII_PC_LAUNCH(false, 0, 4096);
         else if (WM == 1 && g_pc_abl == 2512) TSII_PC_LAUNCH(false, 0, 2512);
-        else TSII_PC_LAUNCH(false, 0, 0);
+        else
+#endif
+        TSII_PC_LAUNCH(false, 0, 0);
     }
 #undef TSII_PC_LAUNCH
     return check_launch("gemm_nt_pc");

@@ -26,7 +26,26 @@ struct Epilogue {
     const float* bn_beta;
     float bn_eps, bn_neg, bn_hi;
     float* bn_part;      // [row blocks][2][N]
+    // Forward with an up-sampled addend (round 4): rows are the pixels of [.., up_h, up_w] images and the accumulator of row
+    // (n, y, x) gets up_add[(n, y / 2, x / 2)][col] (a [M / 4, N] matrix) added BEFORE the count division / bias / hole zeroing:
+    // the low-resolution half of a 1x1 convolution over cat(nearest-x2(low), skip), computed at low resolution.  NULL: none.
+    const float* up_add;
+    unsigned up_w, up_magic, up_shift;   // row / up_w = umulhi(row, up_magic) >> up_shift for row < 2^31 (make_up_div)
 };
+
+// exact unsigned division by a constant for numerators below 2^31: q = umulhi(n, magic) >> shift
+static inline void make_up_div(unsigned d, unsigned* magic, unsigned* shift) {
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;                               // s = ceil(log2 d), d >= 2
+    *magic = (unsigned)(((1ull << (31 + s)) + d - 1) / d);     // < 2^32; error term n * e < 2^(31+s) for n < 2^31
+    *shift = s - 1;
+}
+// row of the [M/4, N] addend for GEMM row `row` (pixel (n, y, x) of images up_w wide, even height)
+__device__ __forceinline__ unsigned up_low_row(unsigned row, unsigned w, unsigned magic, unsigned shift) {
+    const unsigned q = __umulhi(row, magic) >> shift;          // n * H + y
+    const unsigned x = row - q * w;
+    return (q >> 1) * (w >> 1) + (x >> 1);
+}
 
 
 // ---- tile loaders ----------------------------------------------------------------------
@@ -344,6 +363,15 @@ __device__ __forceinline__ void nt_epilogue(float* __restrict__ smem, f32x16 (&a
                 for (int i = 0; i < F4_PER_THREAD; ++i) c1v[i] = ep.cs.r1[rowv[i] < Mout ? rowv[i] : 0];
             }
         }
+        float4 zq[F4_PER_THREAD];                              // up-sampled addend (N % 4 == 0, checked by the entry point)
+        if (ep.up_add != nullptr) {
+#pragma unroll
+            for (int i = 0; i < F4_PER_THREAD; ++i) {
+                zq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rowv[i] < Mout && col_ok)
+                    zq[i] = *reinterpret_cast<const float4*>(ep.up_add + (int64_t)up_low_row((unsigned)rowv[i], ep.up_w, ep.up_magic, ep.up_shift) * N + col);
+            }
+        }
         float4 yq[BNB ? F4_PER_THREAD : 1];
         if constexpr (BNB) {     // the raw BatchNorm input at the positions this thread stores (N % 4 == 0, 16-byte rows)
 #pragma unroll
@@ -376,6 +404,7 @@ __device__ __forceinline__ void nt_epilogue(float* __restrict__ smem, f32x16 (&a
             if (row >= Mout || !col_ok) continue;
             const float4 q = *reinterpret_cast<const float4*>(Cs + rr * CS + c4 * 4);
             float v[4] = {q.x, q.y, q.z, q.w};
+            if (ep.up_add != nullptr) { v[0] += zq[i].x; v[1] += zq[i].y; v[2] += zq[i].z; v[3] += zq[i].w; }
             if (ep.denom != nullptr) {
                 const float rd = 1.0f / dnv[i];      // one IEEE division per row, then multiplies (<= 1 ulp apart)
 #pragma unroll

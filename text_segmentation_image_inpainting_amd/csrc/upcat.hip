@@ -85,9 +85,49 @@ __global__ void upcat_bwd_skip_kernel(const float* __restrict__ dout, int64_t np
     }
 }
 
+// dlow[n, y, x, :] = sum over the 2 x 2 block of dout[n, 2y + dy, 2x + dx, :] * scale[n, 2y + dy, 2x + dx]  (scale: a per-pixel
+// plane or NULL): the gradient of an up-sampled ADDEND (gemm_tiles.h: Epilogue::up_add) -- the adjoint of nearest x2 applied to
+// the gradient that reaches the accumulator, dy * inv.  One output vector per thread, four streaming reads.
+template <int W>
+__global__ void pool2x2_scaled_kernel(const float* __restrict__ dout, const float* __restrict__ scale, int n, int h, int w, int c,
+                                      float* __restrict__ dlow) {
+    const int CG = c / W;
+    const int w2 = 2 * w;
+    const int64_t total = (int64_t)n * h * w * CG;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int cc = (int)(idx % CG) * W;
+        const int64_t pix = idx / CG;
+        const int x = (int)(pix % w);
+        const int y = (int)((pix / w) % h);
+        const int64_t b = pix / ((int64_t)w * h);
+        const int64_t p00 = (b * 2 * h + 2 * y) * w2 + 2 * x;
+        const VecF<W> a0 = vload_nt<W>(dout + p00 * c + cc);
+        const VecF<W> a1 = vload_nt<W>(dout + (p00 + 1) * c + cc);
+        const VecF<W> a2 = vload_nt<W>(dout + (p00 + w2) * c + cc);
+        const VecF<W> a3 = vload_nt<W>(dout + (p00 + w2 + 1) * c + cc);
+        float s0 = 1.f, s1 = 1.f, s2 = 1.f, s3 = 1.f;
+        if (scale != nullptr) { s0 = scale[p00]; s1 = scale[p00 + 1]; s2 = scale[p00 + w2]; s3 = scale[p00 + w2 + 1]; }
+        VecF<W> s;
+#pragma unroll
+        for (int i = 0; i < W; ++i) s.v[i] = (a0.v[i] * s0 + a1.v[i] * s1) + (a2.v[i] * s2 + a3.v[i] * s3);
+        vstore<W>(dlow + pix * c + cc, s);
+    }
+}
+
 }  // namespace tsii
 
 using namespace tsii;
+
+extern "C" int tsii_pool2x2_scaled(const float* dout, const float* scale, int n, int h, int w, int c, float* dlow, void* stream) {
+    TSII_REQUIRE(dout && dlow, "pool2x2_scaled: null pointer");
+    TSII_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0, "pool2x2_scaled: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (c % 4 == 0) && aligned16(dout) && aligned16(dlow);
+    const int64_t total = (int64_t)n * h * w * (vec ? c / 4 : c);
+    if (vec) hipLaunchKernelGGL((pool2x2_scaled_kernel<4>), dim3(flat_grid(total, 256)), dim3(256), 0, st, dout, scale, n, h, w, c, dlow);
+    else hipLaunchKernelGGL((pool2x2_scaled_kernel<1>), dim3(flat_grid(total, 256)), dim3(256), 0, st, dout, scale, n, h, w, c, dlow);
+    return check_launch("pool2x2_scaled");
+}
 
 extern "C" int tsii_upcat_fwd(const float* low, const float* skip, int n, int h, int w, int c1, int c2, float* out,
                               void* stream) {

@@ -17,13 +17,15 @@ from .partial_convolution import DoubleUpSample, PartialConv, partial_convolutio
 
 
 def _upcat_with_mask(x, mp, skip_x, skip_m, virtual=False):
-    """DoubleUpSample + torch.cat on features and masks (models/image_inpainting.py:82-84).  ``virtual``: the consumer is the
-    output head, which can read the two tensors directly (ops.VirtualCat, K4c) -- the concatenation is not written."""
+    """DoubleUpSample + torch.cat on features and masks (models/image_inpainting.py:82-84).  ``virtual``: the consumer can
+    read the two tensors directly (ops.VirtualCat: the output head, K4c; a block opening with a 1x1 partial convolution,
+    K7b) -- the concatenation is not written unless that consumer falls back to ``materialize()``."""
     up_m = mp.upsample2x()
     sp = skip_m.parts[0]
     if len(skip_m.parts) != 1 or len(up_m.parts) != 1:
         raise NotImplementedError("decoder concat expects single-part masks on both sides")
-    cat = (lambda a, b: ops.VirtualCat(a, b)) if virtual else ops.upcat
+    low_plane = mp.parts[0].plane if len(mp.parts) == 1 and mp.parts[0].planar else None
+    cat = (lambda a, b: ops.VirtualCat(a, b, low_plane)) if virtual else ops.upcat
     if sp.planar:
         return cat(x, skip_x), up_m.cat(skip_m)
     # general per-channel skip mask (the raw input level): multiply the skip features once here, so
@@ -46,9 +48,13 @@ class _UNetBase(BaseModule):
     def _decode(self, x, mp, fx, fm):
         last = len(self.decoder) - 1
         for i, layer in enumerate(self.decoder):
-            # the last level feeds a bare PartialConv (the output head): hand it the concatenation unwritten
+            # the last level feeds a bare PartialConv (the output head): hand it the concatenation unwritten; so does a level
+            # whose first block is an inverted residual without a skip connection (its 1x1 expand convolution is the only reader)
             head = i == last and isinstance(layer, nn.Sequential) and len(layer) == 1 and type(layer[0]) is PartialConv
-            x, mp = _upcat_with_mask(x, mp, fx.pop(-1), fm.pop(-1), virtual=head)
+            first = layer[0] if isinstance(layer, nn.Sequential) and len(layer) > 0 else None
+            expand = (isinstance(first, PartialInvertedResidual) and not first.res_connect and isinstance(first.conv[0][0], PartialConv)
+                      and tuple(first.conv[0][0].feature_conv.kernel_size) == (1, 1))
+            x, mp = _upcat_with_mask(x, mp, fx.pop(-1), fm.pop(-1), virtual=head or expand)
             x, mp = run_nhwc(layer, x, mp)
         return x
 

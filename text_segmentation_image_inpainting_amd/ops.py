@@ -110,9 +110,10 @@ class _Pointwise(torch.autograd.Function):
     of y as a second, non-differentiable output."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, r0, r1, denom, keep, inv, split, in_scale, in_shift, in_act, in_slope, want_stats, bn=None):
+    def forward(ctx, x, w, bias, r0, r1, denom, keep, inv, split, in_scale, in_shift, in_act, in_slope, want_stats, bn=None, up_add=None):
         _lib.check_device(x)
         ctx.bn = bn     # (mean, var, gamma, beta, eps, slot) of the lazily applied producer BatchNorm (K6c) or None
+        ctx.has_up = up_add is not None   # K7b: [n, h/2, w/2, cout] addend, up-sampled x2 onto the accumulator (differentiable)
         x, w = x.contiguous(), w.contiguous()
         n, h, wd, k = x.shape
         cout = w.shape[0]
@@ -122,7 +123,15 @@ class _Pointwise(torch.autograd.Function):
         part = None
         wbytes = _lib.lib().tsii_pw_ws_bytes(cout, k)
         wws = _ws(wbytes, x)
-        if in_scale is None and not want_stats:
+        if up_add is not None:
+            assert in_scale is None, "the up-sampled addend has no BatchNorm-on-load form"
+            up_add = up_add.contiguous()
+            assert tuple(up_add.shape) == (n, h // 2, wd // 2, cout), "up_add must be [n, h/2, w/2, cout]"
+            if want_stats:
+                part = torch.empty((_lib.lib().tsii_pw_stat_rows(m), 4, cout), dtype=torch.float32, device=x.device)
+            call("tsii_pw_fwd_up", ptr(x), m, k, ptr(w), cout, ptr(bias), ptr(r0), int(split), ptr(r1), ptr(denom), ptr(keep),
+                 ptr(up_add), h, wd, ptr(part), ptr(y), ptr(wws), wbytes, _lib.stream())
+        elif in_scale is None and not want_stats:
             call("tsii_pw_fwd", ptr(x), m, k, ptr(w), cout, ptr(bias), ptr(r0), int(split), ptr(r1),
                  ptr(denom), ptr(keep), ptr(y), ptr(wws), wbytes, _lib.stream())
         else:
@@ -143,7 +152,7 @@ class _Pointwise(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, *_):
         if gy is None:
-            return (None,) * 15
+            return (None,) * 16
         x, w, r0, r1, inv, keep, in_scale, in_shift = ctx.saved_tensors
         gy = gy.contiguous()
         n, h, wd, k = x.shape
@@ -175,12 +184,27 @@ class _Pointwise(torch.autograd.Function):
             else:
                 call("tsii_pw_bwd_dw_bn", ptr(gy), ptr(x), m, cout, k, ptr(inv), ptr(keep), ptr(r0), ctx.split, ptr(r1),
                      ptr(in_scale), ptr(in_shift), ctx.in_cfg[0], ctx.in_cfg[1], ptr(dw), ptr(db), ptr(ws), nbytes, st)
-        return (dx, dw, db) + (None,) * 12
+        dz = None
+        if ctx.has_up and ctx.needs_input_grad[15]:
+            # the addend joins the accumulator before the count division: its gradient is the 2x2 sum of dy * inv
+            dz = torch.empty((n, h // 2, wd // 2, cout), dtype=torch.float32, device=x.device)
+            call("tsii_pool2x2_scaled", ptr(gy), ptr(inv), n, h // 2, wd // 2, cout, ptr(dz), st)
+        return (dx, dw, db) + (None,) * 12 + (dz,)
 
 
-def pconv_pointwise(x, w, bias=None, r0=None, split=0, r1=None, denom=None, keep=None, inv=None, want_stats=False):
-    """y = keep ? (x*rs) @ w^T / denom + bias : 0   (include/tsii_hip.h, K3).  ``x`` may be a LazyBN (K6b);
-    with ``want_stats`` returns (y, stat_part)."""
+def pointwise_up_ok(vc: "VirtualCat", cout: int) -> bool:
+    """Can a 1x1 convolution over this virtual concatenation run its low half at low resolution (tsii_pw_fwd_up)?"""
+    n, h, w, _ = vc.shape
+    return vc.low_plane is not None and cout % 4 == 0 and h % 2 == 0 and w % 4 == 0 and n * h * w < 2 ** 31 and _al16(vc.low, vc.skip)
+
+
+def pconv_pointwise(x, w, bias=None, r0=None, split=0, r1=None, denom=None, keep=None, inv=None, want_stats=False, up_add=None):
+    """y = keep ? ((x*rs) @ w^T [+ up2(up_add)]) / denom + bias : 0   (include/tsii_hip.h, K3 / K7b).  ``x`` may be a LazyBN
+    (K6b); with ``want_stats`` returns (y, stat_part)."""
+    if up_add is not None:
+        if isinstance(x, LazyBN):
+            x = x.materialize()
+        return _Pointwise.apply(x, w, bias, r0, r1, denom, keep, inv, split, None, None, 0, 0.0, want_stats, None, up_add)
     if isinstance(x, LazyBN):
         if x.token.shape[-1] % 4 == 0:
             x.consumed()
@@ -691,15 +715,17 @@ def upcat(low, skip):
 
 
 class VirtualCat:
-    """cat(nearest-x2(low), skip) along channels, NOT written (K4c): the decoder's last DoubleUpSample + torch.cat, consumed by
-    the few-output-channel head kernels straight from the two tensors.  Anything else calls ``materialize()`` (= upcat)."""
+    """cat(nearest-x2(low), skip) along channels, NOT written: the decoder's DoubleUpSample + torch.cat.  Consumers that read
+    the two tensors directly: the few-output-channel head kernels (K4c) and 1x1 partial convolutions, which run their low half
+    at low resolution (K7b, include/tsii_hip.h).  Anything else calls ``materialize()`` (= upcat)."""
 
-    __slots__ = ("low", "skip")
+    __slots__ = ("low", "skip", "low_plane")
 
-    def __init__(self, low, skip):
+    def __init__(self, low, skip, low_plane=None):
         n, h, w, _ = low.shape
         assert skip.shape[0] == n and skip.shape[1] == 2 * h and skip.shape[2] == 2 * w, "upcat: shape mismatch"
         self.low, self.skip = low, skip
+        self.low_plane = low_plane      # [n, h, w] mask plane of ``low`` BEFORE up-sampling (K7b: the low half runs at low resolution)
 
     @property
     def shape(self):

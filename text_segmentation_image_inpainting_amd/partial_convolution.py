@@ -22,6 +22,9 @@ import os
 # A/B knob for the K6b BatchNorm folding: "1" (default) statistics in the conv epilogue + apply on load,
 # "stats" statistics only, "0" the separate-kernel path
 FUSE_BN = os.environ.get("TSII_FUSE_BN", "1")
+# A/B knob for K7b (1x1 convolutions over a decoder concatenation run their low half at low resolution): "0" = materialise the
+# concatenation (K7) and run one product over it, as the reference does
+FUSE_UPCAT = os.environ.get("TSII_FUSE_UPCAT", "1") != "0"
 
 inplace_batch_norm = False  # reference: optional un-vendored InPlaceABN (:12-17); never available
 
@@ -87,6 +90,17 @@ class PartialConv(BaseModule):
                 r0, _, r1 = mp.row_scale()
                 y = ops.pconv_head_cat(x, w, b, r0, r1, denom, keep, inv)
                 return y, MaskParts.from_plane(new_mask, cout)
+            if (groups == 1 and pointwise and mp.fusable and len(mp.parts) == 2 and mp.parts[0].channels == x.low.shape[3]
+                    and FUSE_UPCAT and ops.pointwise_up_ok(x, cout)):
+                # K7b: conv1x1(cat(up2(low), skip) * mask) = up2(conv1x1(low * mask_low)) + conv1x1(skip * mask_skip): the low
+                # half at low resolution (a quarter of its multiply-adds), the concatenation never written
+                _, cl, r1 = mp.row_scale()                 # r1: the skip part's plane (None: premultiplied / all ones)
+                z = ops.pconv_pointwise(x.low, w[:, :cl], None, x.low_plane, cl, None)
+                y = ops.pconv_pointwise(x.skip, w[:, cl:], b, r1, cin - cl, None, denom, keep, inv, want_stats=want_stats, up_add=z)
+                if want_stats:
+                    y, part = y
+                new_mp = MaskParts.from_plane(new_mask, cout)
+                return (y, new_mp, part) if want_stats else (y, new_mp)
             x = x.materialize()
         if groups == 1:
             if mp.fusable:
