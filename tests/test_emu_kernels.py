@@ -598,3 +598,40 @@ def test_pointwise_upsampled_addend_rejects_bad_geometry(emu):
     for hh, ww in ((8, 6), (3, 16), (5, 8)):
         assert L.tsii_pw_fwd_up(P(x), 48, 8, P(w), 8, None, None, 0, None, None, None, P(z), hh, ww, None, P(y), P(ws), nb, None) != 0
         assert b"pw_fwd_up" in L.tsii_last_error()
+
+
+@pytest.mark.parametrize("rows,c", [(3, 8), (256, 40), (1024, 33), (1025, 32), (5000, 36)])
+def test_bn_finalize_from_partials(emu, rows, c):
+    """tsii_bn_finalize: (count, pivot, sum(y-p), sum((y-p)^2)) rows -> mean / biased variance / running statistics / (scale,
+    shift); <= 1024 rows take the one-kernel path, more the two-level one; rows with count 0 are ignored."""
+    L = emu
+    rng = np.random.default_rng(rows)
+    cnt = rng.integers(0, 130, size=(rows, 1)).astype(np.float32) * np.ones((1, c), np.float32)
+    cnt[0] = 128
+    piv = rng.standard_normal((rows, c)).astype(np.float32) * 3
+    mu_b = piv + rng.standard_normal((rows, c)).astype(np.float32) * 0.1
+    var_b = rng.uniform(0.5, 2.0, size=(rows, c)).astype(np.float32)
+    s1 = (cnt * (mu_b - piv)).astype(np.float32)
+    s2 = (cnt * (var_b + (mu_b - piv) ** 2)).astype(np.float32)
+    part = np.stack([cnt, piv, s1, s2], axis=1).copy()            # [rows][4][c]
+    part[cnt[:, 0] == 0, 1:] = np.nan                              # empty rows may hold anything
+    m = int(cnt[:, 0].sum())
+    d = lambda a: a.astype(np.float64)
+    mean_r = (d(cnt) * d(piv) + d(s1)).sum(0) / m
+    ex2_r = (d(s2) + 2 * d(piv) * d(s1) + d(cnt) * d(piv) ** 2)
+    ex2_r = np.where(cnt > 0, ex2_r, 0.0).sum(0) / m
+    mean_r = np.where(cnt > 0, d(cnt) * d(piv) + d(s1), 0.0).sum(0) / m
+    var_r = ex2_r - mean_r ** 2
+    gamma = rng.uniform(0.5, 1.5, size=c).astype(np.float32); beta = rng.standard_normal(c).astype(np.float32)
+    rm = rng.standard_normal(c).astype(np.float32); rv = rng.uniform(0.5, 1.5, size=c).astype(np.float32)
+    rm0, rv0 = rm.copy(), rv.copy()
+    mean = np.zeros(c, np.float32); var = np.zeros(c, np.float32); sc = np.zeros(c, np.float32); sh = np.zeros(c, np.float32)
+    nb = L.tsii_bn_finalize_ws_bytes(rows, c)
+    ws = WS(nb)
+    assert L.tsii_bn_finalize(P(part), rows, c, m, P(mean), P(var), P(rm), P(rv), 0.1, P(gamma), P(beta), 1e-5, P(sc), P(sh), P(ws), nb, None) == 0, L.tsii_last_error()
+    assert np.abs(mean - mean_r).max() <= 1e-6 * max(1.0, np.abs(mean_r).max())
+    assert np.abs(var - var_r).max() <= 1e-5 * var_r.max()
+    assert np.allclose(rm, 0.9 * rm0 + 0.1 * mean, rtol=1e-6, atol=1e-7)
+    assert np.allclose(rv, 0.9 * rv0 + 0.1 * var * m / (m - 1), rtol=1e-5)
+    scr = gamma / np.sqrt(var + 1e-5)
+    assert np.allclose(sc, scr, rtol=1e-5) and np.allclose(sh, beta - mean * scr, rtol=1e-4, atol=1e-5)

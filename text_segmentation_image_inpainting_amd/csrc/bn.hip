@@ -118,33 +118,99 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
 // block into (n*mu_b, M2_b, n*mu_b^2) and folds 128-block chunks in fp64; the final kernel combines them
 // (var = (sum M2_b + sum n mu_b^2)/M - mean^2 in fp64), updates the running statistics and emits the
 // (scale, shift) pair the consumer applies on load.
+// (n mu_b and M2_b + n mu_b^2 need no division: n mu_b = n p + s1 and M2_b + n mu_b^2 = s2 + 2 p s1 + n p^2 -- the s1^2 / n terms
+// cancel.)  Round 4: every thread requests all its 16 rows before the first use (the loop of dependent 4-load groups made a
+// 256-row finalize take 16 us, as long as the 16384-row one), and up to 1024 rows are combined by ONE kernel.
+__device__ __forceinline__ void bn_part_fold(const float n, const float p, const float s1, const float s2, double& a, double& bq) {
+    const double dn = (double)n, dp = (double)p, d1 = (double)s1;
+    a += dn * dp + d1;
+    bq += (double)s2 + dp * (2.0 * d1 + dn * dp);
+}
+
 __global__ __launch_bounds__(256) void bn_parts_l1_kernel(const float* __restrict__ part, int64_t R, int C, int chunk_rows,
                                                           double* __restrict__ out) {
-    __shared__ double sh[3][8][33];
+    __shared__ double sh[2][8][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + tx;
     const int64_t r0 = (int64_t)blockIdx.y * chunk_rows;
     const int64_t r1 = r0 + chunk_rows < R ? r0 + chunk_rows : R;
-    double a = 0.0, b = 0.0, q = 0.0;
+    double a = 0.0, bq = 0.0;
     if (c < C) {
-        for (int64_t r = r0 + ty; r < r1; r += 8) {
-            const float* pr = part + r * 4 * C + c;
-            const double n = (double)pr[0], p = (double)pr[C], s1 = (double)pr[2 * (int64_t)C], s2 = (double)pr[3 * (int64_t)C];
-            if (n > 0.0) {
-                const double mu = p + s1 / n;
-                double m2 = s2 - s1 * s1 / n;
-                if (m2 < 0.0) m2 = 0.0;
-                a += n * mu; b += m2; q += n * mu * mu;
+        for (int64_t rb = r0 + ty; rb < r1; rb += 8 * 16) {
+            float v[16][4];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int64_t r = rb + 8 * u;
+                const float* pr = part + (r < r1 ? r : r0) * 4 * C + c;
+                v[u][0] = r < r1 ? pr[0] : 0.f; v[u][1] = pr[C]; v[u][2] = pr[2 * (int64_t)C]; v[u][3] = pr[3 * (int64_t)C];
             }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (v[u][0] > 0.f) bn_part_fold(v[u][0], v[u][1], v[u][2], v[u][3], a, bq);
         }
     }
-    sh[0][ty][tx] = a; sh[1][ty][tx] = b; sh[2][ty][tx] = q;
+    sh[0][ty][tx] = a; sh[1][ty][tx] = bq;
     __syncthreads();
     if (ty == 0 && c < C) {
-        a = 0.0; b = 0.0; q = 0.0;
-        for (int j = 0; j < 8; ++j) { a += sh[0][j][tx]; b += sh[1][j][tx]; q += sh[2][j][tx]; }
+        a = 0.0; bq = 0.0;
+        for (int j = 0; j < 8; ++j) { a += sh[0][j][tx]; bq += sh[1][j][tx]; }
         double* o = out + (int64_t)blockIdx.y * 3 * C + c;
-        o[0] = a; o[C] = b; o[2 * (int64_t)C] = q;
+        o[0] = a; o[C] = bq; o[2 * (int64_t)C] = 0.0;
+    }
+}
+
+__device__ __forceinline__ void bn_finish(double a, double bq, int64_t M, int c, float* __restrict__ mean, float* __restrict__ var,
+                                          float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                          float* __restrict__ scale, float* __restrict__ shift) {
+    const double mu = a / (double)M;
+    double v = bq / (double)M - mu * mu;
+    if (v < 0.0) v = 0.0;
+    mean[c] = (float)mu;
+    var[c] = (float)v;
+    if (running_mean != nullptr) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+    if (running_var != nullptr) {
+        const double unb = M > 1 ? v * (double)M / (double)(M - 1) : v;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+    if (scale != nullptr) {
+        const float sc = (1.0f / sqrtf((float)v + eps)) * gamma[c];
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mu * sc;
+    }
+}
+
+// R <= 1024 partial rows: 32 channels x 32 row lanes per block, <= 32 rows per thread in batches of 8 rows in flight
+__global__ __launch_bounds__(1024) void bn_parts_small_kernel(const float* __restrict__ part, int R, int64_t M, int C,
+                                                              float* __restrict__ mean, float* __restrict__ var,
+                                                              float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                              float momentum, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps,
+                                                              float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double sh[2][32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    double a = 0.0, bq = 0.0;
+    if (c < C) {
+        for (int rb = ty; rb < R; rb += 32 * 8) {
+            float v[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = rb + 32 * u;
+                const float* pr = part + (int64_t)(r < R ? r : 0) * 4 * C + c;
+                v[u][0] = r < R ? pr[0] : 0.f; v[u][1] = pr[C]; v[u][2] = pr[2 * (int64_t)C]; v[u][3] = pr[3 * (int64_t)C];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (v[u][0] > 0.f) bn_part_fold(v[u][0], v[u][1], v[u][2], v[u][3], a, bq);
+        }
+    }
+    sh[0][ty][tx] = a; sh[1][ty][tx] = bq;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        a = 0.0; bq = 0.0;
+        for (int j = 0; j < 32; ++j) { a += sh[0][j][tx]; bq += sh[1][j][tx]; }
+        bn_finish(a, bq, M, c, mean, var, running_mean, running_var, momentum, gamma, beta, eps, scale, shift);
     }
 }
 
@@ -154,35 +220,21 @@ __global__ __launch_bounds__(256) void bn_parts_final_kernel(const double* __res
                                                              float* __restrict__ running_var, float momentum,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps, float* __restrict__ scale, float* __restrict__ shift) {
-    __shared__ double sh[3][8][33];
+    __shared__ double sh[2][8][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + tx;
-    double a = 0.0, b = 0.0, q = 0.0;
+    double a = 0.0, bq = 0.0;
     if (c < C)
         for (int r = ty; r < chunks; r += 8) {
             const double* p = l1 + (int64_t)r * 3 * C + c;
-            a += p[0]; b += p[C]; q += p[2 * (int64_t)C];
+            a += p[0]; bq += p[C];
         }
-    sh[0][ty][tx] = a; sh[1][ty][tx] = b; sh[2][ty][tx] = q;
+    sh[0][ty][tx] = a; sh[1][ty][tx] = bq;
     __syncthreads();
     if (ty == 0 && c < C) {
-        a = 0.0; b = 0.0; q = 0.0;
-        for (int j = 0; j < 8; ++j) { a += sh[0][j][tx]; b += sh[1][j][tx]; q += sh[2][j][tx]; }
-        const double mu = a / (double)M;
-        double v = (b + q) / (double)M - mu * mu;
-        if (v < 0.0) v = 0.0;
-        mean[c] = (float)mu;
-        var[c] = (float)v;
-        if (running_mean != nullptr) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-        if (running_var != nullptr) {
-            const double unb = M > 1 ? v * (double)M / (double)(M - 1) : v;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
-        }
-        if (scale != nullptr) {
-            const float sc = (1.0f / sqrtf((float)v + eps)) * gamma[c];
-            scale[c] = sc;
-            shift[c] = beta[c] - (float)mu * sc;
-        }
+        a = 0.0; bq = 0.0;
+        for (int j = 0; j < 8; ++j) { a += sh[0][j][tx]; bq += sh[1][j][tx]; }
+        bn_finish(a, bq, M, c, mean, var, running_mean, running_var, momentum, gamma, beta, eps, scale, shift);
     }
 }
 
@@ -430,6 +482,11 @@ extern "C" int tsii_bn_finalize(const float* stat_part, int64_t rows, int c, int
     TSII_REQUIRE(scale == nullptr || (gamma && beta), "bn_finalize: scale / shift need gamma and beta");
     TSII_REQUIRE(ws_bytes >= tsii_bn_finalize_ws_bytes(rows, c), "bn_finalize: workspace too small");
     hipStream_t st = (hipStream_t)stream;
+    if (rows <= 1024) {
+        hipLaunchKernelGGL(bn_parts_small_kernel, dim3(cdiv(c, 32)), dim3(1024), 0, st, stat_part, (int)rows, m, c, mean, var, running_mean,
+                           running_var, momentum, gamma, beta, eps, scale, shift);
+        return check_launch("bn_parts_small");
+    }
     const int chunks = bn_l1_chunks(rows);
     hipLaunchKernelGGL(bn_parts_l1_kernel, dim3(cdiv(c, 32), chunks), dim3(256), 0, st, stat_part, rows, c, 128, (double*)ws);
     int rc = check_launch("bn_parts_l1");

@@ -111,11 +111,16 @@ __device__ __forceinline__ void pc_epilogue(f32x16 (&acc)[4], float* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) ynext[j] = *reinterpret_cast<const float*>(Yb + yoff + (unsigned)j * n4);
     }
-    float znext[2] = {0.f, 0.f};
+    // all 16 bands' addend rows are requested up front (32 registers: the A / B fragment registers are dead here): one memory round
+    // trip per tile -- a band ahead left these HBM-bound K = 64 / 128 layers waiting on every band (1.33 ms for 2M x 64 -> 384)
+    float zall[UP ? 16 : 1][2];
     if constexpr (UP) {
-        const unsigned zo = zoff_of(4 * hi);
-        znext[0] = *reinterpret_cast<const float*>(Zb + zo);
-        znext[1] = *reinterpret_cast<const float*>(Zb + zo + n4);
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const unsigned zo = zoff_of((b >> 2) * 32 + 8 * (b & 3) + 4 * hi);
+            zall[b][0] = *reinterpret_cast<const float*>(Zb + zo);
+            zall[b][1] = *reinterpret_cast<const float*>(Zb + zo + n4);
+        }
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -136,14 +141,7 @@ __device__ __forceinline__ void pc_epilogue(f32x16 (&acc)[4], float* __restrict_
                 }
             }
             float zv[2] = {0.f, 0.f};
-            if constexpr (UP) {
-                zv[0] = znext[0]; zv[1] = znext[1];
-                if (t * 4 + g < 15) {
-                    const unsigned zo = zoff_of(rb4 + 8);
-                    znext[0] = *reinterpret_cast<const float*>(Zb + zo);
-                    znext[1] = *reinterpret_cast<const float*>(Zb + zo + n4);
-                }
-            }
+            if constexpr (UP) { zv[0] = zall[t * 4 + g][0]; zv[1] = zall[t * 4 + g][1]; }
             const float4 x4 = xq, y4 = yq;
             if (t * 4 + g < 15) {
                 xq = *reinterpret_cast<const float4*>(sideX + rb4 + 8);
