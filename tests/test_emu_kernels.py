@@ -635,3 +635,29 @@ def test_bn_finalize_from_partials(emu, rows, c):
     assert np.allclose(rv, 0.9 * rv0 + 0.1 * var * m / (m - 1), rtol=1e-5)
     scr = gamma / np.sqrt(var + 1e-5)
     assert np.allclose(sc, scr, rtol=1e-5) and np.allclose(sh, beta - mean * scr, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("split,has_r1", [(20, False), (20, True), (24, False)])
+def test_pointwise_row_scale_split_inside_a_chunk(emu, split, has_r1):
+    """Row scale r0 on channels < split, r1 (or the factor 1 of a premultiplied second part) after it.  The persistent
+    producer / consumer kernel applies ONE factor per 8-channel chunk, so a split inside a chunk must send the layer to the 4-wave
+    kernels -- with r1 == NULL too (it once scaled the chunk's tail by r0: relative error 0.38 on this shape)."""
+    L = emu
+    assert L.tsii_set_gemm_products(6) == 0
+    M, K, N = 256, 64, 128
+    rng = np.random.default_rng(split + has_r1)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = rng.standard_normal((N, K)).astype(np.float32)
+    r0 = rng.uniform(0.5, 2.0, size=M).astype(np.float32)
+    r1 = rng.uniform(0.5, 2.0, size=M).astype(np.float32) if has_r1 else None
+    y = np.zeros((M, N), np.float32)
+    ws = WS(L.tsii_pw_ws_bytes(N, K))
+    before = L.hipemu_launches(PC_THREADS)
+    assert L.tsii_pw_fwd(P(x), M, K, P(w), N, None, P(r0), split, P(r1), None, None, P(y), P(ws), ws.nbytes, None) == 0, L.tsii_last_error()
+    assert L.hipemu_launches(PC_THREADS) - before == (1 if split % 8 == 0 else 0)
+    xs = x.astype(np.float64).copy()
+    xs[:, :split] *= r0[:, None]
+    if has_r1:
+        xs[:, split:] *= r1[:, None]
+    ref = xs @ w.astype(np.float64).T
+    assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max()

@@ -20,7 +20,7 @@ from oracle import pconv_oracle as O
 from oracle import seg_oracle as S
 from oracle.filler import fill_state_dict_, make_state_dict
 from tests.backends import BACKENDS, both_backends
-from tests.util import assert_close, rel_err
+from tests.util import low_rank_error, assert_close, rel_err
 
 TOL = 1e-3
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -301,6 +301,19 @@ def test_seg_nets_256_vs_reference_fixture_gpu(name, capsys):
         for ratio, k, e, n in rows:
             assert e <= max(3e-3, 16 * max(n, pooled)), (k, e, n, pooled)
         assert float(np.median([r[0] for r in rows])) <= 3.0
+        # Outliers (beyond 4x the noise) must be EXPLAINED like everywhere else (tests/util.py): a weight gradient carries >= 85 % of
+        # its squared error in <= 3 singular values (single activation-kink flips; a wrong kernel gives a dense error); a bias /
+        # BatchNorm vector cannot show that signature and may only ride on a flip some weight tensor of the same run confirms.
+        outliers = [(k, e) for ratio, k, e, n in rows if e > max(3e-3, 4 * max(n, pooled))]
+        judged = {}
+        for k, e in outliers:
+            ok, f = low_rank_error(params[k].grad, G["grad64." + k].astype(np.float32), frac=0.85)
+            judged[k] = (ok, f, G["grad64." + k].squeeze().ndim <= 1)
+            with capsys.disabled():
+                print(f"   outlier {k}: err {e:.2e}, {100 * f:.1f} % of it in <= 3 singular values / entries")
+        confirmed = any(ok and not vec for ok, f, vec in judged.values())
+        for k, (ok, f, vec) in judged.items():
+            assert ok or (vec and confirmed), (k, f, "dense gradient error beyond 4x the reference's own fp32 noise")
 
 
 @pytest.mark.gpu

@@ -1,0 +1,173 @@
+"""The BASELINE.json configurations AT THEIR WORKLOAD SIZE (GPU only): properties that need no oracle run -- determinism, an
+image's independence of its batch mates, bit-exact masks, the fused forms against their unfused spelling, finite and repeatable
+gradients.  (Numerical parity with the reference is pinned at the sizes the fixtures / the CPU oracle reach: test_parity_*.)
+
+  cfg 2  ImageFill 512x512, batch 32 (the bench step)             test_imagefill_bs32_*
+  cfg 3  TextSegament(pixel_shuffle_head=True) 512x512, batch 8   test_textsegament_pixel_shuffle_512_*   (bench batch: 64)
+  cfg 5  XceptionTextSegment 1024x1024, batch 2, products 1 and 6 test_xception_1024_*                    (bench batch: 8)
+"""
+import numpy as np
+import pytest
+import torch
+
+import text_segmentation_image_inpainting_amd as T
+from oracle.filler import fill_state_dict_
+from tests.backends import BACKENDS
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _imagefill(dev, seed=3):
+    torch.manual_seed(0)
+    m = T.ImageFill()
+    fill_state_dict_(m.state_dict(), seed=seed)
+    return m.to(dev)
+
+
+def test_imagefill_bs32_batch_independence_and_masks_gpu():
+    """cfg 2 at batch 32, eval mode: every checked image equals its batch-of-one run (<= 1e-6 of the output range), the mask
+    pyramid of the encoder is BIT-exact between the two runs, and the whole forward is bit-identical when repeated."""
+    from text_segmentation_image_inpainting_amd.BaseModels import to_nhwc
+    from text_segmentation_image_inpainting_amd.masks import as_parts
+    from text_segmentation_image_inpainting_amd.synthetic import make_batch
+    with BACKENDS["gpu"]() as dev:
+        model = _imagefill(dev).eval()
+        corrupted, mask, _ = make_batch(32, 512, seed0=500)
+        corrupted, mask = corrupted.to(dev), mask.to(dev)
+        with torch.no_grad():
+            y = model((corrupted, mask))
+            assert tuple(y.shape) == (32, 3, 512, 512) and bool(torch.isfinite(y).all())
+            assert torch.equal(y, model((corrupted, mask)))
+            _, _, _, fm = model._encode(to_nhwc(corrupted), as_parts(mask))
+            pyramid = [m.as_tensor()[:, :1].clone() for m in fm]
+            for i in (0, 13, 31):
+                yi = model((corrupted[i:i + 1], mask[i:i + 1]))
+                assert_close(yi, y[i:i + 1], 1e-6, f"ImageFill 512^2: image {i} of 32 vs alone")
+                _, _, _, fmi = model._encode(to_nhwc(corrupted[i:i + 1]), as_parts(mask[i:i + 1]))
+                for lvl, (a, b) in enumerate(zip(fmi, pyramid)):
+                    assert torch.equal(a.as_tensor()[:, :1], b[i:i + 1]), f"mask level {lvl}, image {i}"
+
+
+def test_imagefill_bs32_split_resolution_decoder_equals_concat_gpu(monkeypatch):
+    """K7b at the bench size: the decoder's 1x1 expand convolutions with their low half at low resolution (no concatenated tensor)
+    against the same network with the concatenation materialised (K7 + one product), train mode, batch 32: output, loss, running
+    statistics and every gradient.  Two fp32 evaluation orders of the same sums: 1e-5 of each tensor's range on the output,
+    5e-4 on gradients (a LeakyReLU kink may flip: tests/util.py)."""
+    from text_segmentation_image_inpainting_amd import partial_convolution as pc
+    from text_segmentation_image_inpainting_amd.BaseModels import to_nhwc
+    from text_segmentation_image_inpainting_amd.synthetic import make_batch
+    from text_segmentation_image_inpainting_amd.train_step import FlatSGDTrainer
+    with BACKENDS["gpu"]() as dev:
+        corrupted, mask, clean = make_batch(32, 512, seed0=900)
+        corrupted, mask, clean = corrupted.to(dev), mask.to(dev), to_nhwc(clean.to(dev))
+        out = {}
+        for fused in (True, False):
+            monkeypatch.setattr(pc, "FUSE_UPCAT", fused)
+            model = _imagefill(dev, seed=5).train()
+            tr = FlatSGDTrainer(model, lr=1e-3)
+            loss = tr.forward_backward(corrupted, mask, clean)
+            tr.reduce_gradients()
+            with torch.no_grad():
+                y = model.eval()((corrupted[:2], mask[:2]))
+            out[fused] = (float(loss), tr.flat_grad.clone(), y, {k: v.clone() for k, v in model.state_dict().items() if "running" in k},
+                          {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+            tr.close()
+            del tr, model
+        (l1, g1, y1, rs1, pg1), (l0, g0, y0, rs0, pg0) = out[True], out[False]
+        assert abs(l1 - l0) <= 1e-6 * abs(l0)
+        assert_close(y1, y0, 1e-5, "eval output after the step's statistics update")
+        for k in rs0:
+            assert_close(rs1[k], rs0[k], 1e-5, f"running statistic {k}")
+        worst = max((float((pg1[k] - pg0[k]).abs().max() / pg0[k].abs().max().clamp_min(1e-12)), k) for k in pg0)
+        assert worst[0] <= 5e-4, worst
+
+
+def test_textsegament_pixel_shuffle_512_properties_gpu():
+    """cfg 3 with ITS head (Conv2d(128, 16, 3) -> PixelShuffle(4)) at 512x512, batch 8: deterministic forward, batch
+    independence, output = stock torch head applied to the features the net itself produced (wiring at size), finite gradients
+    for every trainable parameter, bit-identical when the step is repeated."""
+    import torch.nn.functional as F
+    from text_segmentation_image_inpainting_amd.synthetic import make_seg_batch
+    with BACKENDS["gpu"]() as dev:
+        x, t = make_seg_batch(8, 512, seed0=310)
+        x, t = x.to(dev), t.to(dev)
+
+        def build():
+            torch.manual_seed(0)
+            m = T.TextSegament(pixel_shuffle_head=True)
+            fill_state_dict_(m.state_dict(), seed=48, gain=1.0)
+            return m.to(dev)
+        m = build().eval()
+        grabbed = []
+        h = m.smooth_feature_4x_conv.register_forward_hook(lambda mod, inp, out: grabbed.append(out.detach()))
+        with torch.no_grad():
+            y1, y2 = m(x), m(x)
+            h.remove()
+            assert tuple(y1.shape) == (8, 1, 512, 512) and torch.equal(y1, y2) and bool(torch.isfinite(y1).all())
+            for i in (0, 6):
+                assert_close(m(x[i:i + 1]), y1[i:i + 1], 1e-5, f"batch independence, image {i}")
+            w, b = m.out_conv[0].weight.detach().double(), m.out_conv[0].bias.detach().double()
+            ref = F.pixel_shuffle(F.conv2d(grabbed[0].double(), w, b, padding=1), 4)      # stock torch head, fp64, same device
+            assert tuple(grabbed[0].shape) == (8, 128, 128, 128)
+            assert_close(y1, ref, 1e-4, "pixel-shuffle head at 512^2 vs the stock head on the net's own features")
+        crit = T.BinaryFocalLoss(0, 1, 2)
+        grads = []
+        for _ in range(2):
+            m2 = build().train()
+            loss = crit(m2(x), t)
+            loss.backward()
+            g = [p.grad for p in m2.parameters() if p.requires_grad]
+            assert bool(torch.isfinite(loss)) and all(v is not None and bool(torch.isfinite(v).all()) for v in g)
+            grads.append(torch.cat([v.reshape(-1) for v in g]))
+            del m2
+        assert torch.equal(grads[0], grads[1])
+
+
+@pytest.mark.parametrize("products", [6, 1])
+def test_xception_1024_properties_gpu(products, capsys):
+    """cfg 5's network at its size (XceptionTextSegment, 1024x1024; batch 2 here, 8 in the bench) in the fp32-class arithmetic
+    (6 partial products) and in the config's "mixed bf16" one (products = 1: bf16 operands in every matrix product): deterministic
+    forward, batch independence, finite gradients for every trainable parameter, bit-identical repeats; and the bf16-operand
+    eval output within 5e-2 (of the output range) of the 6-product one."""
+    from text_segmentation_image_inpainting_amd import _lib
+    from text_segmentation_image_inpainting_amd.synthetic import make_seg_batch
+    with BACKENDS["gpu"]() as dev:
+        saved = _lib._GEMM_PRODUCTS
+        try:
+            x, t = make_seg_batch(2, 1024, seed0=320)
+            x, t = x.to(dev), t.to(dev)
+
+            def build():
+                torch.manual_seed(0)
+                m = T.XceptionTextSegment()
+                fill_state_dict_(m.state_dict(), seed=49, gain=1.0)
+                return m.to(dev)
+            m = build().eval()
+            with torch.no_grad():
+                _lib.set_gemm_products(6)
+                y6 = m(x)
+                _lib.set_gemm_products(products)
+                y1, y2 = m(x), m(x)
+                assert tuple(y1.shape) == (2, 1, 1024, 1024) and torch.equal(y1, y2) and bool(torch.isfinite(y1).all())
+                assert_close(m(x[1:2]), y1[1:2], 1e-5 if products == 6 else 1e-4, "batch independence, image 1")
+                e = float((y1 - y6).abs().max() / y6.abs().max())
+                if products == 1:
+                    assert e <= 5e-2, e
+                else:
+                    assert e == 0.0
+            crit = T.BinaryFocalLoss(0, 1, 2)
+            grads = []
+            for _ in range(2):
+                m2 = build().train()
+                loss = crit(m2(x), t)
+                loss.backward()
+                g = [p.grad for p in m2.parameters() if p.requires_grad]
+                assert bool(torch.isfinite(loss)) and all(v is not None and bool(torch.isfinite(v).all()) for v in g)
+                grads.append(torch.cat([v.reshape(-1) for v in g]))
+                del m2
+            assert torch.equal(grads[0], grads[1])
+        finally:
+            _lib.set_gemm_products(saved)
+        with capsys.disabled():
+            print(f"\n[cfg 5 at size] XceptionTextSegment 1024^2 b2, products={products}: eval output vs the 6-product run {e:.2e}")

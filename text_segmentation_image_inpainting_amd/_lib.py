@@ -172,7 +172,9 @@ def set_gemm_products(products):
     if products is not None and products not in (0, 1, 3, 6, 8):
         raise ValueError("gemm products: 0, 1, 3, 6 or 8")
     global _GEMM_TOUCHED
-    _GEMM_PRODUCTS, _GEMM_TOUCHED = products, True
+    # None hands the switch back to the library default: from then on calls stop re-applying a selection (code that sets the
+    # library's thread-local switch directly and then goes through call() keeps its own mode)
+    _GEMM_PRODUCTS, _GEMM_TOUCHED = products, products is not None
     lib().tsii_set_gemm_products(-1 if products is None else int(products))
 
 

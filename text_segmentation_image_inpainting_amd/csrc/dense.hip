@@ -449,7 +449,7 @@ __device__ __forceinline__ void head_stage(float* __restrict__ tile, float* __re
         if (iy >= 0 && iy < g.h && ix >= 0 && ix < g.w) {
             const int64_t ipix = (n * g.h + iy) * g.w + ix;
             m0 = rs.r0 != nullptr ? rs.r0[ipix] : 1.f;
-            m1 = (rs.r0 != nullptr && rs.r1 != nullptr) ? rs.r1[ipix] : 1.f;
+            m1 = rs.r1 != nullptr ? rs.r1[ipix] : 1.f;          // the two planes are independent (NULL = ones)
         }
         side[p] = m0;
         side[H::NPIX + p] = m1;
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256) void head_dx_kernel(const float* __restrict__ 
         if (iy < g.h && ix < g.w) {
             const int64_t ipix = (n * g.h + iy) * g.w + ix;
             m0 = rs.r0 != nullptr ? rs.r0[ipix] : 1.f;
-            m1 = (rs.r0 != nullptr && rs.r1 != nullptr) ? rs.r1[ipix] : 1.f;
+            m1 = rs.r1 != nullptr ? rs.r1[ipix] : 1.f;          // the two planes are independent (NULL = ones)
         }
         mk[p] = m0; mk[H::NPX + p] = m1;
     }

@@ -597,7 +597,9 @@ bool nt_pc_ok(const float* A, int64_t lda, const RowScale& as, int64_t M, int N,
     if (!g_pc || gemm_products() != 6) return false;
     if (N < g_pc_min_n || N % 32 != 0 || M % (pc_wide(N) ? 128 : 256) != 0 || K % 8 != 0 || lda % 4 != 0 || !aligned16(A)) return false;
     const bool dx = ep.cs.r0 != nullptr || ep.bn_y != nullptr;
-    if (as.r0 != nullptr && as.r1 != nullptr && as.split % 8 != 0) return false;                                   // one row-scale factor per 8-k chunk
+    // one row-scale factor per 8-k chunk: a split inside a chunk (with r1, or with the factor-1 tail of a premultiplied second part)
+    // would scale the chunk's tail by r0 -- those layers stay on the 4-wave kernels
+    if (as.r0 != nullptr && as.split % 8 != 0 && as.split < K) return false;
     if (dx && (ep.denom != nullptr || ep.keep != nullptr || ep.bias != nullptr || ep.stats != nullptr || ib.sc != nullptr)) return false;   // one epilogue mode at a time
     if (ep.bn_y != nullptr && K < g_pc_bnb_min_k) return false;                                                   // (A/B knob)
     if (ib.sc != nullptr && K > 1024) return false;                                                               // (scale, shift) live in LDS

@@ -18,13 +18,13 @@ __global__ void add_act_kernel(const float* __restrict__ a, const float* __restr
     }
 }
 
-// launched with chan_grid(): the channel group of a thread is fixed
+// launched with flat_grid() (one vector per thread; any grid is correct)
 template <int W>
 __global__ void copy_channels_kernel(float* __restrict__ big, int64_t m, int cbig, int coff, float* __restrict__ sm,
                                      int csm, int to_dst) {
     const unsigned CG = (unsigned)(csm / W);
     const int64_t total = m * CG;
-    const unsigned gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int c = (int)(gt % CG) * W;
     const int64_t rstep = stride / CG;
