@@ -93,6 +93,10 @@ CALLS = {
     "tsii_head_cat_fwd": ("dense_conv", lambda a: _headcat(a, 1, 1)), "tsii_head_cat_bwd_dx": ("dense_conv", lambda a: _headcat(a, 1, 1)),
     "tsii_head_cat_bwd_dw": ("dense_conv", lambda a: _headcat(a, 1, 1)),
     "tsii_upcat_fwd": ("upcat", lambda a: _upcat(a, False)), "tsii_upcat_bwd": ("upcat", lambda a: _upcat(a, True)),
+    # K7b: the high-resolution half of a 1x1 conv over cat(up2(low), skip): (m, k, n, ..): reads [m,k] and the [m/4,n] addend, writes [m,n]
+    "tsii_pw_fwd_up": ("gemm_nt", lambda a: (4.0 * a[0] * (a[1] + a[2]) + 1.0 * a[0] * a[2], float(a[0]) * a[1] * a[2])),
+    # its addend's gradient: (n, h, w, c) of the LOW grid: reads [n,2h,2w,c], writes [n,h,w,c]
+    "tsii_pool2x2_scaled": ("upcat", lambda a: (4.0 * a[0] * a[1] * a[2] * a[3] * 5, 0.0)),
 }
 BOUND = {"gemm_nt": None, "gemm_tn": None, "dense_conv": "mfma", "dw_stencil": "hbm", "bn_act": "hbm", "bn_bwd": "hbm", "upcat": "hbm"}
 
@@ -205,7 +209,13 @@ def cpu_baseline(size: int, threads: int):
                       f"{threads} torch threads"}
 
 
-def main():
+# tests/test_bench_multiprocess.py sets this to {"device": cpu, "backend": "gloo"} (inside the kernel emulator's context) to run the
+# N > 1 launch / timing / reporting path of this file on the CPU container; never set in production, where the absence of a ROCm
+# GPU is fatal.
+TEST_RUNTIME = None
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -223,20 +233,27 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU-baseline leg (default: both min(physical cores, 32) and all physical cores, the better one reported)")
     ap.add_argument("--bernoulli-masks", action="store_true", help="stress variant: i.i.d. per-channel masks")
     ap.add_argument("--graph", action="store_true", help="also replay the step from a HIP graph (measured: no gain; off by default)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    on_gpu = TEST_RUNTIME is None
+    if on_gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = TEST_RUNTIME["device"]
     use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # launched by torch.distributed.run
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if on_gpu:
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(TEST_RUNTIME["backend"])
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import text_segmentation_image_inpainting_amd as T
@@ -245,7 +262,8 @@ def main():
     from text_segmentation_image_inpainting_amd.synthetic import make_batch
     from text_segmentation_image_inpainting_amd.train_step import FlatSGDTrainer
 
-    L = _lib.lib()
+    if on_gpu:
+        _lib.lib()           # fails loudly when libtsii_hip.so is missing
     if args.products >= 0:
         _lib.set_gemm_products(args.products)
     products = _lib.get_gemm_products()
@@ -273,31 +291,38 @@ def main():
         corrupted, clean_nhwc = (t.to(dev) for t in make_seg_batch(args.batch, args.size, seed0=rank * args.batch))
         mask = None
     else:
-        model = getattr(T, args.model)().to(dev).train()
-        trainer = FlatSGDTrainer(model, lr=1e-3, momentum=0.9, weight_decay=1e-4)
+        # (the CPU test of the N > 1 path swaps in a two-block network: a whole ImageFill step takes minutes on the kernel emulator)
+        factory = (TEST_RUNTIME or {}).get("model_factory") or (lambda: getattr(T, args.model)())
+        model = factory().to(dev).train()
+        trainer = FlatSGDTrainer(model, lr=1e-3, momentum=0.9, weight_decay=1e-4, **((TEST_RUNTIME or {}).get("trainer_kwargs") or {}))
         trainer.broadcast_parameters()
         corrupted, mask, clean = make_batch(args.batch, args.size, seed0=rank * args.batch, bernoulli=args.bernoulli_masks)
         corrupted, mask = corrupted.to(dev), mask.to(dev)   # inputs resident in HBM before the timed region
         clean_nhwc = to_nhwc(clean.to(dev))
 
     def sync():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
+    # HIP events around entry points need the GPU's streams; the CPU run of the N > 1 path reports no kernel classes
+    start_timing = _lib.start_timing if on_gpu else (lambda names: None)
+    stop_timing = _lib.stop_timing if on_gpu else (lambda: {})
 
     gemm_calls = [n for n, (c, _) in CALLS.items() if c.startswith("gemm")]
     for _ in range(args.warmup):
         loss = trainer.step(corrupted, mask, clean_nhwc)
     sync()
-    _lib.start_timing(gemm_calls)      # HIP events (launch stream) around the GEMM entry points inside the timed region
+    start_timing(gemm_calls)      # HIP events (launch stream) around the GEMM entry points inside the timed region
     trainer.measure_exposed = world > 1    # N > 1: how long each step stalls for all-reduces backward did not hide (2 events / step)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.step(corrupted, mask, clean_nhwc)
     sync()
     elapsed = time.perf_counter() - t0
-    timed = _lib.stop_timing()
+    timed = stop_timing()
     eager_ms = elapsed / args.steps * 1e3
     trainer.measure_exposed = False
     # "comm": bucket layout, stand-alone all-reduce time / bus bandwidth of the whole gradient buffer, and (N > 1) the exposed
@@ -323,10 +348,10 @@ def main():
     # per-class pass: HIP events around EVERY hot entry point for a few extra steps (outside the timed region: the
     # ~1800 extra event records per step would perturb `value`)
     prof_steps = 3
-    _lib.start_timing(list(CALLS))
+    start_timing(list(CALLS))
     for _ in range(prof_steps):
         trainer.step(corrupted, mask, clean_nhwc)
-    classes = class_table(_lib.stop_timing(), prof_steps, products)
+    classes = class_table(stop_timing(), prof_steps, products)
     # forward-only rate (SURVEY.md 8(d) asks for both): train-mode BatchNorm forward + loss, no autograd tape
     fwd_steps = max(2, args.steps // 2)
     with torch.no_grad():
@@ -440,7 +465,7 @@ def main():
                              "ms_per_step": round(fwd_elapsed / fwd_steps * 1e3, 3), "steps": fwd_steps},
             "f32_mfma_mode": f32_leg, "split3_mode": split3_leg, "comm": comm,
         }
-        line["peak_mem_gib"] = round(torch.cuda.max_memory_allocated() / 2**30, 1)
+        line["peak_mem_gib"] = round(torch.cuda.max_memory_allocated() / 2**30, 1) if on_gpu else None
         if not args.no_cpu_baseline and world == 1 and not seg:
             _, phys, logical = host_cpu()
             if args.cpu_threads:

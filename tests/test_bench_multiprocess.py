@@ -1,0 +1,68 @@
+"""bench.py's N > 1 path on the CPU container: two processes rendezvous like under ``torch.distributed.run`` (RANK / WORLD_SIZE /
+MASTER_* in the environment), run the timed loop, the stand-alone all-reduce measurement (``comm_stats``), the exposed /
+overlapped split, the max-over-ranks clock and the JSON line -- with ``gloo`` and the kernel emulator standing in for RCCL and the
+GPU (bench.TEST_RUNTIME).  What it pins: the first real 2 / 4 / 8-GPU run cannot die in launch or reporting code that has never
+executed with world > 1."""
+import json
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank(rank, world, port, out):
+    import contextlib
+    import io
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import bench
+    from tests.backends import emu_backend
+    import text_segmentation_image_inpainting_amd as T
+    act = torch.nn.LeakyReLU(0.3)
+
+    class Tiny(torch.nn.Module):
+        """3 -> 8 stem + one inverted residual + a 3-channel head: every kernel family of a step, seconds on the emulator"""
+
+        def __init__(self):
+            super().__init__()
+            self.stem = T.partial_convolution_block(3, 8, 3, 1, 1, 1, bias=True, BN=False, activation=act)
+            self.body = T.PartialInvertedResidual(8, 8, 3, 1, 1, 1, 2, BN=True, activation=act, use_1_conv=True, same_holes=True)
+            self.head = T.partial_convolution_block(8, 3, 3, 1, 1, 1, bias=True, BN=False, activation=False)
+
+        def forward(self, args):
+            return self.head(self.body(self.stem(args)))[0]
+    with emu_backend() as dev:
+        bench.TEST_RUNTIME = {"device": dev, "backend": "gloo", "model_factory": Tiny, "trainer_kwargs": {"bucket_mb": 0.0005}}
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            bench.main(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--batch", "2", "--size", "32", "--no-cpu-baseline", "--no-f32-leg"])
+    open(f"{out}.{rank}", "w").write(buf.getvalue())
+
+
+def test_bench_two_ranks_gloo():
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "out")
+        mp.spawn(_rank, args=(2, _free_port(), out), nprocs=2, join=True)
+        texts = [open(f"{out}.{r}").read() for r in range(2)]
+    lines = [ln for ln in texts[0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not any(ln.startswith("{") for ln in texts[1].splitlines()), "exactly one JSON line, from rank 0"
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak" and rec["higher_is_better"] is True
+    assert rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
+    assert rec["value"] > 0 and abs(rec["value"] - 4 / (rec["ms_per_step"] / 1e3)) <= 0.05 * rec["value"] + 0.01   # whole-job images / max-over-ranks step time
+    comm = rec["comm"]
+    assert comm["world"] == 2 and comm["backend"] == "gloo" and comm["buckets"] >= 2 and comm["allreduce_ms"] > 0
+    assert comm["exposed_ms_per_step"] >= 0 and comm["overlapped_ms_per_step"] >= 0 and comm["overlap_with_backward"] is True
+    assert rec["forward_only"]["value"] > 0 and rec["cpu_baseline"] is None if "cpu_baseline" in rec else True

@@ -713,7 +713,14 @@ static int env_products() {
     return (v == 0 || v == 1 || v == 3 || v == 6 || v == 8) ? v : 6;
 }
 static thread_local int g_products = env_products();      // per calling thread (tsii_set_gemm_products)
-static int g_abl = getenv("TSII_GEMM_ABL") ? atoi(getenv("TSII_GEMM_ABL")) : 0;     // tools/gemm_bench.py ablations only
+// (TSII_GEMM_PRODUCTS is the documented process default of the arithmetic switch: include/tsii_hip.h.  The two knobs below exist in
+// A/B builds only -- -DTSII_GEMM_PC_ABLATIONS, tools/variants/build_variant.py; the stock library reads nothing else.)
+#ifdef TSII_GEMM_PC_ABLATIONS
+static int g_abl = getenv("TSII_GEMM_ABL") ? atoi(getenv("TSII_GEMM_ABL")) : 0;     // tools/gemm_bench.py ablations
+static const int g_force_tile = getenv("TSII_GEMM_TILE") ? atoi(getenv("TSII_GEMM_TILE")) : 0;   // 1 = 128x64 tiles everywhere
+#else
+static constexpr int g_abl = 0, g_force_tile = 0;
+#endif
 
 int gemm_products() { return g_products; }
 
@@ -781,8 +788,7 @@ int launch_nt_split(const float* A, int64_t lda, RowScale as, const float* B, in
      : g_products == 8 ? launch_nt_split_cfg<WM, WN, TM, TN, 8>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, bpre, stream) \
      : g_products == 3 ? launch_nt_split_cfg<WM, WN, TM, TN, 3>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, bpre, stream) \
                        : launch_nt_split_cfg<WM, WN, TM, TN, 6>(A, lda, as, B, ldb, C, ldc, M, N, K, ep, ib, bpre, stream))
-    static const int force_tile = getenv("TSII_GEMM_TILE") ? atoi(getenv("TSII_GEMM_TILE")) : 0;   // A/B knob: 1 = 128x64 tiles everywhere
-    if (force_tile == 1 && N > 32) return TSII_NT_SPLIT(2, 2, 2, 1);
+    if (g_force_tile == 1 && N > 32) return TSII_NT_SPLIT(2, 2, 2, 1);
     if (N % 128 == 0 || N > 192) return TSII_NT_SPLIT(2, 2, 2, 2);
     if (N > 32) return TSII_NT_SPLIT(2, 2, 2, 1);
     return TSII_NT_SPLIT(4, 1, 1, 1);

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """One GEMM shape through tsii_pw_fwd, a few launches: the thing rocprofv3 counter passes wrap.
-    python tools/pc_probe.py M K N [iters]"""
+    python tools/pc_probe.py M K N [iters]
+The TSII_GEMM_PC* knobs it prints only exist in an A/B build of the library:
+    python tools/variants/build_variant.py abl gemm_pc.hip -DTSII_GEMM_PC_ABLATIONS
+    TSII_LIBRARY=tools/variants/_bin/libtsii_abl.so TSII_GEMM_PC_ABL=128 python tools/pc_probe.py 65536 1024 1024"""
 import os
 import sys
 
