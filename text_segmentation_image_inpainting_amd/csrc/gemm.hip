@@ -447,6 +447,12 @@ static TnPlan plan_tn(int64_t M, int P, int Q, bool allow_narrow = false) {
     pl.big = (P >= 128 && Q >= 128);
     pl.bm = pl.bn = pl.big ? 128 : 64;
     pl.narrow = allow_narrow && pl.big && (Q % 128) >= 1 && (Q % 128) <= 64;
+#ifndef TSII_TN_NARROW64
+#define TSII_TN_NARROW64 1
+#endif
+    // tall x 64 products (the 64-channel skip halves of the decoder's 1x1 convs, K7b: 384 x 64, 256 x 64): 128 x 64 tiles read the
+    // narrow operand's panel once per 128 rows of the wide one instead of once per 64
+    if (TSII_TN_NARROW64 && allow_narrow && P >= 128 && Q > 32 && Q <= 64) { pl.narrow = true; pl.bm = 128; }
     if (pl.narrow) pl.bn = 64;
     const int tiles = cdiv(P, pl.bm) * cdiv(Q, pl.bn);
     int64_t want = 1024 / tiles;

@@ -80,11 +80,12 @@ def main():
             rates[w] = round(k * args.batch / (time.perf_counter() - t0), 1)
             del it, dl
         out["dataloader_imgs_per_s_by_workers"] = rates
-        best_w = max(rates, key=rates.get)
-        per_worker = rates[best_w] / best_w if best_w else per_proc
-        out["imgs_per_s_per_worker_at_scale"] = round(per_worker, 1)
-        out["workers_for_450_imgs_per_s"] = int(np.ceil(450 / per_worker))
-        out["workers_for_3600_imgs_per_s_8_gpus"] = int(np.ceil(3600 / per_worker))
+        # per-worker rate where the loader still scales (beyond that one loader's main process -- collating 9 MB per image --
+        # is the limit; under data parallelism every rank runs its OWN loader, so the per-rank requirement is what counts)
+        per_worker = max(r / w for w, r in rates.items() if w >= 1)
+        out["imgs_per_s_per_worker"] = round(per_worker, 1)
+        out["workers_per_rank_for_450_imgs_per_s"] = int(np.ceil(1.15 * 450 / per_worker))
+        out["workers_on_the_node_for_8_ranks"] = 8 * out["workers_per_rank_for_450_imgs_per_s"]
         if torch.cuda.is_available() and not args.no_gpu:
             import text_segmentation_image_inpainting_amd as T
             from text_segmentation_image_inpainting_amd.BaseModels import to_nhwc
@@ -103,7 +104,7 @@ def main():
                 tr.step(c, m, cl)
             torch.cuda.synchronize()
             out["resident_imgs_per_s"] = round(args.steps * args.batch / (time.perf_counter() - t0), 1)
-            w = min(max(rates), int(np.ceil(1.3 * out["resident_imgs_per_s"] / per_worker)))
+            w = min(max(rates), int(np.ceil(2.0 * out["resident_imgs_per_s"] / per_worker)))
             dl = torch.utils.data.DataLoader(ds, batch_size=args.batch, shuffle=True, num_workers=w, pin_memory=True, drop_last=True,
                                              prefetch_factor=4)
             feed = iter(DevicePrefetcher(dl, dev))
