@@ -9,11 +9,14 @@
 # Copy the outputs into profiles/ and commit them.
 set -u
 ulimit -c 0      # a faulting 70 GiB process must not fill the box with its core file
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"; mkdir -p gpurun_out
 timeout 900 python bench.py > gpurun_out/${TAG}_bench_bs32.log 2>&1; tail -1 gpurun_out/${TAG}_bench_bs32.log | cut -c1-200
 timeout 600 python tools/profile_step.py > gpurun_out/${TAG}_per_shape.log 2>&1
+timeout 600 python tools/profile_step.py --forward > gpurun_out/${TAG}_per_shape_fwd.log 2>&1
+timeout 300 python tools/dw_bench.py > gpurun_out/${TAG}_dw_bench.log 2>&1
+timeout 600 python tools/host_pipeline.py --workers 1,8,16,32,64 --steps 10 2>&1 | tail -1 > gpurun_out/${TAG}_host_pipeline.log
 # secondary configs (BASELINE cfg 3 / cfg 5 shapes), same bench contract, short runs
 timeout 600 python bench.py --model TextSegament --batch 64 --pixel-shuffle --steps 8 --warmup 2 --no-f32-leg 2>&1 | tail -1 > gpurun_out/${TAG}_bench_cfg3_textsegament_bs64.log
 timeout 600 python bench.py --model XceptionTextSegment --size 1024 --batch 8 --products 1 --steps 8 --warmup 2 --no-f32-leg 2>&1 | tail -1 > gpurun_out/${TAG}_bench_cfg5_xception1024_bf16.log
