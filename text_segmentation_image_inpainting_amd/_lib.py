@@ -172,9 +172,12 @@ def set_gemm_products(products):
     if products is not None and products not in (0, 1, 3, 6, 8):
         raise ValueError("gemm products: 0, 1, 3, 6 or 8")
     global _GEMM_TOUCHED
-    # None hands the switch back to the library default: from then on calls stop re-applying a selection (code that sets the
-    # library's thread-local switch directly and then goes through call() keeps its own mode)
-    _GEMM_PRODUCTS, _GEMM_TOUCHED = products, products is not None
+    # _GEMM_TOUCHED stays set for the rest of the process, also after set_gemm_products(None): the library's switch is per THREAD
+    # and autograd's worker threads may still hold an earlier selection -- only re-applying "-1" (the process default) on every
+    # call brings them back.  (Round 4 tried clearing the flag on None, as a review suggested: every backward pass after a
+    # bf16-operand test then ran its GEMMs with bf16 operands on the worker threads -- 11 GPU tests off by 3e-3.)  Code that sets
+    # the library's switch directly must therefore call the raw entry points, not call().
+    _GEMM_PRODUCTS, _GEMM_TOUCHED = products, True
     lib().tsii_set_gemm_products(-1 if products is None else int(products))
 
 

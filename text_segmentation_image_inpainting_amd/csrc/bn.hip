@@ -482,7 +482,10 @@ extern "C" int tsii_bn_finalize(const float* stat_part, int64_t rows, int c, int
     TSII_REQUIRE(scale == nullptr || (gamma && beta), "bn_finalize: scale / shift need gamma and beta");
     TSII_REQUIRE(ws_bytes >= tsii_bn_finalize_ws_bytes(rows, c), "bn_finalize: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    if (rows <= 1024) {
+#ifndef TSII_BN_SMALL_ROWS
+#define TSII_BN_SMALL_ROWS 1024   // A/B: 0 = always the two-level path
+#endif
+    if (rows <= TSII_BN_SMALL_ROWS) {
         hipLaunchKernelGGL(bn_parts_small_kernel, dim3(cdiv(c, 32)), dim3(1024), 0, st, stat_part, (int)rows, m, c, mean, var, running_mean,
                            running_var, momentum, gamma, beta, eps, scale, shift);
         return check_launch("bn_parts_small");

@@ -439,8 +439,11 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
 
 // the lean kernel addresses a slab / an output step with 32-bit byte offsets from a wave-uniform base (and forms the activation
 // offset with a 24-bit multiply)
+#ifndef LS_ENABLE
+#define LS_ENABLE 1              // A/B: 0 sends stride-1 / dilation-1 layers back to the round-3 strip kernel
+#endif
 static inline bool dw_lean_ok(const DtGeom& g) {
-    return g.s == 1 && g.d == 1 && g.c < (1 << 24) && (int64_t)(LS_ROWS * (int64_t)g.win + 64) * 4 < (1ll << 24) &&
+    return LS_ENABLE && g.s == 1 && g.d == 1 && g.c < (1 << 24) && (int64_t)(LS_ROWS * (int64_t)g.win + 64) * 4 < (1ll << 24) &&
            (int64_t)(LS_ROWS * (int64_t)g.win + 64) * g.c * 4 < (1ll << 31) &&
            (int64_t)(LS_ROWS * (int64_t)g.wout + 64) * g.c * 4 < (1ll << 31);
 }

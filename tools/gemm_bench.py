@@ -51,7 +51,7 @@ def main():
 
     modes = [int(v) for v in args.modes.split(",")] if args.modes else [L.tsii_get_gemm_products()]
     for (M, K, N, masked), gm in [(sh, m) for sh in shapes for m in modes]:
-        L.tsii_set_gemm_products(gm)
+        _lib.set_gemm_products(gm)
         x = torch.randn(M, K, device=dev)
         w = torch.randn(N, K, device=dev) * 0.05
         dy = torch.randn(M, N, device=dev)

@@ -48,11 +48,11 @@ def main():
         wws = torch.empty(L.tsii_pw_ws_bytes(N, K) // 4 + 4, device=dev)
         for mode, label, peak in ((0, "f32 MFMA (v_mfma_f32_32x32x2_f32)", 157.3), (6, "split-bf16, 6 products (v_mfma_f32_32x32x16_bf16)", 2500.0 / 6),
                                   (1, "bf16 operands, 1 product", 2500.0)):
-            L.tsii_set_gemm_products(mode)
+            _lib.set_gemm_products(mode)
             ms = timeit(lambda: call("tsii_pw_fwd", ptr(a), M, K, ptr(w), N, None, None, 0, None, None, None, ptr(o), ptr(wws), wws.numel() * 4, st), iters=3)
             tf = 2.0 * M * K * N / ms / 1e9
             print(f"GEMM {M} x {K} x {N} {label}: {ms:.3f} ms  {tf:.1f} TFLOP/s fp32-equivalent ({tf / peak * 100:.0f} % of {peak:.1f})")
-        L.tsii_set_gemm_products(6)
+        _lib.set_gemm_products(None)
 
 if __name__ == "__main__":
     main()
