@@ -267,6 +267,14 @@ int tsii_bn_act_bwd_pre(const float* dout, const float* y, int64_t m, int c,
                         const float* mean, const float* var, const float* gamma, const float* beta,
                         float eps, int act, float slope, int training, const float* bwd_part, int64_t rows,
                         float* dy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+/* tsii_bn_act_bwd_pre that ALSO leaves pooled[n, y/2, x/2, :] = sum over the 2x2 block of dy[n, y, x, :] * pool_scale[n, y, x]
+ * (rows of dy = pixels of [.., up_h, up_w] images, both even; pool_scale NULL = 1): dy is the gradient of a tsii_pw_fwd_up
+ * output, pooled the gradient of its up-sampled addend (= tsii_pool2x2_scaled(dy, pool_scale), without the second pass). */
+int tsii_bn_act_bwd_pre_pool(const float* dout, const float* y, int64_t m, int c,
+                             const float* mean, const float* var, const float* gamma, const float* beta,
+                             float eps, int act, float slope, int training, const float* bwd_part, int64_t rows,
+                             int up_h, int up_w, const float* pool_scale, float* dy, float* pooled,
+                             float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
 /* eval mode: (scale, shift) from the running statistics */
 int tsii_bn_scale_shift(const float* mean, const float* var, const float* gamma, const float* beta, float eps,
                         int c, float* scale, float* shift, void* stream);

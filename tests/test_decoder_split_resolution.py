@@ -1,0 +1,76 @@
+"""K7b at module level (both backends): a decoder level of the U-Net -- DoubleUpSample + cat + PartialInvertedResidual whose 1x1
+expand convolution is the only reader of the concatenation (models/image_inpainting.py:82-84, :29-33) -- computed with the low
+half of that convolution at low resolution (``up2(conv_low(low)) + conv_skip(skip)``, ops.VirtualCat -> tsii_pw_fwd_up) against
+the same level with the concatenation materialised; and the addend's gradient taken inside the BatchNorm backward
+(tsii_bn_act_bwd_pre_pool) against the separate pooling pass (tsii_pool2x2_scaled)."""
+import numpy as np
+import pytest
+import torch
+
+import text_segmentation_image_inpainting_amd as T
+from oracle.filler import fill_state_dict_, seeded_input
+from tests.backends import BACKENDS, both_backends
+from tests.util import assert_close
+
+
+def _level(dev, cl, cs, cout, seed):
+    torch.manual_seed(0)
+    blk = T.PartialInvertedResidual(cl + cs, cout, 3, 1, 1, 1, 2, bias=False, BN=True, activation=torch.nn.LeakyReLU(0.3),
+                                    same_holes=True, no_holes_1_conv=True)
+    fill_state_dict_(blk.state_dict(), seed=seed)
+    return torch.nn.Sequential(blk).to(dev).train()
+
+
+def _run(dev, virtual, pool_in_bn, cl, cs, cout, n, h, w, calls):
+    from text_segmentation_image_inpainting_amd import image_inpainting as ii
+    from text_segmentation_image_inpainting_amd import ops
+    from text_segmentation_image_inpainting_amd.BaseModels import run_nhwc, to_nhwc
+    from text_segmentation_image_inpainting_amd.masks import MaskParts
+    low, mlow = seeded_input(n, cl, h // 2, w // 2, seed=71, hole_frac=0.2)
+    skip, mskip = seeded_input(n, cs, h, w, seed=72, hole_frac=0.15)
+    # the block opens with a no-holes 1x1 convolution (0 / 0 -> NaN where BOTH halves are holes): keep every pixel known in one half
+    mskip = torch.maximum(mskip, 1 - torch.nn.functional.interpolate(mlow[:, :1], scale_factor=2, mode="nearest").expand(-1, cs, -1, -1))
+    level = _level(dev, cl, cs, cout, seed=73)
+    lo = to_nhwc(low.to(dev)).requires_grad_(True)
+    sk = to_nhwc(skip.to(dev)).requires_grad_(True)
+    real, saved = ops.call, ops.FUSE_POOL_BN_BWD
+    ops.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+    ops.FUSE_POOL_BN_BWD = pool_in_bn
+    try:
+        planes = lambda m, c: MaskParts.from_plane(m[:, 0].contiguous().to(dev), c)     # same holes in every channel
+        x, mp = ii._upcat_with_mask(lo, planes(mlow, cl), sk, planes(mskip, cs), virtual=virtual)
+        y, mp = run_nhwc(level, x, mp)
+        gy = torch.from_numpy(np.random.default_rng(74).standard_normal(tuple(y.shape)).astype(np.float32)).to(dev)
+        y.backward(gy)
+    finally:
+        ops.call, ops.FUSE_POOL_BN_BWD = real, saved
+    grads = {k: p.grad.detach().cpu() for k, p in level.named_parameters() if p.grad is not None}
+    stats = {k: v.detach().cpu() for k, v in level.state_dict().items() if "running" in k}
+    return y.detach().cpu(), mp.as_tensor().cpu(), lo.grad.cpu(), sk.grad.cpu(), grads, stats
+
+
+@both_backends
+@pytest.mark.parametrize("cl,cs,cout,n,h,w", [(16, 8, 16, 2, 12, 16), (8, 12, 8, 1, 20, 24)])
+def test_decoder_level_split_resolution(backend, cl, cs, cout, n, h, w):
+    with BACKENDS[backend]() as dev:
+        c_cat, c_split, c_pool = [], [], []
+        ref = _run(dev, False, True, cl, cs, cout, n, h, w, c_cat)
+        two_pass = _run(dev, True, False, cl, cs, cout, n, h, w, c_split)
+        fused = _run(dev, True, True, cl, cs, cout, n, h, w, c_pool)
+    assert "tsii_pw_fwd_up" not in c_cat
+    assert all(bool(torch.isfinite(t).all()) for t in ref[:4])
+    assert "tsii_pw_fwd_up" in c_split and "tsii_pool2x2_scaled" in c_split and "tsii_bn_act_bwd_pre_pool" not in c_split
+    assert "tsii_pw_fwd_up" in c_pool and "tsii_bn_act_bwd_pre_pool" in c_pool and "tsii_pool2x2_scaled" not in c_pool, sorted(set(c_pool))
+    for name, got in (("two-pass", two_pass), ("pooled in the BatchNorm backward", fused)):
+        y, m, dlo, dsk, g, st = got
+        assert torch.equal(m, ref[1]), name
+        assert_close(y, ref[0], 1e-5, f"{name}: y")
+        assert_close(dlo, ref[2], 2e-5, f"{name}: d low")
+        assert_close(dsk, ref[3], 2e-5, f"{name}: d skip")
+        for k in ref[4]:
+            assert_close(g[k], ref[4][k], 1e-4, f"{name}: grad {k}", floor=1e-6)
+        for k in ref[5]:
+            assert_close(st[k], ref[5][k], 1e-5, f"{name}: {k}")
+    # the two spellings of the addend's gradient agree to fp32 rounding of four-term sums
+    assert_close(fused[2], two_pass[2], 1e-6, "d low: pooled in the BatchNorm backward vs the pooling pass")
+    assert torch.equal(fused[3], two_pass[3])

@@ -590,6 +590,47 @@ def test_pointwise_upsampled_addend(emu, mode, n, h, wd, k, N, stats):
     assert np.abs(dz - dzr).max() <= 1e-6 * max(1.0, np.abs(dzr).max())
 
 
+@pytest.mark.parametrize("n,h,wd,c,act,rows", [(2, 8, 12, 8, 2, 5), (1, 4, 6, 5, 1, 3), (3, 6, 4, 36, 0, 600)])
+def test_batchnorm_backward_with_pooled_addend_gradient(emu, n, h, wd, c, act, rows):
+    """tsii_bn_act_bwd_pre_pool = tsii_bn_act_bwd_pre followed by tsii_pool2x2_scaled over its dy: same dy / dgamma / dbeta bit
+    for bit, pooled sums equal to the second pass's (same association; 1e-6 leaves room for FMA contraction)."""
+    L = emu
+    rng = np.random.default_rng(n * 100 + c)
+    m = n * h * wd
+    y = rng.standard_normal((m, c)).astype(np.float32)
+    dout = rng.standard_normal((m, c)).astype(np.float32)
+    mean = y.mean(0); var = y.var(0)
+    gamma = rng.uniform(0.5, 1.5, size=c).astype(np.float32); beta = rng.standard_normal(c).astype(np.float32) * 0.3
+    # any partial rows do: both entries reduce the same ones
+    part = rng.standard_normal((rows, 2, c)).astype(np.float32)
+    inv = (rng.uniform(size=m) > 0.2).astype(np.float32) / rng.integers(1, 9, size=m).astype(np.float32)
+    nb = L.tsii_bn_ws_bytes(m, c)
+    out = {}
+    for pooled in (False, True):
+        dy = np.full((m, c), np.nan, np.float32); dg = np.zeros(c, np.float32); db = np.zeros(c, np.float32)
+        ws = WS(nb)
+        if pooled:
+            dz = np.full((n, h // 2, wd // 2, c), np.nan, np.float32)
+            assert L.tsii_bn_act_bwd_pre_pool(P(dout), P(y), m, c, P(mean), P(var), P(gamma), P(beta), 1e-5, act, 0.2, 1, P(part), rows,
+                                              h, wd, P(inv), P(dy), P(dz), P(dg), P(db), P(ws), nb, None) == 0, L.tsii_last_error()
+        else:
+            dz = np.full((n, h // 2, wd // 2, c), np.nan, np.float32)
+            assert L.tsii_bn_act_bwd_pre(P(dout), P(y), m, c, P(mean), P(var), P(gamma), P(beta), 1e-5, act, 0.2, 1, P(part), rows,
+                                         P(dy), P(dg), P(db), P(ws), nb, None) == 0, L.tsii_last_error()
+            assert L.tsii_pool2x2_scaled(P(dy), P(inv), n, h // 2, wd // 2, c, P(dz), None) == 0, L.tsii_last_error()
+        out[pooled] = (dy, dg, db, dz)
+    (dy0, dg0, db0, dz0), (dy1, dg1, db1, dz1) = out[False], out[True]
+    assert np.array_equal(dy0, dy1) and np.array_equal(dg0, dg1) and np.array_equal(db0, db1)
+    assert np.isfinite(dz1).all() and np.abs(dz1 - dz0).max() <= 1e-6 * max(1.0, np.abs(dz0).max())
+    ref = (dy0.astype(np.float64) * inv[:, None]).reshape(n, h // 2, 2, wd // 2, 2, c).sum(axis=(2, 4))
+    assert np.abs(dz1 - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+    # rows that are not whole even-sized images are refused
+    ws = WS(nb)
+    assert L.tsii_bn_act_bwd_pre_pool(P(dout), P(y), m, c, P(mean), P(var), P(gamma), P(beta), 1e-5, act, 0.2, 1, P(part), rows,
+                                      h + 1, wd, P(inv), P(dy1), P(dz1), P(dg1), P(db1), P(ws), nb, None) != 0
+    assert b"bn_act_bwd_pre_pool" in L.tsii_last_error()
+
+
 def test_pointwise_upsampled_addend_rejects_bad_geometry(emu):
     L = emu
     x = np.zeros((48, 8), np.float32); w = np.zeros((8, 8), np.float32); z = np.zeros((12, 8), np.float32); y = np.zeros((48, 8), np.float32)

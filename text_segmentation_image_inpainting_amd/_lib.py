@@ -66,6 +66,7 @@ SIGNATURES = {
     "tsii_dw_bwd_dx_bn": (_i, [_p, _p, _p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p]),
     "tsii_pw_bwd_dx_bn": (_i, [_p, _l, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p]),
     "tsii_bn_act_bwd_pre": (_i, [_p, _p, _l, _i, _p, _p, _p, _p, _f, _i, _f, _i, _p, _l, _p, _p, _p, _p, _z, _p]),
+    "tsii_bn_act_bwd_pre_pool": (_i, [_p, _p, _l, _i, _p, _p, _p, _p, _f, _i, _f, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
     "tsii_bn_scale_shift": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
     "tsii_act_fwd": (_i, [_p, _l, _i, _f, _p, _p]),
     "tsii_act_bwd": (_i, [_p, _p, _l, _i, _f, _p, _p]),

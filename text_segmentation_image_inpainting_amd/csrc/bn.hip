@@ -380,6 +380,55 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dout, const float*
     }
 }
 
+// The same pass over a tensor whose rows are the pixels of [.., 2h, 2w] images, ALSO leaving the 2 x 2 sums of dy * scale on the
+// half-resolution grid: pooled[(n, yl, xl)] = sum_{dy,dx} dy[(n, 2yl+dy, 2xl+dx)] * scale[..] -- the gradient of an up-sampled
+// addend (K7b, gemm_tiles.h: Epilogue::up_add) taken while dy is written instead of by a second pass over it
+// (tsii_pool2x2_scaled: 1.0 ms per ImageFill step).  One low-resolution pixel x one channel vector per thread.
+template <int W>
+__global__ void bn_bwd_apply_pool_kernel(const float* __restrict__ dout, const float* __restrict__ y, int64_t Ml, int C, int hl, int wl,
+                                         const float* __restrict__ coef, int act, float slope, const float* __restrict__ scale,
+                                         float* __restrict__ dy, float* __restrict__ pooled) {
+    const unsigned CG = (unsigned)(C / W);
+    const int64_t total = Ml * CG;
+    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gt >= total) return;
+    const int c = (int)(gt % CG) * W;
+    const int64_t lp = gt / CG;                                  // (n, yl, xl)
+    const int xl = (int)(lp % wl);
+    const int64_t q = lp / wl;                                   // n * hl + yl
+    const int64_t p00 = (2 * q) * (2 * (int64_t)wl) + 2 * xl;    // (n, 2 yl, 2 xl) on the [.., 2 hl, 2 wl] grid
+    const VecF<W> mu = vload<W>(coef + c), istd = vload<W>(coef + C + c), ga = vload<W>(coef + 2 * C + c), be = vload<W>(coef + 3 * C + c),
+                  k1 = vload<W>(coef + 4 * C + c), k2 = vload<W>(coef + 5 * C + c);
+    const int64_t pix[4] = {p00, p00 + 1, p00 + 2 * wl, p00 + 2 * wl + 1};
+    VecF<W> yv[4], dv[4];
+    float sc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        yv[j] = vload_nt<W>(y + pix[j] * C + c);
+        dv[j] = vload_nt<W>(dout + pix[j] * C + c);
+        sc[j] = scale != nullptr ? scale[pix[j]] : 1.f;
+    }
+    VecF<W> acc;
+#pragma unroll
+    for (int i = 0; i < W; ++i) acc.v[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const float xh = (yv[j].v[i] - mu.v[i]) * istd.v[i];
+            const float z = xh * ga.v[i] + be.v[i];
+            float dz = dv[j].v[i] * act_grad(z, act, slope);
+            dz = dz - k1.v[i] - xh * k2.v[i];
+            dv[j].v[i] = dz * ga.v[i] * istd.v[i];
+        }
+        vstore_nt<W>(dy + pix[j] * C + c, dv[j]);
+    }
+    // same association as tsii_pool2x2_scaled: (a0 s0 + a1 s1) + (a2 s2 + a3 s3)
+#pragma unroll
+    for (int i = 0; i < W; ++i) acc.v[i] = (dv[0].v[i] * sc[0] + dv[1].v[i] * sc[1]) + (dv[2].v[i] * sc[2] + dv[3].v[i] * sc[3]);
+    vstore<W>(pooled + lp * C + c, acc);
+}
+
 static int launch_bn_bwd_apply(const float* dout, const float* y, int64_t m, int c, int act, float slope, float* dy, const float* coef, hipStream_t st) {
     const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(dout) && aligned16(dy) && aligned16(coef);
     const int64_t total = m * (vec ? c / 4 : c);
@@ -557,16 +606,9 @@ extern "C" int tsii_bn_act_bwd(const float* dout, const float* y, int64_t m, int
     return launch_bn_bwd_apply(dout, y, m, c, act, slope, dy, coef, st);
 }
 
-extern "C" int tsii_bn_act_bwd_pre(const float* dout, const float* y, int64_t m, int c, const float* mean,
-                                   const float* var, const float* gamma, const float* beta, float eps, int act,
-                                   float slope, int training, const float* bwd_part, int64_t rows, float* dy,
-                                   float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
-    TSII_REQUIRE(dout && y && mean && var && gamma && beta && dy && dgamma && dbeta && bwd_part && ws, "bn_act_bwd_pre: null pointer");
-    TSII_REQUIRE(m > 0 && c > 0 && rows > 0 && rows < (1ll << 31), "bn_act_bwd_pre: bad shape");
-    TSII_REQUIRE(ws_bytes >= (size_t)cdiv64(rows, BN_L1_ROWS) * 2 * c * sizeof(double) + 16 + bn_coef_bytes(c),
-                 "bn_act_bwd_pre: workspace too small (tsii_bn_ws_bytes)");
-    hipStream_t st = (hipStream_t)stream;
-    float* coef = bn_coef_buffer(ws, ws_bytes, c);
+// reductions of tsii_bn_act_bwd_pre[_pool]: partial rows -> dgamma / dbeta and the apply pass's table of per-channel constants
+static int bn_bwd_pre_reduce(const float* mean, const float* var, const float* gamma, const float* beta, float eps, int training,
+                             const float* bwd_part, int64_t rows, int64_t m, int c, float* dgamma, float* dbeta, void* ws, float* coef, hipStream_t st) {
     const int R = (int)rows;
     int rc;
     if (R > BN_L1_ROWS) {
@@ -581,9 +623,46 @@ extern "C" int tsii_bn_act_bwd_pre(const float* dout, const float* y, int64_t m,
         hipLaunchKernelGGL((bn_bwd_final_kernel<float>), dim3(cdiv(c, 32)), dim3(256), 0, st, bwd_part, R, c, dgamma, dbeta,
                            m, mean, var, gamma, beta, eps, training, coef);
     }
-    rc = check_launch("bn_bwd_final");
+    return check_launch("bn_bwd_final");
+}
+
+extern "C" int tsii_bn_act_bwd_pre(const float* dout, const float* y, int64_t m, int c, const float* mean,
+                                   const float* var, const float* gamma, const float* beta, float eps, int act,
+                                   float slope, int training, const float* bwd_part, int64_t rows, float* dy,
+                                   float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(dout && y && mean && var && gamma && beta && dy && dgamma && dbeta && bwd_part && ws, "bn_act_bwd_pre: null pointer");
+    TSII_REQUIRE(m > 0 && c > 0 && rows > 0 && rows < (1ll << 31), "bn_act_bwd_pre: bad shape");
+    TSII_REQUIRE(ws_bytes >= (size_t)cdiv64(rows, BN_L1_ROWS) * 2 * c * sizeof(double) + 16 + bn_coef_bytes(c),
+                 "bn_act_bwd_pre: workspace too small (tsii_bn_ws_bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    float* coef = bn_coef_buffer(ws, ws_bytes, c);
+    int rc = bn_bwd_pre_reduce(mean, var, gamma, beta, eps, training, bwd_part, rows, m, c, dgamma, dbeta, ws, coef, st);
     if (rc) return rc;
     return launch_bn_bwd_apply(dout, y, m, c, act, slope, dy, coef, st);
+}
+
+extern "C" int tsii_bn_act_bwd_pre_pool(const float* dout, const float* y, int64_t m, int c, const float* mean,
+                                        const float* var, const float* gamma, const float* beta, float eps, int act,
+                                        float slope, int training, const float* bwd_part, int64_t rows,
+                                        int up_h, int up_w, const float* pool_scale, float* dy, float* pooled,
+                                        float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(dout && y && mean && var && gamma && beta && dy && pooled && dgamma && dbeta && bwd_part && ws, "bn_act_bwd_pre_pool: null pointer");
+    TSII_REQUIRE(m > 0 && c > 0 && rows > 0 && rows < (1ll << 31), "bn_act_bwd_pre_pool: bad shape");
+    TSII_REQUIRE(up_h > 0 && up_w > 0 && up_h % 2 == 0 && up_w % 2 == 0 && m % ((int64_t)up_h * up_w) == 0,
+                 "bn_act_bwd_pre_pool: rows must be the pixels of whole images with even height and width (got %d x %d, m=%lld)", up_h, up_w, (long long)m);
+    TSII_REQUIRE(ws_bytes >= (size_t)cdiv64(rows, BN_L1_ROWS) * 2 * c * sizeof(double) + 16 + bn_coef_bytes(c),
+                 "bn_act_bwd_pre_pool: workspace too small (tsii_bn_ws_bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    float* coef = bn_coef_buffer(ws, ws_bytes, c);
+    int rc = bn_bwd_pre_reduce(mean, var, gamma, beta, eps, training, bwd_part, rows, m, c, dgamma, dbeta, ws, coef, st);
+    if (rc) return rc;
+    const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(dout) && aligned16(dy) && aligned16(pooled) && aligned16(coef);
+    const int64_t ml = m / 4;
+    const int64_t total = ml * (vec ? c / 4 : c);
+    const unsigned grid = flat_grid(total, 256);
+    if (vec) hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<4>), dim3(grid), dim3(256), 0, st, dout, y, ml, c, up_h / 2, up_w / 2, coef, act, slope, pool_scale, dy, pooled);
+    else hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<1>), dim3(grid), dim3(256), 0, st, dout, y, ml, c, up_h / 2, up_w / 2, coef, act, slope, pool_scale, dy, pooled);
+    return check_launch("bn_bwd_apply_pool");
 }
 
 extern "C" int tsii_act_fwd(const float* x, int64_t numel, int act, float slope, float* out, void* stream) {

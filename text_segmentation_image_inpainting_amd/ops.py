@@ -23,6 +23,8 @@ import os as _os
 # GEMM epilogue (the raw BatchNorm input is read alongside the store): 90.5 -> 89.3 ms per step.
 FUSE_BN_BWD = _os.environ.get("TSII_FUSE_BN_BWD", "2") != "0"
 FUSE_BN_BWD_PW = _os.environ.get("TSII_FUSE_BN_BWD", "2") == "2"
+# A/B knob: the gradient of a K7b up-sampled addend taken inside the BatchNorm-backward apply pass (tsii_bn_act_bwd_pre_pool)
+FUSE_POOL_BN_BWD = _os.environ.get("TSII_FUSE_POOL_BN_BWD", "1") != "0"
 # A/B knob for K4b (stems as a space-to-depth stride-1 conv on the vector-gather GEMM)
 USE_STEM_S2D = _os.environ.get("TSII_STEM_S2D", "1") != "0"
 
@@ -104,6 +106,23 @@ def plane_upsample2x(p: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------
 # K3 point-wise partial convolution
 # ---------------------------------------------------------------------------------------
+class _PoolHandOver:
+    """K7b backward hand-over: the BatchNorm backward that produces dy for a conv with an up-sampled addend also takes the
+    addend's gradient (2x2 sums of dy * inv) in the same pass (tsii_bn_act_bwd_pre_pool) and leaves it here; the conv's own
+    backward takes it if the dy it receives is that very tensor, and runs tsii_pool2x2_scaled otherwise."""
+
+    __slots__ = ("inv", "h", "w", "dy", "dz")
+
+    def __init__(self, inv, h, w):
+        self.inv, self.h, self.w, self.dy, self.dz = inv, int(h), int(w), None, None
+
+    def take(self, gy):
+        dy, dz, self.dy, self.dz = self.dy, self.dz, None, None
+        if dy is not None and dy.data_ptr() == gy.data_ptr() and dy.shape == gy.shape:
+            return dz
+        return None
+
+
 class _Pointwise(torch.autograd.Function):
     """x may be the raw output of the previous conv whose BatchNorm(+act) is applied on load (in_scale / in_shift:
     K6b, constants here -- the BatchNorm gradient flows through _BNLazy); want_stats adds the BatchNorm partial sums
@@ -113,6 +132,7 @@ class _Pointwise(torch.autograd.Function):
     def forward(ctx, x, w, bias, r0, r1, denom, keep, inv, split, in_scale, in_shift, in_act, in_slope, want_stats, bn=None, up_add=None):
         _lib.check_device(x)
         ctx.bn = bn     # (mean, var, gamma, beta, eps, slot) of the lazily applied producer BatchNorm (K6c) or None
+        ctx.pool = None
         ctx.has_up = up_add is not None   # K7b: [n, h/2, w/2, cout] addend, up-sampled x2 onto the accumulator (differentiable)
         x, w = x.contiguous(), w.contiguous()
         n, h, wd, k = x.shape
@@ -127,6 +147,7 @@ class _Pointwise(torch.autograd.Function):
             assert in_scale is None, "the up-sampled addend has no BatchNorm-on-load form"
             up_add = up_add.contiguous()
             assert tuple(up_add.shape) == (n, h // 2, wd // 2, cout), "up_add must be [n, h/2, w/2, cout]"
+            ctx.pool = _PoolHandOver(inv, h, wd) if FUSE_POOL_BN_BWD else None
             if want_stats:
                 part = torch.empty((_lib.lib().tsii_pw_stat_rows(m), 4, cout), dtype=torch.float32, device=x.device)
             call("tsii_pw_fwd_up", ptr(x), m, k, ptr(w), cout, ptr(bias), ptr(r0), int(split), ptr(r1), ptr(denom), ptr(keep),
@@ -187,8 +208,10 @@ class _Pointwise(torch.autograd.Function):
         dz = None
         if ctx.has_up and ctx.needs_input_grad[15]:
             # the addend joins the accumulator before the count division: its gradient is the 2x2 sum of dy * inv
-            dz = torch.empty((n, h // 2, wd // 2, cout), dtype=torch.float32, device=x.device)
-            call("tsii_pool2x2_scaled", ptr(gy), ptr(inv), n, h // 2, wd // 2, cout, ptr(dz), st)
+            dz = ctx.pool.take(gy) if ctx.pool is not None else None
+            if dz is None:
+                dz = torch.empty((n, h // 2, wd // 2, cout), dtype=torch.float32, device=x.device)
+                call("tsii_pool2x2_scaled", ptr(gy), ptr(inv), n, h // 2, wd // 2, cout, ptr(dz), st)
         return (dx, dw, db) + (None,) * 12 + (dz,)
 
 
@@ -204,7 +227,12 @@ def pconv_pointwise(x, w, bias=None, r0=None, split=0, r1=None, denom=None, keep
     if up_add is not None:
         if isinstance(x, LazyBN):
             x = x.materialize()
-        return _Pointwise.apply(x, w, bias, r0, r1, denom, keep, inv, split, None, None, 0, 0.0, want_stats, None, up_add)
+        out = _Pointwise.apply(x, w, bias, r0, r1, denom, keep, inv, split, None, None, 0, 0.0, want_stats, None, up_add)
+        y = out[0] if want_stats else out
+        pool = getattr(y.grad_fn, "pool", None)
+        if pool is not None:
+            y._tsii_pool = pool      # read by bn_lazy: the BatchNorm backward over y takes the addend's gradient in its pass
+        return out
     if isinstance(x, LazyBN):
         if x.token.shape[-1] % 4 == 0:
             x.consumed()
@@ -565,7 +593,7 @@ class _BNLazy(torch.autograd.Function):
     backward receives the gradient w.r.t. the normalised activation and is the full BatchNorm(+act) backward."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, part, training, momentum, eps, act, slope, slot):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, part, training, momentum, eps, act, slope, slot, pool=None):
         _lib.check_device(y)
         y = y.contiguous()
         c = y.shape[-1]
@@ -573,6 +601,7 @@ class _BNLazy(torch.autograd.Function):
         st = _lib.stream()
         dev = y.device
         ctx.slot = slot
+        ctx.pool = pool     # _PoolHandOver of the conv that produced y (K7b) or None
         scale = torch.empty(c, dtype=torch.float32, device=dev)
         shift = torch.empty(c, dtype=torch.float32, device=dev)
         if training:
@@ -605,7 +634,7 @@ class _BNLazy(torch.autograd.Function):
     @staticmethod
     def backward(ctx, ga, *_):
         if ga is None:
-            return (None,) * 12
+            return (None,) * 13
         y, mean, var, gamma, beta = ctx.saved_tensors
         training, eps, act, slope = ctx.cfg
         ga = ga.contiguous()
@@ -620,14 +649,21 @@ class _BNLazy(torch.autograd.Function):
         part = slot.part if (slot is not None and slot.consumers == 1) else None
         if slot is not None:
             slot.part = None
-        if part is not None:       # K6c: the sole consumer's dX kernel already took sum(dz), sum(dz*xhat)
+        pool = ctx.pool
+        if part is not None and pool is not None and y.dim() == 4 and (y.shape[1], y.shape[2]) == (pool.h, pool.w):
+            dz = torch.empty((y.shape[0], pool.h // 2, pool.w // 2, c), dtype=torch.float32, device=y.device)
+            call("tsii_bn_act_bwd_pre_pool", ptr(ga), ptr(y), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), eps, act,
+                 slope, int(training), ptr(part), part.shape[0], pool.h, pool.w, ptr(pool.inv), ptr(dy), ptr(dz), ptr(dgamma),
+                 ptr(dbeta), ptr(ws), nbytes, _lib.stream())
+            pool.dy, pool.dz = dy, dz
+        elif part is not None:     # K6c: the sole consumer's dX kernel already took sum(dz), sum(dz*xhat)
             call("tsii_bn_act_bwd_pre", ptr(ga), ptr(y), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), eps, act,
                  slope, int(training), ptr(part), part.shape[0], ptr(dy), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes,
                  _lib.stream())
         else:
             call("tsii_bn_act_bwd", ptr(ga), ptr(y), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), eps, act,
                  slope, int(training), ptr(dy), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _lib.stream())
-        return (dy, dgamma, dbeta) + (None,) * 9
+        return (dy, dgamma, dbeta) + (None,) * 10
 
 
 class _LazyApply(torch.autograd.Function):
@@ -655,7 +691,7 @@ def bn_lazy(y, gamma, beta, running_mean, running_var, training, momentum=0.1, e
     """BatchNorm(+act) of a conv output as a LazyBN; ``part``: the statistics partials the conv left behind."""
     slot = _BwdSlot()
     token, scale, shift, mean, var = _BNLazy.apply(y, gamma, beta, running_mean, running_var, part, training,
-                                                   momentum, eps, act, slope, slot)
+                                                   momentum, eps, act, slope, slot, getattr(y, "_tsii_pool", None))
     return LazyBN(token, scale, shift, act, slope, mean, var, gamma.detach(), beta.detach(), eps, slot)
 
 
