@@ -166,6 +166,14 @@ int tsii_head_cat_bwd_dx(const float* dy, const float* inv, const float* w, int 
 int tsii_head_cat_bwd_dw(const float* dy, const float* inv, const float* keep, const float* low, const float* skip,
                          int c1, int c2, const float* r0, const float* r1, int n, int h, int wd, int cout,
                          float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream);
+/* K4d: tsii_head_cat_bwd_dw on the f32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32), with the low part's mask given where
+ * it lives: r0_low [n, h/2, wd/2] is the mask plane of `low` itself (NULL = ones) -- the up-sampled half is then constant over
+ * each 2x2 block and its share of the product runs over LOW-resolution pixels against 2x2 box sums of dy*inv.
+ * tsii_head_cat_low_ok() != 0: h, wd even, c1 in {32, 64}, 1 <= c2 <= 16, cout <= 3.  Same workspace as tsii_head_cat_bwd_dw. */
+int tsii_head_cat_low_ok(int n, int h, int wd, int c1, int c2, int cout);
+int tsii_head_cat_bwd_dw_low(const float* dy, const float* inv, const float* keep, const float* low, const float* skip,
+                             int c1, int c2, const float* r0_low, const float* r1, int n, int h, int wd, int cout,
+                             float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- K4b: stems (odd k, stride 2, pad (k-1)/2, very few input channels; models/image_inpainting.py:23) as a stride-1
  * valid convolution over the space-to-depth image, so they run on the vector-gather implicit GEMM:

@@ -474,36 +474,62 @@ def test_imagefill_full_size_properties_gpu():
 
 
 @both_backends
-@pytest.mark.parametrize("n,h,w,c1,c2,cout,premult", [(2, 12, 40, 32, 3, 3, False), (1, 18, 34, 24, 4, 4, True), (2, 16, 16, 64, 3, 3, True),
-                                                       (1, 8, 66, 32, 3, 2, False)])
-def test_head_over_virtual_concat(backend, n, h, w, c1, c2, cout, premult):
+@pytest.mark.parametrize("n,h,w,c1,c2,cout,premult,low_mask", [(2, 12, 40, 32, 3, 3, False, False), (1, 18, 34, 24, 4, 4, True, False),
+                                                                (2, 16, 16, 64, 3, 3, True, False), (1, 8, 66, 32, 3, 2, False, False),
+                                                                (2, 16, 64, 32, 3, 3, False, True), (2, 32, 64, 64, 3, 3, True, True),
+                                                                (1, 16, 128, 32, 3, 2, False, True), (1, 48, 192, 32, 3, 3, False, True),
+                                                                (1, 16, 64, 32, 3, 3, True, True), (1, 32, 128, 64, 4, 1, False, True),
+                                                                (2, 12, 40, 32, 3, 3, False, True), (1, 18, 34, 24, 4, 4, True, True)])
+def test_head_over_virtual_concat(backend, n, h, w, c1, c2, cout, premult, low_mask):
     """K4c: the 3x3 output head over cat(nearest-x2(low), skip) WITHOUT the concatenated tensor (tsii_head_cat_*) against the
     same head over the materialised concatenation (tsii_upcat_fwd + tsii_dense_*): output, d low, d skip, dW, dbias; two mask
-    planes with holes (or a pre-multiplied skip part, as at ImageFill's input level), maps that are not tile multiples."""
-    from text_segmentation_image_inpainting_amd import ops
+    planes with holes (or a pre-multiplied skip part, as at ImageFill's input level), maps that are not tile multiples.
+    ``low_mask``: the low part's plane is the nearest-x2 up-sampling of the low tensor's own plane, which the VirtualCat carries
+    (what the decoder hands over) -- the weight gradient then runs on the matrix cores over low-resolution pixels (K4d,
+    tsii_head_cat_bwd_dw_low) where that kernel exists (c1 = 32 / 64, cout <= 3, whole 16 x 64 tiles); the emulator run caps its grid at 3 blocks so
+    that blocks walk several tiles."""
+    from text_segmentation_image_inpainting_amd import _lib, ops
     rng = np.random.default_rng(n * 1000 + h * 10 + w + c1)
+    calls = []
+    real = ops.call
     with BACKENDS[backend]() as dev:
         low = torch.from_numpy(rng.standard_normal((n, h // 2, w // 2, c1)).astype(np.float32)).to(dev)
         skip = torch.from_numpy(rng.standard_normal((n, h, w, c2)).astype(np.float32)).to(dev)
         wt = torch.from_numpy((rng.standard_normal((cout, c1 + c2, 3, 3)) * 0.2).astype(np.float32)).to(dev)
         bias = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(dev)
-        r0 = torch.from_numpy((rng.uniform(size=(n, h, w)) > 0.3).astype(np.float32)).to(dev)
+        r0_low = None
+        if low_mask:
+            r0_low = torch.from_numpy((rng.uniform(size=(n, h // 2, w // 2)) > 0.3).astype(np.float32)).to(dev)
+            r0 = r0_low.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2).contiguous()
+        else:
+            r0 = torch.from_numpy((rng.uniform(size=(n, h, w)) > 0.3).astype(np.float32)).to(dev)
         r1 = None if premult else torch.from_numpy((rng.uniform(size=(n, h, w)) > 0.3).astype(np.float32)).to(dev)
         g = ops.make_geom((3, 3), (1, 1), (1, 1), (1, 1))
         p1 = r1 if r1 is not None else torch.ones_like(r0)
         denom, new_mask, inv = ops.mask_update(r0, float(c1), p1, float(c2), g, 1.0, True)
         gy = torch.from_numpy(rng.standard_normal((n, h, w, cout)).astype(np.float32)).to(dev)
         res = []
-        for fused in (True, False):
-            a, b = low.clone().requires_grad_(True), skip.clone().requires_grad_(True)
-            ww, bb = wt.clone().requires_grad_(True), bias.clone().requires_grad_(True)
-            if fused:
-                vc = ops.VirtualCat(a, b)
-                assert ops.head_cat_ok(vc, cout, g)
-                y = ops.pconv_head_cat(vc, ww, bb, r0, r1, denom, new_mask, inv)
-            else:
-                y = ops.pconv_dense(ops.upcat(a, b), ww, bb, None, r0, c1, r1, denom, new_mask, inv, g)
-            y.backward(gy)
-            res.append((y.detach(), a.grad, b.grad, ww.grad, bb.grad))
+        hook = _lib.lib().tsii_emu_set_head_blocks if backend == "emu" else None      # test-only symbol of the emulator build
+        ops.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+        if hook is not None:
+            hook(3)
+        try:
+            for fused in (True, False):
+                a, b = low.clone().requires_grad_(True), skip.clone().requires_grad_(True)
+                ww, bb = wt.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+                if fused:
+                    vc = ops.VirtualCat(a, b, r0_low)
+                    assert ops.head_cat_ok(vc, cout, g)
+                    y = ops.pconv_head_cat(vc, ww, bb, r0, r1, denom, new_mask, inv)
+                else:
+                    y = ops.pconv_dense(ops.upcat(a, b), ww, bb, None, r0, c1, r1, denom, new_mask, inv, g)
+                y.backward(gy)
+                res.append((y.detach(), a.grad, b.grad, ww.grad, bb.grad))
+        finally:
+            ops.call = real
+            if hook is not None:
+                hook(0)
         for name, u, v in zip(("y", "d low", "d skip", "dW", "dbias"), *res):
             assert_close(u, v, 2e-6, f"head over virtual concat: {name}", floor=1e-6)
+    matrix_core = low_mask and c1 in (32, 64) and cout <= 3 and h % 16 == 0 and w % 64 == 0      # whole 16 x 64 tiles
+    assert ("tsii_head_cat_bwd_dw_low" in calls) == matrix_core and ("tsii_head_cat_bwd_dw" in calls) == (not matrix_core), sorted(set(calls))

@@ -560,19 +560,6 @@ int launch_conv_gemm_dx_phases(const float* dy, const float* inv, const float* w
     return 0;
 }
 
-__global__ void conv_dw_reduce_kernel(const float* __restrict__ part, int S, int cout, int cin, int T, float* __restrict__ dw) {
-    const int64_t len = (int64_t)cout * cin * T;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < len; j += (int64_t)gridDim.x * blockDim.x) {
-        const int t = (int)(j % T);
-        const int ci = (int)((j / T) % cin);
-        const int64_t co = j / ((int64_t)T * cin);
-        const int64_t src = (co * T + t) * cin + ci;     // partial layout [co][(t, ci)]
-        double a = 0.0;
-        for (int z = 0; z < S; ++z) a += (double)part[(int64_t)z * len + src];
-        dw[j] = (float)a;
-    }
-}
-
 size_t conv_gemm_dw_ws_floats(const ConvGemmGeom& g) {
     const int K = g.kh * g.kw * g.cin;
     const TnPlan pl = plan_tn((int64_t)g.n * g.ho * g.wo, g.cout, K);
@@ -593,8 +580,7 @@ int launch_conv_gemm_dw(const float* dy, const float* inv, const float* x, const
     if (!elem && (pl.big || gemm_products() == 1) && tn_split_conv_ok(dy, g.cout, x, M, g.cout, K, cg)) {
         int rc = launch_tn_split_conv(dy, g.cout, inv, x, cg, ws, M, g.cout, K, pl.chunk, pl.splits, pl.big, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3(stream_grid((int64_t)g.cout * K, 256)), dim3(256), 0, st, ws, pl.splits, g.cout, g.cin, T, dwgt);
-        return check_launch("conv_dw_reduce");
+        return launch_reduce_rows_conv(ws, pl.splits, g.cout, g.cin, T, dwgt, st);
     }
     if (pl.big && !elem) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 2, 2, true, 1>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg, kNoBN);
     else if (!elem) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, 1>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg, kNoBN);
@@ -602,8 +588,7 @@ int launch_conv_gemm_dw(const float* dy, const float* inv, const float* x, const
     else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 1, 1, true, 2>), grid, dim3(256), 0, st, dy, (int64_t)g.cout, inv, x, (int64_t)0, none, ws, M, g.cout, K, pl.chunk, cg, kNoBN);
     int rc = check_launch("conv_gemm_tn");
     if (rc) return rc;
-    hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3(stream_grid((int64_t)g.cout * K, 256)), dim3(256), 0, st, ws, pl.splits, g.cout, g.cin, T, dwgt);
-    return check_launch("conv_dw_reduce");
+    return launch_reduce_rows_conv(ws, pl.splits, g.cout, g.cin, T, dwgt, st);
 }
 
 }  // namespace tsii

@@ -91,6 +91,8 @@ __device__ __forceinline__ float row_scale_at(const RowScale& rs, int64_t row, i
 // generic helpers shared across translation units (reduce.hip)
 // out[j] = sum_r ws[r*len + j]  (double accumulation), r in [0,rows)
 int launch_reduce_rows(const float* ws, int rows, int64_t len, float* out, hipStream_t stream);
+// the same over partial rows laid out [co][t][ci], written as the weight gradient [co][ci][t]
+int launch_reduce_rows_conv(const float* ws, int rows, int cout, int cin, int T, float* out, hipStream_t stream);
 // out[c*rows_in + r] = in[r*cols_in + c]  (2-D transpose of a [rows_in, cols_in] matrix)
 int launch_transpose(const float* in, int rows_in, int cols_in, float* out, hipStream_t stream);
 

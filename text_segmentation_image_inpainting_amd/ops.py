@@ -25,6 +25,8 @@ FUSE_BN_BWD = _os.environ.get("TSII_FUSE_BN_BWD", "2") != "0"
 FUSE_BN_BWD_PW = _os.environ.get("TSII_FUSE_BN_BWD", "2") == "2"
 # A/B knob: the gradient of a K7b up-sampled addend taken inside the BatchNorm-backward apply pass (tsii_bn_act_bwd_pre_pool)
 FUSE_POOL_BN_BWD = _os.environ.get("TSII_FUSE_POOL_BN_BWD", "1") != "0"
+# A/B knob for K4d (head weight gradient on the f32 matrix cores)
+USE_HEAD_MFMA = _os.environ.get("TSII_HEAD_MFMA", "1") != "0"
 # A/B knob for K4b (stems as a space-to-depth stride-1 conv on the vector-gather GEMM)
 USE_STEM_S2D = _os.environ.get("TSII_STEM_S2D", "1") != "0"
 
@@ -781,8 +783,9 @@ def head_cat_ok(vc: "VirtualCat", cout: int, g) -> bool:
 
 class _HeadCat(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, low, skip, w, bias, r0, r1, denom, keep, inv):
+    def forward(ctx, low, skip, w, bias, r0, r1, denom, keep, inv, r0_low=None):
         _lib.check_device(low)
+        ctx.r0_low = r0_low      # the low tensor's own mask plane (r0 = its nearest-x2 up-sampling), or None when r0 is None
         low, skip, w = low.contiguous(), skip.contiguous(), w.contiguous()
         n, h, wd, c2 = skip.shape
         c1, cout = low.shape[3], w.shape[0]
@@ -817,14 +820,18 @@ class _HeadCat(torch.autograd.Function):
             db = torch.empty(cout, dtype=torch.float32, device=low.device) if ctx.has_bias else None
             nbytes = L.tsii_dense_bwd_dw_ws_bytes(n, h, wd, c1 + c2, cout, 3, 3)
             ws = _ws(nbytes, low)
-            call("tsii_head_cat_bwd_dw", ptr(gy), ptr(inv), ptr(keep), ptr(low), ptr(skip), c1, c2, ptr(r0), ptr(r1),
-                 n, h, wd, cout, ptr(dw), ptr(db), ptr(ws), nbytes, st)
-        return dlow, dskip, dw, db, None, None, None, None, None
+            if USE_HEAD_MFMA and (ctx.r0_low is not None or r0 is None) and L.tsii_head_cat_low_ok(n, h, wd, c1, c2, cout):
+                call("tsii_head_cat_bwd_dw_low", ptr(gy), ptr(inv), ptr(keep), ptr(low), ptr(skip), c1, c2, ptr(ctx.r0_low), ptr(r1),
+                     n, h, wd, cout, ptr(dw), ptr(db), ptr(ws), nbytes, st)
+            else:
+                call("tsii_head_cat_bwd_dw", ptr(gy), ptr(inv), ptr(keep), ptr(low), ptr(skip), c1, c2, ptr(r0), ptr(r1),
+                     n, h, wd, cout, ptr(dw), ptr(db), ptr(ws), nbytes, st)
+        return dlow, dskip, dw, db, None, None, None, None, None, None
 
 
 def pconv_head_cat(vc: VirtualCat, w, bias, r0, r1, denom, keep, inv):
     """PartialConv 3x3 head over a VirtualCat (K4c): y = keep ? conv(cat * mask) / denom + bias : 0."""
-    return _HeadCat.apply(vc.low, vc.skip, w, bias, r0, r1, denom, keep, inv)
+    return _HeadCat.apply(vc.low, vc.skip, w, bias, r0, r1, denom, keep, inv, vc.low_plane if r0 is not None else None)
 
 
 class _Up2x(torch.autograd.Function):
