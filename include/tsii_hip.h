@@ -169,8 +169,16 @@ int tsii_head_cat_bwd_dw(const float* dy, const float* inv, const float* keep, c
 /* K4d: tsii_head_cat_bwd_dw on the f32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32), with the low part's mask given where
  * it lives: r0_low [n, h/2, wd/2] is the mask plane of `low` itself (NULL = ones) -- the up-sampled half is then constant over
  * each 2x2 block and its share of the product runs over LOW-resolution pixels against 2x2 box sums of dy*inv.
- * tsii_head_cat_low_ok() != 0: h, wd even, c1 in {32, 64}, 1 <= c2 <= 16, cout <= 3.  Same workspace as tsii_head_cat_bwd_dw. */
+ * tsii_head_cat_low_ok() != 0: h % 16 == 0, wd % 64 == 0 (whole 16 x 64 tiles), c1 in {32, 64}, 1 <= c2 <= 16, cout <= 3.
+ * Same workspace as tsii_head_cat_bwd_dw. */
 int tsii_head_cat_low_ok(int n, int h, int wd, int c1, int c2, int cout);
+/* ... and the forward pass: the up-sampled half as Z[low pixel][(tap, cout)] = W_low x low on the matrix cores (kept in LDS per
+ * tile), 9 entries of Z per output pixel and channel + the 3-channel skip half on the vector ALU.  tsii_head_cat_fwd_low_ok():
+ * tsii_head_cat_low_ok() and c2 == 3.  No workspace. */
+int tsii_head_cat_fwd_low_ok(int n, int h, int wd, int c1, int c2, int cout);
+int tsii_head_cat_fwd_low(const float* low, const float* skip, int c1, int c2, const float* r0_low, const float* r1,
+                          const float* w, const float* bias, const float* denom, const float* keep,
+                          int n, int h, int wd, int cout, float* y, void* stream);
 int tsii_head_cat_bwd_dw_low(const float* dy, const float* inv, const float* keep, const float* low, const float* skip,
                              int c1, int c2, const float* r0_low, const float* r1, int n, int h, int wd, int cout,
                              float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream);

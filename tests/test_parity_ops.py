@@ -533,3 +533,4 @@ def test_head_over_virtual_concat(backend, n, h, w, c1, c2, cout, premult, low_m
             assert_close(u, v, 2e-6, f"head over virtual concat: {name}", floor=1e-6)
     matrix_core = low_mask and c1 in (32, 64) and cout <= 3 and h % 16 == 0 and w % 64 == 0      # whole 16 x 64 tiles
     assert ("tsii_head_cat_bwd_dw_low" in calls) == matrix_core and ("tsii_head_cat_bwd_dw" in calls) == (not matrix_core), sorted(set(calls))
+    assert ("tsii_head_cat_fwd_low" in calls) == (matrix_core and c2 == 3) and ("tsii_head_cat_fwd" in calls) == (not (matrix_core and c2 == 3))

@@ -97,13 +97,13 @@ int launch_transpose(const float* in, int rows_in, int cols_in, float* out, hipS
 }
 
 // ---- scaled column sums (bias gradients) -----------------------------------------
-// block = NB columns x L row lanes (NB = min(N,256), L = 256/NB); the [rows, N] slab of a block is one
-// contiguous stream, four independent rows in flight per lane (one row at a time ran the 2 M x 64 stem gradient at 2 TB/s);
-// lanes are combined through LDS.  part[block][n]
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, const float* __restrict__ rowmul,
+// block = NB columns x L row lanes (NB = min(N,256), L = min(1024/NB, 64)); the [rows, N] slab of a block is one
+// contiguous stream, four independent rows in flight per lane (256 threads with one row at a time ran the 2 M x 64 stem gradient
+// at 2 TB/s: 128 dependent memory latencies per lane); lanes are combined through LDS.  part[block][n]
+__global__ __launch_bounds__(1024) void colsum_partial_kernel(const float* __restrict__ a, const float* __restrict__ rowmul,
                                                              int64_t M, int N, int NB, int L, int64_t rows_per_block,
                                                              float* __restrict__ part) {
-    __shared__ float sh[256];
+    __shared__ float sh[1024];
     const int col0 = blockIdx.y * NB;
     const int cl = threadIdx.x % NB, lane = threadIdx.x / NB;
     const int col = col0 + cl;
@@ -139,8 +139,8 @@ int launch_colsum_scaled(const float* a, const float* rowmul, int64_t M, int N, 
                          hipStream_t stream) {
     const int64_t rpb = colsum_rpb(M);
     const int rows = (int)cdiv64(M, rpb);
-    const int NB = N < 256 ? N : 256, L = 256 / NB;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(rows, cdiv(N, NB)), dim3(256), 0, stream, a, rowmul, M, N, NB, L, rpb, ws);
+    const int NB = N < 256 ? N : 256, L = 1024 / NB < 64 ? 1024 / NB : 64;      // <= 64 lanes: lane 0 adds them up serially
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(rows, cdiv(N, NB)), dim3(1024), 0, stream, a, rowmul, M, N, NB, L, rpb, ws);
     int rc = check_launch("colsum_partial");
     if (rc) return rc;
     return launch_reduce_rows(ws, rows, N, out, stream);

@@ -23,6 +23,14 @@ namespace tsii {
 #ifndef HM_ABLATE
 #define HM_ABLATE 0
 #endif
+// a value the compiler must have materialised at this point (keeps the FMAs that produce it from being sunk below later LDS
+// reads, whose results then all stay live); no-op on the test emulator
+#ifndef TSII_PIN_F2
+#define TSII_PIN_F2(x) asm volatile("" : "+v"(x))
+#endif
+#ifndef HF_ABLATE
+#define HF_ABLATE 0     // forward ablations: 1 = no matrix product phase, 2 = no output phase arithmetic, 4 = no skip half in it
+#endif
 #ifndef HM_WAVES
 #define HM_WAVES 4      // resident waves per SIMD asked of the register allocator for c1 = 32 (A/B build knob)
 #endif
@@ -249,6 +257,225 @@ __global__ __launch_bounds__(256, NB == 2 ? HM_WAVES : 3) void head_cat_dw_mfma_
     }
 }
 
+
+// ---- forward -------------------------------------------------------------------------------------------------------------------
+//   y[p][co] = sum_t ( sum_ci L[(p + t - 1) >> 1][ci] W[co][ci][t]  +  sum_cs XS[p + t - 1][cs] W[co][c1 + cs][t] )
+// The inner sum of the up-sampled half depends on the LOW pixel only: Z[j][(t, co)] = sum_ci L[j][ci] W[co][ci][t] is a
+// [27 x c1] x [c1 x low pixels] product on the matrix cores (a quarter of the multiply-adds of the full-resolution form, low read
+// once), left in LDS for the tile with its one-pixel halo; every output pixel then adds 9 of its entries per output channel, and the
+// 3-channel skip half (81 multiply-adds per pixel, weights in scalar registers) from a staged patch.  (head_fwd_kernel, dense.hip,
+// runs all 945 multiply-adds per pixel through the vector ALU from LDS: 0.67 ms for ImageFill's batch, 0.1 ms of HBM traffic.)
+constexpr int HF_ZH = HM_LH + 2, HF_ZW = HM_LW + 2;                   // low pixels of a tile with halo: 10 x 34
+constexpr int HF_GROUPS = (HF_ZH * HF_ZW + 15) / 16;                  // 16-pixel column blocks of the product: 22
+constexpr int HF_ROUNDS = (HF_GROUPS + 3) / 4;                        // per wave: 6
+constexpr int HF_ZP = 356;                                            // Z row stride (4 * HF_ZP % 64 == 16: the 4 row groups of a store hit different banks)
+constexpr int HF_XH = 2 * HM_LH + 2, HF_XW = 2 * HM_LW + 2, HF_XS = HF_XW + 1;   // skip patch 18 x 66, row stride 67
+constexpr int HF_XIT = (HF_XH * HF_XW * 3 + 255) / 256;               // staging rounds of the skip patch (3 channels)
+static_assert(HF_GROUPS * 16 <= HF_ZP, "Z row holds every column block");
+
+__device__ __attribute__((aligned(16))) float g_zero_page[64] = {};   // what a load outside the image reads (zero padding without a select)
+__device__ float g_one = 1.f;                                          // what an absent denom / keep plane reads (stride 0)
+
+template <int NB, bool R0, bool R1>
+__global__ __launch_bounds__(256, 2) void head_cat_fwd_mfma_kernel(const float* __restrict__ low, const float* __restrict__ skip,
+                                                                   const float* __restrict__ r0l, const float* __restrict__ r1,
+                                                                   const float* __restrict__ wgt, const float* __restrict__ bias,
+                                                                   const float* __restrict__ denom, const float* __restrict__ keep,
+                                                                   int n, int h, int w, int cout, int tiles_per_block, float* __restrict__ y) {
+    constexpr int C1 = 16 * NB, C2 = 3;
+    const float* zeros = g_zero_page;
+    constexpr int GB = NB == 2 ? HF_ROUNDS : HF_ROUNDS / 2;            // column blocks whose loads are in flight together
+    static_assert(HF_ROUNDS % GB == 0, "whole batches");
+    __shared__ float Z[32 * HF_ZP];                                     // rows 27..31 are written (zeros) and never read
+    __shared__ float XS[3 * HF_XH * HF_XS];
+    __shared__ __attribute__((aligned(16))) float WS[9 * C2 * 4];
+    const int hl = h >> 1, wl = w >> 1;
+    const int ntx = wl / HM_LW, nty = hl / HM_LH;
+    const int total = n * nty * ntx;
+    const int cin = C1 + C2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nn = lane & 15, kk = lane >> 4;
+    // The contraction index of one matrix instruction is spread over the four 16-lane groups: instruction (j, e) lets group kk
+    // carry channel 16 j + 4 kk + e -- so a lane's right operands for e = 0..3 are ONE 16-byte load of its pixel (channels
+    // 16 j + 4 kk ..), and the left operand (fixed for the kernel) is W as [m = t * 3 + co][that channel], rows >= 27 and output
+    // channels >= cout zero.
+    float wl_[2][NB][4];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int m = 16 * mb + nn;
+        const int t = m / 3, co = m - 3 * t;
+        const bool ok = m < 27 && co < cout;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wl_[mb][j][e] = ok ? wgt[((int64_t)co * cin + 16 * j + 4 * kk + e) * 9 + t] : 0.f;
+    }
+    // the skip half's 81 weights as [tap][cs][co (padded to 4)] in LDS: one broadcast 16-byte read per (tap, cs) in the output phase
+    // (as 81 scalar registers they do not fit beside the rest and spill through v_readlane)
+    for (int k = threadIdx.x; k < 9 * C2 * 4; k += 256) {
+        const int co = k & 3, cs = (k >> 2) % C2, t = k / (4 * C2);
+        WS[k] = co < cout ? wgt[((int64_t)co * cin + C1 + cs) * 9 + t] : 0.f;
+    }
+    const float* kbase = keep != nullptr ? keep : &g_one;
+    const float* dbase = denom != nullptr ? denom : &g_one;
+    const int64_t kstride = keep != nullptr ? 1 : 0, dstride = denom != nullptr ? 1 : 0;
+    float bv[3];
+#pragma unroll
+    for (int co = 0; co < 3; ++co) bv[co] = (bias != nullptr && co < cout) ? bias[co] : 0.f;
+    const int t_beg = blockIdx.x * tiles_per_block;
+    const int t_end = t_beg + tiles_per_block < total ? t_beg + tiles_per_block : total;
+    for (int tl = t_beg; tl < t_end; ++tl) {
+        const int bx = tl % ntx, by = (tl / ntx) % nty;
+        const int64_t img = tl / (ntx * nty);
+        const int ly0 = by * HM_LH, lx0 = bx * HM_LW;
+        const int y0 = 2 * ly0, x0 = 2 * lx0;
+        const float* low_img = low + img * hl * wl * C1;
+        const float* r0_img = R0 ? r0l + img * hl * wl : nullptr;
+        const float* skip_img = skip + img * h * w * C2;
+        const float* r1_img = R1 ? r1 + img * h * w : nullptr;
+        // (the thread index goes through an opaque copy per tile: everything derived from it is tile-invariant, and hoisted out of
+        // the tile loop it is ~100 registers of staging indices that spill)
+        unsigned tid = threadIdx.x;
+        TSII_OPAQUE_U32(tid);
+        // the skip patch (with its halo), one float per thread and round: rows of 66 x 3 contiguous floats
+        float xv[HF_XIT], xm[R1 ? HF_XIT : 1];
+#pragma unroll
+        for (int i = 0; i < HF_XIT; ++i) {
+            const int idx = (int)tid + 256 * i;
+            const int r = idx / (HF_XW * 3), j = idx - r * (HF_XW * 3);
+            const int c = j / 3;
+            const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+            const bool ok = idx < HF_XH * HF_XW * 3 && yy >= 0 && yy < h && xx >= 0 && xx < w;
+            const unsigned pix = ok ? (unsigned)(yy * w + xx) : 0u;
+            const float* src = ok ? skip_img + pix * 3 + (j - 3 * c) : zeros;      // zero padding: a load of a zero
+            xv[i] = *src;
+            if (R1) xm[i] = r1_img[pix];
+        }
+        f32x4 bq[GB][NB];
+        float mq[R0 ? GB : 1];
+        auto fetch_low = [&](int batch) {
+#pragma unroll
+            for (int q = 0; q < GB; ++q) {
+                const int pg = 16 * (wave + 4 * (batch * GB + q)) + nn;
+                const int ry = pg / HF_ZW, rx = pg - ry * HF_ZW;
+                const int ly = ly0 - 1 + ry, lx = lx0 - 1 + rx;
+                const bool ok = pg < HF_ZH * HF_ZW && ly >= 0 && ly < hl && lx >= 0 && lx < wl;
+                const unsigned lp = ok ? (unsigned)(ly * wl + lx) : 0u;
+                if (R0) mq[q] = r0_img[lp];
+                const float* src = ok ? low_img + lp * C1 + 4 * kk : zeros;          // pixels outside the image: zeros (64 of them at `zeros`)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) bq[q][j] = *reinterpret_cast<const f32x4*>(src + 16 * j);
+            }
+        };
+        if (!(HF_ABLATE & 1)) fetch_low(0);
+        __syncthreads();                              // the previous tile's Z and patch are consumed
+        unsigned tid2 = threadIdx.x;
+        TSII_OPAQUE_U32(tid2);
+#pragma unroll
+        for (int i = 0; i < HF_XIT; ++i) {
+            const int idx = (int)tid2 + 256 * i;
+            const int r = idx / (HF_XW * 3), j = idx - r * (HF_XW * 3);
+            const int c = j / 3;
+            if (idx < HF_XH * HF_XW * 3) XS[(j - 3 * c) * (HF_XH * HF_XS) + r * HF_XS + c] = R1 ? xv[i] * xm[i] : xv[i];
+        }
+        // ---- Z = W_low x L over the tile's low pixels with halo: 16 pixels per column block, wave w takes blocks w, w + 4, ...
+#pragma unroll
+        for (int batch = 0; batch < ((HF_ABLATE & 1) ? 0 : HF_ROUNDS / GB); ++batch) {
+            if (batch > 0) fetch_low(batch);
+#pragma unroll
+            for (int q = 0; q < GB; ++q) {
+                const int g = wave + 4 * (batch * GB + q);
+                f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl_[mb][j][e], bq[q][j][e], acc[mb], 0, 0, 0);
+                if (g < HF_GROUPS) {                  // (wave-uniform) the lane's results all belong to its pixel: the mask goes on here
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) Z[(16 * mb + 4 * kk + i) * HF_ZP + 16 * g + nn] = R0 ? acc[mb][i] * mq[q] : acc[mb][i];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        // ---- outputs: thread = column x of the tile, rows 4 * wave .. 4 * wave + 3 (the row arithmetic is wave-uniform)
+        unsigned tid3 = threadIdx.x;
+        TSII_OPAQUE_U32(tid3);
+        const int x = (int)(tid3 & 63u), yq = __builtin_amdgcn_readfirstlane((int)(tid3 >> 6));
+        int rxo[3];
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) rxo[tx] = ((x + tx - 1) >> 1) + 1;
+        const int64_t pix0 = (img * h + y0 + 4 * yq) * w + x0 + x;
+        float kp[4], dn[4];                            // (absent planes: a 1 read with stride 0 -- no branches around the loads)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            kp[i] = kbase[(pix0 + (int64_t)i * w) * kstride];
+            dn[i] = dbase[(pix0 + (int64_t)i * w) * dstride];
+        }
+        float a[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int co = 0; co < 3; ++co) a[i][co] = 0.f;
+        // skip half: per (column tap, channel) the 6 patch rows of the thread's 4 output rows are read once; the weight reads go
+        // through an opaque zero so that they stay here (hoisted out of the tile loop they are 108 registers)
+        unsigned zt = 0u;
+        TSII_OPAQUE_U32(zt);
+#pragma unroll
+        for (int tx = 0; tx < ((HF_ABLATE & 6) ? 0 : 3); ++tx)
+#pragma unroll
+            for (int cs = 0; cs < C2; ++cs) {
+                float xs[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) xs[r] = XS[cs * (HF_XH * HF_XS) + (4 * yq + r) * HF_XS + x + tx];
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(WS + ((ty * 3 + tx) * C2 + cs) * 4 + zt);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int co = 0; co < 3; ++co) a[i][co] = fmaf(xs[i + ty], wv[co], a[i][co]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int co = 0; co < 3; ++co) TSII_PIN_F2(a[i][co]);     // (else every LDS read of the phase is issued first and
+                __builtin_amdgcn_sched_barrier(0);                            //  the FMAs sink below them: 270 live registers)
+            }
+        // up-sampled half: 9 entries of Z per output pixel and channel
+#pragma unroll
+        for (int i = 0; i < ((HF_ABLATE & 2) ? 0 : 4); ++i) {
+            const int yy = 4 * yq + i;
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty) {
+                const int ry = ((yy + ty - 1) >> 1) + 1;
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) {
+                    const float* zp = Z + ((ty * 3 + tx) * 3) * HF_ZP + ry * HF_ZW + rxo[tx];
+#pragma unroll
+                    for (int co = 0; co < 3; ++co) a[i][co] += zp[co * HF_ZP];
+                }
+            }
+#pragma unroll
+            for (int co = 0; co < 3; ++co) TSII_PIN_F2(a[i][co]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                if (co >= cout) break;
+                float v = a[i][co] / dn[i] + bv[co];
+                if (kp[i] == 0.f) v = 0.f;
+                y[(pix0 + (int64_t)i * w) * cout + co] = v;
+            }
+    }
+}
+
 }  // namespace tsii
 
 using namespace tsii;
@@ -295,4 +522,33 @@ extern "C" int tsii_head_cat_bwd_dw_low(const float* dy, const float* inv, const
     if (rc) return rc;
     if (dbias != nullptr) rc = launch_colsum_scaled(dy, keep, (int64_t)n * h * wd, cout, dbias, part + (size_t)blocks * len, st);
     return rc;
+}
+
+extern "C" int tsii_head_cat_fwd_low_ok(int n, int h, int wd, int c1, int c2, int cout) {
+    return tsii_head_cat_low_ok(n, h, wd, c1, c2, cout) && c2 == 3 ? 1 : 0;
+}
+
+extern "C" int tsii_head_cat_fwd_low(const float* low, const float* skip, int c1, int c2, const float* r0_low, const float* r1,
+                                     const float* w, const float* bias, const float* denom, const float* keep,
+                                     int n, int h, int wd, int cout, float* y, void* stream) {
+    TSII_REQUIRE(low && skip && w && y, "head_cat_fwd_low: null pointer");
+    TSII_REQUIRE(aligned16(low), "head_cat_fwd_low: low must be 16-byte aligned");
+    TSII_REQUIRE(tsii_head_cat_fwd_low_ok(n, h, wd, c1, c2, cout), "head_cat_fwd_low: geometry has no matrix-core head (tsii_head_cat_fwd_low_ok)");
+    hipStream_t st = (hipStream_t)stream;
+    int tpb = 0;
+    const int blocks = hm_blocks(n, h, wd, &tpb);
+#define TSII_HF_LAUNCH(NB, R0, R1) \
+    hipLaunchKernelGGL((head_cat_fwd_mfma_kernel<NB, R0, R1>), dim3(blocks), dim3(256), 0, st, low, skip, r0_low, r1, w, bias, denom, keep, n, h, wd, cout, tpb, y)
+#define TSII_HF_MASKS(NB)                                           \
+    do {                                                            \
+        if (r0_low != nullptr && r1 != nullptr) TSII_HF_LAUNCH(NB, true, true);   \
+        else if (r0_low != nullptr) TSII_HF_LAUNCH(NB, true, false);              \
+        else if (r1 != nullptr) TSII_HF_LAUNCH(NB, false, true);                  \
+        else TSII_HF_LAUNCH(NB, false, false);                                    \
+    } while (0)
+    if (c1 == 32) TSII_HF_MASKS(2);
+    else TSII_HF_MASKS(4);
+#undef TSII_HF_MASKS
+#undef TSII_HF_LAUNCH
+    return check_launch("head_cat_fwd_mfma");
 }

@@ -790,10 +790,14 @@ class _HeadCat(torch.autograd.Function):
         n, h, wd, c2 = skip.shape
         c1, cout = low.shape[3], w.shape[0]
         y = torch.empty((n, h, wd, cout), dtype=torch.float32, device=low.device)
-        nbytes = _lib.lib().tsii_dense_ws_bytes(c1 + c2, cout, 3, 3)
-        ws = _ws(nbytes, low)
-        call("tsii_head_cat_fwd", ptr(low), ptr(skip), c1, c2, ptr(r0), ptr(r1), ptr(w), ptr(bias), ptr(denom), ptr(keep),
-             n, h, wd, cout, ptr(y), ptr(ws), nbytes, _lib.stream())
+        if USE_HEAD_MFMA and (r0_low is not None or r0 is None) and _lib.lib().tsii_head_cat_fwd_low_ok(n, h, wd, c1, c2, cout):
+            call("tsii_head_cat_fwd_low", ptr(low), ptr(skip), c1, c2, ptr(r0_low), ptr(r1), ptr(w), ptr(bias), ptr(denom), ptr(keep),
+                 n, h, wd, cout, ptr(y), _lib.stream())
+        else:
+            nbytes = _lib.lib().tsii_dense_ws_bytes(c1 + c2, cout, 3, 3)
+            ws = _ws(nbytes, low)
+            call("tsii_head_cat_fwd", ptr(low), ptr(skip), c1, c2, ptr(r0), ptr(r1), ptr(w), ptr(bias), ptr(denom), ptr(keep),
+                 n, h, wd, cout, ptr(y), ptr(ws), nbytes, _lib.stream())
         ctx.save_for_backward(low, skip, w, r0, r1, inv, keep)
         ctx.has_bias = bias is not None
         return y

@@ -29,6 +29,17 @@ def main():
         return e0.elapsed_time(e1) / reps
     new = lambda: ops.call("tsii_head_cat_bwd_dw_low", ptr(dy), ptr(inv), None, ptr(low), ptr(skip), c1, c2, ptr(r0l), None, n, h, w, cout, ptr(dw), None, ptr(ws), nb, st)
     old = lambda: ops.call("tsii_head_cat_bwd_dw", ptr(dy), ptr(inv), None, ptr(low), ptr(skip), c1, c2, ptr(r0), None, n, h, w, cout, ptr(dw), None, ptr(ws), nb, st)
+    wt = torch.randn((cout, c1 + c2, 3, 3), device=dev, generator=g) * 0.1
+    bias = torch.randn(cout, device=dev, generator=g)
+    denom = torch.rand((n, h, w), device=dev, generator=g) + 0.5
+    keep = (torch.rand((n, h, w), device=dev, generator=g) > 0.05).float()
+    yo = torch.empty((n, h, w, cout), device=dev)
+    nf = L.tsii_dense_ws_bytes(c1 + c2, cout, 3, 3)
+    wsf = torch.empty(nf // 4 + 64, device=dev)
+    fnew = lambda: ops.call("tsii_head_cat_fwd_low", ptr(low), ptr(skip), c1, c2, ptr(r0l), None, ptr(wt), ptr(bias), ptr(denom), ptr(keep), n, h, w, cout, ptr(yo), st)
+    fold = lambda: ops.call("tsii_head_cat_fwd", ptr(low), ptr(skip), c1, c2, ptr(r0), None, ptr(wt), ptr(bias), ptr(denom), ptr(keep), n, h, w, cout, ptr(yo), ptr(wsf), nf, st)
+    fnew(); ya = yo.clone(); fold(); yb = yo.clone()
+    print(f"lib={os.environ.get('TSII_LIBRARY', 'default')}  forward matrix-core {timed(fnew):.3f} ms   vector-ALU {timed(fold):.3f} ms   max rel diff {float((ya - yb).abs().max() / yb.abs().max()):.2e}")
     new(); a = dw.clone(); old(); b = dw.clone()
     print(f"lib={os.environ.get('TSII_LIBRARY', 'default')}  dW matrix-core {timed(new):.3f} ms   vector-ALU {timed(old):.3f} ms   (no dbias; incl. the partial-row reduction)   max rel diff {float((a - b).abs().max() / b.abs().max()):.2e}")
 
