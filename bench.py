@@ -85,6 +85,7 @@ CALLS = {
     "tsii_dw_bwd_dw": ("dw_stencil", lambda a: _dw(a, (1, 1))), "tsii_dw_bwd_dw_bn": ("dw_stencil", lambda a: _dw(a, (1, 1))),
     "tsii_bn_act_fwd": ("bn_act", lambda a: _bn(a, 2)), "tsii_bn_stats": ("bn_act", lambda a: _bn(a, 1)),
     "tsii_bn_act_bwd": ("bn_bwd", lambda a: _bn(a, 3)), "tsii_bn_act_bwd_pre": ("bn_bwd", lambda a: _bn(a, 3)),
+    "tsii_bn_act_bwd_pre_pool": ("bn_bwd", lambda a: _bn(a, 3.25)),       # + the pooled addend gradient [m/4, c] (K7b)
     "tsii_act_fwd": ("bn_act", lambda a: (8.0 * a[0], 0.0)), "tsii_act_bwd": ("bn_act", lambda a: (12.0 * a[0], 0.0)),
     "tsii_dense_fwd": ("dense_conv", lambda a: _dense(a[1:], 1, 0, 0, 1)), "tsii_dense_fwd_bn": ("dense_conv", lambda a: _dense(a[1:], 1, 0, 0, 1)),
     "tsii_dense_bwd_dx": ("dense_conv", lambda a: _dense(a[1:], 0, 1, 1, 0)),
@@ -92,6 +93,7 @@ CALLS = {
     # K4c head over the virtual concatenation: (c1, c2, n, h, w, cout, ...): low [n,h/2,w/2,c1] + skip [n,h,w,c2] <-> y [n,h,w,cout]
     "tsii_head_cat_fwd": ("dense_conv", lambda a: _headcat(a, 1, 1)), "tsii_head_cat_bwd_dx": ("dense_conv", lambda a: _headcat(a, 1, 1)),
     "tsii_head_cat_bwd_dw": ("dense_conv", lambda a: _headcat(a, 1, 1)),
+    "tsii_head_cat_fwd_low": ("dense_conv", lambda a: _headcat(a, 1, 1)), "tsii_head_cat_bwd_dw_low": ("dense_conv", lambda a: _headcat(a, 1, 1)),
     "tsii_upcat_fwd": ("upcat", lambda a: _upcat(a, False)), "tsii_upcat_bwd": ("upcat", lambda a: _upcat(a, True)),
     # K7b: the high-resolution half of a 1x1 conv over cat(up2(low), skip): (m, k, n, ..): reads [m,k] and the [m/4,n] addend, writes [m,n]
     "tsii_pw_fwd_up": ("gemm_nt", lambda a: (4.0 * a[0] * (a[1] + a[2]) + 1.0 * a[0] * a[2], float(a[0]) * a[1] * a[2])),

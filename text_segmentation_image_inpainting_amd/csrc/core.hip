@@ -64,7 +64,47 @@ __global__ __launch_bounds__(64 * RR_LANES) void reduce_rows_kernel(const float*
     }
 }
 
+// wide rows (the [splits][P x Q] slabs of the split-K weight-gradient GEMMs: up to 64 x 1 MB, read at 2.5 TB/s by the kernel
+// above): four columns per thread, 16-byte loads
+__global__ __launch_bounds__(64 * RR_LANES) void reduce_rows_vec4_kernel(const float* __restrict__ ws, int rows, int64_t len4, float* __restrict__ out) {
+    __shared__ double sh[RR_LANES][64][4];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const f32x4* __restrict__ w4 = reinterpret_cast<const f32x4*>(ws);
+    for (int64_t j0 = (int64_t)blockIdx.x * 64; j0 < len4; j0 += (int64_t)gridDim.x * 64) {
+        const int64_t j = j0 + tx;
+        double a[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+        if (j < len4) {
+            for (int r = ty; r < rows; r += 4 * RR_LANES) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int rr = r + RR_LANES * u;
+                    v[u] = rr < rows ? w4[(int64_t)rr * len4 + j] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[u & 1][e] += (double)v[u][e];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sh[ty][tx][e] = a[0][e] + a[1][e];
+        __syncthreads();
+        if (ty < 4 && j < len4) {                 // lane e of the first four adds up component e
+            double t = 0.0;
+#pragma unroll
+            for (int l = 0; l < RR_LANES; ++l) t += sh[l][tx][ty];
+            out[j * 4 + ty] = (float)t;
+        }
+    }
+}
+
 int launch_reduce_rows(const float* ws, int rows, int64_t len, float* out, hipStream_t stream) {
+    if (len >= 4096 && len % 4 == 0 && aligned16(ws) && rows >= 8) {
+        hipLaunchKernelGGL(reduce_rows_vec4_kernel, dim3(stream_grid(cdiv64(len / 4, 64) * 256, 256)), dim3(64 * RR_LANES), 0, stream, ws, rows, len / 4, out);
+        return check_launch("reduce_rows_vec4");
+    }
     hipLaunchKernelGGL(reduce_rows_kernel, dim3(stream_grid(cdiv64(len, 64) * 256, 256)), dim3(64 * RR_LANES), 0, stream, ws, rows, len, out, 0, 0);
     return check_launch("reduce_rows");
 }

@@ -261,14 +261,17 @@ static constexpr int ST_R = 8, ST_TW = 16, ST_CB = 32;
 #ifndef ST_UNROLL
 #define ST_UNROLL 2
 #endif
-static constexpr int ST_UNROLL_K = ST_UNROLL;   // pixels of a thread processed together (all 4: ~150 VGPRs of LDS data in flight)
+static constexpr int ST_UNROLL_K = ST_UNROLL;
+#ifndef ST_S2_WAVES
+#define ST_S2_WAVES 2     // A/B build knob: waves per SIMD asked of the register allocator for the fused stride-2 forms
+#endif   // pixels of a thread processed together (all 4: ~150 VGPRs of LDS data in flight)
 
 // MODE 0: plain; 1: forward with BatchNorm on load and / or statistics partials (K6b; either may be off at run time);
 // 2: dX feeding a BatchNorm backward (K6c).  MODE 1 / 2 need ~210 VGPRs = 2 waves per SIMD.  (Tried for MODE 1: a build capped
 // at 3 waves per SIMD with the 9 x 4 weights read from LDS per tap and one pixel in flight -- 18-20 spilled registers and
 // 17.2 -> 20.4 ms over the depth-wise kernels of a step: the plain-register form stays.)
 template <int S, int D, int MODE>
-__global__ __launch_bounds__(256, MODE != 0 ? 2 : 3) void dw_strip_kernel(
+__global__ __launch_bounds__(256, MODE != 0 ? (S == 2 ? ST_S2_WAVES : 2) : 3) void dw_strip_kernel(
     const float* __restrict__ in, const float* __restrict__ pre, const float* __restrict__ wT, const float* __restrict__ bias,
     const float* __restrict__ denom, const float* __restrict__ keep, const float* __restrict__ post_mul, DtGeom g, int chunk_rows,
     unsigned strips_x, unsigned chunks_y, unsigned cblocks, DwBN ib, float* __restrict__ stats, DwBnBwd bb,

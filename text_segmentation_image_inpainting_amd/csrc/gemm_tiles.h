@@ -2,6 +2,10 @@
 #pragma once
 #include "tsii_common.h"
 
+#ifndef NT_EPI_NT_STORE
+#define NT_EPI_NT_STORE 0     // A/B build knob: non-temporal stores of the output tile (shared LDS-staged epilogue)
+#endif
+
 namespace tsii {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -437,7 +441,8 @@ __device__ __forceinline__ void nt_epilogue(float* __restrict__ smem, f32x16 (&a
             }
             float* cp = C + row * ldc + col;
             if (ep.vec_store && col + 3 < N) {
-                *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                if (NT_EPI_NT_STORE) __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(cp));
+                else *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
