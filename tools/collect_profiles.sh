@@ -23,8 +23,8 @@ timeout 600 python bench.py --model XceptionTextSegment --size 1024 --batch 8 --
 timeout 600 python bench.py --model XceptionTextSegment --size 1024 --batch 8 --steps 8 --warmup 2 --no-f32-leg 2>&1 | tail -1 > gpurun_out/${TAG}_bench_cfg5_xception1024_fp32class.log
 timeout 300 python tools/microbench.py > gpurun_out/${TAG}_microbench.log 2>&1
 # evidence lines: the two Origin nets, the Bernoulli-mask stress variant, the step with the reference's full InpaintingLoss
-timeout 600 python bench.py --model ImageFillOrigin --batch 16 --steps 8 --warmup 2 --no-f32-leg --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${TAG}_bench_imagefillorigin_bs16.log
-timeout 600 python bench.py --model ImageFillOriginV2 --batch 16 --steps 8 --warmup 2 --no-f32-leg --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${TAG}_bench_imagefilloriginv2_bs16.log
+timeout 600 python bench.py --model ImageFillOrigin --batch 16 --steps 12 --warmup 4 --no-f32-leg --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${TAG}_bench_imagefillorigin_bs16.log
+timeout 600 python bench.py --model ImageFillOriginV2 --batch 16 --steps 12 --warmup 4 --no-f32-leg --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${TAG}_bench_imagefilloriginv2_bs16.log
 timeout 600 python bench.py --bernoulli-masks --steps 10 --warmup 3 --no-f32-leg --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${TAG}_bench_bernoulli_masks.log
 timeout 600 python tools/full_loss_step.py --batch 32 --size 512 --steps 5 2>&1 | tail -1 > gpurun_out/${TAG}_full_loss_step.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${TAG}_smoke.log 2>&1; tail -1 gpurun_out/${TAG}_smoke.log
