@@ -542,6 +542,68 @@ def _strip_entry_points(L, n, h, wd, c, masked, bias, act):
     assert np.all(np.abs(bp[1] - (dz * xh).reshape(-1, c).sum(0)) <= slack * max(1.0, np.abs(xh).max()))
 
 
+@pytest.mark.parametrize("n,h,wd,c,masked,bias,act", [
+    (2, 21, 37, 40, True, True, 2),      # odd sizes: row / column / channel tails
+    (1, 16, 32, 32, True, False, 3),     # two steps, two strips exactly, ReLU6
+    (1, 5, 7, 4, False, True, 0),        # smaller than a step and a strip, no mask planes
+    (2, 70, 34, 36, True, True, 1),      # many steps (both LDS buffers in turn), strip tail of one column, channel tail
+    (1, 64, 64, 8, False, False, 2),     # whole tiles, no planes
+])
+@pytest.mark.parametrize("target", [1536, 1])
+def test_depthwise_stride2_forward_strip(emu, n, h, wd, c, masked, bias, act, target):
+    """The stride-2 forward strip (dw_lean_s2.h: 3x3, stride 2, pad 1) through tsii_dw_fwd / tsii_dw_fwd_bn: plain forward,
+    BatchNorm + activation on load with the statistics partials, statistics alone (bit-identical output); chunks of one and of
+    several marching steps (target, see test_depthwise_strip_entry_points)."""
+    L = emu
+    L.tsii_emu_set_strip_target(target)
+    try:
+        rng = np.random.default_rng(h * 100 + wd + 7)
+        slope = 0.3
+        ho, wo = (h - 1) // 2 + 1, (wd - 1) // 2 + 1
+        x = rng.standard_normal((n, h, wd, c)).astype(np.float32) + 0.5
+        w = rng.standard_normal((c, 1, 3, 3)).astype(np.float32)
+        b = rng.standard_normal(c).astype(np.float32) if bias else None
+        rmask = (rng.uniform(size=(n, h, wd)) > 0.25).astype(np.float32) if masked else None
+        keep = denom = None
+        if masked:
+            pm = np.zeros((n, h + 2, wd + 2)); pm[:, 1:-1, 1:-1] = rmask
+            cnt = sum(pm[:, ky:ky + 2 * (ho - 1) + 1:2, kx:kx + 2 * (wo - 1) + 1:2] for ky in range(3) for kx in range(3))
+            keep = (cnt > 0).astype(np.float32)
+            denom = (np.where(cnt > 0, cnt, 1.0) * c).astype(np.float32)
+        geom = (3, 3, 2, 2, 1, 1, 1, 1)
+        ws = WS(4 * (9 * c + 16))
+        before = L.hipemu_launches(256)
+        y = np.full((n, ho, wo, c), np.nan, np.float32)
+        assert L.tsii_dw_fwd(P(x), P(rmask), P(w), P(b), P(denom), P(keep), n, h, wd, c, *geom, ho, wo, P(y), P(ws), None) == 0, L.tsii_last_error()
+        yr = _dw_ref_fwd(x, rmask, w, b, denom, keep, 2, 1, 1)
+        assert np.abs(y - yr).max() <= 2e-6 * max(1.0, np.abs(yr).max())
+        sc = (rng.uniform(size=c) + 0.5).astype(np.float32); sh = rng.standard_normal(c).astype(np.float32)
+        rows = L.tsii_dw_stat_rows(n, ho, wo, c, 3, 3, 2, 2, 1, 1)
+        assert rows > 0
+        part = WS(4 * rows * 4 * c)
+        y2 = np.full((n, ho, wo, c), np.nan, np.float32)
+        assert L.tsii_dw_fwd_bn(P(x), P(rmask), P(w), P(b), P(denom), P(keep), n, h, wd, c, *geom, ho, wo, P(sc), P(sh), act, slope,
+                                P(part), P(y2), P(ws), None) == 0, L.tsii_last_error()
+        xa = _act(x.astype(np.float64) * sc + sh, act, slope)
+        y2r = _dw_ref_fwd(xa, rmask, w, b, denom, keep, 2, 1, 1)
+        assert np.abs(y2 - y2r).max() <= 2e-6 * max(1.0, np.abs(y2r).max())
+        pr = part[:rows * 4 * c].reshape(rows, 4, c).astype(np.float64)
+        cnts, piv, s1, s2 = pr[:, 0], pr[:, 1], pr[:, 2], pr[:, 3]
+        m_tot = n * ho * wo
+        assert np.all(cnts.sum(0) == m_tot)
+        mean = (cnts * piv + s1).sum(0) / m_tot
+        ex2 = (s2 + 2 * piv * s1 + cnts * piv * piv).sum(0) / m_tot
+        y2d = y2.astype(np.float64).reshape(-1, c)
+        assert np.abs(mean - y2d.mean(0)).max() <= 1e-5 * max(1.0, np.abs(y2d).max())
+        assert np.abs(ex2 - (y2d ** 2).mean(0)).max() <= 1e-5 * max(1.0, (y2d ** 2).max())
+        y3 = np.full((n, ho, wo, c), np.nan, np.float32)
+        assert L.tsii_dw_fwd_bn(P(x), P(rmask), P(w), P(b), P(denom), P(keep), n, h, wd, c, *geom, ho, wo, None, None, 0, 0.0,
+                                P(part), P(y3), P(ws), None) == 0, L.tsii_last_error()
+        assert np.array_equal(y3, y)
+    finally:
+        L.tsii_emu_set_strip_target(0)
+
+
 # ---- 1x1 convolution over cat(nearest-x2(low), skip) with the low half computed at low resolution (K7b) -------------------------
 @pytest.mark.parametrize("n,h,wd,k,N,stats", [(2, 8, 16, 40, 128, True),      # producer / consumer kernel (256-row tiles)
                                               (1, 16, 32, 64, 256, False),     # producer / consumer kernel, 128 x 256 tiles

@@ -727,6 +727,7 @@ __global__ __launch_bounds__(256, 3) void dw_strip_dx2_kernel(const float* __res
 
 }  // namespace tsii
 #include "dw_lean.h"
+#include "dw_lean_s2.h"
 namespace tsii {
 
 struct StripPlan {
@@ -796,6 +797,17 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
         else TSII_DW_LEAN(0, false);
 #undef TSII_DW_LEAN
         return check_launch("dw_lean");
+    }
+    if (dw_lean_s2_ok(g) && post_mul == nullptr && bb.y == nullptr) {
+#define TSII_DW_LEAN_S2(MODE) do { \
+            if (pre != nullptr) hipLaunchKernelGGL((dw_lean_s2_kernel<MODE, true>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, g, \
+                                                   sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, out); \
+            else hipLaunchKernelGGL((dw_lean_s2_kernel<MODE, false>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, g, \
+                                    sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, out); } while (0)
+        if (fused) TSII_DW_LEAN_S2(1);
+        else TSII_DW_LEAN_S2(0);
+#undef TSII_DW_LEAN_S2
+        return check_launch("dw_lean_s2");
     }
 #define TSII_DW_STRIP(S, D, MODE) hipLaunchKernelGGL((dw_strip_kernel<S, D, MODE>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, \
                                                      sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out)
