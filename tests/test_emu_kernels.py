@@ -604,6 +604,88 @@ def test_depthwise_stride2_forward_strip(emu, n, h, wd, c, masked, bias, act, ta
         L.tsii_emu_set_strip_target(0)
 
 
+@pytest.mark.parametrize("n,h,wd,c,d,masked,bias,act", [
+    (2, 32, 32, 40, 8, True, True, 2),     # ImageFill's dilated level geometry; channel tail (40 = 2 x 16 + 8); 2 partial rows per image
+    (1, 32, 32, 16, 8, True, False, 3),    # ReLU6 clamp
+    (3, 9, 13, 20, 8, False, True, 0),     # odd map smaller than the dilation's reach, no planes
+    (1, 20, 40, 8, 17, True, True, 1),     # dilation larger than the map's height: whole tap rows fall outside
+])
+def test_depthwise_small_map_dilated(emu, n, h, wd, c, d, masked, bias, act):
+    """Dilated 3x3 depth-wise stencils on small maps (dw_small.h: the whole map of a 16-channel block in LDS): forward, forward
+    with BatchNorm on load + statistics partials (rows laid out as the strip plan's, the extra rows empty), dX, dX with the
+    BatchNorm-backward reductions."""
+    L = emu
+    rng = np.random.default_rng(h * 100 + wd + d)
+    slope = 0.3
+    x = rng.standard_normal((n, h, wd, c)).astype(np.float32) + 0.5
+    w = rng.standard_normal((c, 1, 3, 3)).astype(np.float32)
+    b = rng.standard_normal(c).astype(np.float32) if bias else None
+    rmask = (rng.uniform(size=(n, h, wd)) > 0.2).astype(np.float32) if masked else None
+    keep = denom = None
+    if masked:
+        pm = np.zeros((n, h + 2 * d, wd + 2 * d)); pm[:, d:-d, d:-d] = rmask
+        cnt = sum(pm[:, ky * d:ky * d + h, kx * d:kx * d + wd] for ky in range(3) for kx in range(3))
+        keep = (cnt > 0).astype(np.float32)
+        denom = (np.where(cnt > 0, cnt, 1.0) * c).astype(np.float32)
+    geom = (3, 3, 1, 1, d, d, d, d)
+    ws = WS(4 * (9 * c + 16))
+    y = np.full((n, h, wd, c), np.nan, np.float32)
+    assert L.tsii_dw_fwd(P(x), P(rmask), P(w), P(b), P(denom), P(keep), n, h, wd, c, *geom, h, wd, P(y), P(ws), None) == 0, L.tsii_last_error()
+    yr = _dw_ref_fwd(x, rmask, w, b, denom, keep, 1, d, d)
+    assert np.abs(y - yr).max() <= 2e-6 * max(1.0, np.abs(yr).max())
+    sc = (rng.uniform(size=c) + 0.5).astype(np.float32); sh = rng.standard_normal(c).astype(np.float32)
+    rows = L.tsii_dw_stat_rows(n, h, wd, c, 3, 3, 1, 1, d, d)
+    if rows > 0:
+        part = WS(4 * rows * 4 * c)
+        part[:] = np.nan
+        y2 = np.full((n, h, wd, c), np.nan, np.float32)
+        assert L.tsii_dw_fwd_bn(P(x), P(rmask), P(w), P(b), P(denom), P(keep), n, h, wd, c, *geom, h, wd, P(sc), P(sh), act, slope,
+                                P(part), P(y2), P(ws), None) == 0, L.tsii_last_error()
+        xa = _act(x.astype(np.float64) * sc + sh, act, slope)
+        y2r = _dw_ref_fwd(xa, rmask, w, b, denom, keep, 1, d, d)
+        assert np.abs(y2 - y2r).max() <= 2e-6 * max(1.0, np.abs(y2r).max())
+        pr = part[:rows * 4 * c].reshape(rows, 4, c).astype(np.float64)
+        cnts = pr[:, 0]
+        assert np.isfinite(cnts).all() and np.all(cnts.sum(0) == n * h * wd)
+        live = cnts > 0
+        piv, s1, s2 = np.where(live, pr[:, 1], 0.0), np.where(live, pr[:, 2], 0.0), np.where(live, pr[:, 3], 0.0)
+        m_tot = n * h * wd
+        mean = (cnts * piv + s1).sum(0) / m_tot
+        ex2 = (s2 + 2 * piv * s1 + cnts * piv * piv).sum(0) / m_tot
+        y2d = y2.astype(np.float64).reshape(-1, c)
+        assert np.abs(mean - y2d.mean(0)).max() <= 1e-5 * max(1.0, np.abs(y2d).max())
+        assert np.abs(ex2 - (y2d ** 2).mean(0)).max() <= 1e-5 * max(1.0, (y2d ** 2).max())
+    dy = rng.standard_normal((n, h, wd, c)).astype(np.float32)
+    inv = (keep / denom).astype(np.float32) if masked else None
+    dx = np.full((n, h, wd, c), np.nan, np.float32)
+    assert L.tsii_dw_bwd_dx(P(dy), P(inv), P(w), P(rmask), n, h, wd, c, *geom, h, wd, P(dx), P(ws), None) == 0, L.tsii_last_error()
+    dxr = _dw_ref_fwd(dy, inv, w[:, :, ::-1, ::-1], None, None, None, 1, d, d)
+    if masked:
+        dxr = dxr * rmask.astype(np.float64)[..., None]
+    assert np.abs(dx - dxr).max() <= 2e-6 * max(1.0, np.abs(dxr).max())
+    brows = L.tsii_dw_bwd_stat_rows(n, h, wd, c, *geom)
+    if brows > 0:
+        bpart = WS(4 * brows * 2 * c)
+        bpart[:] = np.nan
+        mean_b = rng.standard_normal(c).astype(np.float32); var_b = (rng.uniform(size=c) + 0.5).astype(np.float32)
+        gam = (rng.uniform(size=c) + 0.5).astype(np.float32); bet = rng.standard_normal(c).astype(np.float32)
+        dx2 = np.full((n, h, wd, c), np.nan, np.float32)
+        assert L.tsii_dw_bwd_dx_bn(P(dy), P(inv), P(w), P(rmask), n, h, wd, c, *geom, h, wd, P(x), P(mean_b), P(var_b), P(gam), P(bet),
+                                   1e-5, act, slope, P(dx2), P(bpart), P(ws), None) == 0, L.tsii_last_error()
+        assert np.array_equal(dx2, dx)
+        xh = (x.astype(np.float64) - mean_b) / np.sqrt(var_b.astype(np.float64) + 1e-5)
+        z = xh * gam + bet
+        g1 = {0: np.ones_like(z), 1: (z > 0) * 1.0, 2: np.where(z > 0, 1.0, slope), 3: ((z > 0) & (z < 6)) * 1.0}[act]
+        dz = dx.astype(np.float64) * g1
+        bp = bpart[:brows * 2 * c].reshape(brows, 2, c).astype(np.float64)
+        assert np.isfinite(bp).all()
+        bp = bp.sum(0)
+        near = (np.abs(z) < 1e-5) | (np.abs(z - 6) < 1e-5)
+        slack = (np.abs(dx) * near).reshape(-1, c).sum(0) * 2 + 1e-4 * np.abs(dz).reshape(-1, c).sum(0).max()
+        assert np.all(np.abs(bp[0] - dz.reshape(-1, c).sum(0)) <= slack)
+        assert np.all(np.abs(bp[1] - (dz * xh).reshape(-1, c).sum(0)) <= slack * max(1.0, np.abs(xh).max()))
+
+
 # ---- 1x1 convolution over cat(nearest-x2(low), skip) with the low half computed at low resolution (K7b) -------------------------
 @pytest.mark.parametrize("n,h,wd,k,N,stats", [(2, 8, 16, 40, 128, True),      # producer / consumer kernel (256-row tiles)
                                               (1, 16, 32, 64, 256, False),     # producer / consumer kernel, 128 x 256 tiles

@@ -728,6 +728,7 @@ __global__ __launch_bounds__(256, 3) void dw_strip_dx2_kernel(const float* __res
 }  // namespace tsii
 #include "dw_lean.h"
 #include "dw_lean_s2.h"
+#include "dw_small.h"
 namespace tsii {
 
 struct StripPlan {
@@ -774,6 +775,25 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
     if (g.c % 4 != 0 || !aligned16(in) || !aligned16(out) || !aligned16(wT)) return 1;
     if (ib.sc != nullptr && (!aligned16(ib.sc) || !aligned16(ib.sh))) return 1;
     const StripPlan sp = plan_strip(g.n, g.hout, g.wout, g.c, g.s, g.d);
+    const bool fused_any = ib.sc != nullptr || stats != nullptr || bb.y != nullptr;
+    // small maps: the whole map of a channel block in LDS (any dilation; the fused forms where the strip plan defines the partial rows)
+    if (dw_small_ok(g) && !(post_mul != nullptr && (denom != nullptr || keep != nullptr || bias != nullptr)) && (!fused_any || (sp.ok && dw_fused_ok(g.s, g.d))) &&
+        !(fused_any && bb.y == nullptr && post_mul != nullptr)) {
+        const bool dxe = denom == nullptr && keep == nullptr && bias == nullptr;
+        if (bb.y == nullptr || dxe) {
+            const unsigned scb = (unsigned)cdiv(g.c, SM_CB), rpi = sp.ok ? sp.chunks_y * sp.strips_x : 1u;
+            const dim3 sgrid((unsigned)g.n * scb);
+#define TSII_DW_SMALL(MODE, DXE) do { \
+            if (pre != nullptr) hipLaunchKernelGGL((dw_small_kernel<MODE, DXE, true>), sgrid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, scb, rpi, ib, stats, bb, out); \
+            else hipLaunchKernelGGL((dw_small_kernel<MODE, DXE, false>), sgrid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, scb, rpi, ib, stats, bb, out); } while (0)
+            if (bb.y != nullptr) TSII_DW_SMALL(2, true);
+            else if (fused_any) TSII_DW_SMALL(1, false);
+            else if (dxe) TSII_DW_SMALL(0, true);
+            else TSII_DW_SMALL(0, false);
+#undef TSII_DW_SMALL
+            return check_launch("dw_small");
+        }
+    }
     if (!sp.ok) return 1;
     const int64_t nblk = (int64_t)sp.strips_x * sp.chunks_y * sp.cblocks * g.n;
     const dim3 grid((unsigned)nblk);
