@@ -19,11 +19,16 @@ namespace tsii {
 
 static constexpr int SM_CB = 16;                 // channels per block
 static constexpr int SM_MAXPIX = 1024;           // pixels of a map
-static constexpr int SM_NP = SM_MAXPIX / 64;     // outputs per thread
+static constexpr int SM_THREADS = 512;           // 8 waves per block: two blocks (64 KB of LDS each) give a CU 16 waves
+static constexpr int SM_LANES = SM_THREADS / 4;  // pixel lanes (4 channel quads per pixel)
+static constexpr int SM_NP = SM_MAXPIX / SM_LANES;   // outputs per thread
 
 #ifndef SM_MIN_DIL
 #define SM_MIN_DIL 8             // smallest dilation sent here: measured on the chip (32 x 32 x 1024, fused forward) 0.131 ms per layer at any
 #endif                           // dilation against 0.107 / 0.111 / 0.203 ms of the strips at dilation 2 / 4 / 8
+#ifndef SM_ABL
+#define SM_ABL 0                 // ablation builds: 1 = no output stores, 2 = no slab loads, 4 = no taps
+#endif
 #ifndef SM_ENABLE
 #define SM_ENABLE 1              // A/B: 0 sends small maps back to the strip kernels
 #endif
@@ -33,14 +38,14 @@ static inline bool dw_small_ok(const DtGeom& g) {
 }
 
 template <int MODE, bool DXE, bool PRE>
-__global__ __launch_bounds__(256, 2) void dw_small_kernel(
+__global__ __launch_bounds__(SM_THREADS, 2) void dw_small_kernel(
     const float* __restrict__ in, const float* __restrict__ pre, const float* __restrict__ wT, const float* __restrict__ bias,
     const float* __restrict__ denom, const float* __restrict__ keep, const float* __restrict__ post_mul, DtGeom g,
     unsigned cblocks, unsigned rows_per_image, DwBN ib, float* __restrict__ stats, DwBnBwd bb, float* __restrict__ out) {
     constexpr bool FUSED = (MODE == 1), BNB = (MODE == 2);
     static_assert(!BNB || DXE, "K6c rides on the dX epilogue");
     static_assert(!FUSED || !DXE, "K6b rides on the forward epilogue");
-    __shared__ __attribute__((aligned(16))) float tile[SM_MAXPIX * SM_CB];      // [pixel][16 channels]
+    __shared__ __attribute__((aligned(16))) float tile[(SM_MAXPIX + 1) * SM_CB];      // [pixel][16 channels] + one pixel of zeros: what a tap outside the map reads
     const unsigned b = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned cb = b % cblocks;
     const int64_t n = b / cblocks;
@@ -59,9 +64,9 @@ __global__ __launch_bounds__(256, 2) void dw_small_kernel(
     float pm[SM_NP];
 #pragma unroll
     for (int j = 0; j < SM_NP; ++j) {
-        const int p = lane + 64 * j;
+        const int p = lane + SM_LANES * j;
         const unsigned pc = (unsigned)(p < HW ? p : HW - 1);
-        pf[j] = *reinterpret_cast<const f32x4*>(ibase + opq(__umul24(pc * 4u, (unsigned)C) + c0b));
+        pf[j] = (SM_ABL & 2) ? f32x4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(ibase + opq(__umul24(pc * 4u, (unsigned)C) + c0b));
         pm[j] = PRE ? pbase[pc] : 1.f;
     }
     f32x4 w[9];
@@ -92,11 +97,12 @@ __global__ __launch_bounds__(256, 2) void dw_small_kernel(
             v = cat4(z0, z1);
         }
         v *= pm[j];
-        if (lane + 64 * j < HW) *reinterpret_cast<f32x4*>(lthr + 256 * 16 * j) = v;       // pixel p, quad cq at byte (p * 4 + cq) * 16
+        if (lane + SM_LANES * j < HW) *reinterpret_cast<f32x4*>(lthr + SM_THREADS * 16 * j) = v;       // pixel p, quad cq at byte (p * 4 + cq) * 16
     }
+    if (t < 4) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(tile) + (SM_MAXPIX * 4 + t) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
-    // ---- outputs: pixel p = lane + 64 j; taps outside the map are zeros (selected, never multiplied) ---------------------------
+    // ---- outputs: pixel p = lane + SM_LANES j; taps outside the map are zeros (selected, never multiplied) ---------------------------
     const char* const rthr = reinterpret_cast<const char*>(tile) + cq * 16;
     char* const obase = reinterpret_cast<char*>(out + n * HW * (int64_t)C);
     const char* const ybase = reinterpret_cast<const char*>(BNB ? bb.y + n * HW * (int64_t)C : nullptr);
@@ -109,8 +115,8 @@ __global__ __launch_bounds__(256, 2) void dw_small_kernel(
     const unsigned wmagic = (unsigned)(((1 << 20) + W - 1) / W);    // p / W for p < 1024, W <= 1024: (p * magic) >> 20 is exact
 #pragma unroll 2
     for (int j = 0; j < SM_NP; ++j) {
-        const int p = lane + 64 * j;
-        if (j * 64 >= HW) break;                                  // block-uniform
+        const int p = lane + SM_LANES * j;
+        if (j * SM_LANES >= HW) break;                            // block-uniform
         const bool pok = p < HW && cok;
         const int pc = p < HW ? p : HW - 1;
         const int y = (int)(((unsigned)pc * wmagic) >> 20), x = pc - y * W;
@@ -120,17 +126,21 @@ __global__ __launch_bounds__(256, 2) void dw_small_kernel(
         f32x4 yv = {0.f, 0.f, 0.f, 0.f};
         if (BNB) yv = *reinterpret_cast<const f32x4*>(ybase + opq(__umul24((unsigned)pc * 4u, (unsigned)C) + c0b));
         f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+        // a tap outside the map reads the zero pixel (one select on the index, none on the data)
+        int qrow[3], qcol[3];
+        bool rok[3], cokx[3];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int yy = y + (ky - 1) * D;
-            const bool rok = (unsigned)yy < (unsigned)H;
+        for (int k = 0; k < 3; ++k) {
+            const int yy = y + (k - 1) * D, xx = x + (k - 1) * D;
+            rok[k] = (unsigned)yy < (unsigned)H; cokx[k] = (unsigned)xx < (unsigned)W;
+            qrow[k] = yy * W; qcol[k] = xx;
+        }
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int xx = x + (kx - 1) * D;
-                const bool ok = rok && (unsigned)xx < (unsigned)W;
-                const int q = ok ? yy * W + xx : pc;
-                f32x4 v = *reinterpret_cast<const f32x4*>(rthr + q * (SM_CB * 4));
-                if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < ((SM_ABL & 4) ? 1 : 3); ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < ((SM_ABL & 4) ? 1 : 3); ++kx) {
+                const int q = (rok[ky] && cokx[kx]) ? qrow[ky] + qcol[kx] : SM_MAXPIX;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(rthr + q * (SM_CB * 4));
                 a0 = fma2(v.xy, w[ky * 3 + kx].xy, a0);
                 a1 = fma2(v.zw, w[ky * 3 + kx].zw, a1);
             }
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void dw_small_kernel(
             if (e1 == 0.f) { a0 = f32x2{0.f, 0.f}; a1 = a0; }
         }
         if (pok) {
-            __builtin_nontemporal_store(cat4(a0, a1), reinterpret_cast<f32x4*>(obase + opq(__umul24((unsigned)p * 4u, (unsigned)C) + (unsigned)c0 * 4u)));
+            if (!(SM_ABL & 1) || a0.x == 12345.f) __builtin_nontemporal_store(cat4(a0, a1), reinterpret_cast<f32x4*>(obase + opq(__umul24((unsigned)p * 4u, (unsigned)C) + (unsigned)c0 * 4u)));
             if (FUSED) {
                 if (cnt == 0) P = cat4(a0, a1);
                 const f32x2 d0 = a0 - P.xy, d1 = a1 - P.zw;
@@ -167,9 +177,9 @@ __global__ __launch_bounds__(256, 2) void dw_small_kernel(
         }
     }
     if (!(BNB || (FUSED && stats != nullptr))) return;
-    // ---- merge the 64 pixel lanes of every channel through the (now free) tile ----------------------------------------------------
+    // ---- merge the pixel lanes of every channel through the (now free) tile ----------------------------------------------------
     __syncthreads();
-    float* mrg = tile;                                   // [256][13]
+    float* mrg = tile;                                   // [512][13]
     float* mt = mrg + t * 13;
     mt[0] = (float)cnt;
     mt[1] = P.x; mt[2] = P.y; mt[3] = P.z; mt[4] = P.w;
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void dw_small_kernel(
             const int which = t / SM_CB, ch = t % SM_CB;
             if ((int)cb * SM_CB + ch < C) {
                 float sum = 0.f;
-                for (int l = 0; l < 64; ++l) sum += mrg[(l * 4 + ch / 4) * 13 + 5 + which * 4 + ch % 4];
+                for (int l = 0; l < SM_LANES; ++l) sum += mrg[(l * 4 + ch / 4) * 13 + 5 + which * 4 + ch % 4];
                 bb.part[(n * rows_per_image * 2 + which) * C + (int)cb * SM_CB + ch] = sum;
                 for (unsigned r = 1; r < rows_per_image; ++r) bb.part[((n * rows_per_image + r) * 2 + which) * C + (int)cb * SM_CB + ch] = 0.f;
             }
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void dw_small_kernel(
             const float* qi = mrg + (33 * 4 + mcg) * 13;
             if (qi[0] != 0.f) { pv = qi[1 + mi]; have = true; }
         }
-        for (int l = 0; l < 64; ++l) {
+        for (int l = 0; l < SM_LANES; ++l) {
             const float* q = mrg + (l * 4 + mcg) * 13;
             const float n_t = q[0];
             if (n_t == 0.f) continue;

@@ -784,8 +784,8 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
             const unsigned scb = (unsigned)cdiv(g.c, SM_CB), rpi = sp.ok ? sp.chunks_y * sp.strips_x : 1u;
             const dim3 sgrid((unsigned)g.n * scb);
 #define TSII_DW_SMALL(MODE, DXE) do { \
-            if (pre != nullptr) hipLaunchKernelGGL((dw_small_kernel<MODE, DXE, true>), sgrid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, scb, rpi, ib, stats, bb, out); \
-            else hipLaunchKernelGGL((dw_small_kernel<MODE, DXE, false>), sgrid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, scb, rpi, ib, stats, bb, out); } while (0)
+            if (pre != nullptr) hipLaunchKernelGGL((dw_small_kernel<MODE, DXE, true>), sgrid, dim3(SM_THREADS), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, scb, rpi, ib, stats, bb, out); \
+            else hipLaunchKernelGGL((dw_small_kernel<MODE, DXE, false>), sgrid, dim3(SM_THREADS), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, scb, rpi, ib, stats, bb, out); } while (0)
             if (bb.y != nullptr) TSII_DW_SMALL(2, true);
             else if (fused_any) TSII_DW_SMALL(1, false);
             else if (dxe) TSII_DW_SMALL(0, true);
