@@ -3,6 +3,7 @@
 #include <ucontext.h>
 
 #include <cstdlib>
+#include <deque>
 #include <vector>
 
 namespace hipemu {
@@ -25,8 +26,32 @@ static const std::function<void()>* body = nullptr;
 static unsigned xbuf[16][64][2];
 static unsigned short bbuf[16][64][2][8];
 
+// Counted asynchronous loads (tsii_common.h: async_load16 / async_load4 / async_wait<N>): issued loads land only when a wait
+// retires them, oldest first, exactly as vmcnt counts them on the chip; until then the destination holds a NaN pattern, so a wait
+// count that is too large (a register read before its load is guaranteed to have landed) shows up as NaNs in a parity test
+// instead of passing on a host that completes every load at issue.
+struct PendingLoad {
+    void* dst;
+    const void* src;
+    int bytes;
+};
+static std::vector<std::deque<PendingLoad>> pending;
+
+void async_issue(void* dst, const void* src, int bytes) {
+    std::memset(dst, 0xFF, (size_t)bytes);
+    pending[cur].push_back(PendingLoad{dst, src, bytes});
+}
+void async_retire(int keep) {
+    std::deque<PendingLoad>& q = pending[cur];
+    while ((int)q.size() > keep) {
+        std::memcpy(q.front().dst, q.front().src, (size_t)q.front().bytes);
+        q.pop_front();
+    }
+}
+
 static void entry() {
     (*body)();
+    pending[cur].clear();          // loads still in flight at the end of a thread were never consumed
     fibers[cur].state = DONE;
     swapcontext(&fibers[cur].ctx, &sched_ctx);
 }
@@ -36,7 +61,8 @@ static void yield_to_sched(int st) {
     swapcontext(&fibers[cur].ctx, &sched_ctx);
 }
 
-void syncthreads() { yield_to_sched(WAIT_BLOCK); }
+void syncthreads() { async_retire(0); yield_to_sched(WAIT_BLOCK); }     // __syncthreads() = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier
+void barrier_only() { yield_to_sched(WAIT_BLOCK); }                     // lds_barrier(): loads in flight stay in flight
 static long spins = 0;
 void yield() {
     if (++spins > 200000000L) { std::fprintf(stderr, "hipemu: livelock (spin-wait never satisfied)\n"); std::abort(); }
@@ -189,6 +215,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& fn) {
         size_t old = fibers.size();
         fibers.resize(nthreads);
         for (size_t i = old; i < fibers.size(); ++i) fibers[i].stack = (char*)std::malloc(kStack);
+        pending.resize(fibers.size());
     }
     body = &fn;
     bDim = block;

@@ -56,6 +56,9 @@ namespace hipemu {
 extern dim3 tIdx, bIdx, bDim, gDim;
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void syncthreads();
+void barrier_only();
+void async_issue(void* dst, const void* src, int bytes);
+void async_retire(int keep);
 void yield();            // spin-wait loops (s_sleep): let the other fibers of the block run
 unsigned exchange32(unsigned v, int src_lane_delta_mode, int arg, int width);
 f32x16_emu mfma_32x32x2(float a, float b, f32x16_emu c);
@@ -99,18 +102,19 @@ static inline unsigned long long __builtin_amdgcn_s_memtime() { return 0ull; }
 #ifndef __HIP_MEMORY_SCOPE_WORKGROUP      // (the __hip_atomic_* builtins themselves exist in the host compiler too)
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
 #endif
-// counted asynchronous loads (tsii_common.h): synchronous on the host
+// counted asynchronous loads (tsii_common.h): queued per thread and retired, oldest first, by async_wait<N> (all but the N newest)
+// and by __syncthreads() -- not by lds_barrier(); see emu_runtime.cpp
 #define TSII_ASYNC_LOADS 1
 typedef float f32x4_emu2 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_emu2 __attribute__((ext_vector_type(4)));
 namespace tsii {
-static inline void async_load16(f32x4_emu2& d, const void* p) { std::memcpy(&d, p, 16); }
-static inline void async_load16(u32x4_emu2& d, const void* p) { std::memcpy(&d, p, 16); }
-static inline void async_load4(float& d, const void* p) { std::memcpy(&d, p, 4); }
-static inline void async_load16(f32x4_emu2& d, const void* base, unsigned off) { std::memcpy(&d, (const char*)base + off, 16); }
-static inline void async_load4(float& d, const void* base, unsigned off) { std::memcpy(&d, (const char*)base + off, 4); }
-template <int N, class... T> static inline void async_wait(T&...) {}
-static inline void lds_barrier() { hipemu::syncthreads(); }
+static inline void async_load16(f32x4_emu2& d, const void* p) { hipemu::async_issue(&d, p, 16); }
+static inline void async_load16(u32x4_emu2& d, const void* p) { hipemu::async_issue(&d, p, 16); }
+static inline void async_load4(float& d, const void* p) { hipemu::async_issue(&d, p, 4); }
+static inline void async_load16(f32x4_emu2& d, const void* base, unsigned off) { hipemu::async_issue(&d, (const char*)base + off, 16); }
+static inline void async_load4(float& d, const void* base, unsigned off) { hipemu::async_issue(&d, (const char*)base + off, 4); }
+template <int N, class... T> static inline void async_wait(T&...) { hipemu::async_retire(N); }
+static inline void lds_barrier() { hipemu::barrier_only(); }
 }
 static inline f32x16_emu __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16_emu c, int, int, int) {
     return hipemu::mfma_32x32x2(a, b, c);
