@@ -32,6 +32,31 @@ def test_inpainting_dataset_contract(tmp_path):
     assert float(mask.min()) == 0.0                                                # random_masks always adds holes
 
 
+def test_compact_items_expand_to_the_float_triple_bit_for_bit(tmp_path):
+    """``compact=True`` (uint8 transport, not in the reference): with the same RNG stream the expanded batch equals the float
+    pipeline's (corrupted, mask, clean) exactly -- /255 is the same division, the mask exactly 0 / 1."""
+    import random
+    rng = np.random.default_rng(2)
+    for name in ("a", "b", "c"):
+        clean = rng.integers(0, 255, (96, 128, 3), dtype=np.uint8)
+        diff = np.zeros((96, 128), np.uint8)
+        diff[20:60, 30:90] = rng.integers(0, 255, (40, 60), dtype=np.uint8)
+        _save(clean, str(tmp_path / "clean" / f"{name}.png"))
+        _save(diff, str(tmp_path / "mask" / f"{name}.png"))
+    ds_f = D.ImageInpaintingData(str(tmp_path), image_size=(64, 64), add_random_masks=True)
+    ds_c = D.ImageInpaintingData(str(tmp_path), image_size=(64, 64), add_random_masks=True, compact=True)
+    ds_c.images = list(ds_f.images)
+    for i in range(6):
+        random.seed(100 + i)
+        corrupted, mask, clean_t = ds_f[i % 3]
+        random.seed(100 + i)
+        cu8, vu8 = ds_c[i % 3]
+        assert cu8.dtype == vu8.dtype == torch.uint8 and cu8.shape == (3, 64, 64) and vu8.shape == (1, 64, 64)
+        c2, m2, k2 = D.expand_compact_batch(cu8[None], vu8[None])
+        assert torch.equal(k2[0], clean_t) and torch.equal(m2[0], mask) and torch.equal(c2[0], corrupted)
+        assert c2.dtype == torch.float32 and m2.is_contiguous()
+
+
 def test_binary_mask_threshold_and_dilation():
     m = np.zeros((40, 40), np.uint8)
     m[20, 20] = 103          # > 0.4*255 = 102  -> hole seed
