@@ -686,6 +686,36 @@ def test_depthwise_small_map_dilated(emu, n, h, wd, c, d, masked, bias, act):
         assert np.all(np.abs(bp[1] - (dz * xh).reshape(-1, c).sum(0)) <= slack * max(1.0, np.abs(xh).max()))
 
 
+@pytest.mark.parametrize("pad", [0, 2])
+def test_depthwise_stride2_forward_strip_other_paddings(emu, pad):
+    """The stride-2 strip with padding 0 (valid) and 2: the kernel's buffer geometry (9 rows, 17 columns per 4 x 8 outputs) does not
+    depend on the padding, only the origin of the slab does."""
+    L = emu
+    L.tsii_emu_set_strip_target(1)
+    try:
+        n, h, wd, c = 2, 27, 41, 12
+        rng = np.random.default_rng(pad + 11)
+        ho, wo = (h + 2 * pad - 3) // 2 + 1, (wd + 2 * pad - 3) // 2 + 1
+        x = rng.standard_normal((n, h, wd, c)).astype(np.float32)
+        w = rng.standard_normal((c, 1, 3, 3)).astype(np.float32)
+        b = rng.standard_normal(c).astype(np.float32)
+        rmask = (rng.uniform(size=(n, h, wd)) > 0.2).astype(np.float32)
+        geom = (3, 3, 2, 2, pad, pad, 1, 1)
+        ws = WS(4 * (9 * c + 16))
+        y = np.full((n, ho, wo, c), np.nan, np.float32)
+        assert L.tsii_dw_fwd(P(x), P(rmask), P(w), P(b), None, None, n, h, wd, c, *geom, ho, wo, P(y), P(ws), None) == 0, L.tsii_last_error()
+        xm = x.astype(np.float64) * rmask[..., None]
+        xp = np.zeros((n, h + 2 * pad, wd + 2 * pad, c)); xp[:, pad:pad + h, pad:pad + wd] = xm
+        yr = np.zeros((n, ho, wo, c))
+        for ky in range(3):
+            for kx in range(3):
+                yr += xp[:, ky:ky + 2 * (ho - 1) + 1:2, kx:kx + 2 * (wo - 1) + 1:2] * w[:, 0, ky, kx].astype(np.float64)
+        yr += b.astype(np.float64)
+        assert np.abs(y - yr).max() <= 2e-6 * max(1.0, np.abs(yr).max())
+    finally:
+        L.tsii_emu_set_strip_target(0)
+
+
 # ---- 1x1 convolution over cat(nearest-x2(low), skip) with the low half computed at low resolution (K7b) -------------------------
 @pytest.mark.parametrize("n,h,wd,k,N,stats", [(2, 8, 16, 40, 128, True),      # producer / consumer kernel (256-row tiles)
                                               (1, 16, 32, 64, 256, False),     # producer / consumer kernel, 128 x 256 tiles
