@@ -94,6 +94,7 @@ CALLS = {
     "tsii_head_cat_fwd": ("dense_conv", lambda a: _headcat(a, 1, 1)), "tsii_head_cat_bwd_dx": ("dense_conv", lambda a: _headcat(a, 1, 1)),
     "tsii_head_cat_bwd_dw": ("dense_conv", lambda a: _headcat(a, 1, 1)),
     "tsii_head_cat_fwd_low": ("dense_conv", lambda a: _headcat(a, 1, 1)), "tsii_head_cat_bwd_dw_low": ("dense_conv", lambda a: _headcat(a, 1, 1)),
+    "tsii_head_cat_bwd_low": ("dense_conv", lambda a: _headcat(a, 1, 1)),      # dW + d low in one pass
     "tsii_upcat_fwd": ("upcat", lambda a: _upcat(a, False)), "tsii_upcat_bwd": ("upcat", lambda a: _upcat(a, True)),
     # K7b: the high-resolution half of a 1x1 conv over cat(up2(low), skip): (m, k, n, ..): reads [m,k] and the [m/4,n] addend, writes [m,n]
     "tsii_pw_fwd_up": ("gemm_nt", lambda a: (4.0 * a[0] * (a[1] + a[2]) + 1.0 * a[0] * a[2], float(a[0]) * a[1] * a[2])),

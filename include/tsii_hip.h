@@ -172,6 +172,13 @@ int tsii_head_cat_bwd_dw(const float* dy, const float* inv, const float* keep, c
  * tsii_head_cat_low_ok() != 0: h % 16 == 0, wd % 64 == 0 (whole 16 x 64 tiles), c1 in {32, 64}, 1 <= c2 <= 16, cout <= 3.
  * Same workspace as tsii_head_cat_bwd_dw. */
 int tsii_head_cat_low_ok(int n, int h, int wd, int c1, int c2, int cout);
+/* ... the weight gradient AND the gradient of `low` in one pass (the box sums the former holds in LDS are the left operand of the
+ * latter: dlow[j][ci] = r0_low[j] * sum_m S[j][m] W[m][ci]); tsii_head_cat_bwd_low_ok(): tsii_head_cat_low_ok() and c1 == 32.
+ * = tsii_head_cat_bwd_dw_low + the d low half of tsii_head_cat_bwd_dx (no d skip: the skip is a data tensor). */
+int tsii_head_cat_bwd_low_ok(int n, int h, int wd, int c1, int c2, int cout);
+int tsii_head_cat_bwd_low(const float* dy, const float* inv, const float* keep, const float* low, const float* skip,
+                          int c1, int c2, const float* r0_low, const float* r1, const float* w, int n, int h, int wd, int cout,
+                          float* dwgt, float* dbias, float* dlow, void* ws, size_t ws_bytes, void* stream);
 /* ... and the forward pass: the up-sampled half as Z[low pixel][(tap, cout)] = W_low x low on the matrix cores (kept in LDS per
  * tile), 9 entries of Z per output pixel and channel + the 3-channel skip half on the vector ALU.  tsii_head_cat_fwd_low_ok():
  * tsii_head_cat_low_ok() and c2 == 3.  No workspace. */

@@ -532,5 +532,22 @@ def test_head_over_virtual_concat(backend, n, h, w, c1, c2, cout, premult, low_m
         for name, u, v in zip(("y", "d low", "d skip", "dW", "dbias"), *res):
             assert_close(u, v, 2e-6, f"head over virtual concat: {name}", floor=1e-6)
     matrix_core = low_mask and c1 in (32, 64) and cout <= 3 and h % 16 == 0 and w % 64 == 0      # whole 16 x 64 tiles
+    if matrix_core and c1 == 32:
+        # the skip as a data tensor (no gradient): weight gradient and d low come from ONE kernel (tsii_head_cat_bwd_low)
+        calls2 = []
+        with BACKENDS[backend]() as dev2:
+            ops.call = lambda name, *a: (calls2.append(name), real(name, *a))[1]
+            try:
+                a2 = low.to(dev2).clone().requires_grad_(True)
+                ww2, bb2 = wt.to(dev2).clone().requires_grad_(True), bias.to(dev2).clone().requires_grad_(True)
+                y2 = ops.pconv_head_cat(ops.VirtualCat(a2, skip.to(dev2), r0_low.to(dev2)), ww2, bb2, r0.to(dev2), None if r1 is None else r1.to(dev2),
+                                        denom.to(dev2), new_mask.to(dev2), inv.to(dev2))
+                y2.backward(gy.to(dev2))
+            finally:
+                ops.call = real
+            assert "tsii_head_cat_bwd_low" in calls2 and "tsii_head_cat_bwd_dx" not in calls2, sorted(set(calls2))
+            assert_close(a2.grad, res[1][1], 2e-6, "fused d low", floor=1e-6)
+            assert_close(ww2.grad, res[1][3], 2e-6, "dW beside the fused d low", floor=1e-6)
+            assert_close(bb2.grad, res[1][4], 2e-6, "dbias beside the fused d low", floor=1e-6)
     assert ("tsii_head_cat_bwd_dw_low" in calls) == matrix_core and ("tsii_head_cat_bwd_dw" in calls) == (not matrix_core), sorted(set(calls))
     assert ("tsii_head_cat_fwd_low" in calls) == (matrix_core and c2 == 3) and ("tsii_head_cat_fwd" in calls) == (not (matrix_core and c2 == 3))

@@ -43,6 +43,8 @@ SIGNATURES = {
     "tsii_head_cat_bwd_dw": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "tsii_head_cat_low_ok": (_i, [_i, _i, _i, _i, _i, _i]),
     "tsii_head_cat_fwd_low_ok": (_i, [_i, _i, _i, _i, _i, _i]),
+    "tsii_head_cat_bwd_low_ok": (_i, [_i, _i, _i, _i, _i, _i]),
+    "tsii_head_cat_bwd_low": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _z, _p]),
     "tsii_head_cat_fwd_low": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "tsii_head_cat_bwd_dw_low": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "tsii_dense_bwd_dw_ws_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),

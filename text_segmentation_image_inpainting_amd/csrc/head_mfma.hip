@@ -55,10 +55,15 @@ static int hm_blocks(int n, int h, int w, int* tiles_per_block) {
 }
 }  // namespace
 
-template <int NB, bool R0, bool R1>   // 16-channel column blocks of the low tensor (c1 = 16 * NB); mask planes present
-__global__ __launch_bounds__(256, NB == 2 ? HM_WAVES : 3) void head_cat_dw_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
+// DLOW: the same pass also writes the gradient of `low`,  dlow[j][ci] = r0l[j] * sum_m S[j][m] W[m][ci]  -- the four full-resolution
+// pixels of a low pixel share every term, so it is a [low pixels x 27] x [27 x c1] product over the box sums S that are already
+// in LDS for the weight gradient (head_dx_kernel, dense.hip, walks 36 accumulators per full-resolution pixel through the vector ALU:
+// 0.30 ms; here 7 matrix instructions per 16 low pixels and column block).  wgt: W[co][c1 + c2][3][3].
+template <int NB, bool R0, bool R1, bool DLOW>   // 16-channel column blocks of the low tensor (c1 = 16 * NB); mask planes present
+__global__ __launch_bounds__(256, (NB == 2 && !DLOW) ? HM_WAVES : 3) void head_cat_dw_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
                                                                const float* __restrict__ low, const float* __restrict__ skip,
                                                                const float* __restrict__ r0l, const float* __restrict__ r1,
+                                                               const float* __restrict__ wgt, float* __restrict__ dlow,
                                                                int n, int h, int w, int c2, int cout, int tiles_per_block,
                                                                float* __restrict__ part) {
     constexpr int C1 = 16 * NB;
@@ -96,6 +101,22 @@ __global__ __launch_bounds__(256, NB == 2 ? HM_WAVES : 3) void head_cat_dw_mfma_
         acc_skip[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc_low[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // DLOW operands, fixed for the kernel, kept in LDS (as registers they would be 21 more kernel-lifetime values on top of a
+    // budget that is full): row m = 4 ks + kk of the box sums (its T offset) and of W as [28][c1]
+    __shared__ float WD[DLOW ? 28 * C1 : 1];
+    __shared__ int DT[DLOW ? 28 : 1];
+    if (DLOW) {
+        for (int k = threadIdx.x; k < 28 * C1; k += 256) {
+            const int m = k / C1, ci = k - m * C1;
+            const int co = m / 9, t = m % 9;
+            WD[k] = (m < 27 && co < cout) ? wgt[((int64_t)co * (C1 + c2) + ci) * 9 + t] : 0.f;
+        }
+        if (threadIdx.x < 28) {
+            const int mm = threadIdx.x < 27 ? threadIdx.x : 26;
+            const int co = mm / 9, t = mm % 9;
+            DT[threadIdx.x] = co * HM_PLANE + (2 - t / 3) * HM_GS + (2 - t % 3);
+        }
     }
     constexpr int LSTEPS = HM_LH * HM_LW / 16;        // 4-pixel steps of this wave over the tile's 256 low pixels
     constexpr int SROUNDS = 4, SSTEPS = 4 * HM_LH * HM_LW / 16 / SROUNDS;   // ... over a quarter of its 1024 full-resolution pixels
@@ -216,6 +237,38 @@ __global__ __launch_bounds__(256, NB == 2 ? HM_WAVES : 3) void head_cat_dw_mfma_
                     else acc_low[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], bl[u][nb], acc_low[mb][nb], 0, 0, 0);
                 }
             if (u % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- d low: 16 low pixels per column block, wave w takes groups w, w + 4, w + 8, w + 12 (pixel (g / 2, 16 (g % 2) + lane % 16));
+        //      contraction index k = 4 ks + kk <-> row m = k of the box sums and of W
+        if (DLOW) {
+            float* const dl_t = dlow + ((img * hl + ly0) * wl + lx0) * C1;
+            int doff[7];
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) doff[ks] = DT[4 * ks + kk] + 2 * nn;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int g = wave + 4 * r;                               // wave-uniform
+                const int gorg = 2 * (g >> 1) * HM_GS + 32 * (g & 1);     // T offset of the group's first pixel
+                f32x4 accd[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) accd[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 7; ++ks) {
+                    const float a = T[doff[ks] + gorg];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        accd[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, WD[(4 * ks + kk) * C1 + 16 * nb + nn], accd[nb], 0, 0, 0);
+                }
+                // lane holds pixels 4 kk + i of the group, channel 16 nb + nn
+                const int64_t prow = (int64_t)(g >> 1) * wl + 16 * (g & 1) + 4 * kk;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float mk = R0 ? r0l[(img * hl + ly0) * wl + lx0 + prow + i] : 1.f;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) dl_t[(prow + i) * C1 + 16 * nb + nn] = accd[nb][i] * mk;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         // ---- skip half: 1024 full-resolution pixels, channels in the first c2 columns of one 16-wide block
 #pragma unroll
@@ -492,9 +545,28 @@ extern "C" int tsii_head_cat_low_ok(int n, int h, int wd, int c1, int c2, int co
     return (c1 == 32 || c1 == 64) && c2 >= 1 && c2 <= 16 && cout >= 1 && cout <= 3 ? 1 : 0;
 }
 
+static int head_cat_bwd_low_impl(const float* dy, const float* inv, const float* keep, const float* low, const float* skip,
+                                 int c1, int c2, const float* r0_low, const float* r1, const float* w, int n, int h, int wd, int cout,
+                                 float* dwgt, float* dbias, float* dlow, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int tsii_head_cat_bwd_dw_low(const float* dy, const float* inv, const float* keep, const float* low, const float* skip,
                                         int c1, int c2, const float* r0_low, const float* r1, int n, int h, int wd, int cout,
                                         float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream) {
+    return head_cat_bwd_low_impl(dy, inv, keep, low, skip, c1, c2, r0_low, r1, nullptr, n, h, wd, cout, dwgt, dbias, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int tsii_head_cat_bwd_low(const float* dy, const float* inv, const float* keep, const float* low, const float* skip,
+                                     int c1, int c2, const float* r0_low, const float* r1, const float* w, int n, int h, int wd, int cout,
+                                     float* dwgt, float* dbias, float* dlow, void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(w && dlow, "head_cat_bwd_low: null pointer");
+    TSII_REQUIRE(c1 == 32, "head_cat_bwd_low: the fused d low exists for 32 low channels (tsii_head_cat_bwd_low_ok)");
+    TSII_REQUIRE(aligned16(dlow), "head_cat_bwd_low: dlow must be 16-byte aligned");
+    return head_cat_bwd_low_impl(dy, inv, keep, low, skip, c1, c2, r0_low, r1, w, n, h, wd, cout, dwgt, dbias, dlow, ws, ws_bytes, stream);
+}
+
+static int head_cat_bwd_low_impl(const float* dy, const float* inv, const float* keep, const float* low, const float* skip,
+                                 int c1, int c2, const float* r0_low, const float* r1, const float* w, int n, int h, int wd, int cout,
+                                 float* dwgt, float* dbias, float* dlow, void* ws, size_t ws_bytes, void* stream) {
     TSII_REQUIRE(dy && low && skip && dwgt && ws, "head_cat_bwd_dw_low: null pointer");
     TSII_REQUIRE(tsii_head_cat_low_ok(n, h, wd, c1, c2, cout), "head_cat_bwd_dw_low: geometry has no matrix-core head (tsii_head_cat_low_ok)");
     TSII_REQUIRE(ws_bytes >= tsii_dense_bwd_dw_ws_bytes(n, h, wd, c1 + c2, cout, 3, 3), "head_cat_bwd_dw_low: workspace too small");
@@ -502,8 +574,9 @@ extern "C" int tsii_head_cat_bwd_dw_low(const float* dy, const float* inv, const
     float* part = (float*)ws;
     int tpb = 0;
     const int blocks = hm_blocks(n, h, wd, &tpb);
-#define TSII_HM_LAUNCH(NB, R0, R1) \
-    hipLaunchKernelGGL((head_cat_dw_mfma_kernel<NB, R0, R1>), dim3(blocks), dim3(256), 0, st, dy, inv, low, skip, r0_low, r1, n, h, wd, c2, cout, tpb, part)
+#define TSII_HM_LAUNCH(NB, R0, R1) do { \
+    if (NB == 2 && dlow != nullptr) hipLaunchKernelGGL((head_cat_dw_mfma_kernel<2, R0, R1, true>), dim3(blocks), dim3(256), 0, st, dy, inv, low, skip, r0_low, r1, w, dlow, n, h, wd, c2, cout, tpb, part); \
+    else hipLaunchKernelGGL((head_cat_dw_mfma_kernel<NB, R0, R1, false>), dim3(blocks), dim3(256), 0, st, dy, inv, low, skip, r0_low, r1, w, dlow, n, h, wd, c2, cout, tpb, part); } while (0)
 #define TSII_HM_MASKS(NB)                                           \
     do {                                                            \
         if (r0_low != nullptr && r1 != nullptr) TSII_HM_LAUNCH(NB, true, true);   \
@@ -522,6 +595,10 @@ extern "C" int tsii_head_cat_bwd_dw_low(const float* dy, const float* inv, const
     if (rc) return rc;
     if (dbias != nullptr) rc = launch_colsum_scaled(dy, keep, (int64_t)n * h * wd, cout, dbias, part + (size_t)blocks * len, st);
     return rc;
+}
+
+extern "C" int tsii_head_cat_bwd_low_ok(int n, int h, int wd, int c1, int c2, int cout) {
+    return tsii_head_cat_low_ok(n, h, wd, c1, c2, cout) && c1 == 32 ? 1 : 0;
 }
 
 extern "C" int tsii_head_cat_fwd_low_ok(int n, int h, int wd, int c1, int c2, int cout) {

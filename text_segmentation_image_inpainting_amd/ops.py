@@ -27,6 +27,8 @@ FUSE_BN_BWD_PW = _os.environ.get("TSII_FUSE_BN_BWD", "2") == "2"
 FUSE_POOL_BN_BWD = _os.environ.get("TSII_FUSE_POOL_BN_BWD", "1") != "0"
 # A/B knob for K4d (head weight gradient on the f32 matrix cores)
 USE_HEAD_MFMA = _os.environ.get("TSII_HEAD_MFMA", "1") != "0"
+# ... and its d low taken in the weight-gradient kernel's pass (tsii_head_cat_bwd_low) instead of by the vector-ALU dX kernel
+FUSE_HEAD_DLOW = _os.environ.get("TSII_HEAD_DLOW", "1") != "0"
 # A/B knob for K4b (stems as a space-to-depth stride-1 conv on the vector-gather GEMM)
 USE_STEM_S2D = _os.environ.get("TSII_STEM_S2D", "1") != "0"
 
@@ -810,6 +812,19 @@ class _HeadCat(torch.autograd.Function):
         c1, cout = low.shape[3], w.shape[0]
         L, st = _lib.lib(), _lib.stream()
         dlow = dskip = dw = db = None
+        want_dw = ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3])
+        low_mask_ok = USE_HEAD_MFMA and (ctx.r0_low is not None or r0 is None)
+        if (low_mask_ok and FUSE_HEAD_DLOW and want_dw and ctx.needs_input_grad[0] and not ctx.needs_input_grad[1]
+                and L.tsii_head_cat_bwd_low_ok(n, h, wd, c1, c2, cout)):
+            # K4d: weight gradient and d low in one pass over dy (the skip is a data tensor: no d skip)
+            dw = torch.empty_like(w)
+            db = torch.empty(cout, dtype=torch.float32, device=low.device) if ctx.has_bias else None
+            dlow = torch.empty_like(low)
+            nbytes = L.tsii_dense_bwd_dw_ws_bytes(n, h, wd, c1 + c2, cout, 3, 3)
+            ws = _ws(nbytes, low)
+            call("tsii_head_cat_bwd_low", ptr(gy), ptr(inv), ptr(keep), ptr(low), ptr(skip), c1, c2, ptr(ctx.r0_low), ptr(r1), ptr(w),
+                 n, h, wd, cout, ptr(dw), ptr(db), ptr(dlow), ptr(ws), nbytes, st)
+            return dlow, None, dw, db, None, None, None, None, None, None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dlow = torch.empty_like(low)
             dskip = torch.empty_like(skip) if ctx.needs_input_grad[1] else None
@@ -819,12 +834,12 @@ class _HeadCat(torch.autograd.Function):
                  ptr(dlow), ptr(dskip), ptr(ws), nbytes, st)
             if not ctx.needs_input_grad[0]:
                 dlow = None
-        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+        if want_dw:
             dw = torch.empty_like(w)
             db = torch.empty(cout, dtype=torch.float32, device=low.device) if ctx.has_bias else None
             nbytes = L.tsii_dense_bwd_dw_ws_bytes(n, h, wd, c1 + c2, cout, 3, 3)
             ws = _ws(nbytes, low)
-            if USE_HEAD_MFMA and (ctx.r0_low is not None or r0 is None) and L.tsii_head_cat_low_ok(n, h, wd, c1, c2, cout):
+            if low_mask_ok and L.tsii_head_cat_low_ok(n, h, wd, c1, c2, cout):
                 call("tsii_head_cat_bwd_dw_low", ptr(gy), ptr(inv), ptr(keep), ptr(low), ptr(skip), c1, c2, ptr(ctx.r0_low), ptr(r1),
                      n, h, wd, cout, ptr(dw), ptr(db), ptr(ws), nbytes, st)
             else:
