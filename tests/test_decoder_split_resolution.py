@@ -74,3 +74,19 @@ def test_decoder_level_split_resolution(backend, cl, cs, cout, n, h, w):
     # the two spellings of the addend's gradient agree to fp32 rounding of four-term sums
     assert_close(fused[2], two_pass[2], 1e-6, "d low: pooled in the BatchNorm backward vs the pooling pass")
     assert torch.equal(fused[3], two_pass[3])
+
+
+def test_pool_hand_over_only_for_the_very_tensor():
+    """ops._PoolHandOver: the pooled addend gradient the BatchNorm backward left behind is taken only when the convolution's backward
+    receives that very dy (same storage, same shape); anything else -- autograd summed two gradients, a view, a second backward --
+    gets None and the separate pooling pass runs."""
+    from text_segmentation_image_inpainting_amd import ops
+    h = ops._PoolHandOver(None, 8, 8)
+    dy, dz = torch.zeros(2, 8, 8, 4), torch.ones(2, 4, 4, 4)
+    h.dy, h.dz = dy, dz
+    assert h.take(dy) is dz and h.dy is None and h.dz is None          # consumed once
+    assert h.take(dy) is None
+    h.dy, h.dz = dy, dz
+    assert h.take(dy.clone()) is None and h.dz is None                 # another tensor: nothing, and the stale pair is dropped
+    h.dy, h.dz = dy, dz
+    assert h.take(dy[:1]) is None                                      # same storage, other shape

@@ -815,6 +815,30 @@ def test_pointwise_upsampled_addend_rejects_bad_geometry(emu):
         assert b"pw_fwd_up" in L.tsii_last_error()
 
 
+def test_head_matrix_core_entries_refuse_what_they_do_not_cover(emu):
+    """K4d entry points: geometry queries and loud refusals (whole 16 x 64 tiles, 32 / 64 low channels, <= 3 output channels; forward:
+    3 skip channels; fused d low: 32 low channels) -- the callers fall back to tsii_head_cat_* on a 0."""
+    L = emu
+    assert L.tsii_head_cat_low_ok(2, 32, 64, 32, 3, 3) == 1 and L.tsii_head_cat_low_ok(2, 32, 64, 64, 5, 1) == 1
+    for bad in ((2, 24, 64, 32, 3, 3), (2, 32, 96, 32, 3, 3), (2, 32, 64, 48, 3, 3), (2, 32, 64, 32, 3, 4), (2, 32, 64, 32, 0, 3)):
+        assert L.tsii_head_cat_low_ok(*bad) == 0, bad
+    assert L.tsii_head_cat_fwd_low_ok(1, 16, 64, 64, 3, 2) == 1 and L.tsii_head_cat_fwd_low_ok(1, 16, 64, 32, 4, 2) == 0
+    assert L.tsii_head_cat_bwd_low_ok(1, 16, 64, 32, 3, 3) == 1 and L.tsii_head_cat_bwd_low_ok(1, 16, 64, 64, 3, 3) == 0
+    n, h, w, c1, c2, co = 1, 16, 64, 64, 3, 3
+    low = np.zeros((n, h // 2, w // 2, c1), np.float32); skip = np.zeros((n, h, w, c2), np.float32)
+    wt = np.zeros((co, c1 + c2, 3, 3), np.float32); dy = np.zeros((n, h, w, co), np.float32)
+    dw = np.zeros_like(wt); dlow = np.zeros_like(low); y = np.zeros_like(dy)
+    nb = L.tsii_dense_bwd_dw_ws_bytes(n, h, w, c1 + c2, co, 3, 3); ws = WS(nb)
+    # 64 low channels have no fused d low
+    assert L.tsii_head_cat_bwd_low(P(dy), None, None, P(low), P(skip), c1, c2, None, None, P(wt), n, h, w, co, P(dw), None, P(dlow), P(ws), nb, None) != 0
+    assert b"head_cat_bwd_low" in L.tsii_last_error()
+    # a map that is not whole tiles
+    assert L.tsii_head_cat_fwd_low(P(low), P(skip), c1, c2, None, None, P(wt), None, None, None, n, h + 2, w, co, P(y), None) != 0
+    assert b"head_cat_fwd_low" in L.tsii_last_error()
+    assert L.tsii_head_cat_bwd_dw_low(P(dy), None, None, P(low), P(skip), c1, c2, None, None, n, h, w + 2, co, P(dw), None, P(ws), nb, None) != 0
+    assert b"head_cat_bwd_dw_low" in L.tsii_last_error()
+
+
 @pytest.mark.parametrize("rows,c", [(3, 8), (256, 40), (1024, 33), (1025, 32), (5000, 36)])
 def test_bn_finalize_from_partials(emu, rows, c):
     """tsii_bn_finalize: (count, pivot, sum(y-p), sum((y-p)^2)) rows -> mean / biased variance / running statistics / (scale,
