@@ -129,6 +129,12 @@ def test_bench_class_table_and_traffic_gate(tmp_path, monkeypatch):
     # the K4c entry points are accounted for (virtual concatenation: bytes of low + skip + y only)
     hc = bench.class_table({"tsii_head_cat_fwd": [(0.5, (32, 3, 32, 512, 512, 3, 5184))]}, 1, 6)["dense_conv"]
     assert abs(hc["alg_gb_per_step"] - 4.0 * 32 * (512 * 512 // 4 * 32 + 512 * 512 * 3 + 512 * 512 * 3) / 1e9) < 1e-2
+    # ... and so are the matrix-core head entries (K4d: same bytes) and the BatchNorm backward that also pools the K7b addend gradient
+    for name in ("tsii_head_cat_fwd_low", "tsii_head_cat_bwd_dw_low", "tsii_head_cat_bwd_low"):
+        hl = bench.class_table({name: [(0.2, (32, 3, 32, 512, 512, 3, 5184))]}, 1, 6)["dense_conv"]
+        assert abs(hl["alg_gb_per_step"] - hc["alg_gb_per_step"]) < 1e-6, name
+    bp = bench.class_table({"tsii_bn_act_bwd_pre_pool": [(1.0, (m, n, 1e-5, 2, 0.3, 1, 512, 256, 256, 4096))]}, 1, 6)["bn_bwd"]
+    assert abs(bp["alg_gb_per_step"] - 4.0 * m * n * 3.25 / 1e9) < 1e-2
     # several kernels behind one class in the traffic lookup
     # traffic gate
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
