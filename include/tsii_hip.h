@@ -390,6 +390,51 @@ int tsii_masked_l1_bwd(const float* out, const float* gt, const float* mask, int
 int tsii_tv_fwd(const float* x, int n, int h, int w, int c, float* loss, void* ws, size_t ws_bytes, void* stream);
 int tsii_tv_bwd(const float* x, int n, int h, int w, int c, const float* gscale, float* dx, void* stream);
 
+/* ==== bf16 ACTIVATION STORAGE (BASELINE config 5: "mixed bf16 with fp32 mask renorm"; round 5) ==========================
+ * The segmentation nets (models/text_segmentation.py:18-114 and their blocks: models/MobileNetV2.py:114-149,
+ * models/Xception.py:13-114, models/common.py:53-156, models/BaseModels.py:91-127) with activations AND activation
+ * gradients kept in HBM as bf16 NHWC; parameters, parameter gradients, BatchNorm statistics, every accumulation and every
+ * reduction stay fp32.  `uint16_t*` = raw bf16 bits; every channel count is a multiple of 8 (one 16-byte vector; the host
+ * pads the 3-channel stem to 4 and a 1-channel head to 8), every tensor base is 16-byte aligned.  A kernel reads bf16,
+ * computes in fp32 and rounds once (RNE) when it stores; the BatchNorm partials a kernel emits describe the ROUNDED values.
+ * These nets carry no mask planes, so the entry points have none (the partial-convolution family keeps fp32 storage: its
+ * count division / hole logic is the "fp32 mask renorm" of the config and no shipped model combines the two).
+ * Layouts of the partial rows are those of the fp32 entry points above (stat_part [rows][4][c], bwd_part [rows][2][c]), so
+ * tsii_bn_finalize and the fp32 reductions are shared. */
+
+/* ---- matrix products: 1x1 convolutions (bf16 x bf16 -> fp32 on v_mfma_f32_32x32x16_bf16) ---------------------------- */
+int64_t tsii_bf16_stat_rows(int64_t m);                 /* partial rows of the NT kernels: one per 128 output rows */
+size_t tsii_bf16_pw_ws_bytes(int n, int k);             /* bf16 image of the weights, written once per call */
+/* y[m,n] = sum_k a(x[m,k]) w[n,k] + bias[n],  a = act(in_scale*x + in_shift) applied while loading (in_scale NULL: a = x);
+ * stat_part (or NULL): BatchNorm partials of y [tsii_bf16_stat_rows(m)][4][n] */
+int tsii_bf16_pw_fwd(const uint16_t* x, int64_t m, int k, const float* w, int n, const float* bias,
+                     const float* in_scale, const float* in_shift, int in_act, float in_slope,
+                     float* stat_part, uint16_t* y, void* ws, size_t ws_bytes, void* stream);
+/* dx[m,k] = sum_n dy[m,n] w[n,k]; with bn_y (raw [m,k] input of the BatchNorm the conv consumed on load, K6c) also
+ * bwd_part[tsii_bf16_stat_rows(m)][2][k] = (sum dz, sum dz*xhat), dz = dx*act'(z).  ws: tsii_bf16_pw_ws_bytes(n, k). */
+int tsii_bf16_pw_bwd_dx(const uint16_t* dy, int64_t m, int n, const float* w, int k,
+                        const uint16_t* bn_y, const float* bn_mean, const float* bn_var, const float* bn_gamma,
+                        const float* bn_beta, float bn_eps, int bn_act, float bn_slope,
+                        uint16_t* dx, float* bwd_part, void* ws, size_t ws_bytes, void* stream);
+/* dw[n,k] = sum_m dy[m,n] a(x[m,k]) (fp32);  dbias[n] = sum_m dy[m,n] (or NULL) */
+size_t tsii_bf16_pw_bwd_dw_ws_bytes(int64_t m, int n, int k);
+int tsii_bf16_pw_bwd_dw(const uint16_t* dy, const uint16_t* x, int64_t m, int n, int k,
+                        const float* in_scale, const float* in_shift, int in_act, float in_slope,
+                        float* dw, float* dbias, void* ws, size_t ws_bytes, void* stream);
+/* ---- dense k x k convolutions, groups == 1, as implicit GEMM (w: reference layout [cout,cin,kh,kw], fp32) ------------- */
+size_t tsii_bf16_dense_ws_bytes(int cin, int cout, int kh, int kw);
+int tsii_bf16_dense_fwd(const uint16_t* x, const float* w, const float* bias, int n, int h, int wd, int cin, int cout,
+                        int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo,
+                        float* stat_part /* [tsii_bf16_stat_rows(n*ho*wo)][4][cout] or NULL */, uint16_t* y,
+                        void* ws, size_t ws_bytes, void* stream);
+int tsii_bf16_dense_bwd_dx(const uint16_t* dy, const float* w, int n, int h, int wd, int cin, int cout,
+                           int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo,
+                           uint16_t* dx, void* ws, size_t ws_bytes, void* stream);
+size_t tsii_bf16_dense_bwd_dw_ws_bytes(int n, int ho, int wo, int cin, int cout, int kh, int kw);
+int tsii_bf16_dense_bwd_dw(const uint16_t* dy, const uint16_t* x, int n, int h, int wd, int cin, int cout,
+                           int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo,
+                           float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,265 @@
+"""bf16 ACTIVATION STORAGE (include/tsii_hip.h, "bf16 activation storage"): every tsii_bf16_* entry point straight through the
+C ABI on the TEST-ONLY emulator against float64 numpy evaluated on the SAME bf16-rounded operands.  The definition under test:
+operands are the bf16 values in memory, products and sums are fp32-class, the result is rounded once (RNE) when stored; partial
+rows (BatchNorm statistics, K6c reductions) describe the rounded values.  Tolerance of a stored tensor: one bf16 ulp of the
+reference (2^-8 relative, + an fp32-accumulation allowance); fp32 outputs (weight gradients, partials): 1e-4 class."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from text_segmentation_image_inpainting_amd import _lib
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from tests.emu import build_emu
+    if not build_emu.available():
+        pytest.skip("host clang++ not available")
+    return _lib.bind(ctypes.CDLL(build_emu.build()))
+
+
+def P(a):
+    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+_CANARY = np.float32(-12345.678)
+_guarded = []
+
+
+def WS(nbytes):
+    n = (int(nbytes) + 3) // 4
+    buf = np.zeros(n + 64, np.float32)
+    buf[n:] = _CANARY
+    _guarded.append((buf, n))
+    return buf[:max(n, 1)]
+
+
+@pytest.fixture(autouse=True)
+def _check_workspace_tails():
+    _guarded.clear()
+    yield
+    for buf, n in _guarded:
+        assert np.all(buf[n:] == _CANARY), f"a kernel wrote past its {4 * n}-byte workspace"
+    _guarded.clear()
+
+
+# ---- bf16 <-> numpy -------------------------------------------------------------------------------------------------
+def bf16_bits(a):
+    """float32 array -> uint16 bf16 bits, round to nearest even"""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    return ((u + (((u >> 16) & 1) + np.uint32(0x7FFF))) >> 16).astype(np.uint16)
+
+
+def bf16_val(b):
+    """uint16 bf16 bits -> float32 values"""
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def rb(a):
+    """round a float array to bf16 and back (float64 result for reference arithmetic)"""
+    return bf16_val(bf16_bits(np.asarray(a, np.float32))).astype(np.float64)
+
+
+def rand_bf16(rng, shape, scale=1.0, shift=0.0):
+    bits = bf16_bits((rng.standard_normal(shape) * scale + shift).astype(np.float32))
+    return bits, bf16_val(bits).astype(np.float64)
+
+
+def close_bf16(got_bits, ref, extra=0.0):
+    """stored bf16 tensor vs float64 reference: one bf16 ulp of the element, plus an allowance for the fp32 accumulation"""
+    got = bf16_val(got_bits).astype(np.float64)
+    tol = np.abs(ref) * 2.0 ** -8 + (2e-6 + extra) * np.abs(ref).max() + 1e-30
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), f"{bad.sum()} of {bad.size} elements off; worst {np.abs(got - ref).max():.3e} vs max|ref| {np.abs(ref).max():.3e}"
+
+
+def act_np(z, act, slope):
+    return {0: z, 1: np.maximum(z, 0), 2: np.where(z > 0, z, slope * z), 3: np.clip(z, 0, 6)}[act]
+
+
+def act_grad_np(z, act, slope):
+    return {0: np.ones_like(z), 1: (z > 0) * 1.0, 2: np.where(z > 0, 1.0, slope), 3: ((z > 0) & (z < 6)) * 1.0}[act]
+
+
+def inbn_np(xv, sc, sh, act, slope):
+    """the load-time BatchNorm + activation as the kernels evaluate it: fp32 fma, then the result is rounded to bf16 (it is an MFMA operand)"""
+    z = np.float32(xv.astype(np.float32) * sc.astype(np.float32) + sh.astype(np.float32)).astype(np.float64)
+    return rb(act_np(z, act, slope))
+
+
+def stats_from_part(part, m):
+    """(mean, biased var) from [rows][4][c] partials (count, pivot, s1, s2)"""
+    n, p, s1, s2 = (part[:, i].astype(np.float64) for i in range(4))
+    assert n.sum(0).min() == m and n.sum(0).max() == m
+    mean = (n * p + s1).sum(0) / m
+    ex2 = (s2 + 2 * p * s1 + n * p * p).sum(0) / m
+    return mean, ex2 - mean * mean
+
+
+# ---- 1x1 convolutions -----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,N,bias,act", [(300, 64, 128, True, 2), (257, 96, 192, False, None), (130, 40, 32, True, 1),
+                                            (260, 128, 256, False, 3), (200, 136, 48, True, None), (70, 8, 8, True, 0)])
+def test_pointwise_forward_dx_dw(emu, M, K, N, bias, act):
+    L = emu
+    rng = np.random.default_rng(M + 3 * K + 7 * N)
+    xb, xv = rand_bf16(rng, (M, K), 1.5, 0.3)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32) if bias else None
+    slope = 0.3
+    sc = rng.uniform(0.5, 1.5, K).astype(np.float32) if act is not None else None
+    sh = rng.standard_normal(K).astype(np.float32) if act is not None else None
+    a = inbn_np(xv, sc, sh, act, slope) if act is not None else xv
+    wv = rb(w)
+    rows = L.tsii_bf16_stat_rows(M)
+    assert rows == (M + 127) // 128
+    part = np.zeros((rows, 4, N), np.float32)
+    y = np.zeros((M, N), np.uint16)
+    ws = WS(L.tsii_bf16_pw_ws_bytes(N, K))
+    assert L.tsii_bf16_pw_fwd(P(xb), M, K, P(w), N, P(b), P(sc), P(sh), act or 0, slope, P(part), P(y), P(ws), ws.nbytes, None) == 0, L.tsii_last_error()
+    ref = a @ wv.T + (b if bias else 0.0)
+    close_bf16(y, ref)
+    # the partials describe the values AS STORED
+    yv = bf16_val(y).astype(np.float64)
+    mean, var = stats_from_part(part, M)
+    assert np.abs(mean - yv.mean(0)).max() <= 1e-5 * np.abs(yv).max()
+    assert np.abs(var - yv.var(0)).max() <= 1e-4 * yv.var(0).max()
+
+    # dX (+ the BatchNorm-backward reductions of the layer that produced x, K6c)
+    dyb, dyv = rand_bf16(rng, (M, N))
+    dx = np.zeros((M, K), np.uint16)
+    ws = WS(L.tsii_bf16_pw_ws_bytes(N, K))
+    assert L.tsii_bf16_pw_bwd_dx(P(dyb), M, N, P(w), K, None, None, None, None, None, 0.0, 0, 0.0, P(dx), None, P(ws), ws.nbytes, None) == 0, L.tsii_last_error()
+    rdx = dyv @ wv
+    close_bf16(dx, rdx)
+    if act is not None:
+        mean_ = rng.standard_normal(K).astype(np.float32)
+        var_ = rng.uniform(0.5, 2.0, K).astype(np.float32)
+        gamma = rng.uniform(0.5, 1.5, K).astype(np.float32)
+        beta = rng.standard_normal(K).astype(np.float32)
+        eps = 1e-5
+        bpart = np.zeros((rows, 2, K), np.float32)
+        dx2 = np.zeros((M, K), np.uint16)
+        assert L.tsii_bf16_pw_bwd_dx(P(dyb), M, N, P(w), K, P(xb), P(mean_), P(var_), P(gamma), P(beta), eps, act, slope, P(dx2), P(bpart),
+                                     P(ws), ws.nbytes, None) == 0, L.tsii_last_error()
+        assert np.array_equal(dx2, dx)
+        xh = (xv - mean_) / np.sqrt(var_.astype(np.float64) + eps)
+        z = xh * gamma + beta
+        dz = bf16_val(dx).astype(np.float64) * act_grad_np(z, act, slope)
+        s1, s2 = dz.sum(0), (dz * xh).sum(0)
+        kink = np.abs(z) < 1e-4          # an fp32 z on the other side of the kink than the float64 one
+        assert kink.mean() < 1e-3
+        assert np.abs(bpart[:, 0].sum(0, dtype=np.float64) - s1).max() <= 1e-4 * np.abs(dz).sum(0).max() + np.abs(dz * kink).sum(0).max()
+        assert np.abs(bpart[:, 1].sum(0, dtype=np.float64) - s2).max() <= 1e-4 * np.abs(dz * xh).sum(0).max() + np.abs(dz * xh * kink).sum(0).max()
+
+    # dW / dbias (fp32 outputs)
+    nbytes = L.tsii_bf16_pw_bwd_dw_ws_bytes(M, N, K)
+    ws = WS(nbytes)
+    dw = np.zeros((N, K), np.float32)
+    db = np.zeros(N, np.float32)
+    assert L.tsii_bf16_pw_bwd_dw(P(dyb), P(xb), M, N, K, P(sc), P(sh), act or 0, slope, P(dw), P(db) if bias else None, P(ws), nbytes, None) == 0, L.tsii_last_error()
+    rdw = dyv.T @ a
+    assert np.abs(dw - rdw).max() <= 2e-5 * np.abs(rdw).max()
+    if bias:
+        assert np.abs(db - dyv.sum(0)).max() <= 1e-5 * np.abs(dyv).sum(0).max()
+
+
+def test_pointwise_rejects_odd_channel_counts(emu):
+    L = emu
+    x = np.zeros((16, 12), np.uint16)
+    w = np.zeros((8, 12), np.float32)
+    y = np.zeros((16, 8), np.uint16)
+    ws = WS(1024)
+    assert L.tsii_bf16_pw_fwd(P(x), 16, 12, P(w), 8, None, None, None, 0, 0.0, None, P(y), P(ws), ws.nbytes, None) != 0
+    assert b"multiples of 8" in L.tsii_last_error()
+
+
+# ---- dense convolutions (implicit GEMM) -------------------------------------------------------------------------------------
+def conv_ref(x, w, geom, bias=None):
+    """x [n,h,w,cin], w [cout,cin,kh,kw] float64 -> [n,ho,wo,cout]"""
+    kh, kw, sh, sw, ph, pw, dh, dw = geom
+    n, h, wd, cin = x.shape
+    cout = w.shape[0]
+    ho = (h + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    wo = (wd + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    xp = np.zeros((n, h + 2 * ph, wd + 2 * pw, cin))
+    xp[:, ph:ph + h, pw:pw + wd] = x
+    y = np.zeros((n, ho, wo, cout))
+    for ky in range(kh):
+        for kx in range(kw):
+            patch = xp[:, ky * dh: ky * dh + (ho - 1) * sh + 1: sh, kx * dw: kx * dw + (wo - 1) * sw + 1: sw]
+            y += patch @ w[:, :, ky, kx].T
+    return y + (bias if bias is not None else 0.0)
+
+
+def conv_dx_ref(dy, w, geom, h, wd):
+    kh, kw, sh, sw, ph, pw, dh, dw = geom
+    n, ho, wo, cout = dy.shape
+    cin = w.shape[1]
+    dxp = np.zeros((n, h + 2 * ph, wd + 2 * pw, cin))
+    for ky in range(kh):
+        for kx in range(kw):
+            dxp[:, ky * dh: ky * dh + (ho - 1) * sh + 1: sh, kx * dw: kx * dw + (wo - 1) * sw + 1: sw] += dy @ w[:, :, ky, kx]
+    return dxp[:, ph:ph + h, pw:pw + wd]
+
+
+def conv_dw_ref(dy, x, geom, kshape):
+    kh, kw, sh, sw, ph, pw, dh, dw = geom
+    n, h, wd, cin = x.shape
+    _, ho, wo, cout = dy.shape
+    xp = np.zeros((n, h + 2 * ph, wd + 2 * pw, cin))
+    xp[:, ph:ph + h, pw:pw + wd] = x
+    g = np.zeros(kshape)
+    for ky in range(kh):
+        for kx in range(kw):
+            patch = xp[:, ky * dh: ky * dh + (ho - 1) * sh + 1: sh, kx * dw: kx * dw + (wo - 1) * sw + 1: sw]
+            g[:, :, ky, kx] = np.einsum("nyxo,nyxi->oi", dy, patch)
+    return g
+
+
+@pytest.mark.parametrize("n,h,wd,cin,cout,geom,bias", [
+    (2, 12, 10, 16, 32, (3, 3, 1, 1, 1, 1, 1, 1), False),       # 3x3 same
+    (1, 14, 14, 32, 136, (3, 3, 1, 1, 3, 3, 3, 3), False),      # ASP: dilation 3
+    (2, 9, 11, 24, 8, (3, 3, 1, 1, 1, 1, 1, 1), True),          # padded 1-channel head (cout 8)
+    (2, 12, 12, 16, 64, (1, 1, 2, 2, 0, 0, 1, 1), False),       # strided 1x1 shortcut
+    (2, 13, 13, 16, 32, (2, 2, 1, 1, 0, 0, 1, 1), False),       # space-to-depth stem
+    (1, 16, 16, 8, 16, (3, 3, 2, 2, 1, 1, 1, 1), True),         # strided 3x3
+])
+def test_dense_forward_dx_dw(emu, n, h, wd, cin, cout, geom, bias):
+    L = emu
+    kh, kw, sh, sw, ph, pw, dh, dw = geom
+    ho = (h + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    wo = (wd + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    rng = np.random.default_rng(n + h + 3 * cin + 5 * cout + kh)
+    xb, xv = rand_bf16(rng, (n, h, wd, cin))
+    w = (rng.standard_normal((cout, cin, kh, kw)) / np.sqrt(cin * kh * kw)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) if bias else None
+    wv = rb(w)
+    m = n * ho * wo
+    rows = L.tsii_bf16_stat_rows(m)
+    part = np.zeros((rows, 4, cout), np.float32)
+    y = np.zeros((n, ho, wo, cout), np.uint16)
+    ws = WS(L.tsii_bf16_dense_ws_bytes(cin, cout, kh, kw))
+    assert L.tsii_bf16_dense_fwd(P(xb), P(w), P(b), n, h, wd, cin, cout, *geom, ho, wo, P(part), P(y), P(ws), ws.nbytes, None) == 0, L.tsii_last_error()
+    ref = conv_ref(xv, wv, geom, b)
+    close_bf16(y, ref)
+    yv = bf16_val(y).astype(np.float64).reshape(m, cout)
+    mean, var = stats_from_part(part, m)
+    assert np.abs(mean - yv.mean(0)).max() <= 1e-5 * np.abs(yv).max()
+    assert np.abs(var - yv.var(0)).max() <= 1e-4 * yv.var(0).max()
+
+    dyb, dyv = rand_bf16(rng, (n, ho, wo, cout))
+    dx = np.zeros((n, h, wd, cin), np.uint16)
+    ws = WS(L.tsii_bf16_dense_ws_bytes(cin, cout, kh, kw))
+    assert L.tsii_bf16_dense_bwd_dx(P(dyb), P(w), n, h, wd, cin, cout, *geom, ho, wo, P(dx), P(ws), ws.nbytes, None) == 0, L.tsii_last_error()
+    close_bf16(dx, conv_dx_ref(dyv, wv, geom, h, wd))
+
+    nbytes = L.tsii_bf16_dense_bwd_dw_ws_bytes(n, ho, wo, cin, cout, kh, kw)
+    ws = WS(nbytes)
+    dwg = np.zeros((cout, cin, kh, kw), np.float32)
+    db = np.zeros(cout, np.float32)
+    assert L.tsii_bf16_dense_bwd_dw(P(dyb), P(xb), n, h, wd, cin, cout, *geom, ho, wo, P(dwg), P(db) if bias else None, P(ws), nbytes, None) == 0, L.tsii_last_error()
+    rdw = conv_dw_ref(dyv, xv, geom, w.shape)
+    assert np.abs(dwg - rdw).max() <= 2e-5 * np.abs(rdw).max()
+    if bias:
+        assert np.abs(db - dyv.reshape(m, cout).sum(0)).max() <= 1e-5 * np.abs(dyv).reshape(m, cout).sum(0).max()

@@ -100,6 +100,18 @@ SIGNATURES = {
     "tsii_masked_l1_bwd": (_i, [_p, _p, _p, _l, _f, _f, _p, _p, _p]),
     "tsii_tv_fwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _z, _p]),
     "tsii_tv_bwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
+    # ---- bf16 activation storage (round 5) ----
+    "tsii_bf16_stat_rows": (_l, [_l]),
+    "tsii_bf16_pw_ws_bytes": (_z, [_i, _i]),
+    "tsii_bf16_pw_fwd": (_i, [_p, _l, _i, _p, _i, _p, _p, _p, _i, _f, _p, _p, _p, _z, _p]),
+    "tsii_bf16_pw_bwd_dx": (_i, [_p, _l, _i, _p, _i, _p, _p, _p, _p, _p, _f, _i, _f, _p, _p, _p, _z, _p]),
+    "tsii_bf16_pw_bwd_dw_ws_bytes": (_z, [_l, _i, _i]),
+    "tsii_bf16_pw_bwd_dw": (_i, [_p, _p, _l, _i, _i, _p, _p, _i, _f, _p, _p, _p, _z, _p]),
+    "tsii_bf16_dense_ws_bytes": (_z, [_i, _i, _i, _i]),
+    "tsii_bf16_dense_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _p, _z, _p]),
+    "tsii_bf16_dense_bwd_dx": (_i, [_p, _p, _i, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _z, _p]),
+    "tsii_bf16_dense_bwd_dw_ws_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
+    "tsii_bf16_dense_bwd_dw": (_i, [_p, _p, _i, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _p, _z, _p]),
 }
 
 _LIB = None

@@ -22,7 +22,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-
 # at ~1/15 of the scalar rate (measured on MI355X, tools/probes/valu_rates.hip: 9 vs 100-180 cycles per instruction beside a
 # v_mfma_f32_32x32x16_bf16 stream).  The stencil / streaming kernels keep them: without MFMAs around they are two flops per slot.
 NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-MFMA_SOURCES = ("gemm.hip", "gemm_split.hip", "gemm_pc.hip", "head_mfma.hip")
+MFMA_SOURCES = ("gemm.hip", "gemm_split.hip", "gemm_pc.hip", "head_mfma.hip", "bf16_gemm.hip")
 
 
 def flags_for(src):

@@ -1,0 +1,842 @@
+// bf16 ACTIVATION STORAGE, matrix products: the 1x1 convolutions and (as implicit GEMM) the dense k x k convolutions of the
+// segmentation nets with bf16 activations / activation gradients in HBM, bf16 x bf16 -> fp32 on v_mfma_f32_32x32x16_bf16
+// (models/BaseModels.py:91-127, models/Xception.py:13-114, models/common.py:53-93; BASELINE config 5's "mixed bf16").
+//
+// Unlike gemm_split.hip there is nothing to split: an operand chunk is 8 bf16 = one 16-byte load that goes to LDS as it is
+// (through the producer's BatchNorm + activation when that is fused, K6b), the weights are rounded to bf16 once per call into a
+// caller workspace, and the fp32 accumulators are rounded once, on their way out.
+//   NT kernel  C[M,N] = op(A)[M,K] . B[N,K]^T : forward (A = activations, B = weights) and dX (A = dy, B = weights^T);
+//              A is a row-major matrix or the im2col VIEW of an NHWC tensor (AMODE 1 forward taps, 2 dX taps).
+//              256 threads = 4 waves, 128 x {128, 64, 32} tile, BK = 32, two LDS stages (ONE barrier per K tile), operand image
+//              [row][32 bf16] with the 16-byte chunk index XOR-swizzled by (row >> 2) & 3 (conflict free for the staging
+//              ds_write_b128 and the fragment ds_read_b128, same image as gemm_split.hip).  Epilogue through LDS: bias, RNE
+//              rounding, BatchNorm statistics partials of the ROUNDED values (K6b), the BatchNorm-backward reductions of the
+//              consumer-side fusion (K6c), 16-byte stores.
+//   TN kernel  C[P,Q] = A[M,P]^T . B[M,Q] (weight gradients): the MFMA wants 8 consecutive m per lane, i.e. both operands
+//              transposed: a thread loads a 4(m) x 8(channel) micro-tile of each operand, transposes it in registers (8
+//              dword merges per operand and channel pair) and writes 8 bytes per channel -- half of a [channel][8 m] atom at
+//              atom(c, ch) = c * 128 + (ch ^ ((ch >> 3) & 7)): a 16-lane ds_write_b64 group (8 channel octets x 2 halves)
+//              covers all 32 banks, the fragment ds_read_b128 of a 16-lane group hit 16 distinct atoms.  64-m stages, split-M
+//              partial slabs + the shared row reduction.
+#include "bf16_common.h"
+
+namespace tsii {
+
+static constexpr int HBK = 32;      // K elements per tile: one LDS row = 32 bf16 = 64 bytes = 4 chunks of 8
+__device__ __forceinline__ int h_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// im2col view of an NHWC bf16 tensor [n, h, w, c] (c % 8 == 0): row m = pixel (n, ry, rx) of the row grid [n, rh, rw], column
+// k = (tap t = ky * kw + kx, channel ci);  AMODE 1: source (ry*sh - ph + ky*dh, rx*sw - pw + kx*dw);
+// AMODE 2 (dX: rows = input pixels, source = dy): ((ry + ph - ky*dh) / sh, (rx + pw - kx*dw) / sw) where divisible.
+struct HGather {
+    int h, w, c, rh, rw, kw, sh, sw, ph, pw, dh, dw;
+};
+template <int AMODE>
+__device__ __forceinline__ bool h_conv_src(const HGather& cg, int ry, int rx, int ky, int kx, int& sy, int& sx) {
+    if (AMODE == 1) {
+        sy = ry * cg.sh - cg.ph + ky * cg.dh;
+        sx = rx * cg.sw - cg.pw + kx * cg.dw;
+        return sy >= 0 && sy < cg.h && sx >= 0 && sx < cg.w;
+    }
+    const int ty = ry + cg.ph - ky * cg.dh, tx = rx + cg.pw - kx * cg.dw;
+    if (ty < 0 || tx < 0 || (ty % cg.sh) != 0 || (tx % cg.sw) != 0) return false;
+    sy = ty / cg.sh; sx = tx / cg.sw;
+    return sy < cg.h && sx < cg.w;
+}
+
+struct HEpi {
+    const float* bias;      // [N] or NULL
+    float* stats;           // [row blocks][4][N]: (count, pivot, sum(y - pivot), sum((y - pivot)^2)) of the STORED values, or NULL
+    // K6c (BNB instantiations): the stored values are the gradient w.r.t. a = act(gamma * xhat + beta) of the raw [M, N] bf16
+    // tensor bn_y; the epilogue also leaves per row block (sum dz, sum dz * xhat), dz = stored value * act'(z)
+    const bf16_t* bn_y;
+    const float* bn_mean;
+    const float* bn_var;
+    const float* bn_gamma;
+    const float* bn_beta;
+    float bn_eps, bn_neg, bn_hi;
+    float* bn_part;         // [row blocks][2][N]
+};
+
+template <int ROWS>
+struct HChunks { static constexpr int value = (ROWS * 4 + 255) / 256; };
+
+// this thread's chunks of a ROWS x 32 tile of a row-major bf16 matrix: f = tid + 256 i -> row f >> 2, chunk f & 3.
+// BRANCH-FREE (clamped addresses, zeroed by the store pass): a branch around a load makes hipcc wait vmcnt(0) per load.
+template <int ROWS>
+__device__ __forceinline__ void h_load(const bf16_t* __restrict__ Pm, int64_t ld, int64_t row0, int64_t nrows, int k0, int K,
+                                       hu32x4 (&regs)[HChunks<ROWS>::value]) {
+    const int tid = threadIdx.x;
+    const char* __restrict__ base = reinterpret_cast<const char*>(Pm + row0 * ld);
+    const int last = (int)((nrows - row0 < ROWS) ? (nrows - row0) : ROWS) - 1;
+#pragma unroll
+    for (int i = 0; i < HChunks<ROWS>::value; ++i) {
+        const int f = tid + 256 * i;
+        int r = f >> 2;
+        r = r < last ? r : last;
+        int k = k0 + (f & 3) * 8;
+        k = k < K - 8 ? k : K - 8;                                       // K % 8 == 0, K >= 8
+        regs[i] = *reinterpret_cast<const hu32x4*>(base + (unsigned)((r * (int)ld + k) * 2));
+    }
+}
+
+template <int ROWS, bool BNIN>
+__device__ __forceinline__ void h_store(unsigned char* __restrict__ S, const hu32x4 (&regs)[HChunks<ROWS>::value], int k0, int nvalid, int K,
+                                        const InBN8& bn, float neg, float hi) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < HChunks<ROWS>::value; ++i) {
+        const int f = tid + 256 * i;
+        if (ROWS * 4 % 256 != 0 && f >= ROWS * 4) continue;
+        const int r = f >> 2, c = f & 3;
+        const bool valid = r < nvalid && k0 + c * 8 < K;
+        hu32x4 u = regs[i];
+        if constexpr (BNIN) {
+            float v[8];
+            unpack8(u, v);
+            apply_inbn8(v, bn, neg, hi);
+            u = pack8(v);
+        }
+        const hu32x4 z = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<hu32x4*>(S + h_off(r, c)) = valid ? u : z;
+    }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void h_conv_rows(const HGather& cg, int64_t row0, int64_t nrows, int (&rn)[HChunks<ROWS>::value],
+                                            int (&ry)[HChunks<ROWS>::value], int (&rx)[HChunks<ROWS>::value]) {
+#pragma unroll
+    for (int i = 0; i < HChunks<ROWS>::value; ++i) {
+        const int64_t row = row0 + ((threadIdx.x + 256 * i) >> 2);
+        rn[i] = -1; ry[i] = 0; rx[i] = 0;
+        if (row < nrows) {
+            rx[i] = (int)(row % cg.rw);
+            ry[i] = (int)((row / cg.rw) % cg.rh);
+            rn[i] = (int)(row / ((int64_t)cg.rw * cg.rh));
+        }
+    }
+}
+
+// gathered A: the thread's chunk column (8 channels of ONE tap: c % 8 == 0) advances with the K loop, its rows are fixed
+template <int ROWS, int AMODE>
+__device__ __forceinline__ void h_conv_load(const bf16_t* __restrict__ src, const HGather& cg, const int (&rn)[HChunks<ROWS>::value],
+                                            const int (&ry)[HChunks<ROWS>::value], const int (&rx)[HChunks<ROWS>::value], int k0, int K,
+                                            hu32x4 (&regs)[HChunks<ROWS>::value], unsigned& okm) {
+    int k = k0 + (threadIdx.x & 3) * 8;
+    const bool kok = k < K;
+    k = kok ? k : K - 8;
+    const int t = k / cg.c, ci = k - t * cg.c;
+    const int ky = t / cg.kw, kx = t - ky * cg.kw;
+    okm = 0u;
+#pragma unroll
+    for (int i = 0; i < HChunks<ROWS>::value; ++i) {
+        int sy = 0, sx = 0;
+        const bool ok = kok && rn[i] >= 0 && h_conv_src<AMODE>(cg, ry[i], rx[i], ky, kx, sy, sx);
+        const int64_t spix = ok ? ((int64_t)rn[i] * cg.h + sy) * cg.w + sx : 0;
+        regs[i] = ld8(src + spix * cg.c + ci);
+        okm |= ok ? (1u << i) : 0u;
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void h_conv_store(unsigned char* __restrict__ S, const hu32x4 (&regs)[HChunks<ROWS>::value], unsigned okm) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < HChunks<ROWS>::value; ++i) {
+        const int f = tid + 256 * i;
+        if (ROWS * 4 % 256 != 0 && f >= ROWS * 4) continue;
+        const hu32x4 z = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<hu32x4*>(S + h_off(f >> 2, f & 3)) = ((okm >> i) & 1u) ? regs[i] : z;
+    }
+}
+
+// ---- epilogue: accumulators -> LDS band -> (bias, round, statistics / K6c reductions) -> 16-byte bf16 stores --------------
+template <int WM, int WN, int TM, int TN, bool BNB, int SMEM_FLOATS>
+__device__ __forceinline__ void h_nt_epilogue(float* __restrict__ smem, hf32x16 (&acc)[TM][TN], bf16_t* __restrict__ C, int64_t ldc,
+                                              int64_t M, int N, const HEpi& ep, int64_t m0, int n0, unsigned rowblk) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int CS = BN + 4;                       // padded LDS row stride (floats)
+    constexpr int BAND = WM * 32;                    // rows staged per pass over t
+    constexpr int G = BN / 8;                        // 8-column groups per row
+    constexpr int RPP = 256 / G;                     // rows per store pass
+    constexpr int NPASS = BAND / RPP;
+    static_assert(BAND * CS <= SMEM_FLOATS, "epilogue band must fit the block's LDS");
+    static_assert(BAND % RPP == 0 && 256 % G == 0, "fixed column group per thread");
+    static_assert(2 * RPP * BN + BN <= SMEM_FLOATS, "statistics reduction must fit the block's LDS");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, hi = lane >> 5;
+    const int g = tid % G, rr0 = tid / G;
+    const int col = n0 + g * 8;
+    const bool col_ok = col < N;                     // N % 8 == 0: a group is all in or all out
+    float bv[8], st1[8], st2[8], pvt[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bv[e] = 0.f; st1[e] = 0.f; st2[e] = 0.f; pvt[e] = 0.f; }
+    if (ep.bias != nullptr && col_ok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = ep.bias[col + e];
+    }
+    float bmu[8], bis[8], bga[8], bbe[8];
+    if constexpr (BNB) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int cc = col_ok ? col + e : 0;
+            bmu[e] = ep.bn_mean[cc]; bis[e] = 1.0f / sqrtf(ep.bn_var[cc] + ep.bn_eps);
+            bga[e] = ep.bn_gamma[cc]; bbe[e] = ep.bn_beta[cc];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        int64_t rowv[NPASS];
+        hu32x4 yq[BNB ? NPASS : 1];
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int rr = rr0 + RPP * i;
+            rowv[i] = m0 + ((rr >> 5) * TM + t) * 32 + (rr & 31);
+            if constexpr (BNB) {
+                const hu32x4 z = {0u, 0u, 0u, 0u};
+                yq[i] = z;
+                if (rowv[i] < M && col_ok) yq[i] = ld8(ep.bn_y + rowv[i] * (int64_t)N + col);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                smem[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * CS + (wn * TN + u) * 32 + li] = acc[t][u][r];
+        __syncthreads();
+        if (t == 0 && ep.stats != nullptr) {
+            // block pivot per column: the (rounded) value of the block's first row -- any number typical of the column does, it
+            // only has to be the same for every thread of the column group
+            const float4 q0 = *reinterpret_cast<const float4*>(smem + g * 8), q1 = *reinterpret_cast<const float4*>(smem + g * 8 + 4);
+            const float qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pvt[e] = bf16_round(qv[e] + bv[e]);
+        }
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int rr = rr0 + RPP * i;
+            const int64_t row = rowv[i];
+            if (row >= M || !col_ok) continue;
+            const float4 q0 = *reinterpret_cast<const float4*>(smem + rr * CS + g * 8), q1 = *reinterpret_cast<const float4*>(smem + rr * CS + g * 8 + 4);
+            float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bv[e];
+            const hu32x4 o = pack8(v);
+            if (ep.stats != nullptr || BNB) unpack8(o, v);            // the values as stored
+            if (ep.stats != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = v[e] - pvt[e];
+                    st1[e] += d;
+                    st2[e] = fmaf(d, d, st2[e]);
+                }
+            }
+            if constexpr (BNB) {
+                float ye[8];
+                unpack8(yq[i], ye);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = (ye[e] - bmu[e]) * bis[e];
+                    const float z = fmaf(xh, bga[e], bbe[e]);
+                    const float dz = v[e] * inbn_grad(z, ep.bn_neg, ep.bn_hi);
+                    st1[e] += dz;
+                    st2[e] = fmaf(dz, xh, st2[e]);
+                }
+            }
+            st8_nt(C + row * ldc + col, o);
+        }
+    }
+    if (ep.stats == nullptr && !BNB) return;
+    // RPP threads share a column group: combine through LDS, one partial row per row block
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        smem[(rr0 * BN + g * 8 + e) * 2 + 0] = st1[e];
+        smem[(rr0 * BN + g * 8 + e) * 2 + 1] = st2[e];
+    }
+    if (rr0 == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) smem[RPP * BN * 2 + g * 8 + e] = pvt[e];
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < N) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll 4
+        for (int j = 0; j < RPP; ++j) { a1 += smem[(j * BN + tid) * 2 + 0]; a2 += smem[(j * BN + tid) * 2 + 1]; }
+        if constexpr (BNB) {
+            float* sp = ep.bn_part + (int64_t)rowblk * 2 * N;
+            sp[n0 + tid] = a1;
+            sp[N + n0 + tid] = a2;
+        } else {
+            float* sp = ep.stats + (int64_t)rowblk * 4 * N;
+            const int64_t left = M - m0;
+            sp[n0 + tid] = (float)(left < BM ? left : BM);
+            sp[N + n0 + tid] = smem[RPP * BN * 2 + tid];
+            sp[2 * N + n0 + tid] = a1;
+            sp[3 * N + n0 + tid] = a2;
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int AMODE, bool BNIN, bool BNB>
+__global__ __launch_bounds__(256) void hgemm_nt_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
+                                                       bf16_t* __restrict__ C, int64_t ldc, int64_t M, int N, int K, HEpi ep, unsigned ntn,
+                                                       InBN ib, HGather cg) {
+    constexpr bool CONV = AMODE != 0;
+    static_assert(!CONV || !BNIN, "the gathered operand has no BatchNorm-on-load form");
+    static_assert(WM * WN == 4, "4 waves per block");
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int STAGE_BYTES = (BM + BN) * 64;
+    constexpr int OP_FLOATS = 2 * STAGE_BYTES / 4;               // two stages
+    constexpr int EP_FLOATS = WM * 32 * (BN + 4);
+    constexpr int ST_FLOATS = 2 * (256 / (BN / 8)) * BN + BN;
+    constexpr int SMEM_FLOATS = OP_FLOATS > EP_FLOATS ? (OP_FLOATS > ST_FLOATS ? OP_FLOATS : ST_FLOATS) : (EP_FLOATS > ST_FLOATS ? EP_FLOATS : ST_FLOATS);
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    unsigned char* S0 = reinterpret_cast<unsigned char*>(smem);
+
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t m0 = (int64_t)(bid / ntn) * BM;
+    const int n0 = (int)(bid % ntn) * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, hi = lane >> 5;
+
+    hf32x16 acc[TM][TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    constexpr int NA = HChunks<BM>::value, NB = HChunks<BN>::value;
+    const int mvalid = (int)((M - m0 < BM) ? (M - m0) : BM), nvalid = (N - n0 < BN) ? (N - n0) : BN;
+    hu32x4 ra[NA], rb[NB];
+    int rn[NA], ry[NA], rx[NA];
+    unsigned okm = 0u;
+    InBN8 bn;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bn.sc[e] = 0.f; bn.sh[e] = 0.f; }
+    const int pk = (tid & 3) * 8;
+    if constexpr (CONV) {
+        h_conv_rows<BM>(cg, m0, M, rn, ry, rx);
+        h_conv_load<BM, AMODE>(A, cg, rn, ry, rx, 0, K, ra, okm);
+    } else {
+        h_load<BM>(A, lda, m0, M, 0, K, ra);
+    }
+    h_load<BN>(B, K, n0, N, 0, K, rb);
+    if constexpr (BNIN) load_inbn8(ib, pk < K ? pk : K - 8, bn);
+    if constexpr (CONV) h_conv_store<BM>(S0, ra, okm);
+    else h_store<BM, BNIN>(S0, ra, 0, mvalid, K, bn, ib.neg, ib.hi);
+    h_store<BN, false>(S0 + BM * 64, rb, 0, nvalid, K, bn, 1.f, 0.f);
+    __syncthreads();
+
+    // fragment addresses: row li of a 32-row tile, k-chunk 2s + hi; the swizzle term depends on li only
+    const int swz = (li >> 2) & 3;
+    const int fo0 = li * 64 + (((0 + hi) ^ swz) << 4), fo1 = li * 64 + (((2 + hi) ^ swz) << 4);
+
+    const int nk = (K + HBK - 1) / HBK;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1 < nk);
+        unsigned char* Sc = S0 + (kt & 1) * STAGE_BYTES;
+        unsigned char* Sn = S0 + ((kt + 1) & 1) * STAGE_BYTES;
+        if (more) {          // the next tile's global loads fly during the MFMA phase
+            if constexpr (CONV) h_conv_load<BM, AMODE>(A, cg, rn, ry, rx, (kt + 1) * HBK, K, ra, okm);
+            else h_load<BM>(A, lda, m0, M, (kt + 1) * HBK, K, ra);
+            h_load<BN>(B, K, n0, N, (kt + 1) * HBK, K, rb);
+        }
+        const unsigned char* Aw = Sc + (wm * TM) * 32 * 64;
+        const unsigned char* Bw = Sc + BM * 64 + (wn * TN) * 32 * 64;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int fo = s == 0 ? fo0 : fo1;
+            hbf16x8 b[TN];
+#pragma unroll
+            for (int u = 0; u < TN; ++u) b[u] = __builtin_bit_cast(hbf16x8, *reinterpret_cast<const hu32x4*>(Bw + u * (32 * 64) + fo));
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const hbf16x8 a = __builtin_bit_cast(hbf16x8, *reinterpret_cast<const hu32x4*>(Aw + t * (32 * 64) + fo));
+#pragma unroll
+                for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[u], acc[t][u], 0, 0, 0);
+            }
+        }
+        if (more) {
+            if constexpr (BNIN) {       // (scale, shift) of the next tile's channels: L2 hits, fetched behind the MFMA phase
+                const int k = (kt + 1) * HBK + pk;
+                load_inbn8(ib, k < K ? k : K - 8, bn);
+            }
+            // the other stage was last read one iteration ago, before the barrier every wave has passed since
+            if constexpr (CONV) h_conv_store<BM>(Sn, ra, okm);
+            else h_store<BM, BNIN>(Sn, ra, (kt + 1) * HBK, mvalid, K, bn, ib.neg, ib.hi);
+            h_store<BN, false>(Sn + BM * 64, rb, (kt + 1) * HBK, nvalid, K, bn, 1.f, 0.f);
+        }
+        __syncthreads();
+    }
+    h_nt_epilogue<WM, WN, TM, TN, BNB, SMEM_FLOATS>(smem, acc, C, ldc, M, N, ep, m0, n0, bid / ntn);
+}
+
+// ---- TN (weight gradients) ------------------------------------------------------------------------------------------------
+static constexpr int HTN_STAGE = 64;         // m rows per stage
+__device__ __forceinline__ int htn_atom(int c, int ch) { return c * 128 + (ch ^ ((ch >> 3) & 7)); }
+
+// this thread's 4(m) x 8(channel) micro-tile of a row-major bf16 matrix; rows / columns outside are clamped (zeroed at the store)
+__device__ __forceinline__ void htn_load(const bf16_t* __restrict__ Pm, int64_t ld, int64_t m0, int64_t mend, int c0, int ncols, int co, int mq,
+                                         hu32x4 (&regs)[4]) {
+    const char* __restrict__ base = reinterpret_cast<const char*>(Pm + m0 * ld);
+    const int last = (int)((mend - m0 < HTN_STAGE) ? (mend - m0) : HTN_STAGE) - 1;
+    int c = c0 + co * 8;
+    c = c < ncols - 8 ? c : ncols - 8;                                   // ncols % 8 == 0, ncols >= 8
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        int r = mq * 4 + jj;
+        r = r < last ? r : last;
+        regs[jj] = *reinterpret_cast<const hu32x4*>(base + ((int64_t)r * ld + c) * 2);
+    }
+}
+// gathered B (dW of a dense conv): the thread's column octet is ONE (tap, 8 channels) for the whole block, rows = output pixels
+__device__ __forceinline__ void htn_conv_load(const bf16_t* __restrict__ src, const HGather& cg, int64_t m0, int64_t mend, int ky, int kx, int ci,
+                                              bool kok, int mq, hu32x4 (&regs)[4], unsigned& okm) {
+    okm = 0u;
+    const int64_t last = mend - 1;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        int64_t row = m0 + mq * 4 + jj;
+        const bool in = row <= last;
+        row = in ? row : last;
+        const int64_t q = row / cg.rw;
+        const int rx = (int)(row - q * cg.rw);
+        const int64_t n = q / cg.rh;
+        const int ry = (int)(q - n * cg.rh);
+        int sy = 0, sx = 0;
+        const bool ok = in && kok && h_conv_src<1>(cg, ry, rx, ky, kx, sy, sx);
+        const int64_t spix = ok ? (n * cg.h + sy) * cg.w + sx : 0;
+        regs[jj] = ld8(src + spix * cg.c + ci);
+        okm |= ok ? (1u << jj) : 0u;
+    }
+}
+// (BatchNorm + activation) -> zero outside -> 4 x 8 register transpose -> 8 bytes per channel into the [channel][8 m] atoms
+template <bool BNIN>
+__device__ __forceinline__ void htn_store(unsigned char* __restrict__ S, hu32x4 (&regs)[4], int co, int mq, unsigned rowmask, bool col_ok,
+                                          const InBN8& bn, float neg, float hi) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        if constexpr (BNIN) {
+            float v[8];
+            unpack8(regs[jj], v);
+            apply_inbn8(v, bn, neg, hi);
+            regs[jj] = pack8(v);
+        }
+        const hu32x4 z = {0u, 0u, 0u, 0u};
+        regs[jj] = (col_ok && ((rowmask >> jj) & 1u)) ? regs[jj] : z;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int j = e >> 1;
+        unsigned d0, d1;
+        if ((e & 1) == 0) {
+            d0 = (regs[0][j] & 0xffffu) | (regs[1][j] << 16);
+            d1 = (regs[2][j] & 0xffffu) | (regs[3][j] << 16);
+        } else {
+            d0 = (regs[0][j] >> 16) | (regs[1][j] & 0xffff0000u);
+            d1 = (regs[2][j] >> 16) | (regs[3][j] & 0xffff0000u);
+        }
+        const int off = htn_atom(mq >> 1, co * 8 + e) * 16 + (mq & 1) * 8;
+        *reinterpret_cast<hu32x2*>(S + off) = hu32x2{d0, d1};
+    }
+}
+
+template <bool BNIN, bool BCONV>
+__global__ __launch_bounds__(256) void hgemm_tn_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                       float* __restrict__ Cws, int64_t M, int Pn, int Q, int64_t chunk, InBN ib,
+                                                       unsigned qtiles, unsigned ptiles, HGather cg) {
+    static_assert(!BCONV || !BNIN, "the gathered operand has no BatchNorm-on-load form");
+    constexpr int OPB = 8 * 128 * 16;                  // one operand stage: 8 m-chunks x 128 channels x 16 bytes
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * OPB];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + OPB;
+
+    // 1-D grid, XCD-aware: the (p, q) tiles of one m-chunk get consecutive logical ids = one XCD (their panel re-reads hit its L2)
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned zsplit = bid / (qtiles * ptiles), rem = bid % (qtiles * ptiles);
+    const int q0 = (int)(rem % qtiles) * 128, p0 = (int)(rem / qtiles) * 128;
+    const int64_t mbeg = (int64_t)zsplit * chunk;
+    const int64_t mend = (mbeg + chunk < M) ? mbeg + chunk : M;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, hi = lane >> 5;
+    const int co = (lane & 7) | (((lane >> 4) & 1) << 3);                       // channel octet 0..15
+    const int mq = ((lane >> 3) & 1) | ((lane >> 5) << 1) | (wave << 2);        // m quad 0..15
+
+    hf32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    InBN8 bn;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bn.sc[e] = 0.f; bn.sh[e] = 0.f; }
+    const bool acol_ok = p0 + co * 8 < Pn, bcol_ok = q0 + co * 8 < Q;
+    if constexpr (BNIN) load_inbn8(ib, bcol_ok ? q0 + co * 8 : Q - 8, bn);     // this thread's 8 B columns, fixed for the block
+    int cky = 0, ckx = 0, cci = 0;
+    if constexpr (BCONV) {
+        const int k = bcol_ok ? q0 + co * 8 : Q - 8;
+        const int t = k / cg.c;
+        cci = k - t * cg.c;
+        cky = t / cg.kw; ckx = t - cky * cg.kw;
+    }
+    hu32x4 ra[4], rb[4];
+    unsigned okm = 0u;
+    auto rowmask = [&](int64_t m0s) -> unsigned {
+        const int left = (int)((mend - m0s < HTN_STAGE) ? (mend - m0s) : HTN_STAGE);
+        unsigned mk = 0u;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) mk |= (mq * 4 + jj < left) ? (1u << jj) : 0u;
+        return mk;
+    };
+    auto load_stage = [&](int64_t m0s) {
+        htn_load(A, lda, m0s, mend, p0, Pn, co, mq, ra);
+        if constexpr (BCONV) htn_conv_load(B, cg, m0s, mend, cky, ckx, cci, bcol_ok, mq, rb, okm);
+        else htn_load(B, ldb, m0s, mend, q0, Q, co, mq, rb);
+    };
+    auto store_stage = [&](int64_t m0s) {
+        const unsigned mk = rowmask(m0s);
+        htn_store<false>(As, ra, co, mq, mk, acol_ok, bn, 1.f, 0.f);
+        if constexpr (BCONV) htn_store<false>(Bs, rb, co, mq, okm, bcol_ok, bn, 1.f, 0.f);
+        else htn_store<BNIN>(Bs, rb, co, mq, mk, bcol_ok, bn, ib.neg, ib.hi);
+    };
+    load_stage(mbeg);
+    store_stage(mbeg);
+    __syncthreads();
+
+    int foA[2][4], foB[2][4];          // fragment byte offsets: channel li of wave tile t, m-chunk 2s + hi
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            foA[t][s] = htn_atom(2 * s + hi, (wm * 2 + t) * 32 + li) * 16;
+            foB[t][s] = htn_atom(2 * s + hi, (wn * 2 + t) * 32 + li) * 16;
+        }
+    auto mfma_phase = [&]() {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            hbf16x8 b[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) b[u] = __builtin_bit_cast(hbf16x8, *reinterpret_cast<const hu32x4*>(Bs + foB[u][s]));
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const hbf16x8 a = __builtin_bit_cast(hbf16x8, *reinterpret_cast<const hu32x4*>(As + foA[t][s]));
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[u], acc[t][u], 0, 0, 0);
+            }
+        }
+    };
+    // every iteration loads the NEXT stage unconditionally (the last stage is peeled)
+    for (int64_t mt = mbeg; mt + HTN_STAGE < mend; mt += HTN_STAGE) {
+        load_stage(mt + HTN_STAGE);
+        mfma_phase();
+        __syncthreads();
+        store_stage(mt + HTN_STAGE);
+        __syncthreads();
+    }
+    mfma_phase();
+
+    float* Cz = Cws + (int64_t)zsplit * Pn * Q;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = p0 + (wm * 2 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (p >= Pn) continue;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = q0 + (wn * 2 + u) * 32 + li;
+                if (q < Q) Cz[(int64_t)p * Q + q] = acc[t][u][r];
+            }
+        }
+}
+
+// ---- weights: fp32 reference layout -> the bf16 B operand of the NT kernel, once per call ----------------------------------
+//   mode 0 (1x1 forward)   out[n][k]              = w[n][k]
+//   mode 1 (1x1 dX)        out[k][n]              = w[n][k]
+//   mode 2 (dense forward) out[co][t*cin + ci]    = w[co][ci][t]
+//   mode 3 (dense dX)      out[ci][t*cout + co]   = w[co][ci][t]
+__global__ void hprep_w_kernel(const float* __restrict__ w, int cout, int cin, int T, int mode, bf16_t* __restrict__ out) {
+    const int64_t total = (int64_t)cout * cin * T;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t src;
+        if (mode == 0) src = i;
+        else if (mode == 1) { const int k = (int)(i / cout), n = (int)(i % cout); src = (int64_t)n * cin + k; }
+        else if (mode == 2) { const int co = (int)(i / ((int64_t)T * cin)); const int r = (int)(i % ((int64_t)T * cin)); const int t = r / cin, ci = r % cin; src = ((int64_t)co * cin + ci) * T + t; }
+        else { const int ci = (int)(i / ((int64_t)T * cout)); const int r = (int)(i % ((int64_t)T * cout)); const int t = r / cout, co = r % cout; src = ((int64_t)co * cin + ci) * T + t; }
+        out[i] = bf16_bits(w[src]);
+    }
+}
+
+// column sums of a bf16 [M, N] matrix (bias gradients): partial rows, then the shared row reduction
+__global__ __launch_bounds__(256) void hcolsum_kernel(const bf16_t* __restrict__ a, int64_t M, int N, int R, float* __restrict__ part) {
+    const int G = N / 8;
+    const int64_t tasks = (int64_t)R * G;
+    for (int64_t task = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; task < tasks; task += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(task % G) * 8;
+        const int r = (int)(task / G);
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int64_t m = r; m < M; m += R) {
+            float v[8];
+            unpack8(ld8(a + m * N + c), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[(int64_t)r * N + c + e] = s[e];
+    }
+}
+
+static const HGather kNoHGather = {0, 0, 8, 1, 1, 1, 1, 1, 0, 0, 1, 1};
+
+static inline bf16_t* ws_align16(void* ws) { return reinterpret_cast<bf16_t*>((reinterpret_cast<uintptr_t>(ws) + 15) & ~(uintptr_t)15); }
+
+template <int WM, int WN, int TM, int TN>
+static int launch_hnt_cfg(int amode, const bf16_t* A, int64_t lda, const bf16_t* B, bf16_t* C, int64_t ldc, int64_t M, int N, int K,
+                          const HEpi& ep, const InBN& ib, const HGather& cg, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const unsigned ntn = (unsigned)cdiv(N, BN);
+    const int64_t nblocks = cdiv64(M, BM) * ntn;
+    TSII_REQUIRE(nblocks < (1ll << 31), "bf16 gemm_nt: grid too large");
+    const dim3 grid((unsigned)nblocks);
+#define TSII_HNT(AM, BI, BB) hipLaunchKernelGGL((hgemm_nt_kernel<WM, WN, TM, TN, AM, BI, BB>), grid, dim3(256), 0, st, A, lda, B, C, ldc, M, N, K, ep, ntn, ib, cg)
+    if (amode == 1) TSII_HNT(1, false, false);
+    else if (amode == 2) TSII_HNT(2, false, false);
+    else if (ep.bn_y != nullptr) TSII_HNT(0, false, true);
+    else if (ib.sc != nullptr) TSII_HNT(0, true, false);
+    else TSII_HNT(0, false, false);
+#undef TSII_HNT
+    return check_launch("bf16 gemm_nt");
+}
+
+// A: [M, K] bf16 (amode 0, lda) or gathered by cg (1 / 2); B: bf16 [N, K]; C: bf16 [M, N] (ldc)
+static int launch_hnt(int amode, const bf16_t* A, int64_t lda, const bf16_t* B, bf16_t* C, int64_t ldc, int64_t M, int N, int K,
+                      const HEpi& ep, const InBN& ib, const HGather& cg, hipStream_t st) {
+    TSII_REQUIRE(K % 8 == 0 && K >= 8 && N % 8 == 0 && ldc % 8 == 0 && (amode != 0 || lda % 8 == 0), "bf16 gemm_nt: K, N and the row strides must be multiples of 8");
+    TSII_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C), "bf16 gemm_nt: operands must be 16-byte aligned");
+    TSII_REQUIRE(!(ep.bn_y != nullptr && (ib.sc != nullptr || amode != 0 || ldc != N)), "bf16 gemm_nt: the BatchNorm-backward epilogue is a plain-operand form");
+    if (N % 128 == 0 || N > 192) return launch_hnt_cfg<2, 2, 2, 2>(amode, A, lda, B, C, ldc, M, N, K, ep, ib, cg, st);
+    if (N > 32) return launch_hnt_cfg<2, 2, 2, 1>(amode, A, lda, B, C, ldc, M, N, K, ep, ib, cg, st);
+    return launch_hnt_cfg<4, 1, 1, 1>(amode, A, lda, B, C, ldc, M, N, K, ep, ib, cg, st);
+}
+
+// split of the M rows of a weight-gradient product into chunks (multiples of the 64-row stage): enough blocks to fill the chip
+static void htn_plan(int64_t M, int Pn, int Q, int64_t* chunk, int* splits) {
+    const int64_t tiles = (int64_t)cdiv(Pn, 128) * cdiv(Q, 128);
+    int64_t want = cdiv64(768, tiles);
+    const int64_t stages = cdiv64(M, HTN_STAGE);
+    if (want > stages) want = stages;
+    if (want > 256) want = 256;
+    if (want < 1) want = 1;
+    const int64_t per = cdiv64(stages, want);
+    *chunk = per * HTN_STAGE;
+    *splits = (int)cdiv64(M, *chunk);
+}
+static size_t htn_ws_floats(int64_t M, int Pn, int Q) {
+    int64_t chunk; int splits;
+    htn_plan(M, Pn, Q, &chunk, &splits);
+    return (size_t)splits * Pn * Q;
+}
+// slabs of partial [Pn, Q] products in ws (htn_ws_floats floats); returns the number of slabs in *nslabs
+static int launch_htn(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, bool bconv, const HGather& cg, float* ws, int64_t M, int Pn, int Q,
+                      const InBN& ib, int* nslabs, hipStream_t st) {
+    TSII_REQUIRE(Pn % 8 == 0 && Q % 8 == 0 && lda % 8 == 0 && (bconv || ldb % 8 == 0) && aligned16(A) && aligned16(B), "bf16 gemm_tn: channel counts must be multiples of 8, operands 16-byte aligned");
+    TSII_REQUIRE(M > 0 && M < (1ll << 40), "bf16 gemm_tn: bad row count");
+    int64_t chunk; int splits;
+    htn_plan(M, Pn, Q, &chunk, &splits);
+    const unsigned qt = (unsigned)cdiv(Q, 128), pt = (unsigned)cdiv(Pn, 128);
+    const int64_t nblocks = (int64_t)qt * pt * splits;
+    TSII_REQUIRE(nblocks < (1ll << 31), "bf16 gemm_tn: grid too large");
+    const dim3 grid((unsigned)nblocks);
+    if (bconv) hipLaunchKernelGGL((hgemm_tn_kernel<false, true>), grid, dim3(256), 0, st, A, lda, B, ldb, ws, M, Pn, Q, chunk, ib, qt, pt, cg);
+    else if (ib.sc != nullptr) hipLaunchKernelGGL((hgemm_tn_kernel<true, false>), grid, dim3(256), 0, st, A, lda, B, ldb, ws, M, Pn, Q, chunk, ib, qt, pt, cg);
+    else hipLaunchKernelGGL((hgemm_tn_kernel<false, false>), grid, dim3(256), 0, st, A, lda, B, ldb, ws, M, Pn, Q, chunk, ib, qt, pt, cg);
+    *nslabs = splits;
+    return check_launch("bf16 gemm_tn");
+}
+
+static int prep_weights(const float* w, int cout, int cin, int T, int mode, bf16_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(hprep_w_kernel, dim3(stream_grid((int64_t)cout * cin * T, 256)), dim3(256), 0, st, w, cout, cin, T, mode, out);
+    return check_launch("bf16 prep_w");
+}
+
+static inline int hcolsum_rows(int64_t M, int N) { return partial_rows(M, N / 8); }
+static int launch_hcolsum(const bf16_t* a, int64_t M, int N, float* out, float* ws, hipStream_t st) {
+    const int R = hcolsum_rows(M, N);
+    hipLaunchKernelGGL(hcolsum_kernel, dim3(stream_grid((int64_t)R * (N / 8), 256)), dim3(256), 0, st, a, M, N, R, ws);
+    int rc = check_launch("bf16 colsum");
+    if (rc) return rc;
+    return launch_reduce_rows(ws, R, N, out, st);
+}
+
+static int make_inbn_checked(const float* sc, const float* sh, int act, float slope, InBN* ib, const char* who) {
+    if (sc == nullptr) { ib->sc = nullptr; ib->sh = nullptr; ib->neg = 1.f; ib->hi = __builtin_huge_valf(); return 0; }
+    TSII_REQUIRE(sh != nullptr && aligned16(sc) && aligned16(sh), "%s: in_scale / in_shift go together and must be 16-byte aligned", who);
+    TSII_REQUIRE(make_in_bn(sc, sh, act, slope, ib) == 0, "%s: activation %d (slope %g) has no load-time form", who, act, (double)slope);
+    return 0;
+}
+
+static HGather make_gather(int h, int w, int c, int rh, int rw, int kw, int sh, int sw, int ph, int pw, int dh, int dw) {
+    HGather g = {h, w, c, rh, rw, kw, sh, sw, ph, pw, dh, dw};
+    return g;
+}
+
+}  // namespace tsii
+
+using namespace tsii;
+
+// ================================================================================================================================
+// C ABI (include/tsii_hip.h, "bf16 activation storage")
+// ================================================================================================================================
+extern "C" int64_t tsii_bf16_stat_rows(int64_t m) { return m > 0 ? cdiv64(m, 128) : 0; }
+
+extern "C" size_t tsii_bf16_pw_ws_bytes(int n, int k) { return (n > 0 && k > 0) ? (size_t)n * k * sizeof(bf16_t) + 16 : 0; }
+
+extern "C" int tsii_bf16_pw_fwd(const uint16_t* x, int64_t m, int k, const float* w, int n, const float* bias,
+                                const float* in_scale, const float* in_shift, int in_act, float in_slope,
+                                float* stat_part, uint16_t* y, void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(x && w && y && ws, "bf16_pw_fwd: null pointer");
+    TSII_REQUIRE(m > 0 && k > 0 && n > 0 && k % 8 == 0 && n % 8 == 0, "bf16_pw_fwd: channel counts must be positive multiples of 8 (got k=%d n=%d)", k, n);
+    TSII_REQUIRE(ws_bytes >= tsii_bf16_pw_ws_bytes(n, k), "bf16_pw_fwd: workspace too small (tsii_bf16_pw_ws_bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    InBN ib;
+    if (make_inbn_checked(in_scale, in_shift, in_act, in_slope, &ib, "bf16_pw_fwd")) return -1;
+    bf16_t* wb = ws_align16(ws);
+    int rc = prep_weights(w, n, k, 1, 0, wb, st);
+    if (rc) return rc;
+    HEpi ep = {bias, stat_part, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 1.f, 0.f, nullptr};
+    return launch_hnt(0, x, k, wb, y, n, m, n, k, ep, ib, kNoHGather, st);
+}
+
+extern "C" int tsii_bf16_pw_bwd_dx(const uint16_t* dy, int64_t m, int n, const float* w, int k,
+                                   const uint16_t* bn_y, const float* bn_mean, const float* bn_var, const float* bn_gamma,
+                                   const float* bn_beta, float bn_eps, int bn_act, float bn_slope,
+                                   uint16_t* dx, float* bwd_part, void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(dy && w && dx && ws, "bf16_pw_bwd_dx: null pointer");
+    TSII_REQUIRE(m > 0 && k > 0 && n > 0 && k % 8 == 0 && n % 8 == 0, "bf16_pw_bwd_dx: channel counts must be positive multiples of 8");
+    TSII_REQUIRE(ws_bytes >= tsii_bf16_pw_ws_bytes(n, k), "bf16_pw_bwd_dx: workspace too small (tsii_bf16_pw_ws_bytes)");
+    TSII_REQUIRE((bn_y == nullptr) == (bwd_part == nullptr), "bf16_pw_bwd_dx: bn_y and bwd_part go together");
+    hipStream_t st = (hipStream_t)stream;
+    bf16_t* wb = ws_align16(ws);
+    int rc = prep_weights(w, n, k, 1, 1, wb, st);       // [k][n]
+    if (rc) return rc;
+    HEpi ep = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 1.f, 0.f, nullptr};
+    InBN none = {nullptr, nullptr, 1.f, __builtin_huge_valf()};
+    if (bn_y != nullptr) {
+        TSII_REQUIRE(bn_mean && bn_var && bn_gamma && bn_beta, "bf16_pw_bwd_dx: BatchNorm parameters missing");
+        InBN tmp;
+        TSII_REQUIRE(make_in_bn(bn_mean, bn_var, bn_act, bn_slope, &tmp) == 0, "bf16_pw_bwd_dx: activation %d has no load-time form", bn_act);
+        ep.bn_y = bn_y; ep.bn_mean = bn_mean; ep.bn_var = bn_var; ep.bn_gamma = bn_gamma; ep.bn_beta = bn_beta;
+        ep.bn_eps = bn_eps; ep.bn_neg = tmp.neg; ep.bn_hi = tmp.hi; ep.bn_part = bwd_part;
+    }
+    return launch_hnt(0, dy, n, wb, dx, k, m, k, n, ep, none, kNoHGather, st);
+}
+
+extern "C" size_t tsii_bf16_pw_bwd_dw_ws_bytes(int64_t m, int n, int k) {
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    const size_t slabs = htn_ws_floats(m, n, k);
+    const size_t bias = (size_t)hcolsum_rows(m, n) * n;
+    return (slabs > bias ? slabs : bias) * sizeof(float) + 16;
+}
+
+extern "C" int tsii_bf16_pw_bwd_dw(const uint16_t* dy, const uint16_t* x, int64_t m, int n, int k,
+                                   const float* in_scale, const float* in_shift, int in_act, float in_slope,
+                                   float* dw, float* dbias, void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(dy && x && dw && ws, "bf16_pw_bwd_dw: null pointer");
+    TSII_REQUIRE(m > 0 && k > 0 && n > 0 && k % 8 == 0 && n % 8 == 0, "bf16_pw_bwd_dw: channel counts must be positive multiples of 8");
+    TSII_REQUIRE(ws_bytes >= tsii_bf16_pw_bwd_dw_ws_bytes(m, n, k), "bf16_pw_bwd_dw: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    InBN ib;
+    if (make_inbn_checked(in_scale, in_shift, in_act, in_slope, &ib, "bf16_pw_bwd_dw")) return -1;
+    float* wsf = reinterpret_cast<float*>(ws_align16(ws));
+    int slabs = 0;
+    int rc = launch_htn(dy, n, x, k, false, kNoHGather, wsf, m, n, k, ib, &slabs, st);
+    if (rc) return rc;
+    rc = launch_reduce_rows(wsf, slabs, (int64_t)n * k, dw, st);
+    if (rc) return rc;
+    if (dbias != nullptr) return launch_hcolsum(dy, m, n, dbias, wsf, st);
+    return 0;
+}
+
+// ---- dense k x k convolutions as implicit GEMM ------------------------------------------------------------------------------
+extern "C" size_t tsii_bf16_dense_ws_bytes(int cin, int cout, int kh, int kw) {
+    return (cin > 0 && cout > 0 && kh > 0 && kw > 0) ? (size_t)cin * cout * kh * kw * sizeof(bf16_t) + 16 : 0;
+}
+
+static int dense_geom_ok(const char* who, int n, int h, int wd, int cin, int cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo) {
+    TSII_REQUIRE(n > 0 && h > 0 && wd > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0 && ph >= 0 && pw >= 0, "%s: bad geometry", who);
+    TSII_REQUIRE(cin % 8 == 0 && cout % 8 == 0, "%s: channel counts must be multiples of 8 (got %d -> %d); pad on the host side", who, cin, cout);
+    TSII_REQUIRE(ho == (h + 2 * ph - dh * (kh - 1) - 1) / sh + 1 && wo == (wd + 2 * pw - dw * (kw - 1) - 1) / sw + 1, "%s: output size does not match the geometry", who);
+    TSII_REQUIRE((int64_t)n * h * wd < (1ll << 31) && (int64_t)n * ho * wo < (1ll << 31), "%s: more than 2^31 pixels", who);
+    return 0;
+}
+
+extern "C" int tsii_bf16_dense_fwd(const uint16_t* x, const float* w, const float* bias, int n, int h, int wd, int cin, int cout,
+                                   int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo,
+                                   float* stat_part, uint16_t* y, void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(x && w && y && ws, "bf16_dense_fwd: null pointer");
+    if (dense_geom_ok("bf16_dense_fwd", n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo)) return -1;
+    TSII_REQUIRE(ws_bytes >= tsii_bf16_dense_ws_bytes(cin, cout, kh, kw), "bf16_dense_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    bf16_t* wb = ws_align16(ws);
+    int rc = prep_weights(w, cout, cin, kh * kw, 2, wb, st);
+    if (rc) return rc;
+    const HGather cg = make_gather(h, wd, cin, ho, wo, kw, sh, sw, ph, pw, dh, dw);
+    HEpi ep = {bias, stat_part, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 1.f, 0.f, nullptr};
+    InBN none = {nullptr, nullptr, 1.f, __builtin_huge_valf()};
+    return launch_hnt(1, x, 0, wb, y, cout, (int64_t)n * ho * wo, cout, kh * kw * cin, ep, none, cg, st);
+}
+
+extern "C" int tsii_bf16_dense_bwd_dx(const uint16_t* dy, const float* w, int n, int h, int wd, int cin, int cout,
+                                      int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo,
+                                      uint16_t* dx, void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(dy && w && dx && ws, "bf16_dense_bwd_dx: null pointer");
+    if (dense_geom_ok("bf16_dense_bwd_dx", n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo)) return -1;
+    TSII_REQUIRE(ws_bytes >= tsii_bf16_dense_ws_bytes(cin, cout, kh, kw), "bf16_dense_bwd_dx: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    bf16_t* wb = ws_align16(ws);
+    int rc = prep_weights(w, cout, cin, kh * kw, 3, wb, st);      // [ci][t * cout + co]
+    if (rc) return rc;
+    // rows = input pixels, source = dy [n, ho, wo, cout]
+    const HGather cg = make_gather(ho, wo, cout, h, wd, kw, sh, sw, ph, pw, dh, dw);
+    HEpi ep = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 1.f, 0.f, nullptr};
+    InBN none = {nullptr, nullptr, 1.f, __builtin_huge_valf()};
+    return launch_hnt(2, dy, 0, wb, dx, cin, (int64_t)n * h * wd, cin, kh * kw * cout, ep, none, cg, st);
+}
+
+extern "C" size_t tsii_bf16_dense_bwd_dw_ws_bytes(int n, int ho, int wo, int cin, int cout, int kh, int kw) {
+    if (n <= 0 || ho <= 0 || wo <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0) return 0;
+    const int64_t m = (int64_t)n * ho * wo;
+    const size_t slabs = htn_ws_floats(m, cout, kh * kw * cin);
+    const size_t bias = (size_t)hcolsum_rows(m, cout) * cout;
+    return (slabs > bias ? slabs : bias) * sizeof(float) + 16;
+}
+
+extern "C" int tsii_bf16_dense_bwd_dw(const uint16_t* dy, const uint16_t* x, int n, int h, int wd, int cin, int cout,
+                                      int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo,
+                                      float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(dy && x && dwgt && ws, "bf16_dense_bwd_dw: null pointer");
+    if (dense_geom_ok("bf16_dense_bwd_dw", n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo)) return -1;
+    TSII_REQUIRE(ws_bytes >= tsii_bf16_dense_bwd_dw_ws_bytes(n, ho, wo, cin, cout, kh, kw), "bf16_dense_bwd_dw: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t m = (int64_t)n * ho * wo;
+    const HGather cg = make_gather(h, wd, cin, ho, wo, kw, sh, sw, ph, pw, dh, dw);
+    InBN none = {nullptr, nullptr, 1.f, __builtin_huge_valf()};
+    float* wsf = reinterpret_cast<float*>(ws_align16(ws));
+    int slabs = 0;
+    int rc = launch_htn(dy, cout, x, 0, true, cg, wsf, m, cout, kh * kw * cin, none, &slabs, st);
+    if (rc) return rc;
+    rc = launch_reduce_rows_conv(wsf, slabs, cout, cin, kh * kw, dwgt, st);      // [co][t][ci] partials -> [co][ci][t]
+    if (rc) return rc;
+    if (dbias != nullptr) return launch_hcolsum(dy, m, cout, dbias, wsf, st);
+    return 0;
+}
