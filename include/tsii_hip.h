@@ -435,6 +435,33 @@ int tsii_bf16_dense_bwd_dw(const uint16_t* dy, const uint16_t* x, int n, int h, 
                            int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo,
                            float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- depth-wise 3x3 convolutions (Conv_block(groups = C), models/BaseModels.py:105-127) and stride-1 average pools -------
+ * w: reference layout [c,1,3,3] fp32.  Geometry: 3x3, stride 1 with any dilation or stride 2 with dilation 1, square padding.
+ * in_scale / in_shift / stat_part: K6b as for the fp32 entry points (the virtual activation a = act(in_scale*x + in_shift) is
+ * rounded to bf16 like a stored one; zero padding pads a).  tsii_bf16_dw_stat_rows: rows of stat_part [rows][4][c] (0: geometry
+ * not supported).  The forward and the stride-1 dX are one kernel (the adjoint is the same stencil with flipped taps). */
+int64_t tsii_bf16_dw_stat_rows(int n, int ho, int wo, int c, int kh, int kw, int sh, int sw, int dh, int dw);
+int tsii_bf16_dw_fwd(const uint16_t* x, const float* w, const float* bias, int n, int h, int wd, int c,
+                     int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo,
+                     const float* in_scale, const float* in_shift, int in_act, float in_slope,
+                     float* stat_part, uint16_t* y, void* stream);
+/* K6c: with bn_y (the raw [n,h,wd,c] tensor this conv consumed through its load-time BatchNorm) the kernel also leaves
+ * bwd_part[tsii_bf16_dw_bwd_stat_rows(..)][2][c]; rows == 0 (stride 2): pass NULL and run tsii_bf16_bn_act_bwd instead */
+int64_t tsii_bf16_dw_bwd_stat_rows(int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw);
+int tsii_bf16_dw_bwd_dx(const uint16_t* dy, const float* w, int n, int h, int wd, int c,
+                        int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo,
+                        const uint16_t* bn_y, const float* bn_mean, const float* bn_var, const float* bn_gamma,
+                        const float* bn_beta, float bn_eps, int bn_act, float bn_slope,
+                        uint16_t* dx, float* bwd_part, void* stream);
+size_t tsii_bf16_dw_bwd_dw_ws_bytes(int n, int ho, int wo, int c, int kh, int kw, int sh, int sw, int dh, int dw);
+int tsii_bf16_dw_bwd_dw(const uint16_t* dy, const uint16_t* x, int n, int h, int wd, int c,
+                        int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int ho, int wo,
+                        const float* in_scale, const float* in_shift, int in_act, float in_slope,
+                        float* dwgt, float* dbias, void* ws, size_t ws_bytes, void* stream);
+/* nn.AvgPool2d(k, stride 1, padding (k-1)/2), count_include_pad (models/common.py:62-68), k in {3, 5, 9}; the operator is
+ * its own adjoint: the backward pass is the same call on the gradient */
+int tsii_bf16_avgpool(const uint16_t* x, int n, int h, int wd, int c, int k, uint16_t* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -263,3 +263,126 @@ def test_dense_forward_dx_dw(emu, n, h, wd, cin, cout, geom, bias):
     assert np.abs(dwg - rdw).max() <= 2e-5 * np.abs(rdw).max()
     if bias:
         assert np.abs(db - dyv.reshape(m, cout).sum(0)).max() <= 1e-5 * np.abs(dyv).reshape(m, cout).sum(0).max()
+
+
+# ---- depth-wise 3x3 ---------------------------------------------------------------------------------------------------------
+def dw_ref(x, w, s, p, d):
+    """x [n,h,w,c] float64, w [c,3,3] -> [n,ho,wo,c]"""
+    n, h, wd, c = x.shape
+    ho = (h + 2 * p - 2 * d - 1) // s + 1
+    wo = (wd + 2 * p - 2 * d - 1) // s + 1
+    xp = np.zeros((n, h + 2 * p, wd + 2 * p, c))
+    xp[:, p:p + h, p:p + wd] = x
+    y = np.zeros((n, ho, wo, c))
+    for ky in range(3):
+        for kx in range(3):
+            y += xp[:, ky * d: ky * d + (ho - 1) * s + 1: s, kx * d: kx * d + (wo - 1) * s + 1: s] * w[:, ky, kx]
+    return y
+
+
+def dw_dx_ref(dy, w, s, p, d, h, wd):
+    n, ho, wo, c = dy.shape
+    dxp = np.zeros((n, h + 2 * p, wd + 2 * p, c))
+    for ky in range(3):
+        for kx in range(3):
+            dxp[:, ky * d: ky * d + (ho - 1) * s + 1: s, kx * d: kx * d + (wo - 1) * s + 1: s] += dy * w[:, ky, kx]
+    return dxp[:, p:p + h, p:p + wd]
+
+
+def dw_dw_ref(dy, a, s, p, d):
+    n, h, wd, c = a.shape
+    _, ho, wo, _ = dy.shape
+    xp = np.zeros((n, h + 2 * p, wd + 2 * p, c))
+    xp[:, p:p + h, p:p + wd] = a
+    g = np.zeros((c, 3, 3))
+    for ky in range(3):
+        for kx in range(3):
+            g[:, ky, kx] = (dy * xp[:, ky * d: ky * d + (ho - 1) * s + 1: s, kx * d: kx * d + (wo - 1) * s + 1: s]).sum((0, 1, 2))
+    return g
+
+
+@pytest.mark.parametrize("n,h,wd,c,s,d,act,bias", [
+    (2, 20, 19, 64, 1, 1, 2, False), (1, 33, 17, 24, 1, 2, None, True), (2, 24, 40, 128, 1, 4, 2, False),
+    (2, 22, 21, 40, 2, 1, 2, False), (1, 16, 16, 8, 2, 1, None, True), (1, 9, 300, 16, 1, 1, 1, False),
+    (3, 70, 6, 256, 1, 2, 3, False)])
+def test_depthwise_forward_dx_dw(emu, n, h, wd, c, s, d, act, bias):
+    L = emu
+    p = d
+    geom = (3, 3, s, s, p, p, d, d)
+    ho = (h + 2 * p - 2 * d - 1) // s + 1
+    wo = (wd + 2 * p - 2 * d - 1) // s + 1
+    rng = np.random.default_rng(n + 3 * h + 5 * c + 11 * s + d)
+    slope = 0.3
+    xb, xv = rand_bf16(rng, (n, h, wd, c), 1.5, 0.2)
+    w = (rng.standard_normal((c, 1, 3, 3)) / 3).astype(np.float32)
+    b = rng.standard_normal(c).astype(np.float32) if bias else None
+    sc = rng.uniform(0.5, 1.5, c).astype(np.float32) if act is not None else None
+    sh = rng.standard_normal(c).astype(np.float32) if act is not None else None
+    a = inbn_np(xv, sc, sh, act, slope) if act is not None else xv
+    w64 = w.astype(np.float64)[:, 0]
+    rows = L.tsii_bf16_dw_stat_rows(n, ho, wo, c, 3, 3, s, s, d, d)
+    assert rows > 0
+    part = np.full((rows, 4, c), np.nan, np.float32)
+    y = np.zeros((n, ho, wo, c), np.uint16)
+    assert L.tsii_bf16_dw_fwd(P(xb), P(w), P(b), n, h, wd, c, *geom, ho, wo, P(sc), P(sh), act or 0, slope, P(part), P(y), None) == 0, L.tsii_last_error()
+    ref = dw_ref(a, w64, s, p, d) + (b if bias else 0.0)
+    close_bf16(y, ref, extra=2e-6)
+    assert not np.isnan(part).any()
+    yv = bf16_val(y).astype(np.float64).reshape(-1, c)
+    mean, var = stats_from_part(part, n * ho * wo)
+    assert np.abs(mean - yv.mean(0)).max() <= 1e-5 * np.abs(yv).max()
+    assert np.abs(var - yv.var(0)).max() <= 1e-4 * yv.var(0).max()
+    # the plain form is the same kernel without the partials
+    y2 = np.zeros_like(y)
+    assert L.tsii_bf16_dw_fwd(P(xb), P(w), P(b), n, h, wd, c, *geom, ho, wo, P(sc), P(sh), act or 0, slope, None, P(y2), None) == 0
+    assert np.array_equal(y2, y)
+
+    dyb, dyv = rand_bf16(rng, (n, ho, wo, c))
+    dx = np.zeros((n, h, wd, c), np.uint16)
+    assert L.tsii_bf16_dw_bwd_dx(P(dyb), P(w), n, h, wd, c, *geom, ho, wo, None, None, None, None, None, 0.0, 0, 0.0, P(dx), None, None) == 0, L.tsii_last_error()
+    close_bf16(dx, dw_dx_ref(dyv, w64, s, p, d, h, wd), extra=2e-6)
+    brows = L.tsii_bf16_dw_bwd_stat_rows(n, h, wd, c, *geom)
+    assert (brows > 0) == (s == 1)
+    if act is not None and brows > 0:
+        mean_ = rng.standard_normal(c).astype(np.float32)
+        var_ = rng.uniform(0.5, 2.0, c).astype(np.float32)
+        gamma = rng.uniform(0.5, 1.5, c).astype(np.float32)
+        beta = rng.standard_normal(c).astype(np.float32)
+        eps = 1e-5
+        bpart = np.full((brows, 2, c), np.nan, np.float32)
+        dx2 = np.zeros_like(dx)
+        assert L.tsii_bf16_dw_bwd_dx(P(dyb), P(w), n, h, wd, c, *geom, ho, wo, P(xb), P(mean_), P(var_), P(gamma), P(beta), eps, act, slope,
+                                     P(dx2), P(bpart), None) == 0, L.tsii_last_error()
+        assert np.array_equal(dx2, dx) and not np.isnan(bpart).any()
+        xh = (xv - mean_) / np.sqrt(var_.astype(np.float64) + eps)
+        z = xh * gamma + beta
+        dz = bf16_val(dx).astype(np.float64) * act_grad_np(z, act, slope)
+        kink = np.abs(z) < 1e-4
+        ax = (0, 1, 2)
+        assert np.abs(bpart[:, 0].sum(0, dtype=np.float64) - dz.sum(ax)).max() <= 1e-4 * np.abs(dz).sum(ax).max() + np.abs(dz * kink).sum(ax).max()
+        assert np.abs(bpart[:, 1].sum(0, dtype=np.float64) - (dz * xh).sum(ax)).max() <= 1e-4 * np.abs(dz * xh).sum(ax).max() + np.abs(dz * xh * kink).sum(ax).max()
+
+    nbytes = L.tsii_bf16_dw_bwd_dw_ws_bytes(n, ho, wo, c, 3, 3, s, s, d, d)
+    ws = WS(nbytes)
+    dwg = np.zeros((c, 1, 3, 3), np.float32)
+    db = np.zeros(c, np.float32)
+    assert L.tsii_bf16_dw_bwd_dw(P(dyb), P(xb), n, h, wd, c, *geom, ho, wo, P(sc), P(sh), act or 0, slope, P(dwg), P(db) if bias else None,
+                                 P(ws), nbytes, None) == 0, L.tsii_last_error()
+    rdw = dw_dw_ref(dyv, a, s, p, d)
+    assert np.abs(dwg[:, 0] - rdw).max() <= 2e-5 * np.abs(rdw).max()
+    if bias:
+        assert np.abs(db - dyv.sum((0, 1, 2))).max() <= 1e-5 * np.abs(dyv).sum((0, 1, 2)).max()
+
+
+@pytest.mark.parametrize("n,h,wd,c,k", [(2, 17, 20, 64, 3), (1, 12, 9, 24, 5), (2, 20, 33, 128, 9), (1, 5, 4, 8, 9)])
+def test_average_pool(emu, n, h, wd, c, k):
+    L = emu
+    rng = np.random.default_rng(n + h + c + k)
+    xb, xv = rand_bf16(rng, (n, h, wd, c))
+    y = np.zeros((n, h, wd, c), np.uint16)
+    assert L.tsii_bf16_avgpool(P(xb), n, h, wd, c, k, P(y), None) == 0, L.tsii_last_error()
+    r = (k - 1) // 2
+    xp = np.zeros((n, h + 2 * r, wd + 2 * r, c))
+    xp[:, r:r + h, r:r + wd] = xv
+    ref = sum(xp[:, i:i + h, j:j + wd] for i in range(k) for j in range(k)) / (k * k)
+    close_bf16(y, ref, extra=2e-6)

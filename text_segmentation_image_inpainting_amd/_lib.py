@@ -112,6 +112,13 @@ SIGNATURES = {
     "tsii_bf16_dense_bwd_dx": (_i, [_p, _p, _i, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _z, _p]),
     "tsii_bf16_dense_bwd_dw_ws_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
     "tsii_bf16_dense_bwd_dw": (_i, [_p, _p, _i, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _p, _z, _p]),
+    "tsii_bf16_dw_stat_rows": (_l, [_i] * 10),
+    "tsii_bf16_dw_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _i, _f, _p, _p, _p]),
+    "tsii_bf16_dw_bwd_stat_rows": (_l, [_i] * 12),
+    "tsii_bf16_dw_bwd_dx": (_i, [_p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _p, _p, _p, _f, _i, _f, _p, _p, _p]),
+    "tsii_bf16_dw_bwd_dw_ws_bytes": (_z, [_i] * 10),
+    "tsii_bf16_dw_bwd_dw": (_i, [_p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _i, _f, _p, _p, _p, _z, _p]),
+    "tsii_bf16_avgpool": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
 }
 
 _LIB = None

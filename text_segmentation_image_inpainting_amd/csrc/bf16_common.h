@@ -61,4 +61,7 @@ __device__ __forceinline__ void apply_inbn8(float (&v)[8], const InBN8& c, float
 // derivative of the load-time activation min(max(z, neg z), hi) at pre-activation z (torch semantics, like act_grad)
 __device__ __forceinline__ float inbn_grad(float z, float neg, float hi) { return (z > 0.f && z < hi) ? 1.f : (z > 0.f ? 0.f : neg); }
 
+// out[n] = sum_m a[m, n] of a bf16 [M, N] matrix (N % 8 == 0); ws: partial_rows(M, N / 8) * N floats   (bf16_gemm.hip)
+int launch_bf16_colsum(const bf16_t* a, int64_t M, int N, float* out, float* ws, hipStream_t st);
+
 }  // namespace tsii

@@ -670,7 +670,7 @@ static int prep_weights(const float* w, int cout, int cin, int T, int mode, bf16
 }
 
 static inline int hcolsum_rows(int64_t M, int N) { return partial_rows(M, N / 8); }
-static int launch_hcolsum(const bf16_t* a, int64_t M, int N, float* out, float* ws, hipStream_t st) {
+int launch_bf16_colsum(const bf16_t* a, int64_t M, int N, float* out, float* ws, hipStream_t st) {
     const int R = hcolsum_rows(M, N);
     hipLaunchKernelGGL(hcolsum_kernel, dim3(stream_grid((int64_t)R * (N / 8), 256)), dim3(256), 0, st, a, M, N, R, ws);
     int rc = check_launch("bf16 colsum");
@@ -763,7 +763,7 @@ extern "C" int tsii_bf16_pw_bwd_dw(const uint16_t* dy, const uint16_t* x, int64_
     if (rc) return rc;
     rc = launch_reduce_rows(wsf, slabs, (int64_t)n * k, dw, st);
     if (rc) return rc;
-    if (dbias != nullptr) return launch_hcolsum(dy, m, n, dbias, wsf, st);
+    if (dbias != nullptr) return launch_bf16_colsum(dy, m, n, dbias, wsf, st);
     return 0;
 }
 
@@ -837,6 +837,6 @@ extern "C" int tsii_bf16_dense_bwd_dw(const uint16_t* dy, const uint16_t* x, int
     if (rc) return rc;
     rc = launch_reduce_rows_conv(wsf, slabs, cout, cin, kh * kw, dwgt, st);      // [co][t][ci] partials -> [co][ci][t]
     if (rc) return rc;
-    if (dbias != nullptr) return launch_hcolsum(dy, m, cout, dbias, wsf, st);
+    if (dbias != nullptr) return launch_bf16_colsum(dy, m, cout, dbias, wsf, st);
     return 0;
 }
