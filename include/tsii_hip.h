@@ -462,6 +462,38 @@ int tsii_bf16_dw_bwd_dw(const uint16_t* dy, const uint16_t* x, int n, int h, int
  * its own adjoint: the backward pass is the same call on the gradient */
 int tsii_bf16_avgpool(const uint16_t* x, int n, int h, int wd, int c, int k, uint16_t* y, void* stream);
 
+/* ---- streaming kernels ------------------------------------------------------------------------------------------------
+ * BatchNorm statistics of a bf16 [m,c] tensor as partial rows in the stat_part layout ([tsii_bf16_bn_stat_rows(m,c)][4][c]);
+ * tsii_bn_finalize turns them into mean / var / running statistics / (scale, shift) like the conv-emitted partials. */
+int64_t tsii_bf16_bn_stat_rows(int64_t m, int c);
+int tsii_bf16_bn_stats(const uint16_t* y, int64_t m, int c, float* stat_part, void* stream);
+/* out = act(scale*y + shift) (+ residual): the materialised form of a BatchNorm(+activation) (models/BaseModels.py:95-99)
+ * from the (scale, shift) pair of tsii_bn_finalize / tsii_bn_scale_shift, i.e. exactly what a load-time consumer computes */
+int tsii_bf16_bn_act_fwd(const uint16_t* y, int64_t m, int c, const float* scale, const float* shift, int act, float slope,
+                         const uint16_t* residual, uint16_t* out, void* stream);
+/* BatchNorm(+act) backward: dy (bf16), dgamma / dbeta (fp32).  bwd_part NULL: the kernel takes its two reductions itself;
+ * else [rows][2][c] partials left by the consumer's dX kernel (K6c).  ws: tsii_bf16_bn_ws_bytes(m, c). */
+size_t tsii_bf16_bn_ws_bytes(int64_t m, int c);
+int tsii_bf16_bn_act_bwd(const uint16_t* dout, const uint16_t* y, int64_t m, int c, const float* mean, const float* var,
+                         const float* gamma, const float* beta, float eps, int act, float slope, int training,
+                         const float* bwd_part, int64_t rows, uint16_t* dy, float* dgamma, float* dbeta,
+                         void* ws, size_t ws_bytes, void* stream);
+/* out = act(a + b); dx = dout * act'(x)   (models/Xception.py:44, models/MobileNetV2.py:146-147, models/common.py:156) */
+int tsii_bf16_add_act_fwd(const uint16_t* a, const uint16_t* b, int64_t numel, int act, float slope, uint16_t* out, void* stream);
+int tsii_bf16_act_bwd(const uint16_t* dout, const uint16_t* x, int64_t numel, int act, float slope, uint16_t* dx, void* stream);
+/* channel concat / slice (tsii_copy_channels), bilinear up-sampling (tsii_bilinear_up_*) on bf16 tensors */
+int tsii_bf16_copy_channels(uint16_t* big, int64_t m, int cbig, int coff, uint16_t* small_, int csmall, int to_dst, void* stream);
+int tsii_bf16_bilinear_up_fwd(const uint16_t* x, int n, int h, int w, int c, int scale, uint16_t* y, void* stream);
+int tsii_bf16_bilinear_up_bwd(const uint16_t* dy, int n, int h, int w, int c, int scale, uint16_t* dx, void* stream);
+/* the fp32 <-> bf16 boundary: the 3-channel image enters through the stem's space-to-depth rearrangement (tsii_stem_s2d with
+ * the channels of each phase padded to 4: out [n,(h+2pad)/2,(w+2pad)/2,16], channel order (row phase, column phase, c4));
+ * the logits leave as channel `ch` of a head padded to 8 channels; plain casts for everything else */
+int tsii_bf16_stem_s2d(const float* x, int n, int h, int w, int c, int pad, uint16_t* out, void* stream);
+int tsii_bf16_from_f32(const float* src, int64_t numel, uint16_t* dst, void* stream);
+int tsii_bf16_to_f32(const uint16_t* src, int64_t numel, float* dst, void* stream);
+int tsii_bf16_channel_to_f32(const uint16_t* src, int64_t m, int c, int ch, float* dst, void* stream);
+int tsii_bf16_channel_from_f32(const float* src, int64_t m, int c, int ch, uint16_t* dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

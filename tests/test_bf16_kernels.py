@@ -386,3 +386,133 @@ def test_average_pool(emu, n, h, wd, c, k):
     xp[:, r:r + h, r:r + wd] = xv
     ref = sum(xp[:, i:i + h, j:j + wd] for i in range(k) for j in range(k)) / (k * k)
     close_bf16(y, ref, extra=2e-6)
+
+
+# ---- streaming kernels ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,C,act,res", [(1000, 64, 2, True), (333, 24, 0, False), (5000, 512, 3, True), (17, 8, 1, False)])
+def test_batchnorm_statistics_apply_backward(emu, M, C, act, res):
+    L = emu
+    rng = np.random.default_rng(M + C)
+    slope = 0.3
+    yb, yv = rand_bf16(rng, (M, C), 2.0, 5.0)
+    rows = L.tsii_bf16_bn_stat_rows(M, C)
+    part = np.full((rows, 4, C), np.nan, np.float32)
+    assert L.tsii_bf16_bn_stats(P(yb), M, C, P(part), None) == 0, L.tsii_last_error()
+    mean, var = stats_from_part(part, M)
+    assert np.abs(mean - yv.mean(0)).max() <= 1e-5 * np.abs(yv).max()
+    assert np.abs(var - yv.var(0)).max() <= 1e-4 * yv.var(0).max()
+    # ... and tsii_bn_finalize accepts them as it does the conv-emitted partials
+    gamma = rng.uniform(0.5, 1.5, C).astype(np.float32)
+    beta = rng.standard_normal(C).astype(np.float32)
+    eps = 1e-5
+    mean32, var32, sc, sh = (np.zeros(C, np.float32) for _ in range(4))
+    rmean, rvar = np.zeros(C, np.float32), np.ones(C, np.float32)
+    ws = WS(L.tsii_bn_finalize_ws_bytes(rows, C))
+    assert L.tsii_bn_finalize(P(part), rows, C, M, P(mean32), P(var32), P(rmean), P(rvar), 0.1, P(gamma), P(beta), eps, P(sc), P(sh), P(ws), ws.nbytes, None) == 0
+    assert np.abs(mean32 - yv.mean(0)).max() <= 1e-5 * np.abs(yv).max() and np.abs(var32 - yv.var(0)).max() <= 1e-4 * yv.var(0).max()
+
+    rb_, rv_ = rand_bf16(rng, (M, C)) if res else (None, None)
+    out = np.zeros((M, C), np.uint16)
+    assert L.tsii_bf16_bn_act_fwd(P(yb), M, C, P(sc), P(sh), act, slope, P(rb_), P(out), None) == 0, L.tsii_last_error()
+    z = np.float32(yv.astype(np.float32) * sc + sh).astype(np.float64)
+    close_bf16(out, act_np(z, act, slope) + (rv_ if res else 0.0), extra=1e-6)
+
+    for training, with_part in ((1, False), (0, False), (1, True)):
+        db, dv = rand_bf16(rng, (M, C))
+        xh = (yv - mean32) / np.sqrt(var32.astype(np.float64) + eps)
+        zz = xh * gamma + beta
+        dz = dv * act_grad_np(zz, act, slope)
+        s1, s2 = dz.sum(0), (dz * xh).sum(0)
+        ref = gamma / np.sqrt(var32.astype(np.float64) + eps) * (dz - (s1 / M + xh * s2 / M if training else 0.0))
+        bp = None
+        if with_part:       # partial rows as a consumer's dX kernel would leave them
+            bp = np.zeros((3, 2, C), np.float32)
+            bp[0, 0], bp[1, 0], bp[2, 0] = s1 * 0.25, s1 * 0.5, s1 * 0.25
+            bp[0, 1], bp[2, 1] = s2 * 0.5, s2 * 0.5
+        dy = np.zeros((M, C), np.uint16)
+        dg, dbt = np.zeros(C, np.float32), np.zeros(C, np.float32)
+        ws = WS(L.tsii_bf16_bn_ws_bytes(M, C))
+        assert L.tsii_bf16_bn_act_bwd(P(db), P(yb), M, C, P(mean32), P(var32), P(gamma), P(beta), eps, act, slope, training, P(bp), 3 if with_part else 0,
+                                      P(dy), P(dg), P(dbt), P(ws), ws.nbytes, None) == 0, L.tsii_last_error()
+        kink = np.abs(zz) < 1e-5
+        assert kink.mean() < 1e-3
+        got = bf16_val(dy).astype(np.float64)
+        tol = np.abs(ref) * 2.0 ** -8 + 3e-5 * np.abs(ref).max()
+        assert (np.abs(got - ref) > tol)[~kink].sum() == 0
+        assert np.abs(dbt - s1).max() <= 1e-4 * np.abs(dz).sum(0).max() + np.abs(dz * kink).sum(0).max()
+        assert np.abs(dg - s2).max() <= 1e-4 * np.abs(dz * xh).sum(0).max() + np.abs(dz * xh * kink).sum(0).max()
+
+
+def test_add_concat_bilinear_casts(emu):
+    L = emu
+    rng = np.random.default_rng(5)
+    n, h, w, c = 2, 5, 7, 24
+    ab, av = rand_bf16(rng, (n, h, w, c))
+    bb, bv = rand_bf16(rng, (n, h, w, c))
+    out = np.zeros((n, h, w, c), np.uint16)
+    assert L.tsii_bf16_add_act_fwd(P(ab), P(bb), ab.size, 2, 0.3, P(out), None) == 0, L.tsii_last_error()
+    s = av + bv
+    close_bf16(out, np.where(s > 0, s, 0.3 * s))
+    db, dv = rand_bf16(rng, (n, h, w, c))
+    dx = np.zeros_like(out)
+    assert L.tsii_bf16_act_bwd(P(db), P(out), out.size, 2, 0.3, P(dx), None) == 0
+    close_bf16(dx, dv * np.where(bf16_val(out) > 0, 1.0, 0.3))
+    # concat / slice
+    big = np.zeros((n * h * w, 24 + 16), np.uint16)
+    sb, _ = rand_bf16(rng, (n * h * w, 16))
+    assert L.tsii_bf16_copy_channels(P(big), n * h * w, 40, 0, P(ab), 24, 1, None) == 0
+    assert L.tsii_bf16_copy_channels(P(big), n * h * w, 40, 24, P(sb), 16, 1, None) == 0
+    assert np.array_equal(big[:, :24], ab.reshape(-1, 24)) and np.array_equal(big[:, 24:], sb)
+    back = np.zeros_like(sb)
+    assert L.tsii_bf16_copy_channels(P(big), n * h * w, 40, 24, P(back), 16, 0, None) == 0
+    assert np.array_equal(back, sb)
+    # bilinear x2 / x4 against the separable definition (align_corners = False), and the adjoint identity <up(x), g> = <x, up^T(g)>
+    for scale in (2, 4):
+        y = np.zeros((n, h * scale, w * scale, c), np.uint16)
+        assert L.tsii_bf16_bilinear_up_fwd(P(ab), n, h, w, c, scale, P(y), None) == 0
+
+        def taps(o, lim):
+            sp = max((o + 0.5) / scale - 0.5, 0.0)
+            i0 = min(int(sp), lim - 1)
+            return i0, min(i0 + 1, lim - 1), sp - i0
+        ref = np.zeros((n, h * scale, w * scale, c))
+        for oy in range(h * scale):
+            y0, y1, ly = taps(oy, h)
+            for ox in range(w * scale):
+                x0, x1, lx = taps(ox, w)
+                ref[:, oy, ox] = (1 - ly) * ((1 - lx) * av[:, y0, x0] + lx * av[:, y0, x1]) + ly * ((1 - lx) * av[:, y1, x0] + lx * av[:, y1, x1])
+        close_bf16(y, ref, extra=1e-6)
+        gb, gv = rand_bf16(rng, y.shape)
+        gx = np.zeros((n, h, w, c), np.uint16)
+        assert L.tsii_bf16_bilinear_up_bwd(P(gb), n, h, w, c, scale, P(gx), None) == 0
+        lhs, rhs = (ref * gv).sum(), (av * bf16_val(gx)).sum()
+        assert abs(lhs - rhs) <= 1e-2 * (np.abs(ref * gv).sum() ** 0.5 + 1)
+    # casts
+    f = rng.standard_normal(4096).astype(np.float32)
+    hb = np.zeros(4096, np.uint16)
+    assert L.tsii_bf16_from_f32(P(f), 4096, P(hb), None) == 0
+    assert np.array_equal(hb, bf16_bits(f))
+    f2 = np.zeros(4096, np.float32)
+    assert L.tsii_bf16_to_f32(P(hb), 4096, P(f2), None) == 0
+    assert np.array_equal(f2, bf16_val(hb))
+    m8 = np.zeros((100, 8), np.uint16)
+    lg = rng.standard_normal(100).astype(np.float32)
+    assert L.tsii_bf16_channel_from_f32(P(lg), 100, 8, 0, P(m8), None) == 0
+    assert np.array_equal(m8[:, 0], bf16_bits(lg)) and not m8[:, 1:].any()
+    lg2 = np.zeros(100, np.float32)
+    assert L.tsii_bf16_channel_to_f32(P(m8), 100, 8, 0, P(lg2), None) == 0
+    assert np.array_equal(lg2, bf16_val(m8[:, 0]))
+
+
+def test_stem_space_to_depth(emu):
+    L = emu
+    rng = np.random.default_rng(9)
+    n, h, w, c, pad = 2, 10, 14, 3, 1
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    h2, w2 = (h + 2 * pad) // 2, (w + 2 * pad) // 2
+    out = np.full((n, h2, w2, 16), 0xFFFF, np.uint16)
+    assert L.tsii_bf16_stem_s2d(P(x), n, h, w, c, pad, P(out), None) == 0, L.tsii_last_error()
+    xp = np.zeros((n, h + 2 * pad, w + 2 * pad, 4), np.float32)
+    xp[:, pad:pad + h, pad:pad + w, :c] = x
+    ref = xp.reshape(n, h2, 2, w2, 2, 4).transpose(0, 1, 3, 2, 4, 5).reshape(n, h2, w2, 16)
+    assert np.array_equal(out, bf16_bits(ref).reshape(out.shape))

@@ -119,6 +119,21 @@ SIGNATURES = {
     "tsii_bf16_dw_bwd_dw_ws_bytes": (_z, [_i] * 10),
     "tsii_bf16_dw_bwd_dw": (_i, [_p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _i, _f, _p, _p, _p, _z, _p]),
     "tsii_bf16_avgpool": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "tsii_bf16_bn_stat_rows": (_l, [_l, _i]),
+    "tsii_bf16_bn_stats": (_i, [_p, _l, _i, _p, _p]),
+    "tsii_bf16_bn_act_fwd": (_i, [_p, _l, _i, _p, _p, _i, _f, _p, _p, _p]),
+    "tsii_bf16_bn_ws_bytes": (_z, [_l, _i]),
+    "tsii_bf16_bn_act_bwd": (_i, [_p, _p, _l, _i, _p, _p, _p, _p, _f, _i, _f, _i, _p, _l, _p, _p, _p, _p, _z, _p]),
+    "tsii_bf16_add_act_fwd": (_i, [_p, _p, _l, _i, _f, _p, _p]),
+    "tsii_bf16_act_bwd": (_i, [_p, _p, _l, _i, _f, _p, _p]),
+    "tsii_bf16_copy_channels": (_i, [_p, _l, _i, _i, _p, _i, _i, _p]),
+    "tsii_bf16_bilinear_up_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "tsii_bf16_bilinear_up_bwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "tsii_bf16_stem_s2d": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "tsii_bf16_from_f32": (_i, [_p, _l, _p, _p]),
+    "tsii_bf16_to_f32": (_i, [_p, _l, _p, _p]),
+    "tsii_bf16_channel_to_f32": (_i, [_p, _l, _i, _i, _p, _p]),
+    "tsii_bf16_channel_from_f32": (_i, [_p, _l, _i, _i, _p, _p]),
 }
 
 _LIB = None
