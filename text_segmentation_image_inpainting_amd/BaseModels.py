@@ -291,12 +291,16 @@ def Conv_block(in_channels, out_channels, kernel_size, stride=1, padding=0,
     return conv_pieces(in_channels, spec, activation if activation else None)[0]
 
 
-def run_chain(mods, x):
+def run_chain(mods, x, final_residual=None):
     """Run a list of modules built from Conv_block pieces on an NCHW-shaped tensor with every ``Conv2d -> BNAct`` pair
     folded (K6b): the conv emits the BatchNorm statistics partials and, when another Conv2d follows, the normalised
     activation stays virtual (ops.LazyBN) and is applied by that conv while loading (models/MobileNetV2.py:127-140,
-    models/BaseModels.py:105-127 chains).  Anything else in the list runs through its own forward()."""
+    models/BaseModels.py:105-127 chains).  Anything else in the list runs through its own forward().
+    ``final_residual`` (NCHW-shaped; the list must end in a ``Conv2d -> BNAct`` pair): added by the pass that writes the last
+    BatchNorm out, i.e. ``chain(x) + final_residual`` without a separate add pass (models/Xception.py:44)."""
     h, lazy, i, n = to_nhwc(x), None, 0, len(mods)
+    if final_residual is not None:
+        assert n >= 2 and isinstance(mods[-2], Conv2d) and isinstance(mods[-1], BNAct), "final_residual needs a closing conv + BatchNorm pair"
     while i < n:
         m = mods[i]
         if isinstance(m, Conv2d) and i + 1 < n and isinstance(mods[i + 1], BNAct) and m.padding_mode == "zeros":
@@ -313,7 +317,8 @@ def run_chain(mods, x):
             if i + 2 < n and isinstance(mods[i + 2], Conv2d) and ops.load_time_act(act, slope):
                 h, lazy = None, lz
             else:
-                h, lazy = lz.materialize(), None
+                res = to_nhwc(final_residual) if (final_residual is not None and i + 2 == n) else None
+                h, lazy = lz.materialize(res), None
             i += 2
             continue
         if lazy is not None:

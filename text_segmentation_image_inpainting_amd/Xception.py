@@ -2,8 +2,7 @@
 construction in the reference itself -- SURVEY.md F7 -- and is out of scope.)"""
 from torch import nn
 
-from . import ops
-from .BaseModels import BaseModule, ConvSpec, DSConvBlock, build_chain, run_chain, to_nchw, to_nhwc
+from .BaseModels import BaseModule, ConvSpec, DSConvBlock, build_chain, run_chain
 
 
 class ResidualBlock(BaseModule):
@@ -27,7 +26,8 @@ class ResidualBlock(BaseModule):
         # the six conv + BatchNorm pairs of the three DSConvBlocks as ONE chain: every BatchNorm but the last stays virtual
         # (applied by the next conv while loading, K6b) and takes its backward reductions from that conv's dX kernel (K6c)
         mods = [m for block in self.conv for m in list(block.depth_wise_conv) + list(block.point_wise_conv)]
-        return to_nchw(ops.add_act(to_nhwc(run_chain(mods, x)), to_nhwc(shortcut)))
+        # ... and the shortcut is added by the pass that writes the last BatchNorm out (x + self.conv(x), models/Xception.py:44)
+        return run_chain(mods, x, final_residual=shortcut)
 
 
 # flow tables: ("conv", out, stride) = 3x3 conv + BN + act; ("res", out, stride, dilation) = ResidualBlock (k 3, pad = dilation)

@@ -11,3 +11,4 @@ from .common import ASP, RFB, SpatialChannelSqueezeExcitation  # noqa: F401,E402
 from .text_segmentation import TextSegament, XceptionTextSegment  # noqa: F401,E402
 from .loss import BinaryFocalLoss, FeatureExtractor, InpaintingLoss, gram_matrix, total_variation_loss  # noqa: F401,E402
 from .recipes import InpaintingRecipe, SegmentationRecipe  # noqa: F401,E402
+from .ops import activation_storage, set_activation_storage  # noqa: F401,E402

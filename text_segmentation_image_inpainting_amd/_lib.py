@@ -171,8 +171,8 @@ def check_device(t: torch.Tensor):
     if not t.is_cuda:
         raise RuntimeError("text_segmentation_image_inpainting_amd: tensors must live on a ROCm GPU "
                            "(MI355X); this implementation has no CPU path")
-    if t.dtype != torch.float32:
-        raise RuntimeError(f"text_segmentation_image_inpainting_amd: fp32 only, got {t.dtype}")
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"text_segmentation_image_inpainting_amd: fp32 tensors (or bf16 activation storage, ops.set_activation_storage), got {t.dtype}")
 
 
 def ptr(t):

@@ -58,6 +58,40 @@ def make_geom(kernel_size, stride=1, padding=0, dilation=1) -> Geom:
     return Geom(kh, kw, sh, sw, ph, pw, dh, dw)
 
 
+# ---------------------------------------------------------------------------------------
+# bf16 ACTIVATION STORAGE (BASELINE config 5; include/tsii_hip.h "bf16 activation storage")
+# ---------------------------------------------------------------------------------------
+# The switch decides ONE thing: the dtype the data layer (a net's stem) hands on.  Everything downstream follows the dtype of
+# the tensor it receives -- bf16 tensors go to the tsii_bf16_* entry points, fp32 tensors to the fp32 ones -- so forward,
+# backward (autograd's own threads) and recomputation agree without further state.  Parameters, their gradients and the
+# BatchNorm statistics are fp32 in both modes.  The partial-convolution family (mask planes) has no bf16 form: it refuses.
+BF16 = torch.bfloat16
+_ACT_STORAGE = torch.float32
+
+
+def set_activation_storage(dtype):
+    """torch.float32 (default) or torch.bfloat16: the storage type of activations / activation gradients of the
+    segmentation nets built from now on ... applied by their stems from the next forward pass on."""
+    global _ACT_STORAGE
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("activation storage: torch.float32 or torch.bfloat16")
+    _ACT_STORAGE = dtype
+
+
+def activation_storage():
+    return _ACT_STORAGE
+
+
+def _h(t) -> bool:
+    return t is not None and t.dtype == torch.bfloat16
+
+
+def _no_masks(who, *planes):
+    if any(p is not None for p in planes):
+        raise NotImplementedError(f"{who}: bf16 activation storage exists for the mask-free (segmentation) layers only; "
+                                  "the partial-convolution family keeps fp32 storage")
+
+
 def _ws(nbytes: int, like: torch.Tensor) -> torch.Tensor:
     return torch.empty(max(4, (int(nbytes) + 3) // 4), dtype=torch.float32, device=like.device)
 
@@ -143,6 +177,22 @@ class _Pointwise(torch.autograd.Function):
         cout = w.shape[0]
         assert w.shape[1] == k and w.shape[2] == 1 and w.shape[3] == 1, "point-wise weight must be [Cout,Cin,1,1]"
         m = n * h * wd
+        if _h(x):        # bf16 activation storage: mask-free layers only
+            _no_masks("1x1 convolution", r0, r1, denom, keep, up_add)
+            L = _lib.lib()
+            y = torch.empty((n, h, wd, cout), dtype=BF16, device=x.device)
+            part = torch.empty((int(L.tsii_bf16_stat_rows(m)), 4, cout), dtype=torch.float32, device=x.device) if want_stats else None
+            wbytes = L.tsii_bf16_pw_ws_bytes(cout, k)
+            wws = _ws(wbytes, x)
+            call("tsii_bf16_pw_fwd", ptr(x), m, k, ptr(w), cout, ptr(bias), ptr(in_scale), ptr(in_shift), int(in_act), float(in_slope),
+                 ptr(part), ptr(y), ptr(wws), wbytes, _lib.stream())
+            ctx.save_for_backward(x, w, None, None, None, None, in_scale, in_shift)
+            ctx.split, ctx.has_bias, ctx.in_cfg = 0, bias is not None, (int(in_act), float(in_slope))
+            ctx.set_materialize_grads(False)
+            if want_stats:
+                ctx.mark_non_differentiable(part)
+                return y, part
+            return y
         y = torch.empty((n, h, wd, cout), dtype=torch.float32, device=x.device)
         part = None
         wbytes = _lib.lib().tsii_pw_ws_bytes(cout, k)
@@ -185,6 +235,31 @@ class _Pointwise(torch.autograd.Function):
         m = n * h * wd
         dx = dw = db = None
         st = _lib.stream()
+        if _h(x):
+            L = _lib.lib()
+            if gy.dtype != BF16:
+                raise RuntimeError("bf16 storage: the incoming gradient of a bf16 layer must be bf16")
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                wbytes = L.tsii_bf16_pw_ws_bytes(cout, k)
+                wt = _ws(wbytes, x)
+                if ctx.bn is not None and FUSE_BN_BWD_PW and load_time_act(*ctx.in_cfg):
+                    mean, var, gamma, beta, eps, slot = ctx.bn
+                    part = torch.empty((int(L.tsii_bf16_stat_rows(m)), 2, k), dtype=torch.float32, device=x.device)
+                    call("tsii_bf16_pw_bwd_dx", ptr(gy), m, cout, ptr(w), k, ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps),
+                         ctx.in_cfg[0], ctx.in_cfg[1], ptr(dx), ptr(part), ptr(wt), wbytes, st)
+                    slot.part = part
+                else:
+                    call("tsii_bf16_pw_bwd_dx", ptr(gy), m, cout, ptr(w), k, None, None, None, None, None, 0.0, 0, 0.0, ptr(dx), None,
+                         ptr(wt), wbytes, st)
+            if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+                dw = torch.empty_like(w)
+                db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+                nbytes = L.tsii_bf16_pw_bwd_dw_ws_bytes(m, cout, k)
+                ws = _ws(nbytes, x)
+                call("tsii_bf16_pw_bwd_dw", ptr(gy), ptr(x), m, cout, k, ptr(in_scale), ptr(in_shift), ctx.in_cfg[0], ctx.in_cfg[1],
+                     ptr(dw), ptr(db), ptr(ws), nbytes, st)
+            return (dx, dw, db) + (None,) * 13
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)   # gradient w.r.t. the (virtual) normalised input when in_scale is set
             wt = _ws(_lib.lib().tsii_pw_ws_bytes(cout, k), x)
@@ -250,11 +325,12 @@ def pconv_pointwise(x, w, bias=None, r0=None, split=0, r1=None, denom=None, keep
 # ---------------------------------------------------------------------------------------
 # K2 depth-wise partial convolution
 # ---------------------------------------------------------------------------------------
-def dw_stat_rows(x_shape, g: "Geom") -> int:
+def dw_stat_rows(x_shape, g: "Geom", dtype=torch.float32) -> int:
     """Partial-sum rows of the fused depth-wise forms; 0 = geometry without the LDS-tiled kernel (unfused only)."""
     n, h, wd, c = x_shape
     ho, wo = g.out_hw(h, wd)
-    return int(_lib.lib().tsii_dw_stat_rows(n, ho, wo, c, g.kh, g.kw, g.sh, g.sw, g.dh, g.dw))
+    fn = _lib.lib().tsii_bf16_dw_stat_rows if dtype == BF16 else _lib.lib().tsii_dw_stat_rows
+    return int(fn(n, ho, wo, c, g.kh, g.kw, g.sh, g.sw, g.dh, g.dw))
 
 
 class _Depthwise(torch.autograd.Function):
@@ -268,6 +344,19 @@ class _Depthwise(torch.autograd.Function):
         n, h, wd, c = x.shape
         assert w.shape[0] == c and w.shape[1] == 1, "depth-wise weight must be [C,1,kh,kw]"
         ho, wo = g.out_hw(h, wd)
+        if _h(x):        # bf16 activation storage
+            _no_masks("depth-wise convolution", rmask, denom, keep)
+            y = torch.empty((n, ho, wo, c), dtype=BF16, device=x.device)
+            part = torch.empty((dw_stat_rows(x.shape, g, BF16), 4, c), dtype=torch.float32, device=x.device) if want_stats else None
+            call("tsii_bf16_dw_fwd", ptr(x), ptr(w), ptr(bias), n, h, wd, c, *g, ho, wo, ptr(in_scale), ptr(in_shift), int(in_act),
+                 float(in_slope), ptr(part), ptr(y), _lib.stream())
+            ctx.save_for_backward(x, w, None, None, None, in_scale, in_shift)
+            ctx.g, ctx.has_bias, ctx.in_cfg = g, bias is not None, (int(in_act), float(in_slope))
+            ctx.set_materialize_grads(False)
+            if want_stats:
+                ctx.mark_non_differentiable(part)
+                return y, part
+            return y
         y = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
         ws = _ws(4 * c * g.kh * g.kw, x)
         part = None
@@ -299,6 +388,32 @@ class _Depthwise(torch.autograd.Function):
         ho, wo = g.out_hw(h, wd)
         st = _lib.stream()
         dx = dw = db = None
+        if _h(x):
+            L = _lib.lib()
+            if gy.dtype != BF16:
+                raise RuntimeError("bf16 storage: the incoming gradient of a bf16 layer must be bf16")
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                rows = 0
+                if ctx.bn is not None and FUSE_BN_BWD and load_time_act(*ctx.in_cfg):
+                    rows = int(L.tsii_bf16_dw_bwd_stat_rows(n, h, wd, c, *g))
+                if rows > 0:
+                    mean, var, gamma, beta, eps, slot = ctx.bn
+                    part = torch.empty((rows, 2, c), dtype=torch.float32, device=x.device)
+                    call("tsii_bf16_dw_bwd_dx", ptr(gy), ptr(w), n, h, wd, c, *g, ho, wo, ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta),
+                         float(eps), ctx.in_cfg[0], ctx.in_cfg[1], ptr(dx), ptr(part), st)
+                    slot.part = part
+                else:
+                    call("tsii_bf16_dw_bwd_dx", ptr(gy), ptr(w), n, h, wd, c, *g, ho, wo, None, None, None, None, None, 0.0, 0, 0.0,
+                         ptr(dx), None, st)
+            if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+                dw = torch.empty_like(w)
+                db = torch.empty(c, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+                nbytes = L.tsii_bf16_dw_bwd_dw_ws_bytes(n, ho, wo, c, g.kh, g.kw, g.sh, g.sw, g.dh, g.dw)
+                ws = _ws(nbytes, x)
+                call("tsii_bf16_dw_bwd_dw", ptr(gy), ptr(x), n, h, wd, c, *g, ho, wo, ptr(in_scale), ptr(in_shift), ctx.in_cfg[0], ctx.in_cfg[1],
+                     ptr(dw), ptr(db), ptr(ws), nbytes, st)
+            return (dx, dw, db) + (None,) * 11
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             ws = _ws(4 * c * g.kh * g.kw, x)
@@ -334,8 +449,10 @@ def pconv_depthwise(x, w, bias, rmask, denom, keep, inv, g: Geom, want_stats=Fal
     fused form (the caller then takes the statistics with the separate pass)."""
     lazy = isinstance(x, LazyBN)
     src = x.token if lazy else x
+    if _h(src) and dw_stat_rows(src.shape, g, BF16) <= 0:
+        raise NotImplementedError(f"bf16 storage: depth-wise geometry {tuple(g)} on {tuple(src.shape)} has no kernel (3x3; stride 1 any dilation, stride 2 dilation 1)")
     # the fused forms need the marching-strip kernel: supported geometry AND 16-byte aligned operands
-    fusable = (lazy or want_stats) and src.is_contiguous() and _al16(src) and dw_stat_rows(src.shape, g) > 0
+    fusable = (lazy or want_stats) and src.is_contiguous() and _al16(src) and dw_stat_rows(src.shape, g, src.dtype) > 0
     if lazy and not fusable:
         x, lazy = x.materialize(), False
     stats = want_stats and fusable
@@ -474,6 +591,185 @@ class _StemS2D(torch.autograd.Function):
         return (None, dw, db) + (None,) * 9
 
 
+class _DenseH(torch.autograd.Function):
+    """bf16 activation storage: dense k x k convolution (groups == 1, no masks) as implicit GEMM on bf16 operands
+    (tsii_bf16_dense_*); channel counts are multiples of 8 (pconv_dense pads a 1-channel head)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, g, want_stats):
+        _lib.check_device(x)
+        x, w = x.contiguous(), w.contiguous()
+        n, h, wd, cin = x.shape
+        cout = w.shape[0]
+        assert w.shape[1] == cin, "dense conv needs groups == 1"
+        ho, wo = g.out_hw(h, wd)
+        L = _lib.lib()
+        y = torch.empty((n, ho, wo, cout), dtype=BF16, device=x.device)
+        part = torch.empty((int(L.tsii_bf16_stat_rows(n * ho * wo)), 4, cout), dtype=torch.float32, device=x.device) if want_stats else None
+        nbytes = L.tsii_bf16_dense_ws_bytes(cin, cout, g.kh, g.kw)
+        ws = _ws(nbytes, x)
+        call("tsii_bf16_dense_fwd", ptr(x), ptr(w), ptr(bias), n, h, wd, cin, cout, *g, ho, wo, ptr(part), ptr(y), ptr(ws), nbytes, _lib.stream())
+        ctx.save_for_backward(x, w)
+        ctx.g, ctx.has_bias = g, bias is not None
+        ctx.set_materialize_grads(False)
+        if want_stats:
+            ctx.mark_non_differentiable(part)
+            return y, part
+        return y
+
+    @staticmethod
+    def backward(ctx, gy, *_):
+        if gy is None:
+            return (None,) * 5
+        x, w = ctx.saved_tensors
+        g = ctx.g
+        gy = gy.contiguous()
+        n, h, wd, cin = x.shape
+        cout = w.shape[0]
+        ho, wo = g.out_hw(h, wd)
+        L, st = _lib.lib(), _lib.stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            nbytes = L.tsii_bf16_dense_ws_bytes(cin, cout, g.kh, g.kw)
+            ws = _ws(nbytes, x)
+            call("tsii_bf16_dense_bwd_dx", ptr(gy), ptr(w), n, h, wd, cin, cout, *g, ho, wo, ptr(dx), ptr(ws), nbytes, st)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(w)
+            db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            nbytes = L.tsii_bf16_dense_bwd_dw_ws_bytes(n, ho, wo, cin, cout, g.kh, g.kw)
+            ws = _ws(nbytes, x)
+            call("tsii_bf16_dense_bwd_dw", ptr(gy), ptr(x), n, h, wd, cin, cout, *g, ho, wo, ptr(dw), ptr(db), ptr(ws), nbytes, st)
+        return dx, dw, db, None, None
+
+
+class _StemS2DH(torch.autograd.Function):
+    """bf16 activation storage enters here: the fp32 image goes through the space-to-depth rearrangement (K4b) straight into a
+    bf16 tensor (3 -> 4 channels per phase, 16 in all) and the stem runs as a stride-1 valid conv on the bf16 implicit GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, g, want_stats):
+        _lib.check_device(x)
+        x, w = x.contiguous(), w.contiguous()
+        n, h, wd, cin = x.shape
+        cout, k, pad = w.shape[0], g.kh, g.ph
+        ka = (k + 1) // 2
+        h2, w2 = (h + 2 * pad) // 2, (wd + 2 * pad) // 2
+        ho, wo = g.out_hw(h, wd)
+        st, L = _lib.stream(), _lib.lib()
+        x2 = torch.empty((n, h2, w2, 16), dtype=BF16, device=x.device)
+        call("tsii_bf16_stem_s2d", ptr(x), n, h, wd, cin, pad, ptr(x2), st)
+        w4 = w.new_zeros((cout, 4, k, k))
+        w4[:, :cin] = w
+        wk = torch.empty((cout, 16, ka, ka), dtype=torch.float32, device=x.device)
+        call("tsii_stem_w_fwd", ptr(w4), cout, 4, k, ptr(wk), st)
+        g2 = Geom(ka, ka, 1, 1, 0, 0, 1, 1)
+        assert g2.out_hw(h2, w2) == (ho, wo)
+        y = torch.empty((n, ho, wo, cout), dtype=BF16, device=x.device)
+        part = torch.empty((int(L.tsii_bf16_stat_rows(n * ho * wo)), 4, cout), dtype=torch.float32, device=x.device) if want_stats else None
+        nbytes = L.tsii_bf16_dense_ws_bytes(16, cout, ka, ka)
+        ws = _ws(nbytes, x)
+        call("tsii_bf16_dense_fwd", ptr(x2), ptr(wk), ptr(bias), n, h2, w2, 16, cout, *g2, ho, wo, ptr(part), ptr(y), ptr(ws), nbytes, st)
+        ctx.save_for_backward(x2)
+        ctx.cfg = (tuple(w.shape), g2, (n, h2, w2, ho, wo), bias is not None)
+        ctx.set_materialize_grads(False)
+        if want_stats:
+            ctx.mark_non_differentiable(part)
+            return y, part
+        return y
+
+    @staticmethod
+    def backward(ctx, gy, *_):
+        if gy is None:
+            return (None,) * 5
+        (x2,) = ctx.saved_tensors
+        wshape, g2, (n, h2, w2, ho, wo), has_bias = ctx.cfg
+        cout, cin, k = wshape[0], wshape[1], wshape[2]
+        gy = gy.contiguous()
+        L, st = _lib.lib(), _lib.stream()
+        dw = db = None
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            ka = g2.kh
+            dwk = torch.empty((cout, 16, ka, ka), dtype=torch.float32, device=gy.device)
+            db = torch.empty(cout, dtype=torch.float32, device=gy.device) if has_bias else None
+            nbytes = L.tsii_bf16_dense_bwd_dw_ws_bytes(n, ho, wo, 16, cout, ka, ka)
+            ws = _ws(nbytes, gy)
+            call("tsii_bf16_dense_bwd_dw", ptr(gy), ptr(x2), n, h2, w2, 16, cout, *g2, ho, wo, ptr(dwk), ptr(db), ptr(ws), nbytes, st)
+            dw4 = torch.empty((cout, 4, k, k), dtype=torch.float32, device=gy.device)
+            call("tsii_stem_w_bwd", ptr(dwk), cout, 4, k, ptr(dw4), st)
+            dw = dw4[:, :cin].contiguous()
+        return None, dw, db, None, None
+
+
+class _ChannelToF32(torch.autograd.Function):
+    """channel `ch` of a bf16 [n,h,w,c] tensor as an fp32 [n,h,w,1] tensor (the logits of a head whose single output channel
+    was padded to 8 for the bf16 kernels); backward writes the fp32 gradient back into that channel, zeros elsewhere."""
+
+    @staticmethod
+    def forward(ctx, y, ch):
+        _lib.check_device(y)
+        y = y.contiguous()
+        n, h, w, c = y.shape
+        out = torch.empty((n, h, w, 1), dtype=torch.float32, device=y.device)
+        call("tsii_bf16_channel_to_f32", ptr(y), n * h * w, c, int(ch), ptr(out), _lib.stream())
+        ctx.cfg = (n, h, w, c, int(ch))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, c, ch = ctx.cfg
+        g = g.contiguous()
+        dy = torch.empty((n, h, w, c), dtype=BF16, device=g.device)
+        call("tsii_bf16_channel_from_f32", ptr(g), n * h * w, c, ch, ptr(dy), _lib.stream())
+        return dy, None
+
+
+class _Cast(torch.autograd.Function):
+    """fp32 <-> bf16 storage of an activation tensor (numel % 8 == 0); the gradient takes the way back."""
+
+    @staticmethod
+    def forward(ctx, x, to_bf16):
+        _lib.check_device(x)
+        x = x.contiguous()
+        ctx.to_bf16 = bool(to_bf16)
+        out = torch.empty(x.shape, dtype=BF16 if to_bf16 else torch.float32, device=x.device)
+        call("tsii_bf16_from_f32" if to_bf16 else "tsii_bf16_to_f32", ptr(x), x.numel(), ptr(out), _lib.stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        out = torch.empty(g.shape, dtype=torch.float32 if ctx.to_bf16 else BF16, device=g.device)
+        call("tsii_bf16_to_f32" if ctx.to_bf16 else "tsii_bf16_from_f32", ptr(g), g.numel(), ptr(out), _lib.stream())
+        return out, None
+
+
+def to_storage(x, dtype):
+    """An activation tensor in the given storage type (torch.float32 / torch.bfloat16); a no-op when it already is."""
+    if x.dtype == dtype:
+        return x
+    if {x.dtype, dtype} != {torch.float32, BF16}:
+        raise ValueError(f"to_storage: {x.dtype} -> {dtype}")
+    return _Cast.apply(x, dtype == BF16)
+
+
+def _dense_bf16(x, w, bias, g: Geom, want_stats):
+    """Dense conv in bf16 storage.  x fp32 is the data layer (a stem: converted on the way in); a single output channel is padded
+    to 8 (zero weights) and handed on as an fp32 tensor -- the logits stay fp32."""
+    cin, cout = x.shape[-1], w.shape[0]
+    if x.dtype == torch.float32:
+        if not _stem_form(x, w, g):
+            raise NotImplementedError("bf16 storage: an fp32 input can only enter through a stem (odd k, stride 2, <= 4 channels, no gradient)")
+        return _StemS2DH.apply(x, w, bias, g, want_stats)
+    if cout % 8 != 0:
+        if cout != 1 or want_stats:
+            raise NotImplementedError(f"bf16 storage: {cout} output channels (multiples of 8, or a 1-channel head without BatchNorm)")
+        w8 = torch.cat([w, w.new_zeros((7,) + tuple(w.shape[1:]))], 0)
+        b8 = None if bias is None else torch.cat([bias, bias.new_zeros(7)], 0)
+        return _ChannelToF32.apply(_DenseH.apply(x, w8, b8, g, False), 0)
+    return _DenseH.apply(x, w, bias, g, want_stats)
+
+
 def _stem_form(x, w, g: Geom):
     """Geometry of _StemS2D: odd square kernel, stride 2, "same" padding, no dilation, <= 4 input channels, GEMM-sized
     Cout, even padded image, and no gradient wanted for the input."""
@@ -485,6 +781,10 @@ def _stem_form(x, w, g: Geom):
 
 def pconv_dense(x, w, bias, mfull, r0, split, r1, denom, keep, inv, g: Geom, want_stats=False):
     """With ``want_stats`` returns (y, stat_part or None) -- None when the geometry is not on the implicit-GEMM path."""
+    if _h(x) or (_ACT_STORAGE == BF16 and mfull is None and r0 is None and denom is None and x.dtype == torch.float32 and _stem_form(x, w, g)):
+        _no_masks("dense convolution", mfull, r0, r1, denom, keep)
+        out = _dense_bf16(x, w, bias, g, want_stats)
+        return (out, None) if (want_stats and not isinstance(out, tuple)) else out
     if _stem_form(x, w, g):
         out = _StemS2D.apply(x, w, bias, mfull, r0, r1, denom, keep, inv, split, g, want_stats)
     else:
@@ -548,6 +848,8 @@ class _BNAct(torch.autograd.Function):
 
 def bn_act(y, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5,
            act=ACT_NONE, slope=0.0, residual=None, part=None):
+    if _h(y):          # bf16 storage: statistics -> (scale, shift) -> one apply pass, the lazy form written out
+        return bn_lazy(y, gamma, beta, running_mean, running_var, training, momentum, eps, act, slope, part).materialize(residual)
     return _BNAct.apply(y, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, slope, part)
 
 
@@ -589,7 +891,7 @@ class LazyBN:
     def materialize(self, residual=None):
         self.consumed()
         return _LazyApply.apply(self.token, self.mean, self.var, self.gamma, self.beta, self.eps, self.act, self.slope,
-                                residual)
+                                residual, self.scale, self.shift)
 
 
 class _BNLazy(torch.autograd.Function):
@@ -611,6 +913,9 @@ class _BNLazy(torch.autograd.Function):
         if training:
             mean = torch.empty(c, dtype=torch.float32, device=dev)
             var = torch.empty(c, dtype=torch.float32, device=dev)
+            if part is None and _h(y):       # bf16 storage: the separate statistics pass emits partials in the fused layout
+                part = torch.empty((int(_lib.lib().tsii_bf16_bn_stat_rows(m, c)), 4, c), dtype=torch.float32, device=dev)
+                call("tsii_bf16_bn_stats", ptr(y), m, c, ptr(part), st)
             if part is not None:
                 rows = part.shape[0]
                 nbytes = _lib.lib().tsii_bn_finalize_ws_bytes(rows, c)
@@ -647,12 +952,20 @@ class _BNLazy(torch.autograd.Function):
         dy = torch.empty_like(y)
         dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
         dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
-        nbytes = _lib.lib().tsii_bn_ws_bytes(m, c)
-        ws = _ws(nbytes, y)
         slot = ctx.slot
         part = slot.part if (slot is not None and slot.consumers == 1) else None
         if slot is not None:
             slot.part = None
+        if _h(y):
+            if ga.dtype != BF16:
+                raise RuntimeError("bf16 storage: the incoming gradient of a bf16 BatchNorm must be bf16")
+            nbytes = _lib.lib().tsii_bf16_bn_ws_bytes(m, c)
+            ws = _ws(nbytes, y)
+            call("tsii_bf16_bn_act_bwd", ptr(ga), ptr(y), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), eps, act, slope, int(training),
+                 ptr(part), 0 if part is None else part.shape[0], ptr(dy), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _lib.stream())
+            return (dy, dgamma, dbeta) + (None,) * 10
+        nbytes = _lib.lib().tsii_bn_ws_bytes(m, c)
+        ws = _ws(nbytes, y)
         pool = ctx.pool
         if part is not None and pool is not None and y.dim() == 4 and (y.shape[1], y.shape[2]) == (pool.h, pool.w):
             dz = torch.empty((y.shape[0], pool.h // 2, pool.w // 2, c), dtype=torch.float32, device=y.device)
@@ -675,19 +988,24 @@ class _LazyApply(torch.autograd.Function):
     lives in _BNLazy)."""
 
     @staticmethod
-    def forward(ctx, token, mean, var, gamma, beta, eps, act, slope, residual):
+    def forward(ctx, token, mean, var, gamma, beta, eps, act, slope, residual, scale=None, shift=None):
         c = token.shape[-1]
         m = token.numel() // c
         residual = _c(residual)
         out = torch.empty_like(token)
-        call("tsii_bn_act_fwd", ptr(token), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), int(act),
-             float(slope), ptr(residual), ptr(out), _lib.stream())
+        if _h(token):      # bf16 storage: the (scale, shift) form -- exactly what a load-time consumer of this BatchNorm computes
+            if residual is not None and residual.dtype != BF16:
+                raise RuntimeError("bf16 storage: the residual of a bf16 BatchNorm must be bf16")
+            call("tsii_bf16_bn_act_fwd", ptr(token), m, c, ptr(scale), ptr(shift), int(act), float(slope), ptr(residual), ptr(out), _lib.stream())
+        else:
+            call("tsii_bn_act_fwd", ptr(token), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), int(act),
+                 float(slope), ptr(residual), ptr(out), _lib.stream())
         ctx.has_res = residual is not None
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        return (gout,) + (None,) * 7 + ((gout if ctx.has_res else None),)
+        return (gout,) + (None,) * 7 + ((gout if ctx.has_res else None),) + (None, None)
 
 
 def bn_lazy(y, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, act=ACT_NONE, slope=0.0,
@@ -962,6 +1280,10 @@ _POOL_W = {}
 
 def avg_pool(x, k: int, stride: int, padding: int):
     """nn.AvgPool2d(k, stride, padding), count_include_pad=True: a depth-wise conv with weights 1/k^2."""
+    if _h(x):
+        if stride != 1 or padding != (k - 1) // 2 or k not in (3, 5, 9):
+            raise NotImplementedError(f"bf16 storage: AvgPool2d({k}, {stride}, {padding}) has no kernel (k in 3/5/9, stride 1, same padding)")
+        return _AvgPoolH.apply(x, k)
     c = x.shape[-1]
     key = (c, k, x.device)
     w = _POOL_W.get(key)
@@ -970,14 +1292,36 @@ def avg_pool(x, k: int, stride: int, padding: int):
     return pconv_depthwise(x, w, None, None, None, None, None, make_geom(k, stride, padding, 1))
 
 
+class _AvgPoolH(torch.autograd.Function):
+    """bf16 storage: k x k / stride 1 / same-padding average pool (count_include_pad); the operator is its own adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        _lib.check_device(x)
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        y = torch.empty_like(x)
+        call("tsii_bf16_avgpool", ptr(x), n, h, w, c, int(k), ptr(y), _lib.stream())
+        ctx.k = int(k)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        n, h, w, c = gy.shape
+        dx = torch.empty_like(gy)
+        call("tsii_bf16_avgpool", ptr(gy), n, h, w, c, ctx.k, ptr(dx), _lib.stream())
+        return dx, None
+
+
 class _AddAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, act, slope):
         _lib.check_device(a)
         a, b = a.contiguous(), b.contiguous()
-        assert a.shape == b.shape
+        assert a.shape == b.shape and a.dtype == b.dtype, "add: operands must agree in shape and storage type"
         out = torch.empty_like(a)
-        call("tsii_add_act_fwd", ptr(a), ptr(b), a.numel(), int(act), float(slope), ptr(out), _lib.stream())
+        call("tsii_bf16_add_act_fwd" if _h(a) else "tsii_add_act_fwd", ptr(a), ptr(b), a.numel(), int(act), float(slope), ptr(out), _lib.stream())
         ctx.cfg = (int(act), float(slope))
         if act != ACT_NONE:
             ctx.save_for_backward(out)
@@ -993,7 +1337,7 @@ class _AddAct(torch.autograd.Function):
             raise NotImplementedError("add+sigmoid backward is not used by the reference networks")
         (out,) = ctx.saved_tensors   # sign / range of the output decides the ReLU-family derivative
         g = torch.empty_like(gout)
-        call("tsii_act_bwd", ptr(gout), ptr(out), out.numel(), act, slope, ptr(g), _lib.stream())
+        call("tsii_bf16_act_bwd" if _h(out) else "tsii_act_bwd", ptr(gout), ptr(out), out.numel(), act, slope, ptr(g), _lib.stream())
         return g, g, None, None
 
 
@@ -1009,11 +1353,14 @@ class _Concat(torch.autograd.Function):
         lead = xs[0].shape[:-1]
         chans = [x.shape[-1] for x in xs]
         m = xs[0].numel() // chans[0]
-        out = torch.empty(lead + (sum(chans),), dtype=torch.float32, device=xs[0].device)
+        dt = xs[0].dtype
+        assert all(x.dtype == dt for x in xs), "concat: mixed storage types"
+        fn = "tsii_bf16_copy_channels" if dt == BF16 else "tsii_copy_channels"
+        out = torch.empty(lead + (sum(chans),), dtype=dt, device=xs[0].device)
         off = 0
         for x, c in zip(xs, chans):
             assert x.shape[:-1] == lead
-            call("tsii_copy_channels", ptr(out), m, sum(chans), off, ptr(x), c, 1, _lib.stream())
+            call(fn, ptr(out), m, sum(chans), off, ptr(x), c, 1, _lib.stream())
             off += c
         ctx.chans, ctx.lead = chans, lead
         return out
@@ -1026,8 +1373,8 @@ class _Concat(torch.autograd.Function):
         grads, off = [], 0
         for i, c in enumerate(chans):
             if ctx.needs_input_grad[i]:
-                g = torch.empty(lead + (c,), dtype=torch.float32, device=gout.device)
-                call("tsii_copy_channels", ptr(gout), m, sum(chans), off, ptr(g), c, 0, _lib.stream())
+                g = torch.empty(lead + (c,), dtype=gout.dtype, device=gout.device)
+                call("tsii_bf16_copy_channels" if _h(gout) else "tsii_copy_channels", ptr(gout), m, sum(chans), off, ptr(g), c, 0, _lib.stream())
                 grads.append(g)
             else:
                 grads.append(None)
@@ -1046,8 +1393,8 @@ class _BilinearUp(torch.autograd.Function):
         _lib.check_device(x)
         x = x.contiguous()
         n, h, w, c = x.shape
-        y = torch.empty((n, h * scale, w * scale, c), dtype=torch.float32, device=x.device)
-        call("tsii_bilinear_up_fwd", ptr(x), n, h, w, c, int(scale), ptr(y), _lib.stream())
+        y = torch.empty((n, h * scale, w * scale, c), dtype=x.dtype, device=x.device)
+        call("tsii_bf16_bilinear_up_fwd" if _h(x) else "tsii_bilinear_up_fwd", ptr(x), n, h, w, c, int(scale), ptr(y), _lib.stream())
         ctx.dims = (n, h, w, c, int(scale))
         return y
 
@@ -1055,8 +1402,8 @@ class _BilinearUp(torch.autograd.Function):
     def backward(ctx, gy):
         n, h, w, c, scale = ctx.dims
         gy = gy.contiguous()
-        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=gy.device)
-        call("tsii_bilinear_up_bwd", ptr(gy), n, h, w, c, scale, ptr(dx), _lib.stream())
+        dx = torch.empty((n, h, w, c), dtype=gy.dtype, device=gy.device)
+        call("tsii_bf16_bilinear_up_bwd" if _h(gy) else "tsii_bilinear_up_bwd", ptr(gy), n, h, w, c, scale, ptr(dx), _lib.stream())
         return dx, None
 
 
