@@ -101,6 +101,30 @@ CALLS = {
     # its addend's gradient: (n, h, w, c) of the LOW grid: reads [n,2h,2w,c], writes [n,h,w,c]
     "tsii_pool2x2_scaled": ("upcat", lambda a: (4.0 * a[0] * a[1] * a[2] * a[3] * 5, 0.0)),
 }
+
+
+def _half(fn):
+    """the same traffic model at 2 bytes per element (bf16 activation storage: tsii_bf16_* entry points)"""
+    def g(a):
+        by, macs = fn(a)
+        return by / 2.0, macs
+    return g
+
+
+CALLS.update({
+    "tsii_bf16_pw_fwd": ("gemm_nt", _half(_pw)),
+    "tsii_bf16_pw_bwd_dx": ("gemm_nt", _half(lambda a: (_pw((a[0], a[1], a[2]))[0] + (4.0 * a[0] * a[2] if a[3] else 0.0), _pw((a[0], a[1], a[2]))[1]))),
+    "tsii_bf16_pw_bwd_dw": ("gemm_tn", _half(lambda a: _pw((a[0], a[1], a[2])))),
+    "tsii_bf16_dw_fwd": ("dw_stencil", _half(lambda a: _dw(a, (1, 1)))),
+    "tsii_bf16_dw_bwd_dx": ("dw_stencil", _half(lambda a: _dw(a, (2 if a[14] else 1, 1)))),     # eps != 0: K6c reads the raw BatchNorm input too
+    "tsii_bf16_dw_bwd_dw": ("dw_stencil", _half(lambda a: _dw(a, (1, 1)))),
+    "tsii_bf16_avgpool": ("dw_stencil", lambda a: (2.0 * 2 * a[0] * a[1] * a[2] * a[3], 0.0)),
+    "tsii_bf16_dense_fwd": ("dense_conv", _half(lambda a: _dense(a, 1, 0, 0, 1))),
+    "tsii_bf16_dense_bwd_dx": ("dense_conv", _half(lambda a: _dense(a, 0, 1, 1, 0))),
+    "tsii_bf16_dense_bwd_dw": ("dense_conv", _half(lambda a: _dense(a, 1, 1, 0, 0))),
+    "tsii_bf16_bn_act_fwd": ("bn_act", _half(lambda a: _bn(a, 2))), "tsii_bf16_bn_stats": ("bn_act", _half(lambda a: _bn(a, 1))),
+    "tsii_bf16_bn_act_bwd": ("bn_bwd", _half(lambda a: _bn(a, 3 if a[6] else 5))),      # rows == 0: the kernel takes its own reduction pass (2 more reads)
+})
 BOUND = {"gemm_nt": None, "gemm_tn": None, "dense_conv": "mfma", "dw_stencil": "hbm", "bn_act": "hbm", "bn_bwd": "hbm", "upcat": "hbm"}
 
 
@@ -231,6 +255,9 @@ def main(argv=None):
     ap.add_argument("--pixel-shuffle", action="store_true", help="TextSegament with the Conv(128,16) + PixelShuffle(4) head (cfg 3)")
     ap.add_argument("--checkpoint", action="store_true", help="TextSegament: recompute the encoder stages in backward (memory saver)")
     ap.add_argument("--products", type=int, default=-1, help="tsii_set_gemm_products for this run (1 = the 'mixed bf16' arithmetic of cfg 5)")
+    ap.add_argument("--storage", default="f32", choices=["f32", "bf16"],
+                    help="activation storage (segmentation nets): bf16 = activations and their gradients in HBM as bf16, fp32 accumulation / statistics / "
+                         "parameters (cfg 5: --model XceptionTextSegment --size 1024 --batch 8 --storage bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the short run in the bit-exact f32-MFMA arithmetic mode")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU-baseline leg (default: both min(physical cores, 32) and all physical cores, the better one reported)")
@@ -270,6 +297,13 @@ def main(argv=None):
     if args.products >= 0:
         _lib.set_gemm_products(args.products)
     products = _lib.get_gemm_products()
+    bf16_storage = args.storage == "bf16"
+    if bf16_storage:
+        if args.model not in ("TextSegament", "XceptionTextSegment"):
+            raise SystemExit("--storage bf16 exists for the segmentation nets (the partial-convolution family keeps fp32 storage)")
+        T.set_activation_storage(torch.bfloat16)
+        products = 1          # accounting only: the tsii_bf16_* matrix products are one bf16 MFMA product per multiply-add
+        args.no_f32_leg = True
     torch.manual_seed(0)  # identical random-init weights on every rank
     seg = args.model in ("TextSegament", "XceptionTextSegment")
     if seg:
@@ -410,6 +444,10 @@ def main(argv=None):
             # tiles evenly (csrc/gemm_pc.hip nt_pc_ok), the block-synchronous split kernel the rest
             kern = {"gemm_nt": (("tsii::gemm_nt_pc_kernel<", "tsii::gemm_nt_split_kernel<") if products else "tsii::gemm_nt_kernel<2, 2, 2, 2"),
                     "gemm_tn": ("tsii::gemm_tn_split_kernel<2, 2, 2, 2" if products else "tsii::gemm_tn_kernel<2, 2, 2, 2")}.get(k, "tsii::" + k)
+            if bf16_storage:
+                kern = {"gemm_nt": "tsii::hgemm_nt_kernel<", "gemm_tn": "tsii::hgemm_tn_kernel<", "dw_stencil": "tsii::hdw_conv_kernel< + hdw_dw_kernel<",
+                        "dense_conv": "tsii::hgemm_nt_kernel< (gathered) + hgemm_tn_kernel<", "bn_bwd": "tsii::hbn_bwd_apply_kernel + partial",
+                        "bn_act": "tsii::hbn_apply_kernel"}.get(k, "tsii::" + k)
             kname = kern if isinstance(kern, str) else " + ".join(x.split("::")[1] + "...>" for x in kern)
             kname = kname.split("::")[1] + "...>" if "::" in kname else kname
             t_hbm = d["alg_gb_per_step"] / (PEAK_HBM_TBS * 1e3)            # seconds per step at the HBM peak
@@ -429,7 +467,8 @@ def main(argv=None):
                         "launches_per_step": d["launches_per_step"],
                         "avg_launch_ms": round(d["ms_per_step"] / max(1, d["launches_per_step"]), 4),
                         "ms_per_step_in_class": d["ms_per_step"],
-                        "arithmetic": (f"split-bf16: {products} v_mfma_f32_32x32x16_bf16 partial products per fp32 product, fp32 accumulate" if products
+                        "arithmetic": ("bf16 operands from HBM, one v_mfma_f32_32x32x16_bf16 product per multiply-add, fp32 accumulate, one RNE rounding per stored value" if bf16_storage
+                                       else f"split-bf16: {products} v_mfma_f32_32x32x16_bf16 partial products per fp32 product, fp32 accumulate" if products
                                        else "v_mfma_f32_32x32x2_f32")}
         ms_per_img = elapsed / imgs * world * 1e3  # per-GPU ms per image
         whole = None
@@ -452,7 +491,7 @@ def main(argv=None):
             workload = (f"{args.model} {args.size}x{args.size} partial-conv inpainting train step (fwd+bwd, train-mode BN, L1 loss, grad all-reduce, "
                         f"fused SGD), {args.batch} imgs/GPU, random line/ellipse hole masks")
             metric = "imgs/sec fwd+bwd on 512x512 partial-conv inpaint"
-        dtype = {0: "f32", 1: "f32 storage / accumulation / stencils / BatchNorm; matrix products on bf16-rounded operands (the 'mixed bf16' arithmetic of cfg 5)"}.get(
+        dtype = "bf16 activation / activation-gradient storage (NHWC, 8 channels per 16-byte vector); fp32 accumulation, BatchNorm statistics, parameters and parameter gradients; matrix products bf16 x bf16 -> fp32 (BASELINE config 5 'mixed bf16')" if bf16_storage else {0: "f32", 1: "f32 storage / accumulation / stencils / BatchNorm; matrix products on bf16-rounded operands (the 'mixed bf16' arithmetic of cfg 5)"}.get(
             products, f"f32 (storage, accumulation, stencils, BatchNorm; matrix products = {products}-term exact bf16 split on the bf16 MFMA, fp32-class error)")
         line = {
             "metric": metric,
@@ -461,7 +500,8 @@ def main(argv=None):
             "vs_baseline": None,
             "dtype": dtype,
             "data": "synthetic",
-            "config": {"workload": workload, "global_batch": world * args.batch, "parallelism": f"dp{world}", "gemm_products": products},
+            "config": {"workload": workload, "global_batch": world * args.batch, "parallelism": f"dp{world}", "gemm_products": products,
+                       "activation_storage": args.storage},
             "roofline": roofline, "kernel_classes": classes, "whole_step_roofline": whole, "final_loss": final_loss,
             "launch": "hip_graph_replay" if graphed else "eager", "eager_ms_per_step": round(eager_ms, 3),
             "forward_only": {"value": round(world * args.batch * fwd_steps / fwd_elapsed, 2), "unit": "imgs/s (rank 0 clock)",

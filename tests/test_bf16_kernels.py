@@ -11,16 +11,71 @@ import pytest
 from text_segmentation_image_inpainting_amd import _lib
 
 
-@pytest.fixture(scope="module")
-def emu():
-    from tests.emu import build_emu
-    if not build_emu.available():
-        pytest.skip("host clang++ not available")
-    return _lib.bind(ctypes.CDLL(build_emu.build()))
+import torch
+
+from tests.backends import both_backends  # noqa: F401  (the same cases run on the emulator and, -m gpu, on the chip)
+
+
+class _Arr:
+    """a numpy array handed to the C ABI: on the GPU backend it is uploaded for the call and copied back afterwards"""
+
+    def __init__(self, a):
+        self.a = a
+
+
+_MODE = {"gpu": False}
 
 
 def P(a):
-    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+    if a is None:
+        return None
+    return _Arr(a) if _MODE["gpu"] else ctypes.c_void_p(a.ctypes.data)
+
+
+class _GpuLib:
+    """the bound library with numpy in / numpy out: every array argument is staged through device memory around the call"""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+
+        def call(*args):
+            staged, conv = [], []
+            for x in args:
+                if isinstance(x, _Arr):
+                    t = torch.from_numpy(x.a.reshape(-1).view(np.uint8)).cuda()
+                    staged.append((x.a, t))
+                    conv.append(ctypes.c_void_p(t.data_ptr()))
+                else:
+                    conv.append(x)
+            if conv and conv[-1] is None and fn.argtypes and fn.argtypes[-1] is ctypes.c_void_p:
+                conv[-1] = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            rc = fn(*conv)
+            torch.cuda.synchronize()
+            for a, t in staged:
+                a.reshape(-1).view(np.uint8)[:] = t.cpu().numpy()
+            return rc
+        return call
+
+
+@pytest.fixture(params=[pytest.param("emu"), pytest.param("gpu", marks=pytest.mark.gpu)])
+def emu(request):
+    """the library under test: the host emulation of the unmodified kernel sources (CPU suite) or libtsii_hip.so on the chip (-m gpu)"""
+    if request.param == "gpu":
+        if not torch.cuda.is_available():
+            pytest.fail("-m gpu tests need a ROCm GPU")
+        _MODE["gpu"] = True
+        try:
+            yield _GpuLib(_lib.lib())
+        finally:
+            _MODE["gpu"] = False
+        return
+    from tests.emu import build_emu
+    if not build_emu.available():
+        pytest.skip("host clang++ not available")
+    yield _lib.bind(ctypes.CDLL(build_emu.build()))
 
 
 _CANARY = np.float32(-12345.678)
