@@ -258,6 +258,8 @@ def main(argv=None):
     ap.add_argument("--storage", default="f32", choices=["f32", "bf16"],
                     help="activation storage (segmentation nets): bf16 = activations and their gradients in HBM as bf16, fp32 accumulation / statistics / "
                          "parameters (cfg 5: --model XceptionTextSegment --size 1024 --batch 8 --storage bf16)")
+    ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B switch of the package (module attribute of ops / partial_convolution, e.g. FUSE_UPCAT=0, FUSE_BN=stats); repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the short run in the bit-exact f32-MFMA arithmetic mode")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU-baseline leg (default: both min(physical cores, 32) and all physical cores, the better one reported)")
@@ -292,6 +294,14 @@ def main(argv=None):
     from text_segmentation_image_inpainting_amd.synthetic import make_batch
     from text_segmentation_image_inpainting_amd.train_step import FlatSGDTrainer
 
+    for kv in args.knob:
+        from text_segmentation_image_inpainting_amd import ops as _ops, partial_convolution as _pc
+        name, _, val = kv.partition("=")
+        mod = _ops if hasattr(_ops, name) else _pc if hasattr(_pc, name) else None
+        if mod is None:
+            raise SystemExit(f"--knob {name}: no such switch")
+        cur = getattr(mod, name)
+        setattr(mod, name, (val not in ("0", "false", "False")) if isinstance(cur, bool) else val)
     if on_gpu:
         _lib.lib()           # fails loudly when libtsii_hip.so is missing
     if args.products >= 0:

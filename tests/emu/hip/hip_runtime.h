@@ -115,6 +115,9 @@ static inline void async_load16(f32x4_emu2& d, const void* base, unsigned off) {
 static inline void async_load4(float& d, const void* base, unsigned off) { hipemu::async_issue(&d, (const char*)base + off, 4); }
 template <int N, class... T> static inline void async_wait(T&...) { hipemu::async_retire(N); }
 static inline void lds_barrier() { hipemu::barrier_only(); }
+// direct global -> LDS load: lane i's 16 bytes land at (wave-uniform) base + 16 i when a wait retires them; NaN pattern until then
+static inline void async_load16_lds(void* lds_wave_base, const void* gptr) { hipemu::async_issue((char*)lds_wave_base + 16 * hipemu::lane_id(), gptr, 16); }
+template <int N> static inline void async_wait_lds() { hipemu::async_retire(N); }
 }
 static inline f32x16_emu __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16_emu c, int, int, int) {
     return hipemu::mfma_32x32x2(a, b, c);

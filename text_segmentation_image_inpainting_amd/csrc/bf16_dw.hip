@@ -394,9 +394,15 @@ __global__ __launch_bounds__(256) void hdw_dw_kernel(const bf16_t* __restrict__ 
     }
 }
 
-// ---- dX of a stride-2 layer (d = 1): dx[y][x] = sum over taps with (y + p - ky, x + p - kx) both even -------------------------
+// ---- dX of a stride-2 layer (d = 1): dx[y][x] = sum over the taps with (y + p - ky, x + p - kx) both even: 1, 2 or 4 of the 9 --
+// the others are skipped, not loaded-and-zeroed (a thread's taps depend on the parities of its pixel only).  Weights of all
+// channels in LDS ([tap][c], c <= 1024).
+static constexpr int HDW_S2_MAXC = 1024;
 __global__ __launch_bounds__(256) void hdw_dx_s2_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ w, int n, int h, int wd, int c,
                                                         int ho, int wo, int p, bf16_t* __restrict__ dx) {
+    __shared__ __attribute__((aligned(16))) float lw[9 * HDW_S2_MAXC];
+    for (int i = threadIdx.x; i < 9 * c; i += 256) { const int t = i / c, ch = i - t * c; lw[i] = w[(int64_t)ch * 9 + t]; }
+    __syncthreads();
     const int G = c / 8;
     const int64_t total = (int64_t)n * h * wd * G;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -406,19 +412,19 @@ __global__ __launch_bounds__(256) void hdw_dx_s2_kernel(const bf16_t* __restrict
     const int x = (int)(pix % wd), yy = (int)((pix / wd) % h);
     const int64_t b = pix / ((int64_t)wd * h);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
+    for (int ky = (yy + p) & 1; ky < 3; ky += 2) {
         const int ty = yy + p - ky;
-        const bool yok = ty >= 0 && (ty & 1) == 0 && (ty >> 1) < ho;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
+        if (ty < 0 || (ty >> 1) >= ho) continue;
+        for (int kx = (x + p) & 1; kx < 3; kx += 2) {
             const int tx = x + p - kx;
-            const bool ok = yok && tx >= 0 && (tx & 1) == 0 && (tx >> 1) < wo;
-            const int64_t sp = ok ? ((b * ho + (ty >> 1)) * wo + (tx >> 1)) : 0;
+            if (tx < 0 || (tx >> 1) >= wo) continue;
             float v[8];
-            unpack8(ld8(dy + sp * c + c0), v);
+            unpack8(ld8(dy + ((b * ho + (ty >> 1)) * wo + (tx >> 1)) * c + c0), v);
+            const float* wt = lw + (ky * 3 + kx) * c + c0;
+            const float4 w0 = *reinterpret_cast<const float4*>(wt), w1 = *reinterpret_cast<const float4*>(wt + 4);
+            const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = fmaf(ok ? v[e] : 0.f, w[(int64_t)(c0 + e) * 9 + ky * 3 + kx], acc[e]);
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(v[e], wv[e], acc[e]);
         }
     }
     st8_nt(dx + pix * c + c0, pack8(acc));
@@ -548,6 +554,7 @@ extern "C" int tsii_bf16_dw_bwd_dx(const uint16_t* dy, const float* w, int n, in
     hipStream_t st = (hipStream_t)stream;
     if (sh == 2) {
         TSII_REQUIRE(bn_y == nullptr, "bf16_dw_bwd_dx: the stride-2 form takes no BatchNorm-backward reductions (tsii_bf16_dw_bwd_stat_rows == 0)");
+        TSII_REQUIRE(c <= HDW_S2_MAXC, "bf16_dw_bwd_dx: the stride-2 form is built for <= %d channels", HDW_S2_MAXC);
         const int64_t total = (int64_t)n * h * wd * (c / 8);
         hipLaunchKernelGGL(hdw_dx_s2_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, st, dy, w, n, h, wd, c, ho, wo, ph, dx);
         return check_launch("bf16_dw_bwd_dx (stride 2)");

@@ -95,24 +95,6 @@ __global__ __launch_bounds__(256) void hbn_bwd_partial_kernel(const bf16_t* __re
     }
 }
 
-// sums[2][C] (reduced partial rows) -> dgamma, dbeta and the apply pass's table of per-channel constants coef[6][C]
-__global__ void hbn_coef_kernel(const float* __restrict__ sums, int C, int64_t M, const float* __restrict__ mean, const float* __restrict__ var,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int training,
-                                float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float s1 = sums[c], s2 = sums[C + c];
-    dbeta[c] = s1;
-    dgamma[c] = s2;
-    const float invM = 1.0f / (float)M;
-    coef[c] = mean[c];
-    coef[C + c] = 1.0f / sqrtf(var[c] + eps);
-    coef[2 * C + c] = gamma[c];
-    coef[3 * C + c] = beta[c];
-    coef[4 * C + c] = training ? s1 * invM : 0.f;
-    coef[5 * C + c] = training ? s2 * invM : 0.f;
-}
-
 // backward pass 2: dy = gamma * istd * (dz - s1/M - xhat * s2/M)  (training)  |  gamma * istd * dz  (eval)
 __global__ __launch_bounds__(256) void hbn_bwd_apply_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y, int64_t M, int C,
                                                             const float* __restrict__ coef, int act, float slope, bf16_t* __restrict__ dy) {
@@ -309,7 +291,16 @@ __global__ __launch_bounds__(256) void hchannel_from_f32_kernel(const float* __r
     st8(dst + row * c + c0, pack8(v));
 }
 
-static inline int hbn_rows(int64_t m, int c) { return partial_rows(m, c / 8); }
+// partial rows of the strided reduction passes: ~256 K tasks (row, channel octet) whatever the channel count, so that narrow
+// tensors ([2M, 64]: 8 octets per row) still fill the chip -- with tsii_common.h's partial_rows() that shape ran 128 blocks of
+// 512 dependent iterations each (2.0 TB/s)
+static inline int hbn_rows(int64_t m, int c) {
+    int64_t r = 262144 / (c / 8);
+    if (r > 32768) r = 32768;
+    if (r > m) r = m;
+    if (r < 1) r = 1;
+    return (int)r;
+}
 static inline size_t hbn_coef_floats(int c) { return (size_t)6 * c + 8; }
 
 }  // namespace tsii
@@ -336,9 +327,11 @@ extern "C" int tsii_bf16_bn_act_fwd(const uint16_t* y, int64_t m, int c, const f
     return check_launch("bf16_bn_act_fwd");
 }
 
+// workspace: [partial rows of the kernel's own reduction pass | level-1 sums of the row reduction] [coef table]
 extern "C" size_t tsii_bf16_bn_ws_bytes(int64_t m, int c) {
     if (m <= 0 || c <= 0 || c % 8 != 0) return 0;
-    return ((size_t)hbn_rows(m, c) * 2 * c + 2 * (size_t)c + hbn_coef_floats(c)) * sizeof(float) + 32;
+    const int R = hbn_rows(m, c);
+    return (size_t)R * 2 * c * sizeof(float) + bn_bwd_reduce_ws_bytes(R, c) + hbn_coef_floats(c) * sizeof(float) + 64;
 }
 
 extern "C" int tsii_bf16_bn_act_bwd(const uint16_t* dout, const uint16_t* y, int64_t m, int c, const float* mean, const float* var,
@@ -350,24 +343,24 @@ extern "C" int tsii_bf16_bn_act_bwd(const uint16_t* dout, const uint16_t* y, int
     TSII_REQUIRE(ws_bytes >= tsii_bf16_bn_ws_bytes(m, c), "bf16_bn_act_bwd: workspace too small (tsii_bf16_bn_ws_bytes)");
     TSII_REQUIRE(bwd_part == nullptr || (rows > 0 && rows < (1ll << 31)), "bf16_bn_act_bwd: bad partial-row count");
     hipStream_t st = (hipStream_t)stream;
-    float* wsf = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 15) & ~(uintptr_t)15);
-    const int R = hbn_rows(m, c);
-    float* part = wsf;                                  // [R][2][c]
-    float* sums = wsf + (size_t)R * 2 * c;              // [2][c]
-    float* coef = sums + 2 * (size_t)c;                 // [6][c]  (c % 8 == 0 keeps it 16-byte aligned)
+    char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ws) + 15) & ~(uintptr_t)15);
+    const size_t usable = ws_bytes - (size_t)(base - reinterpret_cast<char*>(ws));
+    const size_t coef_bytes = ((hbn_coef_floats(c) * sizeof(float)) + 15) & ~(size_t)15;
+    float* coef = reinterpret_cast<float*>(base + ((usable - coef_bytes) & ~(size_t)15));      // table at the end, 16-byte aligned
     int rc;
     if (bwd_part == nullptr) {
+        const int R = hbn_rows(m, c);
+        float* part = reinterpret_cast<float*>(base);                          // [R][2][c]
+        void* l1 = base + (size_t)R * 2 * c * sizeof(float);
         hipLaunchKernelGGL(hbn_bwd_partial_kernel, dim3(stream_grid((int64_t)R * (c / 8), 256)), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta,
                            eps, act, slope, R, part);
         rc = check_launch("bf16_bn_bwd_partial");
         if (rc) return rc;
-        rc = launch_reduce_rows(part, R, 2 * (int64_t)c, sums, st);
+        rc = launch_bn_bwd_reduce(mean, var, gamma, beta, eps, training, part, R, m, c, dgamma, dbeta, l1, coef, st);
     } else {
-        rc = launch_reduce_rows(bwd_part, (int)rows, 2 * (int64_t)c, sums, st);
+        TSII_REQUIRE(bn_bwd_reduce_ws_bytes(rows, c) + coef_bytes + 32 <= usable, "bf16_bn_act_bwd: workspace too small for %lld partial rows", (long long)rows);
+        rc = launch_bn_bwd_reduce(mean, var, gamma, beta, eps, training, bwd_part, rows, m, c, dgamma, dbeta, base, coef, st);
     }
-    if (rc) return rc;
-    hipLaunchKernelGGL(hbn_coef_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, sums, c, m, mean, var, gamma, beta, eps, training, dgamma, dbeta, coef);
-    rc = check_launch("bf16_bn_coef");
     if (rc) return rc;
     hipLaunchKernelGGL(hbn_bwd_apply_kernel, dim3(flat_grid(m * (c / 8), 256)), dim3(256), 0, st, dout, y, m, c, coef, act, slope, dy);
     return check_launch("bf16_bn_bwd_apply");

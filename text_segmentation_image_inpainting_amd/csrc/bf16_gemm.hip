@@ -280,7 +280,10 @@ __device__ __forceinline__ void h_nt_epilogue(float* __restrict__ smem, hf32x16 
 }
 
 template <int WM, int WN, int TM, int TN, int AMODE, bool BNIN, bool BNB>
-__global__ __launch_bounds__(256) void hgemm_nt_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
+#ifndef HNT_WAVES
+#define HNT_WAVES 4      // waves per SIMD the NT kernel is held to (A/B: tools/variants; 1 = whatever the compiler takes)
+#endif
+__global__ __launch_bounds__(256, (HNT_WAVES > 3 && BNB) ? 3 : HNT_WAVES) void hgemm_nt_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
                                                        bf16_t* __restrict__ C, int64_t ldc, int64_t M, int N, int K, HEpi ep, unsigned ntn,
                                                        InBN ib, HGather cg) {
     constexpr bool CONV = AMODE != 0;

@@ -626,6 +626,16 @@ static int bn_bwd_pre_reduce(const float* mean, const float* var, const float* g
     return check_launch("bn_bwd_final");
 }
 
+// the same reduction for other translation units (bf16_elem.hip): partial rows [rows][2][c] -> dgamma / dbeta / coef[6][c];
+// l1_ws: bn_bwd_reduce_ws_bytes(rows, c) bytes of scratch
+namespace tsii {
+size_t bn_bwd_reduce_ws_bytes(int64_t rows, int c) { return (size_t)cdiv64(rows, BN_L1_ROWS) * 2 * c * sizeof(double) + 16; }
+int launch_bn_bwd_reduce(const float* mean, const float* var, const float* gamma, const float* beta, float eps, int training,
+                         const float* bwd_part, int64_t rows, int64_t m, int c, float* dgamma, float* dbeta, void* l1_ws, float* coef, hipStream_t st) {
+    return bn_bwd_pre_reduce(mean, var, gamma, beta, eps, training, bwd_part, rows, m, c, dgamma, dbeta, l1_ws, coef, st);
+}
+}  // namespace tsii
+
 extern "C" int tsii_bn_act_bwd_pre(const float* dout, const float* y, int64_t m, int c, const float* mean,
                                    const float* var, const float* gamma, const float* beta, float eps, int act,
                                    float slope, int training, const float* bwd_part, int64_t rows, float* dy,

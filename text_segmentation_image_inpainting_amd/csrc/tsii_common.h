@@ -96,6 +96,12 @@ int launch_reduce_rows_conv(const float* ws, int rows, int cout, int cin, int T,
 // out[c*rows_in + r] = in[r*cols_in + c]  (2-D transpose of a [rows_in, cols_in] matrix)
 int launch_transpose(const float* in, int rows_in, int cols_in, float* out, hipStream_t stream);
 
+// BatchNorm backward: partial rows [rows][2][c] of (sum dz, sum dz*xhat) -> dgamma, dbeta and the apply pass's table of
+// per-channel constants coef[6][c] = (mean, 1/std, gamma, beta, sum dz / m, sum dz*xhat / m)   (bn.hip)
+size_t bn_bwd_reduce_ws_bytes(int64_t rows, int c);
+int launch_bn_bwd_reduce(const float* mean, const float* var, const float* gamma, const float* beta, float eps, int training,
+                         const float* bwd_part, int64_t rows, int64_t m, int c, float* dgamma, float* dbeta, void* l1_ws, float* coef, hipStream_t st);
+
 // out[n] = sum_m a[m*N+n] * rowmul[m] (rowmul may be null); ws: colsum_ws_floats(M,N) floats
 size_t colsum_ws_floats(int64_t M, int N);
 int launch_colsum_scaled(const float* a, const float* rowmul, int64_t M, int N, float* out, float* ws,
@@ -239,6 +245,15 @@ template <int N, class A, class B, class C, class D>
 __device__ __forceinline__ void async_wait(A& a, B& b, C& c, D& d) { asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory"); }
 // block barrier for LDS traffic only: __syncthreads() also drains vmcnt, i.e. every load in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+// Direct global -> LDS load (global_load_lds_dwordx4): lane i's 16 bytes (per-lane global address) land at lds_wave_base + 16 i --
+// the LDS side is wave-uniform base + lane-linear, swizzles go on the SOURCE address.  Counted by vmcnt like any other load:
+// async_wait_lds<N>() waits until at most N younger loads of this wave are outstanding; a following lds_barrier() makes the
+// other waves' pieces visible.  No staging registers: the prefetch depth is LDS stages, not VGPRs.
+__device__ __forceinline__ void async_load16_lds(void* lds_wave_base, const void* gptr) {
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(gptr)),
+                                     reinterpret_cast<__attribute__((address_space(3))) void*>(static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds_wave_base))), 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void async_wait_lds() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 }  // namespace tsii
 #else
 namespace tsii {

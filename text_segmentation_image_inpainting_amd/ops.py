@@ -15,22 +15,23 @@ from ._lib import call, ptr
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3, 4
 
-import os as _os
-
-# A/B knobs for K6c (BatchNorm-backward reductions taken by the kernel that produces the incoming gradient):
-# TSII_FUSE_BN_BWD = 0 off | 1 in the depth-wise dX strip kernel only | 2 (default) also in the point-wise dX GEMM epilogue.
-# Measured on MI355X (ImageFill 512^2 bs 32, split-bf16 GEMMs): 2 vs 1 = BatchNorm backward 19.9 -> 16.3 ms for +2.0 ms of
-# GEMM epilogue (the raw BatchNorm input is read alongside the store): 90.5 -> 89.3 ms per step.
-FUSE_BN_BWD = _os.environ.get("TSII_FUSE_BN_BWD", "2") != "0"
-FUSE_BN_BWD_PW = _os.environ.get("TSII_FUSE_BN_BWD", "2") == "2"
-# A/B knob: the gradient of a K7b up-sampled addend taken inside the BatchNorm-backward apply pass (tsii_bn_act_bwd_pre_pool)
-FUSE_POOL_BN_BWD = _os.environ.get("TSII_FUSE_POOL_BN_BWD", "1") != "0"
-# A/B knob for K4d (head weight gradient on the f32 matrix cores)
-USE_HEAD_MFMA = _os.environ.get("TSII_HEAD_MFMA", "1") != "0"
+# A/B switches between a fused / matrix-core form and its other spelling.  Plain module attributes (no environment variables: the
+# only process-global configuration the package reads is the library's TSII_GEMM_PRODUCTS / TSII_LIBRARY, include/tsii_hip.h);
+# tests monkeypatch them, bench.py sets them with --knob NAME=VALUE, tools/ A/B scripts likewise.  Both spellings of every
+# switch are tested against the oracle; the defaults are the fused ones.
+# K6c (BatchNorm-backward reductions taken by the kernel that produces the incoming gradient): FUSE_BN_BWD in the depth-wise dX
+# strip kernel, FUSE_BN_BWD_PW also in the point-wise dX GEMM epilogue.  Measured on MI355X (ImageFill 512^2 bs 32, split-bf16
+# GEMMs): PW on vs off = BatchNorm backward 19.9 -> 16.3 ms for +2.0 ms of GEMM epilogue: 90.5 -> 89.3 ms per step.
+FUSE_BN_BWD = True
+FUSE_BN_BWD_PW = True
+# the gradient of a K7b up-sampled addend taken inside the BatchNorm-backward apply pass (tsii_bn_act_bwd_pre_pool)
+FUSE_POOL_BN_BWD = True
+# K4d (head weight gradient on the f32 matrix cores)
+USE_HEAD_MFMA = True
 # ... and its d low taken in the weight-gradient kernel's pass (tsii_head_cat_bwd_low) instead of by the vector-ALU dX kernel
-FUSE_HEAD_DLOW = _os.environ.get("TSII_HEAD_DLOW", "1") != "0"
-# A/B knob for K4b (stems as a space-to-depth stride-1 conv on the vector-gather GEMM)
-USE_STEM_S2D = _os.environ.get("TSII_STEM_S2D", "1") != "0"
+FUSE_HEAD_DLOW = True
+# K4b (stems as a space-to-depth stride-1 conv on the vector-gather GEMM)
+USE_STEM_S2D = True
 
 
 class Geom(NamedTuple):

@@ -17,14 +17,12 @@ from . import ops
 from .BaseModels import BaseModule, act_code, bn_state, to_nchw, to_nhwc
 from .masks import MaskParts, as_parts
 
-import os
-
-# A/B knob for the K6b BatchNorm folding: "1" (default) statistics in the conv epilogue + apply on load,
-# "stats" statistics only, "0" the separate-kernel path
-FUSE_BN = os.environ.get("TSII_FUSE_BN", "1")
-# A/B knob for K7b (1x1 convolutions over a decoder concatenation run their low half at low resolution): "0" = materialise the
+# A/B switches (module attributes, see ops.py): K6b BatchNorm folding -- "1" (default) statistics in the conv epilogue + apply on
+# load, "stats" statistics only, "0" the separate-kernel path
+FUSE_BN = "1"
+# K7b (1x1 convolutions over a decoder concatenation run their low half at low resolution): False = materialise the
 # concatenation (K7) and run one product over it, as the reference does
-FUSE_UPCAT = os.environ.get("TSII_FUSE_UPCAT", "1") != "0"
+FUSE_UPCAT = True
 
 inplace_batch_norm = False  # reference: optional un-vendored InPlaceABN (:12-17); never available
 

@@ -1,0 +1,20 @@
+#!/bin/bash
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$R"; mkdir -p gpurun_out
+for v in free stock w3; do
+  if [ $v = stock ]; then unset TSII_LIBRARY; else export TSII_LIBRARY=$R/tools/variants/_bin/libtsii_nt_$v.so; fi
+  echo "=== $v"; timeout 200 python tools/bf16_bench.py --only pw,dense 2>&1 | grep -v "dW\|amdgpu.ids"
+done > gpurun_out/r05f_nt_occupancy.log 2>&1
+python - <<'PY'
+import re
+cur=None; tab={}
+for ln in open('gpurun_out/r05f_nt_occupancy.log'):
+    if ln.startswith('==='): cur=ln.split()[1]; continue
+    if ln.startswith(('1x1','dense')): shape=ln.strip(); continue
+    m=re.match(r'\s+(.+?)\s+([\d.]+) us',ln)
+    if m: tab.setdefault((shape,m.group(1)),{})[cur]=float(m.group(2))
+vs=["free","stock","w3"]
+print(f"{'':70s}"+''.join(f"{v:>9s}" for v in vs))
+for (sh,w),d in tab.items(): print(f"{sh[:44]:44s} {w[:24]:24s} "+''.join(f"{d.get(v,0):9.1f}" for v in vs))
+PY
