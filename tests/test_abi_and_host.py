@@ -151,3 +151,38 @@ def test_bench_class_table_and_traffic_gate(tmp_path, monkeypatch):
     json.dump(js, open(tmp_path / "profiles" / bench.PMC_SUMMARY, "w"))
     val, why = bench.pmc_traffic(("tsii::gemm_nt_pc_kernel<", "tsii::gemm_nt_split_kernel<"))
     assert abs(val - (2 * 1e9 + 6 * 2e9) / 8) < 1.0
+
+
+# Kernels that are allowed private scratch (register spills), by mangled-name prefix -> largest size in bytes per lane.  Every entry
+# was measured: the fused lean depth-wise strips and the head's weight-gradient forms at 2 waves per SIMD WITHOUT scratch run no
+# faster than at 3 waves with it (profiles/r05i_spill_ab.log: ImageFill 480.8 vs 480.1 img/s, ImageFillOrigin 395.1 vs 394.8, the
+# strips' own timings within 1 %) -- the spilled values live in the epilogues, not in the steady-state loops; the GEMM entries are
+# 8-16 bytes in their epilogues.  Anything else -- in particular every bf16-storage kernel and the headline instantiations of the
+# head (NB = 2, low-tensor mask, d low in the same pass) -- must compile without scratch.
+SCRATCH_ALLOWED = {
+    "_ZN4tsii14dw_lean_kernelILi1ELb0E": 48, "_ZN4tsii14dw_lean_kernelILi2ELb1E": 40,
+    "_ZN4tsii17gemm_nt_pc_kernelILi2ELi4ELi6ELb1E": 8,
+    "_ZN4tsii20gemm_nt_split_kernelILi2ELi2ELi2ELi2E": 16, "_ZN4tsii20gemm_tn_split_kernelILi2ELi2ELi2ELi2E": 16,
+    "_ZN4tsii23head_cat_dw_mfma_kernelILi2ELb0ELb1E": 96, "_ZN4tsii23head_cat_dw_mfma_kernelILi2ELb1ELb0ELb0E": 52,
+    "_ZN4tsii23head_cat_dw_mfma_kernelILi2ELb1ELb1E": 116, "_ZN4tsii23head_cat_dw_mfma_kernelILi4E": 152,
+}
+
+
+def test_no_kernel_spills_outside_the_measured_list():
+    """Build-time resource records (build_ext.kernel_resources, from -Rpass-analysis=kernel-resource-usage of the very compile that
+    produced the library): scratch only where it was measured to be harmless; none in the bf16-storage kernels."""
+    from text_segmentation_image_inpainting_amd import build_ext
+    res = build_ext.kernel_resources()
+    assert sum(len(v) for v in res.values()) > 300
+    offenders = []
+    for src, kernels in res.items():
+        for name, rec in kernels.items():
+            sc = rec.get("scratch", 0)
+            if sc <= 0:
+                continue
+            allowed = max((v for k, v in SCRATCH_ALLOWED.items() if name.startswith(k)), default=0)
+            if src.startswith("bf16_") or sc > allowed:
+                offenders.append((src, name[:90], sc, allowed))
+    assert not offenders, offenders
+    clean = "_ZN4tsii23head_cat_dw_mfma_kernelILi2ELb1ELb0ELb1E"      # the headline head: weight gradient + d low
+    assert any(n.startswith(clean) and r.get("scratch", 1) == 0 for n, r in res["head_mfma.hip"].items())

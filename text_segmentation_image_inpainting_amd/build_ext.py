@@ -6,7 +6,9 @@ hipcc cross-compiles without a GPU, so this also runs in the CPU-only build cont
 the resulting .so travels to the GPU box with the repo snapshot.
 """
 import hashlib
+import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -18,6 +20,9 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libtsii_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
+# every compile also records what each kernel was allocated (VGPRs / AGPRs / scratch / occupancy / LDS) next to its object
+# (<obj>.res.json): tests/test_abi_and_host.py holds the scratch policy against it -- no kernel outside a short, measured list spills
+RESOURCE_REMARKS = ["-Rpass-analysis=kernel-resource-usage"]
 # The MFMA kernels are built without v_pk_{add,mul,fma}_f32 (-packed-fp32-ops): next to a busy matrix pipe the packed forms issue
 # at ~1/15 of the scalar rate (measured on MI355X, tools/probes/valu_rates.hip: 9 vs 100-180 cycles per instruction beside a
 # v_mfma_f32_32x32x16_bf16 stream).  The stencil / streaming kernels keep them: without MFMAs around they are two flops per slot.
@@ -36,6 +41,41 @@ def _hipcc():
     raise RuntimeError("hipcc not found (need ROCm to build libtsii_hip.so)")
 
 
+_REMARK = re.compile(r"remark: +([A-Za-z ]+?)(?: \[[^\]]*\])?: +(\S+)")
+_REMARK_CONT = re.compile(r"^\s+\d+ \| |^\s+\| +\^")
+
+
+def parse_resource_remarks(lines):
+    """{mangled kernel name: {"vgprs", "agprs", "scratch", "occupancy", "lds", "sgprs"}} from -Rpass-analysis=kernel-resource-usage"""
+    keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize": "scratch", "Occupancy": "occupancy", "LDS Size": "lds", "TotalSGPRs": "sgprs",
+            "VGPRs Spill": "vgpr_spill", "SGPRs Spill": "sgpr_spill"}
+    out, cur = {}, None
+    for ln in lines:
+        m = _REMARK.search(ln)
+        if not m:
+            continue
+        k, v = m.group(1).strip(), m.group(2)
+        if k == "Function Name":
+            cur = out.setdefault(v, {})
+        elif cur is not None and k in keys:
+            try:
+                cur[keys[k]] = int(v)
+            except ValueError:
+                pass
+    return out
+
+
+def kernel_resources():
+    """Resource records of every kernel of the library as built (builds if needed): {source file: {mangled name: record}}"""
+    build(verbose=False)
+    res = {}
+    for src in sources():
+        base = os.path.splitext(os.path.basename(src))[0]
+        with open(os.path.join(OBJ, base + ".o.res.json")) as f:
+            res[os.path.basename(src)] = json.load(f)
+    return res
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -51,15 +91,20 @@ def _digest(paths):
 
 def _compile_one(args):
     hipcc, src, obj, stamp, dig = args
-    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+    if os.path.exists(obj) and os.path.exists(stamp) and os.path.exists(obj + ".res.json") and open(stamp).read() == dig:
         return src, 0, "cached"
-    cmd = [hipcc] + flags_for(src) + ["-c", src, "-o", obj]
+    cmd = [hipcc] + flags_for(src) + RESOURCE_REMARKS + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
+    lines = (r.stdout + r.stderr).splitlines()
     if r.returncode == 0:
+        with open(obj + ".res.json", "w") as f:
+            json.dump(parse_resource_remarks(lines), f, indent=0, sort_keys=True)
         with open(stamp, "w") as f:
             f.write(dig)
-    # the HOST pass of a .hip file does not know the device feature named in FLAGS and says so once per pass: not a diagnostic
-    out = "\n".join(ln for ln in (r.stdout + r.stderr).splitlines() if "'-packed-fp32-ops' is not a recognized feature" not in ln).strip()
+    # the HOST pass of a .hip file does not know the device feature named in FLAGS and says so once per pass: not a diagnostic;
+    # the resource remarks went into the .res.json
+    out = "\n".join(ln for ln in lines if "'-packed-fp32-ops' is not a recognized feature" not in ln and "-Rpass-analysis=kernel-resource-usage" not in ln
+                    and not _REMARK_CONT.match(ln)).strip()
     return src, r.returncode, out
 
 

@@ -59,8 +59,12 @@ static int hm_blocks(int n, int h, int w, int* tiles_per_block) {
 // pixels of a low pixel share every term, so it is a [low pixels x 27] x [27 x c1] product over the box sums S that are already
 // in LDS for the weight gradient (head_dx_kernel, dense.hip, walks 36 accumulators per full-resolution pixel through the vector ALU:
 // 0.30 ms; here 7 matrix instructions per 16 low pixels and column block).  wgt: W[co][c1 + c2][3][3].
-template <int NB, bool R0, bool R1, bool DLOW>   // 16-channel column blocks of the low tensor (c1 = 16 * NB); mask planes present
-__global__ __launch_bounds__(256, (NB == 2 && !DLOW) ? HM_WAVES : 3) void head_cat_dw_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
+// template <NB, R0, R1, DLOW>: 16-channel column blocks of the low tensor (c1 = 16 * NB); mask planes present; d low in the same pass
+#ifndef HM_WAVES_OTHER
+#define HM_WAVES_OTHER 3      // waves per SIMD of the other instantiations (c1 = 64, d low): A/B against 2 without scratch
+#endif
+template <int NB, bool R0, bool R1, bool DLOW>
+__global__ __launch_bounds__(256, (NB == 2 && !DLOW) ? HM_WAVES : HM_WAVES_OTHER) void head_cat_dw_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
                                                                const float* __restrict__ low, const float* __restrict__ skip,
                                                                const float* __restrict__ r0l, const float* __restrict__ r1,
                                                                const float* __restrict__ wgt, float* __restrict__ dlow,
