@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _rank(rank, world, port, out):
+def _rank(rank, world, port, out, bodies=1, bucket_mb=0.0005):
     import contextlib
     import io
     import sys
@@ -38,31 +38,53 @@ def _rank(rank, world, port, out):
         def __init__(self):
             super().__init__()
             self.stem = T.partial_convolution_block(3, 8, 3, 1, 1, 1, bias=True, BN=False, activation=act)
-            self.body = T.PartialInvertedResidual(8, 8, 3, 1, 1, 1, 2, BN=True, activation=act, use_1_conv=True, same_holes=True)
+            self.body = torch.nn.Sequential(*[T.PartialInvertedResidual(8, 8, 3, 1, 1, 1, 2, BN=True, activation=act, use_1_conv=True, same_holes=True)
+                                              for _ in range(bodies)])
             self.head = T.partial_convolution_block(8, 3, 3, 1, 1, 1, bias=True, BN=False, activation=False)
 
         def forward(self, args):
-            return self.head(self.body(self.stem(args)))[0]
+            h = self.stem(args)
+            for blk in self.body:
+                h = blk(h)
+            return self.head(h)[0]
     with emu_backend() as dev:
-        bench.TEST_RUNTIME = {"device": dev, "backend": "gloo", "model_factory": Tiny, "trainer_kwargs": {"bucket_mb": 0.0005}}
+        bench.TEST_RUNTIME = {"device": dev, "backend": "gloo", "model_factory": Tiny, "trainer_kwargs": {"bucket_mb": bucket_mb}}
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):
             bench.main(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--batch", "2", "--size", "32", "--no-cpu-baseline", "--no-f32-leg"])
     open(f"{out}.{rank}", "w").write(buf.getvalue())
 
 
-def test_bench_two_ranks_gloo():
+def _run(world, bodies=1, bucket_mb=0.0005):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "out")
-        mp.spawn(_rank, args=(2, _free_port(), out), nprocs=2, join=True)
-        texts = [open(f"{out}.{r}").read() for r in range(2)]
+        mp.spawn(_rank, args=(world, _free_port(), out, bodies, bucket_mb), nprocs=world, join=True)
+        texts = [open(f"{out}.{r}").read() for r in range(world)]
     lines = [ln for ln in texts[0].splitlines() if ln.startswith("{")]
-    assert len(lines) == 1 and not any(ln.startswith("{") for ln in texts[1].splitlines()), "exactly one JSON line, from rank 0"
+    assert len(lines) == 1 and not any(ln.startswith("{") for t in texts[1:] for ln in t.splitlines()), "exactly one JSON line, from rank 0"
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak" and rec["higher_is_better"] is True
-    assert rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
-    assert rec["value"] > 0 and abs(rec["value"] - 4 / (rec["ms_per_step"] / 1e3)) <= 0.05 * rec["value"] + 0.01   # whole-job images / max-over-ranks step time
+    assert rec["n_gpus"] == world and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak" and rec["higher_is_better"] is True
+    assert rec["config"]["global_batch"] == 2 * world and rec["config"]["parallelism"] == f"dp{world}"
+    # whole-job images / max-over-ranks step time
+    assert rec["value"] > 0 and abs(rec["value"] - 2 * world / (rec["ms_per_step"] / 1e3)) <= 0.05 * rec["value"] + 0.01
     comm = rec["comm"]
-    assert comm["world"] == 2 and comm["backend"] == "gloo" and comm["buckets"] >= 2 and comm["allreduce_ms"] > 0
+    assert comm["world"] == world and comm["backend"] == "gloo" and comm["buckets"] >= 2 and comm["allreduce_ms"] > 0
     assert comm["exposed_ms_per_step"] >= 0 and comm["overlapped_ms_per_step"] >= 0 and comm["overlap_with_backward"] is True
     assert rec["forward_only"]["value"] > 0 and rec["cpu_baseline"] is None if "cpu_baseline" in rec else True
+    return rec
+
+
+def test_bench_two_ranks_gloo():
+    _run(2)
+
+
+def test_bench_four_ranks_gloo():
+    """the 4-rank rung of the 1 / 2 / 4 / 8 ladder the driver runs: rendezvous, bucketed all-reduce, max-over-ranks clock, one line"""
+    _run(4)
+
+
+def test_bench_two_ranks_many_buckets_gloo():
+    """a bucket layout like ImageFillOrigin's (131 MB of gradients = 9 buckets of 16 MB): here 3 blocks cut into >= 9 buckets, so the
+    hooks launch, complete and wait on many asynchronous all-reduces per step, in gradient-ready order"""
+    rec = _run(2, bodies=3, bucket_mb=0.0004)
+    assert rec["comm"]["buckets"] >= 9, rec["comm"]

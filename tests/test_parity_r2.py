@@ -275,9 +275,10 @@ def test_seg_nets_256_vs_reference_fixture_gpu(name, capsys):
     """cfg 1 size against what the REFERENCE ITSELF produced (tests/golden/<name>_256.npz, written by
     tests/golden/make_golden_misc.py from /root/reference/models/text_segmentation.py + loss.py in fp32 and fp64; the inputs are
     rebuilt from the recorded seeds): eval output and train output at 1e-3 / noise level, focal loss at 1e-4, and the recorded
-    sample of 24 gradient tensors.  The gradient yardstick is the reference's own fp32-vs-fp64 discrepancy; the fixture holds ONE
-    fp32 run, i.e. one sample of a heavy-tailed noise (see test_seg_nets_256_vs_oracle_gpu), so a tensor's noise is taken no
-    smaller than the median over the recorded tensors.  Bars: 16x that noise per tensor (floor 3e-3), median tensor within 3x."""
+    sample of 24 gradient tensors.  The gradient yardstick is the reference's own fp32-vs-fp64 discrepancy, the largest over THREE
+    fp32 runs of the reference (round 5: the plain one and two with the input moved by one ulp -- a heavy-tailed noise, see
+    test_seg_nets_256_vs_oracle_gpu), and no smaller than the median over the recorded tensors.  Bars: 16x that noise per tensor
+    (floor 3e-3), median tensor within 3x, every tensor beyond 4x explained by the flip signature of tests/util.py (97 %)."""
     G = np.load(os.path.join(GOLD, name.lower() + "_256.npz"))
     x = torch.from_numpy(np.random.default_rng(int(G["seed_x"])).standard_normal((2, 3, 256, 256)).astype(np.float32))
     t = (torch.from_numpy(np.random.default_rng(int(G["seed_t"])).uniform(size=(2, 1, 256, 256))) > 0.8).float()
@@ -305,7 +306,9 @@ def test_seg_nets_256_vs_reference_fixture_gpu(name, capsys):
         for k in names:
             ref64 = G["grad64." + k].astype(np.float64)
             scale = max(float(np.abs(ref64).max()), 1e-3 * gmax)
-            noise[k] = float(np.abs(G["grad." + k] - ref64).max()) / scale
+            # the reference's own fp32 noise for this tensor: the largest of THREE fp32 runs of the reference (plain and two inputs moved
+            # by one ulp; tests/golden/make_golden_misc.py records their distances from its fp64 run) -- a heavy-tailed quantity
+            noise[k] = float(np.max(G["noise3." + k])) * float(np.abs(ref64).max()) / scale
             err[k] = float(np.abs(params[k].grad.detach().cpu().double().numpy() - ref64).max()) / scale
         pooled = float(np.median(list(noise.values())))
         rows = sorted(((err[k] / max(noise[k], pooled, 3e-4), k, err[k], noise[k]) for k in names), reverse=True)
@@ -316,19 +319,19 @@ def test_seg_nets_256_vs_reference_fixture_gpu(name, capsys):
         for ratio, k, e, n in rows:
             assert e <= max(3e-3, 16 * max(n, pooled)), (k, e, n, pooled)
         assert float(np.median([r[0] for r in rows])) <= 3.0
-        # Outliers (beyond 4x the noise) must be EXPLAINED like everywhere else (tests/util.py): a weight gradient carries >= 85 % of
-        # its squared error in <= 3 singular values (single activation-kink flips; a wrong kernel gives a dense error); a bias /
-        # BatchNorm vector cannot show that signature and may only ride on a flip some weight tensor of the same run confirms.
+        # Outliers (beyond 4x the noise) must be EXPLAINED by the rule of tests/util.py: a weight gradient carries >= 97 % of its squared
+        # error in <= 3 singular values (single activation-kink flips; a wrong kernel gives a dense error); a bias / BatchNorm vector
+        # cannot show that signature and may only ride -- up to 2x the outlier bar -- on a flip some weight tensor of the same run confirms.
         outliers = [(k, e) for ratio, k, e, n in rows if e > max(3e-3, 4 * max(n, pooled))]
         judged = {}
         for k, e in outliers:
-            ok, f = low_rank_error(params[k].grad, G["grad64." + k].astype(np.float32), frac=0.85)
+            ok, f = low_rank_error(params[k].grad, G["grad64." + k].astype(np.float32), frac=0.97)
             judged[k] = (ok, f, G["grad64." + k].squeeze().ndim <= 1)
             with capsys.disabled():
                 print(f"   outlier {k}: err {e:.2e}, {100 * f:.1f} % of it in <= 3 singular values / entries")
         confirmed = any(ok and not vec for ok, f, vec in judged.values())
         for k, (ok, f, vec) in judged.items():
-            assert ok or (vec and confirmed), (k, f, "dense gradient error beyond 4x the reference's own fp32 noise")
+            assert ok or (vec and confirmed and err[k] <= 2 * max(3e-3, 4 * max(noise[k], pooled))), (k, f, err[k], "dense gradient error beyond 4x the reference's own fp32 noise")
 
 
 @pytest.mark.gpu
@@ -559,10 +562,14 @@ def test_mixed_bf16_products_mode_gpu(capsys):
         the segmentation path) forward + dX + every parameter gradient within 5e-2 of the fp64 oracle (measured: 3.6e-2 worst, a BatchNorm bias);
       * net level, here: XceptionTextSegment against the reference's fp32 / fp64 fixture -- eval forward (3e-2), train-mode
         forward with batch statistics (5e-2), focal loss (2e-2), and the gradients of the decoder head (0.1).  The encoder's
-        gradients are PRINTED, not bounded: this ~100-layer train-mode BatchNorm net on 8x8 maps amplifies operand rounding by
-        ~1e4 (its fp32 runs already differ by 7e-4 from fp64; tests/test_parity_seg.py), so bf16 operand
-        rounding (4e-3) saturates there (measured: median 0.25, worst 0.46 of the tensor's largest entry) -- a property of the
-        arithmetic BASELINE config 5 names, not of the kernels (which the two levels above pin)."""
+        gradients are bounded at what the arithmetic allows, not at the fp32 bar: this ~100-layer train-mode BatchNorm net on
+        8x8 maps amplifies operand rounding by ~1e4 (its fp32 runs already differ by 7e-4 from fp64, SURVEY.md F11;
+        tests/test_parity_seg.py) and every rounded activation near a LeakyReLU kink flips a derivative, so bf16 operand
+        rounding (4e-3) shows up at median 0.25, worst 0.46-0.49 of a tensor's largest entry (rounds 3 / 4, measured): every
+        recorded tensor must stay within 0.8, the median within 0.4, and every tensor must keep the DIRECTION of the fp64
+        gradient (cosine >= 0.5; measured >= 0.8) -- a wrong kernel gives O(1) errors with no such correlation.  (The kernels
+        themselves are pinned by the two levels above; tests/test_bf16_storage.py does the same for bf16 STORAGE, with a smooth
+        variant of the net in which every gradient tensor meets a 1e-2-class bar.)"""
     from text_segmentation_image_inpainting_amd import _lib
     G = np.load(os.path.join(GOLD, "xceptiontextsegment_64.npz"))
     with BACKENDS["gpu"]() as dev:
@@ -589,6 +596,12 @@ def test_mixed_bf16_products_mode_gpu(capsys):
             gmax = max(float(np.abs(G[k]).max()) for k in G.files if k.startswith("grad64."))
             gerr = sorted((rel_err(params[k[7:]].grad, G[k].astype(np.float32), 1e-3 * gmax), k[7:]) for k in G.files if k.startswith("grad64."))
             head = [(e, k) for e, k in gerr if k.startswith(("out_conv", "feature_4x_conv"))]
+            cosines = []
+            for k in G.files:
+                if k.startswith("grad64."):
+                    a_, b_ = params[k[7:]].grad.detach().cpu().double().reshape(-1), torch.from_numpy(G[k]).double().reshape(-1)
+                    if float(b_.abs().max()) > 1e-3 * gmax:
+                        cosines.append((float((a_ * b_).sum() / (a_.norm() * b_.norm() + 1e-300)), k[7:]))
             e_blk = _rfb_case(dev, 64, 64, 32, seed=1401, smooth=True, coarse_bar=5e-2)
         finally:
             _lib.set_gemm_products(saved)
@@ -603,6 +616,10 @@ def test_mixed_bf16_products_mode_gpu(capsys):
         assert errs[6] <= 1e-3 and errs[3] <= 1e-3 and errs[1] <= 3e-2
         assert e_train <= 5e-2 and e_loss <= 2e-2
         assert len(head) >= 4 and max(head)[0] <= 0.1
+        with capsys.disabled():
+            print(f"[mixed bf16] direction of the recorded gradients vs fp64: worst cosine {min(cosines)[0]:.3f} ({min(cosines)[1]})")
+        assert gerr[-1][0] <= 0.8 and gerr[len(gerr) // 2][0] <= 0.4, (gerr[-1], gerr[len(gerr) // 2])
+        assert min(cosines)[0] >= 0.5, min(cosines)
 
 
 @both_backends

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(SM_THREADS, 2) void dw_small_kernel(
     constexpr bool FUSED = (MODE == 1), BNB = (MODE == 2);
     static_assert(!BNB || DXE, "K6c rides on the dX epilogue");
     static_assert(!FUSED || !DXE, "K6b rides on the forward epilogue");
+    static_assert((SM_MAXPIX + 1) * SM_CB * sizeof(float) <= 160 * 1024, "the whole-map tile must fit gfx950's 160 KB of LDS per CU (65.6 KB: more than the 64 KB of earlier parts)");
     __shared__ __attribute__((aligned(16))) float tile[(SM_MAXPIX + 1) * SM_CB];      // [pixel][16 channels] + one pixel of zeros: what a tap outside the map reads
     const unsigned b = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned cb = b % cblocks;

@@ -762,6 +762,10 @@ static StripPlan plan_strip(int n, int hout, int wout, int c, int s, int d) {
     return p;
 }
 
+// partial rows of the fused forms: ONE definition for the strip kernels, the small-map kernel (which writes the same layout) and the
+// row counts the callers size their buffers with (tsii_dw_stat_rows / tsii_dw_bwd_stat_rows)
+static inline unsigned strip_rows_per_image(const StripPlan& sp) { return sp.ok ? sp.chunks_y * sp.strips_x : 0u; }
+
 // -> 0 launched, 1 not applicable (caller falls back to the direct kernel), <0 error
 static const DwBN kNoDwBN = {nullptr, nullptr, 1.f, 0.f};
 static const DwBnBwd kNoBnBwd = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
@@ -781,7 +785,7 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
         !(fused_any && bb.y == nullptr && post_mul != nullptr)) {
         const bool dxe = denom == nullptr && keep == nullptr && bias == nullptr;
         if (bb.y == nullptr || dxe) {
-            const unsigned scb = (unsigned)cdiv(g.c, SM_CB), rpi = sp.ok ? sp.chunks_y * sp.strips_x : 1u;
+            const unsigned scb = (unsigned)cdiv(g.c, SM_CB), rpi = sp.ok ? strip_rows_per_image(sp) : 1u;
             const dim3 sgrid((unsigned)g.n * scb);
 #define TSII_DW_SMALL(MODE, DXE) do { \
             if (pre != nullptr) hipLaunchKernelGGL((dw_small_kernel<MODE, DXE, true>), sgrid, dim3(SM_THREADS), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, scb, rpi, ib, stats, bb, out); \
@@ -1127,7 +1131,7 @@ extern "C" int64_t tsii_dw_stat_rows(int n, int ho, int wo, int c, int kh, int k
     if (n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || c % 4 != 0) return 0;
     if (!(kh == 3 && kw == 3 && sh == sw && dh == dw) || !dw_fused_ok(sh, dh)) return 0;
     const StripPlan sp = plan_strip(n, ho, wo, c, sh, dh);
-    return sp.ok ? (int64_t)n * sp.chunks_y * sp.strips_x : 0;          // one partial row per strip chunk
+    return (int64_t)n * strip_rows_per_image(sp);          // one partial row per strip chunk
 }
 
 // rows of the partials tsii_dw_bwd_dx_bn writes (0: that geometry has no fused form): strip chunks of the dX (= input) grid
@@ -1137,7 +1141,7 @@ extern "C" int64_t tsii_dw_bwd_stat_rows(int n, int h, int wd, int c, int kh, in
     if (sh == 1 && (dh == 1 || dh == 2 || dh == 4 || dh == 8)) sp = plan_strip(n, h, wd, c, 1, dh);
     else if (sh == 2 && dh == 1 && ph == 1 && pw == 1) sp = plan_strip(n, h, wd, c, 1, 1);
     else return 0;
-    return sp.ok ? (int64_t)n * sp.chunks_y * sp.strips_x : 0;
+    return (int64_t)n * strip_rows_per_image(sp);
 }
 
 extern "C" int tsii_dw_fwd_bn(const float* x, const float* rmask, const float* w, const float* bias,

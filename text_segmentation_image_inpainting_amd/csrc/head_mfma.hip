@@ -578,6 +578,10 @@ static int head_cat_bwd_low_impl(const float* dy, const float* inv, const float*
     float* part = (float*)ws;
     int tpb = 0;
     const int blocks = hm_blocks(n, h, wd, &tpb);
+    // the kernel writes `blocks` partial rows, the bias column sums go behind them: checked against what THIS call writes, not only
+    // against tsii_dense_bwd_dw_ws_bytes()'s own row plan (the two agree today through the 1024-block caps; nothing else ties them)
+    TSII_REQUIRE(((size_t)blocks * cout * (c1 + c2) * 9 + (dbias != nullptr ? colsum_ws_floats((int64_t)n * h * wd, cout) : 0)) * sizeof(float) <= ws_bytes,
+                 "head_cat_bwd_dw_low: workspace too small for %d partial rows", blocks);
 #define TSII_HM_LAUNCH(NB, R0, R1) do { \
     if (NB == 2 && dlow != nullptr) hipLaunchKernelGGL((head_cat_dw_mfma_kernel<2, R0, R1, true>), dim3(blocks), dim3(256), 0, st, dy, inv, low, skip, r0_low, r1, w, dlow, n, h, wd, c2, cout, tpb, part); \
     else hipLaunchKernelGGL((head_cat_dw_mfma_kernel<NB, R0, R1, false>), dim3(blocks), dim3(256), 0, st, dy, inv, low, skip, r0_low, r1, w, dlow, n, h, wd, c2, cout, tpb, part); } while (0)

@@ -150,10 +150,11 @@ class _PoolHandOver:
     addend's gradient (2x2 sums of dy * inv) in the same pass (tsii_bn_act_bwd_pre_pool) and leaves it here; the conv's own
     backward takes it if the dy it receives is that very tensor, and runs tsii_pool2x2_scaled otherwise."""
 
-    __slots__ = ("inv", "h", "w", "dy", "dz")
+    __slots__ = ("inv", "h", "w", "dy", "dz", "want")
 
-    def __init__(self, inv, h, w):
+    def __init__(self, inv, h, w, want=True):
         self.inv, self.h, self.w, self.dy, self.dz = inv, int(h), int(w), None, None
+        self.want = bool(want)      # the addend needs a gradient at all: otherwise nobody would take dz and it would stay pinned
 
     def take(self, gy):
         dy, dz, self.dy, self.dz = self.dy, self.dz, None, None
@@ -202,7 +203,7 @@ class _Pointwise(torch.autograd.Function):
             assert in_scale is None, "the up-sampled addend has no BatchNorm-on-load form"
             up_add = up_add.contiguous()
             assert tuple(up_add.shape) == (n, h // 2, wd // 2, cout), "up_add must be [n, h/2, w/2, cout]"
-            ctx.pool = _PoolHandOver(inv, h, wd) if FUSE_POOL_BN_BWD else None
+            ctx.pool = _PoolHandOver(inv, h, wd, want=ctx.needs_input_grad[15]) if FUSE_POOL_BN_BWD else None
             if want_stats:
                 part = torch.empty((_lib.lib().tsii_pw_stat_rows(m), 4, cout), dtype=torch.float32, device=x.device)
             call("tsii_pw_fwd_up", ptr(x), m, k, ptr(w), cout, ptr(bias), ptr(r0), int(split), ptr(r1), ptr(denom), ptr(keep),
@@ -968,7 +969,7 @@ class _BNLazy(torch.autograd.Function):
         nbytes = _lib.lib().tsii_bn_ws_bytes(m, c)
         ws = _ws(nbytes, y)
         pool = ctx.pool
-        if part is not None and pool is not None and y.dim() == 4 and (y.shape[1], y.shape[2]) == (pool.h, pool.w):
+        if part is not None and pool is not None and pool.want and y.dim() == 4 and (y.shape[1], y.shape[2]) == (pool.h, pool.w):
             dz = torch.empty((y.shape[0], pool.h // 2, pool.w // 2, c), dtype=torch.float32, device=y.device)
             call("tsii_bn_act_bwd_pre_pool", ptr(ga), ptr(y), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), eps, act,
                  slope, int(training), ptr(part), part.shape[0], pool.h, pool.w, ptr(pool.inv), ptr(dy), ptr(dz), ptr(dgamma),
