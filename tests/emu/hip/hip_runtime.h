@@ -118,6 +118,8 @@ static inline void lds_barrier() { hipemu::barrier_only(); }
 // direct global -> LDS load: lane i's 16 bytes land at (wave-uniform) base + 16 i when a wait retires them; NaN pattern until then
 static inline void async_load16_lds(void* lds_wave_base, const void* gptr) { hipemu::async_issue((char*)lds_wave_base + 16 * hipemu::lane_id(), gptr, 16); }
 template <int N> static inline void async_wait_lds() { hipemu::async_retire(N); }
+template <int OFF> static inline void lds_read16(u32x4_emu2& d, const void* p) { d = *reinterpret_cast<const u32x4_emu2*>((const char*)p + OFF); }
+template <int N, class... T> static inline void lds_wait(T&...) {}
 }
 static inline f32x16_emu __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16_emu c, int, int, int) {
     return hipemu::mfma_32x32x2(a, b, c);

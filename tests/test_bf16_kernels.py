@@ -154,7 +154,10 @@ def stats_from_part(part, m):
 
 # ---- 1x1 convolutions -----------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,K,N,bias,act", [(300, 64, 128, True, 2), (257, 96, 192, False, None), (130, 40, 32, True, 1),
-                                            (260, 128, 256, False, 3), (200, 136, 48, True, None), (70, 8, 8, True, 0)])
+                                            (260, 128, 256, False, 3), (200, 136, 48, True, None), (70, 8, 8, True, 0),
+                                            # the 256 x 256 direct-to-LDS kernel (plain operands, K and N >= 256: K tails, row / column tails, three row blocks) and the
+                                            # 128 x 256 tiles of the fused forms (N % 256 == 0)
+                                            (300, 256, 256, True, 2), (520, 264, 512, False, None), (385, 320, 264, True, 1)])
 def test_pointwise_forward_dx_dw(emu, M, K, N, bias, act):
     L = emu
     rng = np.random.default_rng(M + 3 * K + 7 * N)
@@ -279,6 +282,7 @@ def conv_dw_ref(dy, x, geom, kshape):
     (2, 12, 12, 16, 64, (1, 1, 2, 2, 0, 0, 1, 1), False),       # strided 1x1 shortcut
     (2, 13, 13, 16, 32, (2, 2, 1, 1, 0, 0, 1, 1), False),       # space-to-depth stem
     (1, 16, 16, 8, 16, (3, 3, 2, 2, 1, 1, 1, 1), True),         # strided 3x3
+    (1, 13, 11, 256, 256, (3, 3, 1, 1, 2, 2, 2, 2), True),      # 128 x 256 tiles of the gathered forms (forward: cout, dX: cin % 256 == 0)
 ])
 def test_dense_forward_dx_dw(emu, n, h, wd, cin, cout, geom, bias):
     L = emu

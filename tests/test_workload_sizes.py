@@ -124,6 +124,52 @@ def test_textsegament_pixel_shuffle_512_properties_gpu():
         assert torch.equal(grads[0], grads[1])
 
 
+def test_textsegament_cfg3_bs64_checkpointed_step_gpu():
+    """cfg 3 at ITS batch (TextSegament + pixel-shuffle head, 512x512, 64 images; `bench.py --model TextSegament --batch 64
+    --pixel-shuffle --checkpoint`): the step with the encoder stages recomputed in backward (MobileNetV2.forward_checkpoint,
+    /root/reference/models/MobileNetV2.py:109-111) gives the loss, every gradient and every BatchNorm buffer of the plain step
+    BIT FOR BIT (the recomputation pass leaves running statistics alone, INTEGRATION.md), with less than 40 % of its peak memory;
+    everything finite; batch independence of the eval forward at that batch."""
+    from text_segmentation_image_inpainting_amd.synthetic import make_seg_batch
+    with BACKENDS["gpu"]() as dev:
+        x, t = make_seg_batch(64, 512, seed0=311)
+        x, t = x.to(dev), t.to(dev)
+        crit = T.BinaryFocalLoss(0, 1, 2)
+        res = []
+        for ckpt in (True, False):
+            torch.manual_seed(0)
+            m = T.TextSegament(pixel_shuffle_head=True)
+            fill_state_dict_(m.state_dict(), seed=49, gain=1.0)
+            m = m.to(dev).train()
+            m.checkpoint_encoder = ckpt
+            torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats()
+            base = torch.cuda.memory_allocated()
+            loss = crit(m(x), t)
+            loss.backward()
+            torch.cuda.synchronize()
+            peak = torch.cuda.max_memory_allocated() - base
+            g = {k: p.grad.clone() for k, p in m.named_parameters() if p.requires_grad}
+            assert bool(torch.isfinite(loss)) and all(bool(torch.isfinite(v).all()) for v in g.values())
+            bufs = {k: v.clone() for k, v in m.named_buffers()}
+            res.append((loss.detach().clone(), g, bufs, peak))
+            if ckpt:
+                m.eval()
+                with torch.no_grad():
+                    y = m(x)
+                    for i in (0, 37, 63):
+                        assert_close(m(x[i:i + 1]), y[i:i + 1], 1e-5, f"batch independence at bs 64, image {i}")
+                del y
+            del m, loss
+        (l1, g1, b1, p1), (l0, g0, b0, p0) = res
+        assert torch.equal(l1, l0)
+        assert len(g1) == len(g0) >= 100
+        for k in g0:
+            assert torch.equal(g1[k], g0[k]), k
+        for k in b0:
+            assert torch.equal(b1[k], b0[k]), k
+        assert p1 < 0.4 * p0, (p1 / 2**30, p0 / 2**30)
+
+
 @pytest.mark.parametrize("products", [6, 1])
 def test_xception_1024_properties_gpu(products, capsys):
     """cfg 5's network at its size (XceptionTextSegment, 1024x1024; batch 2 here, 8 in the bench) in the fp32-class arithmetic

@@ -254,6 +254,16 @@ __device__ __forceinline__ void async_load16_lds(void* lds_wave_base, const void
                                      reinterpret_cast<__attribute__((address_space(3))) void*>(static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds_wave_base))), 16, 0, 0);
 }
 template <int N> __device__ __forceinline__ void async_wait_lds() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// LDS read the compiler's scheduler leaves where it stands (it sinks a plain ds_read down to its first use, and will not lift one
+// over a direct-to-LDS load anyway): 16 bytes at the LDS pointer p + OFF.  Counted by lgkmcnt, LDS operations return in order:
+// lds_wait<N>(regs...) returns once at most N younger ones are outstanding and ties the registers to that point.
+template <int OFF> __device__ __forceinline__ void lds_read16(u32x4v& d, const void* p) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p))), "n"(OFF) : "memory");
+}
+template <int N, class A, class B, class C, class D, class E, class F>
+__device__ __forceinline__ void lds_wait(A& a, B& b, C& c, D& d, E& e, F& f) {
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(N) : "memory");
+}
 }  // namespace tsii
 #else
 namespace tsii {

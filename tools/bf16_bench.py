@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="pw,dw,dense,bn")
+    ap.add_argument("--big", action="store_true", help="add the plain 65536 x 4096 x 4096 product (the matrix-core microbench)")
     args = ap.parse_args()
     from text_segmentation_image_inpainting_amd import _lib
     from text_segmentation_image_inpainting_amd._lib import call, ptr
@@ -56,7 +57,7 @@ def main():
         print(s, flush=True)
 
     if "pw" in only:
-        for M, K, N in PW:
+        for M, K, N in (([(65536, 4096, 4096), (16384, 8192, 8192)] if args.big else []) + PW):
             print(f"1x1  M={M} K={K} N={N}")
             x, dy, y, dx = bf(M, K), bf(M, N), torch.empty(M, N, dtype=BF16, device=dev), torch.empty(M, K, dtype=BF16, device=dev)
             w = f32(N, K, scale=0.05)
