@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="pw,dw,dense,bn")
     ap.add_argument("--big", action="store_true", help="add the plain 65536 x 4096 x 4096 product (the matrix-core microbench)")
+    ap.add_argument("--gemm", default="", help="M,K,N[;M,K,N...]: time only the plain forward product of these shapes, with operands "
+                    "drawn as --fill says (the chip is power-capped: the sustained matrix rate depends on how many operand bits toggle)")
+    ap.add_argument("--fill", default="normal", choices=["normal", "uniform", "zeros"])
     args = ap.parse_args()
     from text_segmentation_image_inpainting_amd import _lib
     from text_segmentation_image_inpainting_amd._lib import call, ptr
@@ -56,6 +59,23 @@ def main():
             s += f"  {flops / us / 1e6:8.1f} TF/s"
         print(s, flush=True)
 
+    if args.gemm:
+        for spec in args.gemm.split(";"):
+            M, K, N = (int(v) for v in spec.split(","))
+            if args.fill == "zeros":
+                x, w = torch.zeros(M, K, dtype=BF16, device=dev), torch.zeros(N, K, device=dev)
+            elif args.fill == "uniform":
+                x, w = (torch.rand(M, K, device=dev) * 2 - 1).to(BF16), torch.rand(N, K, device=dev) * 2 - 1
+            else:
+                x, w = bf(M, K), f32(N, K, scale=0.05)
+            y = torch.empty(M, N, dtype=BF16, device=dev)
+            wb = L.tsii_bf16_pw_ws_bytes(N, K)
+            w1 = ws(wb)
+            print(f"gemm  M={M} K={K} N={N} fill={args.fill}")
+            for rep in range(3):
+                line(f"fwd plain, {args.iters} launches", timeit(lambda: call("tsii_bf16_pw_fwd", ptr(x), M, K, ptr(w), N, None, None, None, 0, 0.0, None, ptr(y), ptr(w1), wb, st)),
+                     2.0 * M * (K + N), 2.0 * M * K * N)
+        return
     if "pw" in only:
         for M, K, N in (([(65536, 4096, 4096), (16384, 8192, 8192)] if args.big else []) + PW):
             print(f"1x1  M={M} K={K} N={N}")
