@@ -120,6 +120,20 @@ static inline void async_load16_lds(void* lds_wave_base, const void* gptr) { hip
 template <int N> static inline void async_wait_lds() { hipemu::async_retire(N); }
 template <int OFF> static inline void lds_read16(u32x4_emu2& d, const void* p) { d = *reinterpret_cast<const u32x4_emu2*>((const char*)p + OFF); }
 template <int N, class... T> static inline void lds_wait(T&...) {}
+typedef unsigned u32x2_emu2 __attribute__((ext_vector_type(2)));
+// ds_read_b64_tr_b16 (bf16_common.h): lane q of a 16-lane group receives element (q & 3) of the 8 bytes at the addresses of lanes 4 i + (q >> 2)
+template <int OFF> static inline void lds_read8_tr(u32x2_emu2& d, const void* p) {
+    const unsigned long long a = (unsigned long long)((const char*)p + OFF);
+    const int l = hipemu::lane_id(), q = l & 15, g = l & ~15;
+    unsigned short v[4];
+    for (int i = 0; i < 4; ++i) {
+        const int src = g + 4 * i + (q >> 2);
+        const unsigned lo = __shfl((unsigned)(a & 0xffffffffull), src), hi = __shfl((unsigned)(a >> 32), src);
+        v[i] = *reinterpret_cast<const unsigned short*>((((unsigned long long)hi << 32) | lo) + 2 * (q & 3));
+    }
+    d[0] = v[0] | ((unsigned)v[1] << 16); d[1] = v[2] | ((unsigned)v[3] << 16);
+}
+template <int N, class... T> static inline void lds_wait4(T&...) {}
 }
 static inline f32x16_emu __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16_emu c, int, int, int) {
     return hipemu::mfma_32x32x2(a, b, c);

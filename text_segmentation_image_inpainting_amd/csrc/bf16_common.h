@@ -44,6 +44,18 @@ __device__ __forceinline__ hu32x4 ld8_nt(const bf16_t* __restrict__ p) { return 
 __device__ __forceinline__ void st8(bf16_t* __restrict__ p, const hu32x4 u) { *reinterpret_cast<hu32x4*>(p) = u; }
 __device__ __forceinline__ void st8_nt(bf16_t* __restrict__ p, const hu32x4 u) { __builtin_nontemporal_store(u, reinterpret_cast<hu32x4*>(p)); }
 
+// ds_read_b64_tr_b16 (gfx950): 8 bytes per lane at the lane's own address, delivered TRANSPOSED inside each 16-lane group -- lane q of a
+// group gets element (q & 3) of the 8 bytes lanes 4 i + (q >> 2), i = 0 .. 3, of its group supplied (measured, tools/probes/tr_read.hip).
+// With lane q' pointing at (row q' >> 2, columns 4 (q' & 3) ..) of a [4 rows][16 columns] block of a row-major bf16 image, lane q gets
+// column q of the four rows: four consecutive k of one channel, i.e. half an MFMA operand of an operand stored [k][channel].
+#ifndef TSII_ASYNC_LOADS
+template <int OFF> __device__ __forceinline__ void lds_read8_tr(hu32x2& d, const void* p) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p))), "n"(OFF) : "memory");
+}
+template <int N, class A, class B, class C, class D>
+__device__ __forceinline__ void lds_wait4(A& a, B& b, C& c, D& d) { asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory"); }
+#endif
+
 // load-time BatchNorm + activation (tsii_common.h: bn_act_load) on 8 channels; sc == nullptr at the call site means "plain"
 struct InBN8 {
     float sc[8], sh[8];

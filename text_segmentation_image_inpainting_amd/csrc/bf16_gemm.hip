@@ -740,6 +740,205 @@ __global__ __launch_bounds__(256) void hgemm_tn_kernel(const bf16_t* __restrict_
         }
 }
 
+// ---- TN, 256 x 256 tiles: operands straight into LDS in their memory layout, fragments by the transposing LDS read -----------------
+// hgemm_tn_kernel above moves both operands through a register transpose and ds_write_b64 into [channel][8 m] atoms -- the LDS pipe,
+// not the matrix pipe, sets its time (0.34 - 0.45 PF/s).  gfx950's ds_read_b64_tr_b16 removes the transpose: the operands are
+// staged AS THEY LIE IN MEMORY ([m][channel] rows, global_load_lds_dwordx4, no registers, no ds_write) and a lane reads four consecutive
+// m of its channel with one instruction (two per MFMA operand).  Everything else is hgemm_nt_ph_kernel: 256 x 256 tiles (P x Q
+// channels), K tiles of 64 m as four half-tiles (A0, A1: channels p0 + 0 / 128 ..; B0, B1), a half-tile = [64 m][128 channels] = 64 rows
+// of 256 bytes with the 64-byte segment c of row r at slot c ^ (r & 3) (a 32-lane half of the transposing read covers 4 rows x 64
+// bytes: four different slots = all 64 banks), four quadrant phases, two wave groups in counter-phase, the same RAW / WAR argument.
+// BatchNorm-on-load (the B operand is x behind BatchNorm + activation) is applied to the B FRAGMENT: a lane's channel is fixed
+// (column l & 31 of its two B tiles), so scale / shift are four registers, no table.  The gathered B operand of a dense convolution
+// (im2col view, one tap per 128-channel half: cin % 128 == 0) differs in the source address only; taps outside the image and rows past
+// the chunk come from the page of zeros.  Split-M partial slabs in fp32 like the kernel above.
+template <bool BNIN, bool BCONV>
+__global__ __launch_bounds__(512, 1) void hgemm_tn_ph_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                                             float* __restrict__ Cws, int64_t M, int Pn, int Q, int64_t chunk, InBN ib,
+                                                             unsigned qtiles, unsigned ptiles, HGather cg) {
+    static_assert(!BCONV || !BNIN, "the gathered operand has no BatchNorm-on-load form");
+    constexpr int HALF_BYTES = 64 * 256, BUF_BYTES = 4 * HALF_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char S0[2 * BUF_BYTES];
+
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned zsplit = bid / (qtiles * ptiles), rem = bid % (qtiles * ptiles);
+    const int q0 = (int)(rem % qtiles) * 256, p0 = (int)(rem / qtiles) * 256;
+    const int64_t mbeg = (int64_t)zsplit * chunk;
+    const int64_t mend = (mbeg + chunk < M) ? mbeg + chunk : M;
+    const int nkt = (int)((mend - mbeg + 63) / 64);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wm = wave >> 2, wn = wave & 3;                     // 2 (P) x 4 (Q) waves, wave tile 128 x 64
+    const int li = lane & 31, hi = lane >> 5;
+
+    hf32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    // ---- staging: piece j (0, 1) of wave w fills rows 4 (8 j + w) .. + 3 of a half-tile; lane: row + (lane >> 4), 16-byte slot lane & 15
+    const int sr = lane >> 4;                                    // = row & 3
+    const int chunk16 = ((((lane & 15) >> 2) ^ sr) << 2) | (lane & 3);      // the logical 8-channel chunk this slot holds
+    const int rj0 = 4 * wave + sr, rj1 = 4 * (8 + wave) + sr;    // this lane's rows of a K tile
+    const int colA0 = p0 + chunk16 * 8, colB0 = q0 + chunk16 * 8;            // channel of the chunk in half 0 (half 1: + 128)
+    int bky[2] = {0, 0}, bkx[2] = {0, 0}, bci[2] = {0, 0};
+    if constexpr (BCONV) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = colB0 + 128 * h < Q ? colB0 + 128 * h : 0;
+            const int t = k / cg.c;
+            bci[h] = k - t * cg.c;
+            bky[h] = t / cg.kw; bkx[h] = t - bky[h] * cg.kw;
+        }
+    }
+    const bf16_t* zpage = reinterpret_cast<const bf16_t*>(h_zero_page);
+    // BRANCH-FREE: rows past the chunk, channels past the matrix, taps outside the image and K tiles past the end fetch zeros
+    auto stage_piece = [&](int kt, int h, int j) {
+        unsigned char* S = S0 + (kt & 1) * BUF_BYTES + h * HALF_BYTES + (8 * j + wave) * 1024;
+        const int64_t m = mbeg + (int64_t)kt * 64 + (j == 0 ? rj0 : rj1);
+        const bool mok = m < mend;
+        const bf16_t* src;
+        if (h < 2) {
+            const int col = colA0 + 128 * h;
+            src = (mok && col < Pn) ? A + m * lda + col : zpage;
+        } else if constexpr (BCONV) {
+            const int hh = h - 2;
+            const int64_t mm = mok ? m : 0;
+            const int64_t qq = mm / cg.rw;
+            const int rx = (int)(mm - qq * cg.rw);
+            const int64_t n = qq / cg.rh;
+            const int ry = (int)(qq - n * cg.rh);
+            int sy = 0, sx = 0;
+            const bool ok = mok && colB0 + 128 * hh < Q && h_conv_src<1>(cg, ry, rx, bky[hh], bkx[hh], sy, sx);
+            src = ok ? B + ((n * cg.h + sy) * cg.w + sx) * cg.c + bci[hh] : zpage;
+        } else {
+            const int col = colB0 + 128 * (h - 2);
+            src = (mok && col < Q) ? B + m * ldb + col : zpage;
+        }
+        async_load16_lds(S, src);
+    };
+    auto stage_half = [&](int kt, int h) { stage_piece(kt, h, 0); stage_piece(kt, h, 1); };
+    stage_half(0, 0); stage_half(0, 1); stage_half(0, 2); stage_half(0, 3);
+    stage_half(1, 2); stage_half(1, 3);
+
+    // ---- fragments: tile of 32 channels = 64-byte segment c of the half-tile's rows; lane (q = lane & 15, g1 = (lane >> 4) & 1, hi) points
+    // at row 16 s + 8 hi + (q >> 2) [+ 4 for the second read], bytes 32 g1 + 8 (q & 3) of segment c ^ (q >> 2)
+    const int q4 = (lane & 15) >> 2;
+    const int fbase = (8 * hi + q4) * 256 + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+    int offA[4], offB[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) offA[t] = wm * HALF_BYTES + fbase + ((t ^ q4) << 6);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) offB[u] = (2 + (wn >> 1)) * HALF_BYTES + fbase + (((2 * (wn & 1) + u) ^ q4) << 6);
+    float bsc[2] = {0.f, 0.f}, bsh[2] = {0.f, 0.f};
+    if constexpr (BNIN) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int c = q0 + wn * 64 + u * 32 + li;
+            bsc[u] = ib.sc[c < Q ? c : Q - 1]; bsh[u] = ib.sh[c < Q ? c : Q - 1];
+        }
+    }
+    const float bneg = ib.neg, bhi = ib.hi;
+
+    async_wait_lds<4>();                          // this wave's pieces of K tile 0 (the B halves of K tile 1 may be in flight)
+    lds_barrier();
+    if (grp == 1) lds_barrier();                  // group 1 runs one interval behind
+
+    hu32x2 fal[2][4], fah[2][4], fb0l[4], fb0h[4], fb1l[4], fb1h[4];       // low / high half (k 0..3 / 4..7) of each operand
+    auto bn_frag = [&](hu32x2& lo, hu32x2& hi2, int u) {                   // BatchNorm + activation on the 8 values of a B fragment
+        if constexpr (BNIN) {
+            float v[8];
+            const hu32x4 w = {lo[0], lo[1], hi2[0], hi2[1]};
+            unpack8(w, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = bn_act_load(v[e], bsc[u], bsh[u], bneg, bhi);
+            const hu32x4 o = pack8(v);
+            lo[0] = o[0]; lo[1] = o[1]; hi2[0] = o[2]; hi2[1] = o[3];
+        }
+    };
+    // 8 MFMAs of one quadrant; the two pieces of half-tile (SKT, SH) go behind the 2nd and the 6th; HOOK(s2) runs behind the first MFMA of
+    // every K step (P1 uses it for the BatchNorm of b1's fragments: VALU work in the shadow of this wave's own MFMAs instead of in an L
+    // section, where it would be time the partner's 8 MFMAs cannot cover)
+#define TSII_TNPH_QUADRANT(AT, BU, FBL, FBH, SKT, SH, HOOK)                                                                            \
+        __builtin_amdgcn_s_setprio(1);                                                                                                  \
+        _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2)                                                                                \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                             \
+                const hu32x4 av = {fal[t][s2][0], fal[t][s2][1], fah[t][s2][0], fah[t][s2][1]};                                         \
+                const hu32x4 bv = {FBL[s2][0], FBL[s2][1], FBH[s2][0], FBH[s2][1]};                                                     \
+                acc[AT + t][BU] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hbf16x8, av), __builtin_bit_cast(hbf16x8, bv), \
+                                                                          acc[AT + t][BU], 0, 0, 0);                                    \
+                if (t == 0) { HOOK(s2); }                                                                                               \
+                if (s2 == 0 && t == 1) { __builtin_amdgcn_sched_barrier(0); stage_piece(SKT, SH, 0); __builtin_amdgcn_sched_barrier(0); } \
+                if (s2 == 2 && t == 1) { __builtin_amdgcn_sched_barrier(0); stage_piece(SKT, SH, 1); __builtin_amdgcn_sched_barrier(0); } \
+            }                                                                                                                           \
+        __builtin_amdgcn_s_setprio(0);
+#define TSII_TNPH_NOHOOK(S2)
+#define TSII_TNPH_BN1(S2) bn_frag(fb1l[S2], fb1h[S2], 1)
+    for (int kt = 0; kt < nkt; ++kt) {
+        const unsigned char* Sb = S0 + (kt & 1) * BUF_BYTES;
+        // ---- P1: a0 (tiles 0, 1), b0 and b1 --------------------------------------------------------------------------------------
+        // (lgkmcnt counts to 15: b0 is waited for with one tile of a0 behind it, the other 16 reads fly under b0's BatchNorm)
+#define TSII_TNPH_READ4(L, H, BASE)                                                                                       \
+        lds_read8_tr<0>(L[0], BASE); lds_read8_tr<4 * 256>(H[0], BASE); lds_read8_tr<16 * 256>(L[1], BASE); lds_read8_tr<20 * 256>(H[1], BASE); \
+        lds_read8_tr<32 * 256>(L[2], BASE); lds_read8_tr<36 * 256>(H[2], BASE); lds_read8_tr<48 * 256>(L[3], BASE); lds_read8_tr<52 * 256>(H[3], BASE);
+        TSII_TNPH_READ4(fb0l, fb0h, Sb + offB[0])
+        TSII_TNPH_READ4(fal[0], fah[0], Sb + offA[0])
+        lds_wait4<8>(fb0l[0], fb0l[1], fb0l[2], fb0l[3]); lds_wait4<8>(fb0h[0], fb0h[1], fb0h[2], fb0h[3]);
+        TSII_TNPH_READ4(fal[1], fah[1], Sb + offA[1])
+        TSII_TNPH_READ4(fb1l, fb1h, Sb + offB[1])
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) bn_frag(fb0l[s2], fb0h[s2], 0);
+        lds_wait4<0>(fal[0][0], fal[0][1], fal[0][2], fal[0][3]); lds_wait4<0>(fah[0][0], fah[0][1], fah[0][2], fah[0][3]);
+        lds_wait4<0>(fal[1][0], fal[1][1], fal[1][2], fal[1][3]); lds_wait4<0>(fah[1][0], fah[1][1], fah[1][2], fah[1][3]);
+        lds_wait4<0>(fb1l[0], fb1l[1], fb1l[2], fb1l[3]); lds_wait4<0>(fb1h[0], fb1h[1], fb1h[2], fb1h[3]);
+        lds_barrier();
+        TSII_TNPH_QUADRANT(0, 0, fb0l, fb0h, kt + 1, 0, TSII_TNPH_BN1)
+        lds_barrier();
+        // ---- P2: nothing to read ---------------------------------------------------------------------------------------------------
+        lds_barrier();
+        TSII_TNPH_QUADRANT(0, 1, fb1l, fb1h, kt + 1, 1, TSII_TNPH_NOHOOK)
+        lds_barrier();
+        // ---- P3: a1 (tiles 2, 3) over a0 ----------------------------------------------------------------------------------------
+        TSII_TNPH_READ4(fal[0], fah[0], Sb + offA[2])
+        TSII_TNPH_READ4(fal[1], fah[1], Sb + offA[3])
+        lds_wait4<0>(fal[0][0], fal[0][1], fal[0][2], fal[0][3]); lds_wait4<0>(fah[0][0], fah[0][1], fah[0][2], fah[0][3]);
+        lds_wait4<0>(fal[1][0], fal[1][1], fal[1][2], fal[1][3]); lds_wait4<0>(fah[1][0], fah[1][1], fah[1][2], fah[1][3]);
+        lds_barrier();
+        TSII_TNPH_QUADRANT(2, 1, fb1l, fb1h, kt + 2, 2, TSII_TNPH_NOHOOK)
+        lds_barrier();
+        // ---- P4 ------------------------------------------------------------------------------------------------------------------
+        async_wait_lds<2>();                      // everything up to A1 of K tile kt + 1 has landed; B0 of kt + 2 may be in flight
+        lds_barrier();
+        TSII_TNPH_QUADRANT(2, 0, fb0l, fb0h, kt + 2, 3, TSII_TNPH_NOHOOK)
+        lds_barrier();
+    }
+#undef TSII_TNPH_BN1
+#undef TSII_TNPH_READ4
+#undef TSII_TNPH_NOHOOK
+#undef TSII_TNPH_QUADRANT
+    if (grp == 0) lds_barrier();
+    async_wait_lds<0>();
+
+    float* Cz = Cws + (int64_t)zsplit * Pn * Q;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = p0 + wm * 128 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (p >= Pn) continue;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = q0 + wn * 64 + u * 32 + li;
+                if (q < Q) Cz[(int64_t)p * Q + q] = acc[t][u][r];
+            }
+        }
+}
+
 // ---- weights: fp32 reference layout -> the bf16 B operand of the NT kernel, once per call ----------------------------------
 //   mode 0 (1x1 forward)   out[n][k]              = w[n][k]
 //   mode 1 (1x1 dX)        out[k][n]              = w[n][k]
@@ -840,21 +1039,34 @@ static int launch_hnt(int amode, const bf16_t* A, int64_t lda, const bf16_t* B, 
     return launch_hnt_cfg<4, 1, 1, 1>(amode, A, lda, B, C, ldc, M, N, K, ep, ib, cg, st);
 }
 
-// split of the M rows of a weight-gradient product into chunks (multiples of the 64-row stage): enough blocks to fill the chip
-static void htn_plan(int64_t M, int Pn, int Q, int64_t* chunk, int* splits) {
-    const int64_t tiles = (int64_t)cdiv(Pn, 128) * cdiv(Q, 128);
-    int64_t want = cdiv64(768, tiles);
+// split of the M rows of a weight-gradient product into chunks (multiples of the 64-row stage): enough blocks to fill the chip.
+// ph: the 256 x 256 kernel (one 512-thread block per CU: never more blocks than CUs, a second round would run at a fraction of the chip)
+#ifndef HTN_PH
+#define HTN_PH 1         // 0: every weight gradient on the register-transposing kernel (A/B, tools/variants)
+#endif
+static bool htn_use_ph(int Pn, int Q, bool bconv, int cin) {
+    return HTN_PH && Pn >= 256 && Pn % 128 == 0 && Q >= 256 && (!bconv || cin % 128 == 0);
+}
+static void htn_plan(int64_t M, int Pn, int Q, bool ph, int64_t* chunk, int* splits) {
     const int64_t stages = cdiv64(M, HTN_STAGE);
+    int64_t want;
+    if (ph) {
+        const int64_t tiles = (int64_t)cdiv(Pn, 256) * cdiv(Q, 256);
+        want = 256 / tiles;
+    } else {
+        const int64_t tiles = (int64_t)cdiv(Pn, 128) * cdiv(Q, 128);
+        want = cdiv64(768, tiles);
+        if (want > 256) want = 256;
+    }
     if (want > stages) want = stages;
-    if (want > 256) want = 256;
     if (want < 1) want = 1;
     const int64_t per = cdiv64(stages, want);
     *chunk = per * HTN_STAGE;
     *splits = (int)cdiv64(M, *chunk);
 }
-static size_t htn_ws_floats(int64_t M, int Pn, int Q) {
+static size_t htn_ws_floats(int64_t M, int Pn, int Q, bool bconv, int cin) {
     int64_t chunk; int splits;
-    htn_plan(M, Pn, Q, &chunk, &splits);
+    htn_plan(M, Pn, Q, htn_use_ph(Pn, Q, bconv, cin), &chunk, &splits);
     return (size_t)splits * Pn * Q;
 }
 // slabs of partial [Pn, Q] products in ws (htn_ws_floats floats); returns the number of slabs in *nslabs
@@ -862,8 +1074,18 @@ static int launch_htn(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb
                       const InBN& ib, int* nslabs, hipStream_t st) {
     TSII_REQUIRE(Pn % 8 == 0 && Q % 8 == 0 && lda % 8 == 0 && (bconv || ldb % 8 == 0) && aligned16(A) && aligned16(B), "bf16 gemm_tn: channel counts must be multiples of 8, operands 16-byte aligned");
     TSII_REQUIRE(M > 0 && M < (1ll << 40), "bf16 gemm_tn: bad row count");
+    const bool ph = htn_use_ph(Pn, Q, bconv, cg.c);
     int64_t chunk; int splits;
-    htn_plan(M, Pn, Q, &chunk, &splits);
+    htn_plan(M, Pn, Q, ph, &chunk, &splits);
+    *nslabs = splits;
+    if (ph) {
+        const unsigned qt = (unsigned)cdiv(Q, 256), pt = (unsigned)cdiv(Pn, 256);
+        const dim3 grid(qt * pt * (unsigned)splits);
+        if (bconv) hipLaunchKernelGGL((hgemm_tn_ph_kernel<false, true>), grid, dim3(512), 0, st, A, lda, B, ldb, ws, M, Pn, Q, chunk, ib, qt, pt, cg);
+        else if (ib.sc != nullptr) hipLaunchKernelGGL((hgemm_tn_ph_kernel<true, false>), grid, dim3(512), 0, st, A, lda, B, ldb, ws, M, Pn, Q, chunk, ib, qt, pt, cg);
+        else hipLaunchKernelGGL((hgemm_tn_ph_kernel<false, false>), grid, dim3(512), 0, st, A, lda, B, ldb, ws, M, Pn, Q, chunk, ib, qt, pt, cg);
+        return check_launch("bf16 gemm_tn (256 x 256 tiles)");
+    }
     const unsigned qt = (unsigned)cdiv(Q, 128), pt = (unsigned)cdiv(Pn, 128);
     const int64_t nblocks = (int64_t)qt * pt * splits;
     TSII_REQUIRE(nblocks < (1ll << 31), "bf16 gemm_tn: grid too large");
@@ -871,7 +1093,6 @@ static int launch_htn(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb
     if (bconv) hipLaunchKernelGGL((hgemm_tn_kernel<false, true>), grid, dim3(256), 0, st, A, lda, B, ldb, ws, M, Pn, Q, chunk, ib, qt, pt, cg);
     else if (ib.sc != nullptr) hipLaunchKernelGGL((hgemm_tn_kernel<true, false>), grid, dim3(256), 0, st, A, lda, B, ldb, ws, M, Pn, Q, chunk, ib, qt, pt, cg);
     else hipLaunchKernelGGL((hgemm_tn_kernel<false, false>), grid, dim3(256), 0, st, A, lda, B, ldb, ws, M, Pn, Q, chunk, ib, qt, pt, cg);
-    *nslabs = splits;
     return check_launch("bf16 gemm_tn");
 }
 
@@ -954,7 +1175,7 @@ extern "C" int tsii_bf16_pw_bwd_dx(const uint16_t* dy, int64_t m, int n, const f
 
 extern "C" size_t tsii_bf16_pw_bwd_dw_ws_bytes(int64_t m, int n, int k) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    const size_t slabs = htn_ws_floats(m, n, k);
+    const size_t slabs = htn_ws_floats(m, n, k, false, 0);
     const size_t bias = (size_t)hcolsum_rows(m, n) * n;
     return (slabs > bias ? slabs : bias) * sizeof(float) + 16;
 }
@@ -1027,7 +1248,7 @@ extern "C" int tsii_bf16_dense_bwd_dx(const uint16_t* dy, const float* w, int n,
 extern "C" size_t tsii_bf16_dense_bwd_dw_ws_bytes(int n, int ho, int wo, int cin, int cout, int kh, int kw) {
     if (n <= 0 || ho <= 0 || wo <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0) return 0;
     const int64_t m = (int64_t)n * ho * wo;
-    const size_t slabs = htn_ws_floats(m, cout, kh * kw * cin);
+    const size_t slabs = htn_ws_floats(m, cout, kh * kw * cin, true, cin);
     const size_t bias = (size_t)hcolsum_rows(m, cout) * cout;
     return (slabs > bias ? slabs : bias) * sizeof(float) + 16;
 }
