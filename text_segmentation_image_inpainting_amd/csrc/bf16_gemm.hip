@@ -257,42 +257,47 @@ __device__ __forceinline__ void h_nt_epilogue(float* __restrict__ smem, hf32x16 
         }
     }
     if (ep.stats == nullptr && !BNB) return;
-    // RPP threads share a column group: combine through LDS, one partial row per 128 rows (per tile when it is shorter)
+    // RPP threads share a column group: combine through LDS, one partial row per 128 rows (per tile when it is shorter).  Layout
+    // [sum 0 / 1][e][rr0][g]: the writers' lanes (consecutive g) and the readers' lanes (thread -> (e = tid / G, g = tid % G)) both walk
+    // consecutive floats -- as [rr0][g][e][2] a wave's store hit two banks (16-way), 8 us per 256 x 256 tile
 #pragma unroll
     for (int h = 0; h < HALVES; ++h) {
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            smem[(rr0 * BN + g * 8 + e) * 2 + 0] = st1[h][e];
-            smem[(rr0 * BN + g * 8 + e) * 2 + 1] = st2[h][e];
+            smem[((0 * 8 + e) * RPP + rr0) * G + g] = st1[h][e];
+            smem[((1 * 8 + e) * RPP + rr0) * G + g] = st2[h][e];
         }
         if (rr0 == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) smem[RPP * BN * 2 + g * 8 + e] = pvt[e];
+            for (int e = 0; e < 8; ++e) smem[RPP * BN * 2 + e * G + g] = pvt[e];
         }
         __syncthreads();
         const int64_t left = M - (m0 + (HALVES == 1 ? 0 : 128 * h));
-        if (tid < BN && n0 + tid < N && left > 0) {
+        const int re = tid / G, rg = tid % G;                  // this reader's column: 8 rg + re
+        const int rcol = n0 + rg * 8 + re;
+        if (tid < BN && rcol < N && left > 0) {
             float a1 = 0.f, a2 = 0.f;
 #pragma unroll 4
-            for (int j = 0; j < RPP; ++j) { a1 += smem[(j * BN + tid) * 2 + 0]; a2 += smem[(j * BN + tid) * 2 + 1]; }
+            for (int j = 0; j < RPP; ++j) { a1 += smem[((0 * 8 + re) * RPP + j) * G + rg]; a2 += smem[((1 * 8 + re) * RPP + j) * G + rg]; }
             const int64_t prow = (int64_t)rowblk * HALVES + h;
             if constexpr (BNB) {
                 float* sp = ep.bn_part + prow * 2 * N;
-                sp[n0 + tid] = a1;
-                sp[N + n0 + tid] = a2;
+                sp[rcol] = a1;
+                sp[N + rcol] = a2;
             } else {
                 float* sp = ep.stats + prow * 4 * N;
                 constexpr int HR = HALVES == 1 ? BM : 128;
-                sp[n0 + tid] = (float)(left < HR ? left : HR);
-                sp[N + n0 + tid] = smem[RPP * BN * 2 + tid];
-                sp[2 * N + n0 + tid] = a1;
-                sp[3 * N + n0 + tid] = a2;
+                sp[rcol] = (float)(left < HR ? left : HR);
+                sp[N + rcol] = smem[RPP * BN * 2 + re * G + rg];
+                sp[2 * N + rcol] = a1;
+                sp[3 * N + rcol] = a2;
             }
         }
     }
 }
 
+static constexpr int HNT_LBN_MAXK = 1024;
 template <int WM, int WN, int TM, int TN, int AMODE, bool BNIN, bool BNB>
 #ifndef HNT_WAVES
 #define HNT_WAVES 4      // waves per SIMD the NT kernel is held to (A/B: tools/variants; 1 = whatever the compiler takes)
@@ -309,8 +314,26 @@ __global__ __launch_bounds__(256, TM * TN >= 8 ? 2 : ((HNT_WAVES > 3 && BNB) ? 3
     constexpr int EP_FLOATS = WM * 32 * (BN + 4);
     constexpr int ST_FLOATS = 2 * (256 / (BN / 8)) * BN + BN;
     constexpr int SMEM_FLOATS = OP_FLOATS > EP_FLOATS ? (OP_FLOATS > ST_FLOATS ? OP_FLOATS : ST_FLOATS) : (EP_FLOATS > ST_FLOATS ? EP_FLOATS : ST_FLOATS);
-    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    // the 128 x 256 form keeps the BatchNorm-on-load constants of all K input channels in LDS (K <= HNT_LBN_MAXK, checked at the launch):
+    // fetched per K tile from global memory they were four 16-byte loads per thread beside the two of its operand chunks
+    constexpr bool LBN = BNIN && TM * TN >= 8;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS + (LBN ? 2 * HNT_LBN_MAXK : 0)];
     unsigned char* S0 = reinterpret_cast<unsigned char*>(smem);
+    float* lbn = smem + SMEM_FLOATS;
+    auto fetch_bn = [&](int k, InBN8& o) {
+        if constexpr (LBN) {
+            const float4 a0 = *reinterpret_cast<const float4*>(lbn + k), a1 = *reinterpret_cast<const float4*>(lbn + k + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(lbn + HNT_LBN_MAXK + k), b1 = *reinterpret_cast<const float4*>(lbn + HNT_LBN_MAXK + k + 4);
+            o.sc[0] = a0.x; o.sc[1] = a0.y; o.sc[2] = a0.z; o.sc[3] = a0.w; o.sc[4] = a1.x; o.sc[5] = a1.y; o.sc[6] = a1.z; o.sc[7] = a1.w;
+            o.sh[0] = b0.x; o.sh[1] = b0.y; o.sh[2] = b0.z; o.sh[3] = b0.w; o.sh[4] = b1.x; o.sh[5] = b1.y; o.sh[6] = b1.z; o.sh[7] = b1.w;
+        } else {
+            load_inbn8(ib, k, o);
+        }
+    };
+    if constexpr (LBN) {
+        for (int i = threadIdx.x; i < K; i += 256) { lbn[i] = ib.sc[i]; lbn[HNT_LBN_MAXK + i] = ib.sh[i]; }
+        __syncthreads();
+    }
 
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t m0 = (int64_t)(bid / ntn) * BM;
@@ -343,7 +366,7 @@ __global__ __launch_bounds__(256, TM * TN >= 8 ? 2 : ((HNT_WAVES > 3 && BNB) ? 3
         h_load<BM>(A, lda, m0, M, 0, K, ra);
     }
     h_load<BN>(B, K, n0, N, 0, K, rb);
-    if constexpr (BNIN) load_inbn8(ib, pk < K ? pk : K - 8, bn);
+    if constexpr (BNIN) fetch_bn(pk < K ? pk : K - 8, bn);
     if constexpr (CONV) h_conv_store<BM>(S0, ra, okm);
     else h_store<BM, BNIN>(S0, ra, 0, mvalid, K, bn, ib.neg, ib.hi);
     h_store<BN, false>(S0 + BM * 64, rb, 0, nvalid, K, bn, 1.f, 0.f);
@@ -381,7 +404,7 @@ __global__ __launch_bounds__(256, TM * TN >= 8 ? 2 : ((HNT_WAVES > 3 && BNB) ? 3
         if (more) {
             if constexpr (BNIN) {       // (scale, shift) of the next tile's channels: L2 hits, fetched behind the MFMA phase
                 const int k = (kt + 1) * HBK + pk;
-                load_inbn8(ib, k < K ? k : K - 8, bn);
+                fetch_bn(k < K ? k : K - 8, bn);
             }
             // the other stage was last read one iteration ago, before the barrier every wave has passed since
             if constexpr (CONV) h_conv_store<BM>(Sn, ra, okm);
@@ -1032,7 +1055,7 @@ static int launch_hnt(int amode, const bf16_t* A, int64_t lda, const bf16_t* B, 
         return check_launch("bf16 gemm_nt (256-row tiles, K6c)");
     }
 #endif
-    if (HNT_WIDE && N % 256 == 0 && (amode != 0 || ep.bn_y != nullptr || (ib.sc != nullptr && K >= 256)))
+    if (HNT_WIDE && N % 256 == 0 && (amode != 0 || ep.bn_y != nullptr || (ib.sc != nullptr && K >= 256 && K <= HNT_LBN_MAXK)))
         return launch_hnt_cfg<2, 2, 2, 4>(amode, A, lda, B, C, ldc, M, N, K, ep, ib, cg, st);
     if (N % 128 == 0 || N > 192) return launch_hnt_cfg<2, 2, 2, 2>(amode, A, lda, B, C, ldc, M, N, K, ep, ib, cg, st);
     if (N > 32) return launch_hnt_cfg<2, 2, 2, 1>(amode, A, lda, B, C, ldc, M, N, K, ep, ib, cg, st);

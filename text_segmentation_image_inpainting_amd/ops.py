@@ -24,6 +24,10 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3, 4
 # GEMMs): PW on vs off = BatchNorm backward 19.9 -> 16.3 ms for +2.0 ms of GEMM epilogue: 90.5 -> 89.3 ms per step.
 FUSE_BN_BWD = True
 FUSE_BN_BWD_PW = True
+# bf16 storage: where the PLAIN dX product runs on the 256 x 256 direct-to-LDS kernel (k, cout >= 256) the K6c epilogue (register-staged
+# 128 x 256 tiles) costs more in a microbenchmark than that kernel plus the stand-alone reduction pass (131072 x 512 x 512: 153-165 us against 88 + 52) --
+# in the cfg 5 step it does not (profiles/r05x_k6c_unfuse.log: 60.2 ms fused, 61.0 unfused: the reduction pass reads dx and y cold), so: off
+BF16_UNFUSE_K6C_ON_LARGE = False
 # the gradient of a K7b up-sampled addend taken inside the BatchNorm-backward apply pass (tsii_bn_act_bwd_pre_pool)
 FUSE_POOL_BN_BWD = True
 # K4d (head weight gradient on the f32 matrix cores)
@@ -245,7 +249,8 @@ class _Pointwise(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 wbytes = L.tsii_bf16_pw_ws_bytes(cout, k)
                 wt = _ws(wbytes, x)
-                if ctx.bn is not None and FUSE_BN_BWD_PW and load_time_act(*ctx.in_cfg):
+                if (ctx.bn is not None and FUSE_BN_BWD_PW and load_time_act(*ctx.in_cfg)
+                        and not (BF16_UNFUSE_K6C_ON_LARGE and k >= 256 and cout >= 256 and m >= 256)):
                     mean, var, gamma, beta, eps, slot = ctx.bn
                     part = torch.empty((int(L.tsii_bf16_stat_rows(m)), 2, k), dtype=torch.float32, device=x.device)
                     call("tsii_bf16_pw_bwd_dx", ptr(gy), m, cout, ptr(w), k, ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps),

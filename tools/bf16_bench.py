@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--gemm", default="", help="M,K,N[;M,K,N...]: time only the plain forward product of these shapes, with operands "
                     "drawn as --fill says (the chip is power-capped: the sustained matrix rate depends on how many operand bits toggle)")
     ap.add_argument("--fill", default="normal", choices=["normal", "uniform", "zeros"])
+    ap.add_argument("--pw-shapes", default="", help="M,K,N[;...]: replace the 1x1 shape list")
+    ap.add_argument("--split-fused", action="store_true", help="1x1 forward: also time the statistics epilogue and the BatchNorm-on-load alone")
     args = ap.parse_args()
     from text_segmentation_image_inpainting_amd import _lib
     from text_segmentation_image_inpainting_amd._lib import call, ptr
@@ -77,7 +79,8 @@ def main():
                      2.0 * M * (K + N), 2.0 * M * K * N)
         return
     if "pw" in only:
-        for M, K, N in (([(65536, 4096, 4096), (16384, 8192, 8192)] if args.big else []) + PW):
+        pw_list = [tuple(int(v) for v in t.split(",")) for t in args.pw_shapes.split(";")] if args.pw_shapes else (([(65536, 4096, 4096), (16384, 8192, 8192)] if args.big else []) + PW)
+        for M, K, N in pw_list:
             print(f"1x1  M={M} K={K} N={N}")
             x, dy, y, dx = bf(M, K), bf(M, N), torch.empty(M, N, dtype=BF16, device=dev), torch.empty(M, K, dtype=BF16, device=dev)
             w = f32(N, K, scale=0.05)
@@ -93,6 +96,9 @@ def main():
             byt, fl = 2.0 * M * (K + N), 2.0 * M * K * N
             line("fwd plain", timeit(lambda: call("tsii_bf16_pw_fwd", ptr(x), M, K, ptr(w), N, None, None, None, 0, 0.0, None, ptr(y), ptr(w1), wb, st)), byt, fl)
             line("fwd BN-on-load + stats", timeit(lambda: call("tsii_bf16_pw_fwd", ptr(x), M, K, ptr(w), N, None, ptr(sc), ptr(sh), 2, 0.3, ptr(part), ptr(y), ptr(w1), wb, st)), byt, fl)
+            if args.split_fused:
+                line("fwd plain + stats", timeit(lambda: call("tsii_bf16_pw_fwd", ptr(x), M, K, ptr(w), N, None, None, None, 0, 0.0, ptr(part), ptr(y), ptr(w1), wb, st)), byt, fl)
+                line("fwd BN-on-load, no stats", timeit(lambda: call("tsii_bf16_pw_fwd", ptr(x), M, K, ptr(w), N, None, ptr(sc), ptr(sh), 2, 0.3, None, ptr(y), ptr(w1), wb, st)), byt, fl)
             line("dX plain", timeit(lambda: call("tsii_bf16_pw_bwd_dx", ptr(dy), M, N, ptr(w), K, None, None, None, None, None, 0.0, 0, 0.0, ptr(dx), None, ptr(w1), wb, st)), byt, fl)
             line("dX + K6c", timeit(lambda: call("tsii_bf16_pw_bwd_dx", ptr(dy), M, N, ptr(w), K, ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), 1e-5, 2, 0.3, ptr(dx), ptr(bpart), ptr(w1), wb, st)), byt + 2.0 * M * K, fl)
             line("dW plain", timeit(lambda: call("tsii_bf16_pw_bwd_dw", ptr(dy), ptr(x), M, N, K, None, None, 0, 0.0, ptr(dw), None, ptr(w2), nb, st)), byt, fl)
