@@ -24,9 +24,13 @@ struct HDwPlan {
     int n, hin, win, c, hout, wout;   // input tensor [n, hin, win, c] -> output [n, hout, wout, c]
     int s, p, d, flip;                // stride, padding, dilation; flip: use taps (2-ky, 2-kx) (the adjoint)
     int cg, pxb, ncg, colgroups, phases, chunks, jper;
+    int nx;                           // output columns per thread: 2 at stride 1 (x and x + d share two of their three tap columns), else 1
 };
 
-static HDwPlan hdw_plan(int n, int hin, int win, int c, int hout, int wout, int s, int p, int d, int flip) {
+// nxmode: 0 one output column per thread; 1 two where the geometry allows (stride 1, pxb % d == 0); 2 the same for d <= 2 only.
+// Measured on cfg 5's layers (profiles/r05aa_dw_nx.log): forward + K6b 94-100 -> 82 us, plain dX 56-65 -> 54-55, dX + K6c 117-136 -> 113-123
+// at d <= 2 but 117 -> 122 at d = 4, weight gradient 104-110 -> 111-118 (231-256 VGPRs): so forward / plain dX 1, K6c 2, weight gradient 0
+static HDwPlan hdw_plan(int n, int hin, int win, int c, int hout, int wout, int s, int p, int d, int flip, int nxmode) {
     HDwPlan g;
     g.n = n; g.hin = hin; g.win = win; g.c = c; g.hout = hout; g.wout = wout; g.s = s; g.p = p; g.d = d; g.flip = flip;
     const int oct = c / 8;
@@ -34,7 +38,11 @@ static HDwPlan hdw_plan(int n, int hin, int win, int c, int hout, int wout, int 
     while (cg * 2 <= oct && cg * 2 <= 16) cg *= 2;
     g.cg = cg; g.pxb = 256 / cg;
     g.ncg = cdiv(oct, cg);
-    g.colgroups = cdiv(wout, g.pxb);
+#ifndef HDW_NX2
+#define HDW_NX2 1        // 0: one output column per thread everywhere (A/B, tools/variants)
+#endif
+    g.nx = (HDW_NX2 && nxmode != 0 && (nxmode == 1 || d <= 2) && s == 1 && g.pxb % d == 0 && wout >= 2 * d) ? 2 : 1;
+    g.colgroups = cdiv(wout, g.pxb * g.nx);
     g.phases = s == 1 ? (d < hout ? d : hout) : 1;
     const int hp = cdiv(hout, g.phases);                       // rows of the longest phase
     const int64_t base = (int64_t)n * g.colgroups * g.ncg * g.phases;
@@ -75,47 +83,67 @@ __device__ __forceinline__ HDwBlock hdw_decode(const HDwPlan& g) {
     return k;
 }
 
-// what a marching thread needs to address its window
+// what a marching thread needs to address its window: NC = 2 + (output columns per thread) input columns, d apart
+template <int NC>
 struct HDwWin {
     const bf16_t* src;     // image base + channel offset
     int64_t rowstride;     // win * c
     int c;
-    int xc[3];             // clamped input columns of the 3 taps
-    unsigned xmask;        // bit kx: tap column inside the image
+    int xc[NC];            // clamped input columns
+    unsigned xmask;        // bit kc: column inside the image
     int b, dq, hin;        // input row of sequence index q: b + dq * q
 };
-__device__ __forceinline__ void hdw_load_row(const HDwWin& wn, int q, hu32x4 (&dst)[3], unsigned& ok) {
+// this thread's first output column inside the block's window of pxb * nx columns: with two columns per thread (x and x + d) the
+// threads px = 0 .. pxb - 1 take x = 2 d (px / d) + px % d, so that the pairs tile the window
+__device__ __forceinline__ int hdw_first_col(const HDwPlan& g, int colg, int px) {
+    return colg * g.pxb * g.nx + (g.nx == 2 ? 2 * g.d * (px / g.d) + px % g.d : px);
+}
+template <int NC>
+__device__ __forceinline__ void hdw_window(HDwWin<NC>& wn, const HDwPlan& g, int xo, int S) {
+    wn.xmask = 0u;
+#pragma unroll
+    for (int kc = 0; kc < NC; ++kc) {
+        const int xi = xo * S - g.p + kc * g.d;
+        const bool v = xi >= 0 && xi < g.win;
+        wn.xc[kc] = v ? xi : 0;
+        wn.xmask |= v ? (1u << kc) : 0u;
+    }
+}
+template <int NC>
+__device__ __forceinline__ void hdw_load_row(const HDwWin<NC>& wn, int q, hu32x4 (&dst)[NC], unsigned& ok) {
     const int iy = wn.b + wn.dq * q;
     const bool rv = iy >= 0 && iy < wn.hin;
     const int iyc = iy < 0 ? 0 : (iy >= wn.hin ? wn.hin - 1 : iy);
     const bf16_t* rp = wn.src + (int64_t)iyc * wn.rowstride;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) dst[kx] = ld8(rp + (int64_t)wn.xc[kx] * wn.c);
+    for (int kc = 0; kc < NC; ++kc) dst[kc] = ld8(rp + (int64_t)wn.xc[kc] * wn.c);
     ok = rv ? wn.xmask : 0u;
 }
 // the producer's BatchNorm + activation (the virtual activation is a bf16 tensor: rounded like a stored one), zero padding
-template <bool BNIN>
-__device__ __forceinline__ void hdw_commit(hu32x4 (&r)[3], unsigned ok, const float* __restrict__ lsc, const float* __restrict__ lsh, float neg, float hi) {
+template <bool BNIN, int NC>
+__device__ __forceinline__ void hdw_commit(hu32x4 (&r)[NC], unsigned ok, const float* __restrict__ lsc, const float* __restrict__ lsh, float neg, float hi) {
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
+    for (int kc = 0; kc < NC; ++kc) {
         if constexpr (BNIN) {
             float v[8];
-            unpack8(r[kx], v);
+            unpack8(r[kc], v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = bn_act_load(v[e], lsc[e], lsh[e], neg, hi);
-            r[kx] = pack8(v);
+            r[kc] = pack8(v);
         }
         const hu32x4 z = {0u, 0u, 0u, 0u};
-        r[kx] = ((ok >> kx) & 1u) ? r[kx] : z;
+        r[kc] = ((ok >> kc) & 1u) ? r[kc] : z;
     }
 }
 
 // LDS of the marching kernels: [0, 9*128) weights [tap][octet*8+e]; then 4 x 128 constants; then the reduction scratch
 static constexpr int HDW_W = 0, HDW_C0 = 9 * 128, HDW_RED = HDW_C0 + 4 * 128;
 
-template <int S, bool BNIN, int EPI>
+template <int S, bool BNIN, int EPI, int NX>
 __global__ __launch_bounds__(256) void hdw_conv_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                        HDwPlan g, InBN ib, float* __restrict__ part, HDwBn kb, bf16_t* __restrict__ y) {
+    static_assert(NX == 1 || S == 1, "two output columns per thread at stride 1 only");
+    constexpr int NC = NX + 2;
     __shared__ __attribute__((aligned(16))) float sm[HDW_RED + 256 * 16 + 128];
     const HDwBlock bk = hdw_decode(g);
     const int tid = threadIdx.x;
@@ -123,7 +151,7 @@ __global__ __launch_bounds__(256) void hdw_conv_kernel(const bf16_t* __restrict_
     const int oct = bk.cgi * g.cg + o;
     const bool ch_ok = oct * 8 < g.c;
     const int c0 = ch_ok ? oct * 8 : 0;
-    const int xo = bk.colg * g.pxb + px;
+    const int xo = hdw_first_col(g, bk.colg, px);               // output columns xo (+ i d, i < NX)
     const bool x_ok = xo < g.wout;
     // weights (flipped for the adjoint) and per-channel constants of this block's channel group
     for (int i = tid; i < 9 * g.cg * 8; i += 256) {
@@ -154,18 +182,11 @@ __global__ __launch_bounds__(256) void hdw_conv_kernel(const bf16_t* __restrict_
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; pv[e] = 0.f; }
     const bool active = j0 < j1;           // (block-uniform) a late phase may have no rows in the last chunk
     if (active) {
-        HDwWin wn;
+        HDwWin<NC> wn;
         wn.src = x + (int64_t)bk.n * g.hin * g.win * g.c + c0;
         wn.rowstride = (int64_t)g.win * g.c;
         wn.c = g.c; wn.hin = g.hin;
-        wn.xmask = 0u;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int xi = (x_ok ? xo : 0) * S - g.p + kx * g.d;
-            const bool v = xi >= 0 && xi < g.win;
-            wn.xc[kx] = v ? xi : 0;
-            wn.xmask |= v ? (1u << kx) : 0u;
-        }
+        hdw_window<NC>(wn, g, x_ok ? xo : 0, S);
         wn.b = S == 1 ? bk.phase - g.p : -g.p;
         wn.dq = S == 1 ? g.d : 1;
         float bv[8];
@@ -173,86 +194,107 @@ __global__ __launch_bounds__(256) void hdw_conv_kernel(const bf16_t* __restrict_
         for (int e = 0; e < 8; ++e) bv[e] = (bias != nullptr && ch_ok) ? bias[c0 + e] : 0.f;
         const float neg = ib.neg, hi = ib.hi;
 
-        hu32x4 ring[3][3], nxt[S][3], yq;
+        hu32x4 ring[3][NC], nxt[S][NC], yq[NX];
         unsigned rok[3], nok[S];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) hdw_load_row(wn, S * j0 + k, ring[k], rok[k]);
+        for (int k = 0; k < 3; ++k) hdw_load_row<NC>(wn, S * j0 + k, ring[k], rok[k]);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) hdw_commit<BNIN>(ring[k], rok[k], lc, lc + 128, neg, hi);
+        for (int k = 0; k < 3; ++k) hdw_commit<BNIN, NC>(ring[k], rok[k], lc, lc + 128, neg, hi);
         const int64_t orow = (int64_t)g.wout * g.c;
         bf16_t* yout = y + (int64_t)bk.n * g.hout * orow + (int64_t)(x_ok ? xo : 0) * g.c + c0;
         const bf16_t* ybn = EPI == 2 ? kb.y + (int64_t)bk.n * g.hout * orow + (int64_t)(x_ok ? xo : 0) * g.c + c0 : nullptr;
-        const bool st_ok = x_ok && ch_ok;
+        bool st_ok[NX];
+        int64_t coff[NX];                  // element offset of output column i from column xo (clamped inside the row when it is outside)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            st_ok[i] = ch_ok && xo + i * g.d < g.wout;
+            coff[i] = st_ok[i] ? (int64_t)i * g.d * g.c : 0;
+        }
         for (int j = j0; j < j1; ++j) {
             const int yo = S == 1 ? bk.phase + g.d * j : j;
             // the next step's new rows (clamped rows past the end are loaded and never used)
 #pragma unroll
-            for (int i = 0; i < S; ++i) hdw_load_row(wn, S * (j + 1) + 3 - S + i, nxt[i], nok[i]);
-            if constexpr (EPI == 2) yq = ld8(ybn + (int64_t)yo * orow);
-            float acc[8];
+            for (int i = 0; i < S; ++i) hdw_load_row<NC>(wn, S * (j + 1) + 3 - S + i, nxt[i], nok[i]);
+            if constexpr (EPI == 2) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = bv[e];
+                for (int i = 0; i < NX; ++i) yq[i] = ld8(ybn + (int64_t)yo * orow + coff[i]);
+            }
+            float acc[NX][8];
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[i][e] = bv[e];
+            // every window vector is unpacked once and feeds the outputs it belongs to: column kc is tap kx = kc - i of output i
+            // (the weights are read where they are used -- twice per step with two outputs: LDS broadcast reads, no registers held)
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
+                for (int kc = 0; kc < NC; ++kc) {
                     float v[8];
-                    unpack8(ring[k][kx], v);
-                    const float4 w0 = *reinterpret_cast<const float4*>(lw + (k * 3 + kx) * 128), w1 = *reinterpret_cast<const float4*>(lw + (k * 3 + kx) * 128 + 4);
-                    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                    unpack8(ring[k][kc], v);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(wv[e], v[e], acc[e]);
-                }
-            const hu32x4 ob = pack8(acc);
-            if (st_ok) st8_nt(yout + (int64_t)yo * orow, ob);
-            if constexpr (EPI == 1) {
-                float v[8];
-                unpack8(ob, v);
-                if (j == j0) {          // block pivot per channel: the first output of the block's first column (block-uniform branch)
-                    if (px == 0) {
+                    for (int i = 0; i < NX; ++i) {
+                        if (kc - i < 0 || kc - i > 2) continue;
+                        const int t = k * 3 + kc - i;
+                        const float4 w0 = *reinterpret_cast<const float4*>(lw + t * 128), w1 = *reinterpret_cast<const float4*>(lw + t * 128 + 4);
+                        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) sm[HDW_RED + o * 8 + e] = v[e];
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) pv[e] = sm[HDW_RED + o * 8 + e];
-                    __syncthreads();
-                }
-                if (st_ok) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float dlt = v[e] - pv[e];
-                        s1[e] += dlt;
-                        s2[e] = fmaf(dlt, dlt, s2[e]);
+                        for (int e = 0; e < 8; ++e) acc[i][e] = fmaf(wv[e], v[e], acc[i][e]);
                     }
                 }
-            }
-            if constexpr (EPI == 2) {
-                if (st_ok) {
-                    float v[8], yv[8];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const hu32x4 ob = pack8(acc[i]);
+                if (st_ok[i]) st8_nt(yout + (int64_t)yo * orow + coff[i], ob);
+                if constexpr (EPI == 1) {
+                    float v[8];
                     unpack8(ob, v);
-                    unpack8(yq, yv);
+                    if (i == 0 && j == j0) {      // block pivot per channel: the first output of the block's first column (block-uniform branch)
+                        if (px == 0) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float xh = (yv[e] - lc[e]) * lc[128 + e];
-                        const float z = fmaf(xh, lc[256 + e], lc[384 + e]);
-                        const float dz = v[e] * inbn_grad(z, kb.neg, kb.hi);
-                        s1[e] += dz;
-                        s2[e] = fmaf(dz, xh, s2[e]);
+                            for (int e = 0; e < 8; ++e) sm[HDW_RED + o * 8 + e] = v[e];
+                        }
+                        __syncthreads();
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pv[e] = sm[HDW_RED + o * 8 + e];
+                        __syncthreads();
+                    }
+                    if (st_ok[i]) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float dlt = v[e] - pv[e];
+                            s1[e] += dlt;
+                            s2[e] = fmaf(dlt, dlt, s2[e]);
+                        }
+                    }
+                }
+                if constexpr (EPI == 2) {
+                    if (st_ok[i]) {
+                        float v[8], yv[8];
+                        unpack8(ob, v);
+                        unpack8(yq[i], yv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float xh = (yv[e] - lc[e]) * lc[128 + e];
+                            const float z = fmaf(xh, lc[256 + e], lc[384 + e]);
+                            const float dz = v[e] * inbn_grad(z, kb.neg, kb.hi);
+                            s1[e] += dz;
+                            s2[e] = fmaf(dz, xh, s2[e]);
+                        }
                     }
                 }
             }
             // rotate the window
 #pragma unroll
-            for (int i = 0; i < S; ++i) hdw_commit<BNIN>(nxt[i], nok[i], lc, lc + 128, neg, hi);
+            for (int i = 0; i < S; ++i) hdw_commit<BNIN, NC>(nxt[i], nok[i], lc, lc + 128, neg, hi);
 #pragma unroll
             for (int k = 0; k < 3 - S; ++k)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) ring[k][kx] = ring[k + S][kx];
+                for (int kc = 0; kc < NC; ++kc) ring[k][kc] = ring[k + S][kc];
 #pragma unroll
             for (int i = 0; i < S; ++i)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) ring[3 - S + i][kx] = nxt[i][kx];
+                for (int kc = 0; kc < NC; ++kc) ring[3 - S + i][kc] = nxt[i][kc];
         }
     }
     if constexpr (EPI != 0) {
@@ -273,8 +315,8 @@ __global__ __launch_bounds__(256) void hdw_conv_kernel(const bf16_t* __restrict_
                 float a1 = 0.f, a2 = 0.f;
                 for (int p = 0; p < g.pxb; ++p) { a1 += red[(p * g.cg + oo) * 16 + e]; a2 += red[(p * g.cg + oo) * 16 + 8 + e]; }
                 if constexpr (EPI == 1) {
-                    int vpx = g.wout - bk.colg * g.pxb;
-                    vpx = vpx < g.pxb ? vpx : g.pxb;
+                    int vpx = g.wout - bk.colg * g.pxb * g.nx;
+                    vpx = vpx < g.pxb * g.nx ? vpx : g.pxb * g.nx;
                     float* sp = part + bk.prow * 4 * g.c;
                     sp[ch] = active ? (float)((int64_t)vpx * (j1 - j0)) : 0.f;
                     sp[g.c + ch] = sm[HDW_RED + 256 * 16 + oo * 8 + e];
@@ -291,9 +333,11 @@ __global__ __launch_bounds__(256) void hdw_conv_kernel(const bf16_t* __restrict_
 }
 
 // ---- weight gradient: dw[c][ky][kx] = sum dy[n,yo,xo,c] * a[n, yo*S - p + ky*d, xo*S - p + kx*d, c] ------------------------
-template <int S, bool BNIN>
+template <int S, bool BNIN, int NX>
 __global__ __launch_bounds__(256) void hdw_dw_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, HDwPlan g, InBN ib,
                                                      float* __restrict__ part) {
+    static_assert(NX == 1 || S == 1, "two output columns per thread at stride 1 only");
+    constexpr int NC = NX + 2;
     __shared__ __attribute__((aligned(16))) float sm[256 + 256 * 8];
     const HDwBlock bk = hdw_decode(g);
     const int tid = threadIdx.x;
@@ -301,7 +345,7 @@ __global__ __launch_bounds__(256) void hdw_dw_kernel(const bf16_t* __restrict__ 
     const int oct = bk.cgi * g.cg + o;
     const bool ch_ok = oct * 8 < g.c;
     const int c0 = ch_ok ? oct * 8 : 0;
-    const int xo = bk.colg * g.pxb + px;
+    const int xo = hdw_first_col(g, bk.colg, px);
     const bool x_ok = xo < g.wout;
     for (int i = tid; i < g.cg * 8; i += 256) {
         const int ch = bk.cgi * g.cg * 8 + i;
@@ -320,57 +364,63 @@ __global__ __launch_bounds__(256) void hdw_dw_kernel(const bf16_t* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
     if (j0 < j1) {
-        HDwWin wn;
+        HDwWin<NC> wn;
         wn.src = x + (int64_t)bk.n * g.hin * g.win * g.c + c0;
         wn.rowstride = (int64_t)g.win * g.c;
         wn.c = g.c; wn.hin = g.hin;
-        wn.xmask = 0u;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int xi = (x_ok ? xo : 0) * S - g.p + kx * g.d;
-            const bool v = xi >= 0 && xi < g.win;
-            wn.xc[kx] = v ? xi : 0;
-            wn.xmask |= v ? (1u << kx) : 0u;
-        }
+        hdw_window<NC>(wn, g, x_ok ? xo : 0, S);
         wn.b = S == 1 ? bk.phase - g.p : -g.p;
         wn.dq = S == 1 ? g.d : 1;
         const float neg = ib.neg, hi = ib.hi;
-        hu32x4 ring[3][3], nxt[S][3];
+        hu32x4 ring[3][NC], nxt[S][NC];
         unsigned rok[3], nok[S];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) hdw_load_row(wn, S * j0 + k, ring[k], rok[k]);
+        for (int k = 0; k < 3; ++k) hdw_load_row<NC>(wn, S * j0 + k, ring[k], rok[k]);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) hdw_commit<BNIN>(ring[k], rok[k], lc, lc + 128, neg, hi);
+        for (int k = 0; k < 3; ++k) hdw_commit<BNIN, NC>(ring[k], rok[k], lc, lc + 128, neg, hi);
         const int64_t orow = (int64_t)g.wout * g.c;
         const bf16_t* dyp = dy + (int64_t)bk.n * g.hout * orow + (int64_t)(x_ok ? xo : 0) * g.c + c0;
-        const bool st_ok = x_ok && ch_ok;
+        bool st_ok[NX];
+        int64_t coff[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            st_ok[i] = ch_ok && xo + i * g.d < g.wout;
+            coff[i] = st_ok[i] ? (int64_t)i * g.d * g.c : 0;
+        }
         for (int j = j0; j < j1; ++j) {
             const int yo = S == 1 ? bk.phase + g.d * j : j;
 #pragma unroll
-            for (int i = 0; i < S; ++i) hdw_load_row(wn, S * (j + 1) + 3 - S + i, nxt[i], nok[i]);
-            float gv[8];
-            unpack8(ld8(dyp + (int64_t)yo * orow), gv);
+            for (int i = 0; i < S; ++i) hdw_load_row<NC>(wn, S * (j + 1) + 3 - S + i, nxt[i], nok[i]);
+            float gv[NX][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) gv[e] = st_ok ? gv[e] : 0.f;
+            for (int i = 0; i < NX; ++i) {
+                unpack8(ld8(dyp + (int64_t)yo * orow + coff[i]), gv[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gv[i][e] = st_ok[i] ? gv[i][e] : 0.f;
+            }
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
+                for (int kc = 0; kc < NC; ++kc) {
                     float v[8];
-                    unpack8(ring[k][kx], v);
+                    unpack8(ring[k][kc], v);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[k * 3 + kx][e] = fmaf(gv[e], v[e], acc[k * 3 + kx][e]);
+                    for (int i = 0; i < NX; ++i) {
+                        if (kc - i < 0 || kc - i > 2) continue;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[k * 3 + kc - i][e] = fmaf(gv[i][e], v[e], acc[k * 3 + kc - i][e]);
+                    }
                 }
 #pragma unroll
-            for (int i = 0; i < S; ++i) hdw_commit<BNIN>(nxt[i], nok[i], lc, lc + 128, neg, hi);
+            for (int i = 0; i < S; ++i) hdw_commit<BNIN, NC>(nxt[i], nok[i], lc, lc + 128, neg, hi);
 #pragma unroll
             for (int k = 0; k < 3 - S; ++k)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) ring[k][kx] = ring[k + S][kx];
+                for (int kc = 0; kc < NC; ++kc) ring[k][kc] = ring[k + S][kc];
 #pragma unroll
             for (int i = 0; i < S; ++i)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) ring[3 - S + i][kx] = nxt[i][kx];
+                for (int kc = 0; kc < NC; ++kc) ring[3 - S + i][kc] = nxt[i][kc];
         }
     }
     // per tap: the block's pixels are summed through LDS; partial row [c][9] per block
@@ -510,7 +560,7 @@ using namespace tsii;
 
 extern "C" int64_t tsii_bf16_dw_stat_rows(int n, int ho, int wo, int c, int kh, int kw, int sh, int sw, int dh, int dw) {
     if (n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || c % 8 != 0 || kh != 3 || kw != 3 || sh != sw || (sh != 1 && sh != 2) || dh != dw || dh < 1 || (sh == 2 && dh != 1)) return 0;
-    return hdw_rows(hdw_plan(n, 1, 1, c, ho, wo, sh, 0, dh, 0));
+    return hdw_rows(hdw_plan(n, 1, 1, c, ho, wo, sh, 0, dh, 0, 1));
 }
 
 extern "C" int tsii_bf16_dw_fwd(const uint16_t* x, const float* w, const float* bias, int n, int h, int wd, int c,
@@ -526,10 +576,14 @@ extern "C" int tsii_bf16_dw_fwd(const uint16_t* x, const float* w, const float* 
         TSII_REQUIRE(in_shift != nullptr, "bf16_dw_fwd: in_scale / in_shift go together");
         TSII_REQUIRE(make_in_bn(in_scale, in_shift, in_act, in_slope, &ib) == 0, "bf16_dw_fwd: activation %d has no load-time form", in_act);
     }
-    const HDwPlan g = hdw_plan(n, h, wd, c, ho, wo, sh, ph, dh, 0);
+    const HDwPlan g = hdw_plan(n, h, wd, c, ho, wo, sh, ph, dh, 0, 1);
     const dim3 grid((unsigned)hdw_blocks(g));
     const HDwBn nb = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 1.f, 0.f};
-#define TSII_HDW(SS, BI, EP) hipLaunchKernelGGL((hdw_conv_kernel<SS, BI, EP>), grid, dim3(256), 0, st, x, w, bias, g, ib, stat_part, nb, y)
+#define TSII_HDW(SS, BI, EP)                                                                                                              \
+    do {                                                                                                                                   \
+        if (SS == 1 && g.nx == 2) hipLaunchKernelGGL((hdw_conv_kernel<1, BI, EP, 2>), grid, dim3(256), 0, st, x, w, bias, g, ib, stat_part, nb, y); \
+        else hipLaunchKernelGGL((hdw_conv_kernel<SS, BI, EP, 1>), grid, dim3(256), 0, st, x, w, bias, g, ib, stat_part, nb, y);           \
+    } while (0)
     const bool bi = in_scale != nullptr, stt = stat_part != nullptr;
     if (sh == 1) { if (bi) { if (stt) TSII_HDW(1, true, 1); else TSII_HDW(1, true, 0); } else { if (stt) TSII_HDW(1, false, 1); else TSII_HDW(1, false, 0); } }
     else { if (bi) { if (stt) TSII_HDW(2, true, 1); else TSII_HDW(2, true, 0); } else { if (stt) TSII_HDW(2, false, 1); else TSII_HDW(2, false, 0); } }
@@ -539,7 +593,7 @@ extern "C" int tsii_bf16_dw_fwd(const uint16_t* x, const float* w, const float* 
 
 extern "C" int64_t tsii_bf16_dw_bwd_stat_rows(int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw) {
     if (n <= 0 || h <= 0 || wd <= 0 || c <= 0 || c % 8 != 0 || kh != 3 || kw != 3 || sh != 1 || sw != 1 || dh != dw || dh < 1 || ph != pw) return 0;
-    return hdw_rows(hdw_plan(n, 1, 1, c, h, wd, 1, 0, dh, 1));
+    return hdw_rows(hdw_plan(n, 1, 1, c, h, wd, 1, 0, dh, 1, 2));
 }
 
 extern "C" int tsii_bf16_dw_bwd_dx(const uint16_t* dy, const float* w, int n, int h, int wd, int c,
@@ -560,7 +614,7 @@ extern "C" int tsii_bf16_dw_bwd_dx(const uint16_t* dy, const float* w, int n, in
         return check_launch("bf16_dw_bwd_dx (stride 2)");
     }
     // stride 1: the adjoint is the same stencil with flipped taps and padding 2 d - p over dy [n, ho, wo, c] -> dx [n, h, wd, c]
-    const HDwPlan g = hdw_plan(n, ho, wo, c, h, wd, 1, 2 * dh - ph, dh, 1);
+    const HDwPlan g = hdw_plan(n, ho, wo, c, h, wd, 1, 2 * dh - ph, dh, 1, bn_y != nullptr ? 2 : 1);
     const dim3 grid((unsigned)hdw_blocks(g));
     InBN ib = {nullptr, nullptr, 1.f, __builtin_huge_valf()};
     HDwBn kb = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 1.f, 0.f};
@@ -569,16 +623,18 @@ extern "C" int tsii_bf16_dw_bwd_dx(const uint16_t* dy, const float* w, int n, in
         InBN tmp;
         TSII_REQUIRE(make_in_bn(bn_mean, bn_var, bn_act, bn_slope, &tmp) == 0, "bf16_dw_bwd_dx: activation %d has no load-time form", bn_act);
         kb.y = bn_y; kb.mean = bn_mean; kb.var = bn_var; kb.gamma = bn_gamma; kb.beta = bn_beta; kb.eps = bn_eps; kb.neg = tmp.neg; kb.hi = tmp.hi;
-        hipLaunchKernelGGL((hdw_conv_kernel<1, false, 2>), grid, dim3(256), 0, st, dy, w, (const float*)nullptr, g, ib, bwd_part, kb, dx);
+        if (g.nx == 2) hipLaunchKernelGGL((hdw_conv_kernel<1, false, 2, 2>), grid, dim3(256), 0, st, dy, w, (const float*)nullptr, g, ib, bwd_part, kb, dx);
+        else hipLaunchKernelGGL((hdw_conv_kernel<1, false, 2, 1>), grid, dim3(256), 0, st, dy, w, (const float*)nullptr, g, ib, bwd_part, kb, dx);
     } else {
-        hipLaunchKernelGGL((hdw_conv_kernel<1, false, 0>), grid, dim3(256), 0, st, dy, w, (const float*)nullptr, g, ib, (float*)nullptr, kb, dx);
+        if (g.nx == 2) hipLaunchKernelGGL((hdw_conv_kernel<1, false, 0, 2>), grid, dim3(256), 0, st, dy, w, (const float*)nullptr, g, ib, (float*)nullptr, kb, dx);
+        else hipLaunchKernelGGL((hdw_conv_kernel<1, false, 0, 1>), grid, dim3(256), 0, st, dy, w, (const float*)nullptr, g, ib, (float*)nullptr, kb, dx);
     }
     return check_launch("bf16_dw_bwd_dx");
 }
 
 extern "C" size_t tsii_bf16_dw_bwd_dw_ws_bytes(int n, int ho, int wo, int c, int kh, int kw, int sh, int sw, int dh, int dw) {
     if (n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || c % 8 != 0 || kh != 3 || kw != 3 || (sh != 1 && sh != 2) || dh < 1) return 0;
-    const HDwPlan g = hdw_plan(n, 1, 1, c, ho, wo, sh, 0, dh, 0);
+    const HDwPlan g = hdw_plan(n, 1, 1, c, ho, wo, sh, 0, dh, 0, 0);
     const size_t rows = (size_t)hdw_rows(g);
     const size_t bias = (size_t)partial_rows((int64_t)n * ho * wo, c / 8) * c;
     const size_t fl = rows * 9 * c;
@@ -599,12 +655,13 @@ extern "C" int tsii_bf16_dw_bwd_dw(const uint16_t* dy, const uint16_t* x, int n,
         TSII_REQUIRE(in_shift != nullptr, "bf16_dw_bwd_dw: in_scale / in_shift go together");
         TSII_REQUIRE(make_in_bn(in_scale, in_shift, in_act, in_slope, &ib) == 0, "bf16_dw_bwd_dw: activation %d has no load-time form", in_act);
     }
-    const HDwPlan g = hdw_plan(n, h, wd, c, ho, wo, sh, ph, dh, 0);
+    const HDwPlan g = hdw_plan(n, h, wd, c, ho, wo, sh, ph, dh, 0, 0);
     const dim3 grid((unsigned)hdw_blocks(g));
     float* wsf = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 15) & ~(uintptr_t)15);
     const bool bi = in_scale != nullptr;
-    if (sh == 1) { if (bi) hipLaunchKernelGGL((hdw_dw_kernel<1, true>), grid, dim3(256), 0, st, x, dy, g, ib, wsf); else hipLaunchKernelGGL((hdw_dw_kernel<1, false>), grid, dim3(256), 0, st, x, dy, g, ib, wsf); }
-    else { if (bi) hipLaunchKernelGGL((hdw_dw_kernel<2, true>), grid, dim3(256), 0, st, x, dy, g, ib, wsf); else hipLaunchKernelGGL((hdw_dw_kernel<2, false>), grid, dim3(256), 0, st, x, dy, g, ib, wsf); }
+    if (sh == 1 && g.nx == 2) { if (bi) hipLaunchKernelGGL((hdw_dw_kernel<1, true, 2>), grid, dim3(256), 0, st, x, dy, g, ib, wsf); else hipLaunchKernelGGL((hdw_dw_kernel<1, false, 2>), grid, dim3(256), 0, st, x, dy, g, ib, wsf); }
+    else if (sh == 1) { if (bi) hipLaunchKernelGGL((hdw_dw_kernel<1, true, 1>), grid, dim3(256), 0, st, x, dy, g, ib, wsf); else hipLaunchKernelGGL((hdw_dw_kernel<1, false, 1>), grid, dim3(256), 0, st, x, dy, g, ib, wsf); }
+    else { if (bi) hipLaunchKernelGGL((hdw_dw_kernel<2, true, 1>), grid, dim3(256), 0, st, x, dy, g, ib, wsf); else hipLaunchKernelGGL((hdw_dw_kernel<2, false, 1>), grid, dim3(256), 0, st, x, dy, g, ib, wsf); }
     int rc = check_launch("bf16_dw_bwd_dw");
     if (rc) return rc;
     rc = launch_reduce_rows(wsf, (int)hdw_rows(g), (int64_t)c * 9, dwgt, st);
@@ -618,7 +675,7 @@ extern "C" int tsii_bf16_avgpool(const uint16_t* x, int n, int h, int wd, int c,
     TSII_REQUIRE(k == 3 || k == 5 || k == 9, "bf16_avgpool: k = 3, 5 or 9 (stride 1, padding (k-1)/2), got %d", k);
     TSII_REQUIRE(aligned16(x) && aligned16(y), "bf16_avgpool: tensors must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    HDwPlan g = hdw_plan(n, h, wd, c, h, wd, 2 /* one row phase, plain chunks */, 0, 1, 0);
+    HDwPlan g = hdw_plan(n, h, wd, c, h, wd, 2 /* one row phase, plain chunks */, 0, 1, 0, 0);
     const dim3 grid((unsigned)hdw_blocks(g));
     if (k == 3) hipLaunchKernelGGL(havgpool_kernel<3>, grid, dim3(256), 0, st, x, g, y);
     else if (k == 5) hipLaunchKernelGGL(havgpool_kernel<5>, grid, dim3(256), 0, st, x, g, y);
