@@ -351,32 +351,41 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const T* __restrict__
 }
 
 // backward pass 2: dy = gamma*istd*(dz - s1/M - xhat*s2/M)   (training)  |  gamma*istd*dz  (eval)
-// One vector per thread (flat_grid): the six per-channel constants come from the table bn_bwd_final_kernel leaves behind
-// (coef[j][C], j = mean, 1/std, gamma, beta, dbeta/M, dgamma/M) -- re-deriving them per thread (24 scalar loads + 4
-// rsqrt) made the pass 2.3x slower than the grid-stride form it replaced.
-template <int W>
+// A thread owns one channel vector and RPT consecutive rows (flat grid over row blocks x channel vectors): the six per-channel
+// constants come from the table bn_bwd_final_kernel leaves behind (coef[j][C], j = mean, 1/std, gamma, beta, dbeta/M, dgamma/M) --
+// re-deriving them per thread (24 scalar loads + 4 rsqrt) made the pass 2.3x slower than the grid-stride form it replaced -- and are
+// fetched once per RPT rows: with one row per thread they were twice the streamed bytes through the vector cache (round 5; the
+// bf16-storage form of this pass, where they were four times, went from 4.3 to 6 TB/s with 4 rows per thread).
+template <int W, int RPT>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y, int64_t M, int C,
                                     const float* __restrict__ coef, int act, float slope, float* __restrict__ dy) {
     const unsigned CG = (unsigned)(C / W);
-    const int64_t total = M * CG;
+    const int64_t total = ((M + RPT - 1) / RPT) * CG;
     const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (gt >= total) return;
     const int c = (int)(gt % CG) * W;
+    const int64_t r0 = (gt / CG) * RPT;
     const VecF<W> mu = vload<W>(coef + c), istd = vload<W>(coef + C + c), ga = vload<W>(coef + 2 * C + c), be = vload<W>(coef + 3 * C + c),
                   k1 = vload<W>(coef + 4 * C + c), k2 = vload<W>(coef + 5 * C + c);
-    for (int64_t idx = gt; idx < total; idx += stride) {
-        const int64_t off = idx * W;
-        const VecF<W> yv = vload_nt<W>(y + off);
-        VecF<W> dv = vload_nt<W>(dout + off);
+    VecF<W> yv[RPT], dv[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {              // every load of the thread in flight before the first use
+        const int64_t row = r0 + r < M ? r0 + r : M - 1;
+        yv[r] = vload_nt<W>(y + row * C + c);
+        dv[r] = vload_nt<W>(dout + row * C + c);
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        if (r0 + r >= M) break;
 #pragma unroll
         for (int i = 0; i < W; ++i) {
-            const float xh = (yv.v[i] - mu.v[i]) * istd.v[i];
+            const float xh = (yv[r].v[i] - mu.v[i]) * istd.v[i];
             const float z = xh * ga.v[i] + be.v[i];
-            float dz = dv.v[i] * act_grad(z, act, slope);
+            float dz = dv[r].v[i] * act_grad(z, act, slope);
             dz = dz - k1.v[i] - xh * k2.v[i];
-            dv.v[i] = dz * ga.v[i] * istd.v[i];
+            dv[r].v[i] = dz * ga.v[i] * istd.v[i];
         }
-        vstore_nt<W>(dy + off, dv);
+        vstore_nt<W>(dy + (r0 + r) * C + c, dv[r]);
     }
 }
 
@@ -429,12 +438,16 @@ __global__ void bn_bwd_apply_pool_kernel(const float* __restrict__ dout, const f
     vstore<W>(pooled + lp * C + c, acc);
 }
 
+#ifndef BN_APPLY_RPT
+#define BN_APPLY_RPT 4   // rows per thread of the backward apply on the large tensors (A/B: tools/variants)
+#endif
 static int launch_bn_bwd_apply(const float* dout, const float* y, int64_t m, int c, int act, float slope, float* dy, const float* coef, hipStream_t st) {
     const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(dout) && aligned16(dy) && aligned16(coef);
-    const int64_t total = m * (vec ? c / 4 : c);
-    const unsigned grid = flat_grid(total, 256);
-    if (vec) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(grid), dim3(256), 0, st, dout, y, m, c, coef, act, slope, dy);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(grid), dim3(256), 0, st, dout, y, m, c, coef, act, slope, dy);
+    const int cg = vec ? c / 4 : c;
+    if (vec && m * cg >= (1ll << 21) && BN_APPLY_RPT > 1)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4, BN_APPLY_RPT>), dim3(flat_grid(cdiv64(m, BN_APPLY_RPT) * cg, 256)), dim3(256), 0, st, dout, y, m, c, coef, act, slope, dy);
+    else if (vec) hipLaunchKernelGGL((bn_bwd_apply_kernel<4, 1>), dim3(flat_grid(m * cg, 256)), dim3(256), 0, st, dout, y, m, c, coef, act, slope, dy);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1, 1>), dim3(flat_grid(m * cg, 256)), dim3(256), 0, st, dout, y, m, c, coef, act, slope, dy);
     return check_launch("bn_bwd_apply");
 }
 
