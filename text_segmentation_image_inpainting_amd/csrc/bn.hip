@@ -249,19 +249,24 @@ __global__ void bn_scale_shift_kernel(const float* __restrict__ mean, const floa
     }
 }
 
-// launched with flat_grid(): one vector per thread (tsii_common.h); with any other grid (gridDim*blockDim) % CG == 0 must hold
-template <int W>
+#ifndef BN_APPLY_RPT
+#define BN_APPLY_RPT 4   // rows per thread of the forward / backward apply on the large tensors (A/B: tools/variants)
+#endif
+// flat grid over (row blocks of RPT rows) x (channel vectors): a thread fetches its four constant vectors (and takes its rsqrt) once
+// per RPT rows -- per row they were four times the streamed bytes of a plain apply (round 5, like bn_bwd_apply_kernel)
+template <int W, int RPT>
 __global__ void bn_act_fwd_kernel(const float* __restrict__ y, int64_t M, int C, const float* __restrict__ mean,
                                   const float* __restrict__ var, const float* __restrict__ gamma,
                                   const float* __restrict__ beta, float eps, int act, float slope,
                                   const float* __restrict__ residual, float* __restrict__ out) {
     const unsigned CG = (unsigned)(C / W);
-    const int64_t total = M * CG;
+    const int64_t total = ((M + RPT - 1) / RPT) * CG;
     const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (gt >= total) return;
     const int c = (int)(gt % CG) * W;
+    const int64_t r0 = (gt / CG) * RPT;
     float mu[W], sc[W], be[W];
-    {   // per-channel constants as vector loads (the kernel runs one vector per thread)
+    {   // per-channel constants as vector loads
         const VecF<W> m4 = vload<W>(mean + c), v4 = vload<W>(var + c), g4 = vload<W>(gamma + c), b4 = vload<W>(beta + c);
 #pragma unroll
         for (int i = 0; i < W; ++i) {
@@ -270,19 +275,24 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ y, int64_t M, int C,
             be[i] = b4.v[i];
         }
     }
-    for (int64_t idx = gt; idx < total; idx += stride) {
-        const int64_t off = idx * W;
-        VecF<W> v = vload_nt<W>(y + off);
-        VecF<W> res;
-        if (residual != nullptr) res = vload_nt<W>(residual + off);
+    VecF<W> v[RPT], res[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int64_t row = r0 + r < M ? r0 + r : M - 1;
+        v[r] = vload_nt<W>(y + row * C + c);
+        if (residual != nullptr) res[r] = vload_nt<W>(residual + row * C + c);
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        if (r0 + r >= M) break;
 #pragma unroll
         for (int i = 0; i < W; ++i) {
-            float z = (v.v[i] - mu[i]) * sc[i] + be[i];
+            float z = (v[r].v[i] - mu[i]) * sc[i] + be[i];
             z = apply_act(z, act, slope);
-            if (residual != nullptr) z += res.v[i];
-            v.v[i] = z;
+            if (residual != nullptr) z += res[r].v[i];
+            v[r].v[i] = z;
         }
-        vstore_nt<W>(out + off, v);
+        vstore_nt<W>(out + (r0 + r) * C + c, v[r]);
     }
 }
 
@@ -438,9 +448,6 @@ __global__ void bn_bwd_apply_pool_kernel(const float* __restrict__ dout, const f
     vstore<W>(pooled + lp * C + c, acc);
 }
 
-#ifndef BN_APPLY_RPT
-#define BN_APPLY_RPT 4   // rows per thread of the backward apply on the large tensors (A/B: tools/variants)
-#endif
 static int launch_bn_bwd_apply(const float* dout, const float* y, int64_t m, int c, int act, float slope, float* dy, const float* coef, hipStream_t st) {
     const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(dout) && aligned16(dy) && aligned16(coef);
     const int cg = vec ? c / 4 : c;
@@ -578,10 +585,11 @@ extern "C" int tsii_bn_act_fwd(const float* y, int64_t m, int c, const float* me
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (c % 4 == 0) && aligned16(y) && aligned16(out) && (residual == nullptr || aligned16(residual)) &&
                      aligned16(mean) && aligned16(var) && aligned16(gamma) && aligned16(beta);
-    const int64_t total = m * (vec ? c / 4 : c);
-    const unsigned grid = flat_grid(total, 256);
-    if (vec) hipLaunchKernelGGL((bn_act_fwd_kernel<4>), dim3(grid), dim3(256), 0, st, y, m, c, mean, var, gamma, beta, eps, act, slope, residual, out);
-    else hipLaunchKernelGGL((bn_act_fwd_kernel<1>), dim3(grid), dim3(256), 0, st, y, m, c, mean, var, gamma, beta, eps, act, slope, residual, out);
+    const int cg = vec ? c / 4 : c;
+    if (vec && m * cg >= (1ll << 21) && BN_APPLY_RPT > 1)
+        hipLaunchKernelGGL((bn_act_fwd_kernel<4, BN_APPLY_RPT>), dim3(flat_grid(cdiv64(m, BN_APPLY_RPT) * cg, 256)), dim3(256), 0, st, y, m, c, mean, var, gamma, beta, eps, act, slope, residual, out);
+    else if (vec) hipLaunchKernelGGL((bn_act_fwd_kernel<4, 1>), dim3(flat_grid(m * cg, 256)), dim3(256), 0, st, y, m, c, mean, var, gamma, beta, eps, act, slope, residual, out);
+    else hipLaunchKernelGGL((bn_act_fwd_kernel<1, 1>), dim3(flat_grid(m * cg, 256)), dim3(256), 0, st, y, m, c, mean, var, gamma, beta, eps, act, slope, residual, out);
     return check_launch("bn_act_fwd");
 }
 

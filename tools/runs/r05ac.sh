@@ -4,7 +4,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"; mkdir -p gpurun_out/r05ac
 
-for v in stock bn_rpt8_f32 stock bn_rpt8_f32; do
+for v in stock bn_rpt1_f32 stock bn_rpt1_f32; do
   if [ $v = stock ]; then unset TSII_LIBRARY; else export TSII_LIBRARY=$R/tools/variants/_bin/libtsii_$v.so; fi
   timeout 400 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-f32-leg 2>/dev/null | tail -1 | python -c "
 import sys,json
