@@ -28,7 +28,7 @@ PEAK_HBM_TBS = 8.0          # HBM3E spec
 # ImageFill 512^2 forward = 58.8 GFLOP and 2934 MB (train-mode BN) per image; fwd+bwd = 3x
 ALG_GFLOP_PER_IMG = 3 * 58.8
 ALG_GB_PER_IMG = 3 * 2.934
-PMC_SUMMARY = "r05_pmc_hbm_traffic_bs32.json"   # tools/collect_profiles.sh -> tools/pmc_summary.py
+PMC_SUMMARY = "r05f_pmc_hbm_traffic_bs32.json"   # tools/collect_profiles.sh -> tools/pmc_summary.py
 
 
 def csrc_sha():
