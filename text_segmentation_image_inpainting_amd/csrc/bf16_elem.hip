@@ -76,29 +76,17 @@ __global__ __launch_bounds__(256) void hbn_bwd_partial_kernel(const bf16_t* __re
             mu[e] = mean[c + e]; istd[e] = 1.0f / sqrtf(var[c + e] + eps);
             ga[e] = gamma[c + e]; be[e] = beta[c + e]; s1[e] = 0.f; s2[e] = 0.f;
         }
-        // four rows per trip, their eight loads requested before the first use (rows past the end re-read the last row with weight 0)
-        for (int64_t m = r; m < M; m += 4 * (int64_t)R) {
-            hu32x4 yq[4], dq[4];
+        for (int64_t m = r; m < M; m += R) {
+            float yv[8], dv[8];
+            unpack8(ld8(y + m * C + c), yv);
+            unpack8(ld8(dout + m * C + c), dv);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t mm = m + (int64_t)u * R < M ? m + (int64_t)u * R : M - 1;
-                yq[u] = ld8_nt(y + mm * C + c);
-                dq[u] = ld8_nt(dout + mm * C + c);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (m + (int64_t)u * R >= M) break;
-                float yv[8], dv[8];
-                unpack8(yq[u], yv);
-                unpack8(dq[u], dv);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float xh = (yv[e] - mu[e]) * istd[e];
-                    const float z = fmaf(xh, ga[e], be[e]);
-                    const float dz = dv[e] * act_grad(z, act, slope);
-                    s1[e] += dz;
-                    s2[e] = fmaf(dz, xh, s2[e]);
-                }
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (yv[e] - mu[e]) * istd[e];
+                const float z = fmaf(xh, ga[e], be[e]);
+                const float dz = dv[e] * act_grad(z, act, slope);
+                s1[e] += dz;
+                s2[e] = fmaf(dz, xh, s2[e]);
             }
         }
         float* p = part + (int64_t)r * 2 * C;
