@@ -462,9 +462,26 @@ __global__ __launch_bounds__(512, 1) void hgemm_nt_ph_kernel(const bf16_t* __res
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     unsigned char* S0 = reinterpret_cast<unsigned char*>(smem);
 
+    // tile order inside an XCD's share of the grid: groups of PH_GROUP_M row tiles x all column tiles, walked row-tile-fastest, so that
+    // the ~32 blocks an XCD runs at a time cover a squarish patch (8 x 4 tiles: 12 operand panels per K tile through its L2 instead of
+    // the 2 x 16 = 18 of the row-major order)
+#ifndef PH_GROUP_M
+#define PH_GROUP_M 8
+#endif
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int64_t m0 = (int64_t)(bid / ntn) * BM;
-    const int n0 = (int)(bid % ntn) * BN;
+    unsigned tm, tn;
+    if (PH_GROUP_M > 1) {
+        const unsigned ntm = gridDim.x / ntn;
+        const unsigned per = PH_GROUP_M * ntn;
+        const unsigned gid = bid / per, first = gid * PH_GROUP_M;
+        const unsigned gm = ntm - first < (unsigned)PH_GROUP_M ? ntm - first : (unsigned)PH_GROUP_M;
+        tm = first + (bid % per) % gm;
+        tn = (bid % per) / gm;
+    } else {
+        tm = bid / ntn; tn = bid % ntn;
+    }
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = (int)tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;
@@ -576,7 +593,7 @@ __global__ __launch_bounds__(512, 1) void hgemm_nt_ph_kernel(const bf16_t* __res
 #undef TSII_PH_QUADRANT
     if (grp == 0) lds_barrier();
     async_wait_lds<0>();                          // the zero-page pieces of the K tiles past the end: nothing may land in the epilogue's LDS
-    h_nt_epilogue<WM, WN, TM, TN, BNB, SMEM_FLOATS, 512>(smem, acc, C, ldc, M, N, ep, m0, n0, bid / ntn);
+    h_nt_epilogue<WM, WN, TM, TN, BNB, SMEM_FLOATS, 512>(smem, acc, C, ldc, M, N, ep, m0, n0, tm);
 }
 
 // ---- TN (weight gradients) ------------------------------------------------------------------------------------------------
