@@ -524,8 +524,11 @@ __global__ __launch_bounds__(512, 1) void hgemm_nt_ph_kernel(const bf16_t* __res
 #endif
     // 8 MFMAs of one quadrant; with PH_GLDS_IN_C the two pieces of half-tile (skt, sh) go behind the 2nd and the 6th (an LDS-DMA issue
     // costs its wave 60 .. 180 cycles: in the L section that is time the partner's MFMAs cannot hide, here only its own pipe slack)
+#ifndef PH_PRIO
+#define PH_PRIO 1
+#endif
 #define TSII_PH_QUADRANT(AT, BU, FB, SKT, SH)                                                                                          \
-        __builtin_amdgcn_s_setprio(1);                                                                                                  \
+        __builtin_amdgcn_s_setprio(PH_PRIO);                                                                                                  \
         _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2)                                                                                \
             _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                             \
                 acc[AT + t][BU] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hbf16x8, fra[t][s2]),                      \
