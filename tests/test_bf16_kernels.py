@@ -282,7 +282,8 @@ def conv_dw_ref(dy, x, geom, kshape):
     (2, 12, 12, 16, 64, (1, 1, 2, 2, 0, 0, 1, 1), False),       # strided 1x1 shortcut
     (2, 13, 13, 16, 32, (2, 2, 1, 1, 0, 0, 1, 1), False),       # space-to-depth stem
     (1, 16, 16, 8, 16, (3, 3, 2, 2, 1, 1, 1, 1), True),         # strided 3x3
-    (1, 13, 11, 256, 256, (3, 3, 1, 1, 2, 2, 2, 2), True),      # 128 x 256 tiles of the gathered forms (forward: cout, dX: cin % 256 == 0)
+    (2, 13, 11, 256, 256, (3, 3, 1, 1, 2, 2, 2, 2), True),      # 256 x 256 tiles of the gathered forms (forward: cout, dX: cin % 256 == 0; 286 rows)
+    (1, 9, 9, 256, 256, (3, 3, 1, 1, 1, 1, 1, 1), False),       # ... and their 128 x 256 form (fewer than 256 rows)
 ])
 def test_dense_forward_dx_dw(emu, n, h, wd, cin, cout, geom, bias):
     L = emu

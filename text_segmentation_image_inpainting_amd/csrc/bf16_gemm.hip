@@ -449,9 +449,14 @@ __device__ __attribute__((aligned(16))) const unsigned h_zero_page[4] = {0u, 0u,
 // source): 8 waves in lock step, two whole-tile stages (0.91 - 0.98 PF/s: behind every barrier all waves fetch with nothing in the
 // matrix pipe), and the counter-phase scheme on K slabs of 32 in a 4-stage ring (1.0 - 1.05, but 0.74 at K = 8192: 64 bytes of a 16 KB
 // row per request).  BatchNorm-on-load at fragment time is VALU-bound on all of them (218 us against 136 on 131072 x 512 x 512).
-template <bool BNB>
+// AMODE 1 / 2: A is the im2col view of an NHWC tensor (forward / dX taps of a dense convolution, HGather): the LDS-DMA takes a
+// per-lane source address anyway, so the gather is the address -- a K tile of 64 channels lies inside ONE tap (c % 64 == 0, checked at
+// the launch), i.e. tap and channel offset are block-uniform per K tile and a lane only keeps the pixel of its four A rows; taps
+// outside the image fetch the page of zeros.
+template <int AMODE, bool BNB>
 __global__ __launch_bounds__(512, 1) void hgemm_nt_ph_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
-                                                             bf16_t* __restrict__ C, int64_t ldc, int64_t M, int N, int K, HEpi ep, unsigned ntn) {
+                                                             bf16_t* __restrict__ C, int64_t ldc, int64_t M, int N, int K, HEpi ep, unsigned ntn, HGather cg) {
+    constexpr bool CONV = AMODE != 0;
     constexpr int WM = 2, WN = 4, TM = 4, TN = 2;
     constexpr int BM = 256, BN = 256, BK = 64, RB = 128;
     constexpr int HALF_BYTES = 128 * RB, BUF_BYTES = 4 * HALF_BYTES;                        // 16 KB, 64 KB
@@ -498,6 +503,7 @@ __global__ __launch_bounds__(512, 1) void hgemm_nt_ph_kernel(const bf16_t* __res
 
     // this lane's two pieces of each half-tile (index 2 h + j; h: A0, A1, B0, B1): instruction j of wave w fills rows 8 (8 j + w) .. + 7
     const bf16_t* gsrc[8];
+    int apn[4], apyx[4];                                         // gathered A: image and (y << 16 | x) of this lane's four A rows, -1: past M
     const int kc = ((lane & 7) ^ ((((wave & 1) << 3) + (lane >> 3)) >> 1 & 7)) * 8;         // slot ^ ((row >> 1) & 7), row = 8 (8 j + w) + (lane >> 3)
 #pragma unroll
     for (int h = 0; h < 4; ++h)
@@ -506,7 +512,17 @@ __global__ __launch_bounds__(512, 1) void hgemm_nt_ph_kernel(const bf16_t* __res
             const int r = (h & 1) * 128 + 8 * (8 * j + wave) + (lane >> 3);                 // row of the 256-row operand tile
             if (h < 2) {         // rows past the matrix re-read the last one: their products are never stored
                 const int64_t row = m0 + r;
-                gsrc[2 * h + j] = A + (row < M ? row : M - 1) * lda + kc;
+                if constexpr (CONV) {
+                    gsrc[2 * h + j] = A + kc;
+                    apn[2 * h + j] = -1; apyx[2 * h + j] = 0;
+                    if (row < M) {
+                        const int64_t q = row / cg.rw;
+                        apn[2 * h + j] = (int)(q / cg.rh);
+                        apyx[2 * h + j] = ((int)(q % cg.rh) << 16) | (int)(row - q * cg.rw);
+                    }
+                } else {
+                    gsrc[2 * h + j] = A + (row < M ? row : M - 1) * lda + kc;
+                }
             } else {
                 const int row = n0 + r;
                 gsrc[2 * h + j] = B + (int64_t)(row < N ? row : N - 1) * K + kc;
@@ -516,7 +532,16 @@ __global__ __launch_bounds__(512, 1) void hgemm_nt_ph_kernel(const bf16_t* __res
     auto stage_piece = [&](int kt, int h, int j) {   // BRANCH-FREE: a K tile past the end fetches zeros into a half nobody reads again
         unsigned char* S = S0 + (kt & 1) * BUF_BYTES + h * HALF_BYTES + wave * 1024 + j * 8192;
         const int k0 = kt * BK;
-        async_load16_lds(S, (k0 + kc < K) ? gsrc[2 * h + j] + k0 : zpage);
+        if (CONV && h < 2) {
+            const int kk = k0 < K ? k0 : 0;                      // block-uniform: the K tile's tap and first channel
+            const int t = kk / cg.c, ci0 = kk - t * cg.c;
+            const int ky = t / cg.kw, kx = t - ky * cg.kw;
+            int sy = 0, sx = 0;
+            const bool ok = k0 < K && apn[2 * h + j] >= 0 && h_conv_src<AMODE == 2 ? 2 : 1>(cg, apyx[2 * h + j] >> 16, apyx[2 * h + j] & 0xffff, ky, kx, sy, sx);
+            async_load16_lds(S, ok ? gsrc[2 * h + j] + (((int64_t)apn[2 * h + j] * cg.h + sy) * cg.w + sx) * cg.c + ci0 : zpage);
+        } else {
+            async_load16_lds(S, (k0 + kc < K) ? gsrc[2 * h + j] + k0 : zpage);
+        }
     };
     auto stage_half = [&](int kt, int h) { stage_piece(kt, h, 0); stage_piece(kt, h, 1); };
 #ifndef PH_GLDS_IN_C
@@ -1065,13 +1090,26 @@ static int launch_hnt(int amode, const bf16_t* A, int64_t lda, const bf16_t* B, 
         const unsigned ntn = (unsigned)cdiv(N, 256);
         const int64_t nblocks = cdiv64(M, 256) * ntn;
         TSII_REQUIRE(nblocks < (1ll << 31), "bf16 gemm_nt: grid too large");
-        hipLaunchKernelGGL((hgemm_nt_ph_kernel<false>), dim3((unsigned)nblocks), dim3(512), 0, st, A, lda, B, C, ldc, M, N, K, ep, ntn);
+        hipLaunchKernelGGL((hgemm_nt_ph_kernel<0, false>), dim3((unsigned)nblocks), dim3(512), 0, st, A, lda, B, C, ldc, M, N, K, ep, ntn, cg);
         return check_launch("bf16 gemm_nt (256-row tiles)");
+    }
+#ifndef HNT_PH_CONV
+#define HNT_PH_CONV 1    // 0: the gathered operands of the dense convolutions stay on the 128 x 256 register-staged tiles (A/B)
+#endif
+    // forward taps only: 3x3 512 -> 256 at 128^2 361-429 us against 402-476 on the 128 x 256 tiles; the dX taps measured 6-10 % SLOWER
+    // here (535-581 vs 505-527 us, profiles/r05ag_ph_conv.log) and stay there (HNT_PH_CONV=2 sends them here too)
+    if (HNT_DL && HNT_PH_CONV && (amode == 1 || (amode == 2 && HNT_PH_CONV == 2)) && !fused && N % 256 == 0 && M >= 256 && cg.c % 64 == 0 &&
+        cg.rh < 32768 && cg.rw < 65536) {
+        const unsigned ntn = (unsigned)cdiv(N, 256);
+        const dim3 grid((unsigned)(cdiv64(M, 256) * ntn));
+        if (amode == 1) hipLaunchKernelGGL((hgemm_nt_ph_kernel<1, false>), grid, dim3(512), 0, st, A, lda, B, C, ldc, M, N, K, ep, ntn, cg);
+        else hipLaunchKernelGGL((hgemm_nt_ph_kernel<2, false>), grid, dim3(512), 0, st, A, lda, B, C, ldc, M, N, K, ep, ntn, cg);
+        return check_launch("bf16 gemm_nt (256-row tiles, gathered)");
     }
 #ifdef HNT_PH_BNB         // A/B: the K6c epilogue behind the quadrant-phase kernel instead of the 128 x 256 register-staged one
     if (amode == 0 && ep.bn_y != nullptr && ib.sc == nullptr && N >= 256 && M >= 256 && K >= 256) {
         const unsigned ntn = (unsigned)cdiv(N, 256);
-        hipLaunchKernelGGL((hgemm_nt_ph_kernel<true>), dim3((unsigned)(cdiv64(M, 256) * ntn)), dim3(512), 0, st, A, lda, B, C, ldc, M, N, K, ep, ntn);
+        hipLaunchKernelGGL((hgemm_nt_ph_kernel<0, true>), dim3((unsigned)(cdiv64(M, 256) * ntn)), dim3(512), 0, st, A, lda, B, C, ldc, M, N, K, ep, ntn, cg);
         return check_launch("bf16 gemm_nt (256-row tiles, K6c)");
     }
 #endif
