@@ -1072,9 +1072,10 @@ static int launch_hnt(int amode, const bf16_t* A, int64_t lda, const bf16_t* B, 
     TSII_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C), "bf16 gemm_nt: operands must be 16-byte aligned");
     TSII_REQUIRE(!(ep.bn_y != nullptr && (ib.sc != nullptr || amode != 0 || ldc != N)), "bf16 gemm_nt: the BatchNorm-backward epilogue is a plain-operand form");
     // Which kernel (measured on MI355X, tools/bf16_bench.py, profiles/r05n_nt_forms.log, r05q_nt_ph.log):
-    //   plain operands, N and K >= 256: the 256 x 256 direct-to-LDS kernel (1.1 .. 1.2 PF/s on 65536 x 4096 x 4096 against 0.68 for
-    //       the 128-row kernel; 131072 x 512 x 512: 88 vs 97 .. 106 us);
-    //   the fused forms (BatchNorm-on-load, K6c epilogue) and the gathered operands of the dense convolutions, N % 256 == 0: the
+    //   plain operands, N and K >= 256, and the forward taps of the dense convolutions with cout % 256 == 0, cin % 64 == 0: the
+    //       256 x 256 direct-to-LDS kernel (1.1 .. 1.2 PF/s on 65536 x 4096 x 4096 against 0.68 for the 128-row kernel;
+    //       131072 x 512 x 512: 88 vs 97 .. 106 us);
+    //   the fused forms (BatchNorm-on-load, K6c epilogue) and the other gathered operands of the dense convolutions, N % 256 == 0: the
     //       register-staged kernel with 128 x 256 tiles (wave tile 64 x 128: 0.75 KB of fragment reads per MFMA instead of 1), two
     //       blocks per CU -- 512 -> 256 3x3 forward 465 -> 383 us, K6c dX 131072 x 512 x 512 186 -> 158 us; the fragment-time
     //       BatchNorm of the direct-to-LDS kernels is VALU-bound (218 us) and not instantiated;
