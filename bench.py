@@ -31,13 +31,17 @@ ALG_GB_PER_IMG = 3 * 2.934
 PMC_SUMMARY = "r05f_pmc_hbm_traffic_bs32.json"   # tools/collect_profiles.sh -> tools/pmc_summary.py
 
 
-def csrc_sha():
-    """Fingerprint of the kernel sources of the profiled configuration (ImageFill, fp32 storage: every file but the bf16-storage
-    kernels, which that configuration never launches); the committed PMC summary carries the one it was measured at."""
+PMC_SUMMARY_CFG5 = "r05h_pmc_hbm_traffic_cfg5_bf16storage.json"   # the same two passes around the cfg 5 line in bf16 storage
+
+
+def csrc_sha(all_files=False):
+    """Fingerprint of the kernel sources of a profiled configuration; the committed PMC summary carries the one it was measured at.
+    ImageFill in fp32 storage (the headline): every file but the bf16-storage kernels, which it never launches; all_files: everything
+    (cfg 5 in bf16 storage launches kernels of both families)."""
     d = os.path.join(ROOT, "text_segmentation_image_inpainting_amd", "csrc")
     h = hashlib.sha256()
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")) and not f.startswith("bf16_"):
+        if f.endswith((".hip", ".h")) and (all_files or not f.startswith("bf16_")):
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -166,18 +170,19 @@ def class_table(timed, steps, products):
     return out
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of a kernel from the committed PMC summary (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    passes, x2 read correction).  Returned only while the kernel sources are the ones it was measured at."""
-    path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
+def pmc_traffic(kernel_prefix, summary=None, all_files=False):
+    """HBM bytes per launch of the kernels whose names start with (one of) kernel_prefix, from the committed PMC summary -- or
+    (None, why) when there is none for the sources as they are now."""
+    summary = summary or PMC_SUMMARY
+    path = os.path.join(ROOT, "profiles", summary)
     try:
         js = json.load(open(path))
-        if js.get("csrc_sha") != csrc_sha():
-            return None, f"profiles/{PMC_SUMMARY} was measured at csrc {js.get('csrc_sha')}, sources are now {csrc_sha()}: stale, not reported"
+        if js.get("csrc_sha") != csrc_sha(all_files):
+            return None, f"profiles/{summary} was measured at csrc {js.get('csrc_sha')}, sources are now {csrc_sha(all_files)}: stale, not reported"
         prefixes = (kernel_prefix,) if isinstance(kernel_prefix, str) else tuple(kernel_prefix)
         recs = [r for k, r in js["kernels"].items() if k.startswith(prefixes)]
         launches = sum(r["launches"] for r in recs)
-        return sum(r["bytes_per_launch"] * r["launches"] for r in recs) / launches, f"profiles/{PMC_SUMMARY} (csrc {js['csrc_sha']})"
+        return sum(r["bytes_per_launch"] * r["launches"] for r in recs) / launches, f"profiles/{summary} (csrc {js['csrc_sha']})"
     except Exception as exc:  # noqa: BLE001 - no summary committed for this kernel/config
         return None, f"no PMC summary ({type(exc).__name__})"
 
@@ -464,7 +469,14 @@ def main(argv=None):
             t_hbm = d["alg_gb_per_step"] / (PEAK_HBM_TBS * 1e3)            # seconds per step at the HBM peak
             t_mfma = d["ms_per_step"] * 1e-3 * d.get("mfma_frac", 0.0)      # seconds per step at the MFMA peak of the mode
             hbm_bound = t_hbm >= t_mfma
-            traffic, traffic_src = pmc_traffic(kern) if (args.batch == 32 and args.size == 512 and args.model == "ImageFill") else (None, "not the profiled configuration")
+            if args.batch == 32 and args.size == 512 and args.model == "ImageFill":
+                traffic, traffic_src = pmc_traffic(kern)
+            elif bf16_storage and args.model == "XceptionTextSegment" and args.size == 1024 and args.batch == 8 and k == "gemm_nt":
+                # the 1x1 products only: AMODE (5th / 1st template argument) 0 -- the gathered forms of the same kernels are class dense_conv
+                traffic, traffic_src = pmc_traffic(("tsii::hgemm_nt_kernel<2, 2, 2, 4, 0,", "tsii::hgemm_nt_kernel<2, 2, 2, 2, 0,", "tsii::hgemm_nt_kernel<2, 2, 2, 1, 0,",
+                                                    "tsii::hgemm_nt_kernel<4, 1, 1, 1, 0,", "tsii::hgemm_nt_ph_kernel<0,"), PMC_SUMMARY_CFG5, all_files=True)
+            else:
+                traffic, traffic_src = None, "not a profiled configuration"
             roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": kname + " (class " + k + (": 1x1-conv forward + dX GEMMs)" if k == "gemm_nt" else ")"),
                         "achieved": d["tb_per_s"] * 1e3 if hbm_bound else d["fp32_equiv_tflops"],
                         "peak": PEAK_HBM_TBS * 1e3 if hbm_bound else d["mfma_peak_fp32_equiv"],

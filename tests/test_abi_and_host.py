@@ -141,10 +141,10 @@ def test_bench_class_table_and_traffic_gate(tmp_path, monkeypatch):
     os.makedirs(tmp_path / "profiles")
     js = {"csrc_sha": "0" * 12, "kernels": {"tsii::gemm_nt_split_kernel<2, 2, 2, 2, 6>": {"launches": 2, "bytes_per_launch": 1e9}}}
     json.dump(js, open(tmp_path / "profiles" / bench.PMC_SUMMARY, "w"))
-    monkeypatch.setattr(bench, "csrc_sha", lambda: "1" * 12)
+    monkeypatch.setattr(bench, "csrc_sha", lambda *a: "1" * 12)
     val, why = bench.pmc_traffic("tsii::gemm_nt_split_kernel<2, 2, 2, 2")
     assert val is None and "stale" in why
-    monkeypatch.setattr(bench, "csrc_sha", lambda: "0" * 12)
+    monkeypatch.setattr(bench, "csrc_sha", lambda *a: "0" * 12)
     val, why = bench.pmc_traffic("tsii::gemm_nt_split_kernel<2, 2, 2, 2")
     assert val == 1e9
     js["kernels"]["tsii::gemm_nt_pc_kernel<1, 8, 6, false, 0, 0>"] = {"launches": 6, "bytes_per_launch": 2e9}

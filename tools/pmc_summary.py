@@ -14,7 +14,10 @@ SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * SQ_BUSY_CYCLES / 32 SEs).
 import collections
 import csv
 import json
+import os
 import sys
+
+ALL_FILES = os.environ.get("PMC_SUMMARY_ALL_FILES") == "1"   # fingerprint over every kernel file (a bf16-storage configuration)
 
 
 def read_counters(path):
@@ -69,7 +72,7 @@ def hbm(fetch_csv, write_csv, prefix, note):
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "text_segmentation_image_inpainting_amd", "csrc")
     h = hashlib.sha256()
     for fn in sorted(os.listdir(csrc)):
-        if fn.endswith((".hip", ".h")) and not fn.startswith("bf16_"):   # same rule as bench.csrc_sha
+        if fn.endswith((".hip", ".h")) and (ALL_FILES or not fn.startswith("bf16_")):   # same rule as bench.csrc_sha
             h.update(open(os.path.join(csrc, fn), "rb").read())
     # fingerprint of the kernel sources this was measured at: bench.py reports `roofline.traffic` only while it matches
     js = {"_how": how, "csrc_sha": h.hexdigest()[:16], "kernels": {r[0]: {"launches": r[1], "read_bytes_per_launch": r[4], "write_bytes_per_launch": r[5],
