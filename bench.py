@@ -326,7 +326,9 @@ def main(argv=None):
         # secondary workloads: logits = net(image), BinaryFocalLoss against the text mask (train.py of the reference); the
         # trainer sees the same (inputs, mask, target) step signature through a one-line adapter
         from text_segmentation_image_inpainting_amd.synthetic import make_seg_batch
-        net = getattr(T, args.model)(**({"pixel_shuffle_head": True} if (args.pixel_shuffle and args.model == "TextSegament") else {}))
+        # (the CPU test of the N > 1 path swaps in a three-layer network: TEST_RUNTIME["seg_factory"])
+        net = ((TEST_RUNTIME or {}).get("seg_factory") or
+               (lambda: getattr(T, args.model)(**({"pixel_shuffle_head": True} if (args.pixel_shuffle and args.model == "TextSegament") else {}))))()
         if args.checkpoint and hasattr(net, "checkpoint_encoder"):
             net.checkpoint_encoder = True
 

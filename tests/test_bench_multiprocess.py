@@ -88,3 +88,48 @@ def test_bench_two_ranks_many_buckets_gloo():
     hooks launch, complete and wait on many asynchronous all-reduces per step, in gradient-ready order"""
     rec = _run(2, bodies=3, bucket_mb=0.0004)
     assert rec["comm"]["buckets"] >= 9, rec["comm"]
+
+
+def _rank_seg(rank, world, port, out):
+    """the segmentation branch of bench.py (BinaryFocalLoss step) in bf16 ACTIVATION STORAGE under two gloo ranks"""
+    import contextlib
+    import io
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import bench
+    from tests.backends import emu_backend
+    from text_segmentation_image_inpainting_amd.BaseModels import Conv2d, ConvSpec, build_chain, run_chain
+
+    class TinySeg(torch.nn.Module):
+        """fp32 image -> stride-2 stem (space-to-depth entry of the bf16 path) -> 3x3 conv + BatchNorm -> 1-channel logits (fp32) -> x2"""
+
+        def __init__(self):
+            super().__init__()
+            act = torch.nn.LeakyReLU(0.3)
+            self.body = torch.nn.Sequential(*build_chain(3, (ConvSpec(32, 3, 2, 1), ConvSpec(16, 3, 1, 1)), act)[0], Conv2d(16, 1, 3, 1, 1))
+
+        def forward(self, x):
+            return torch.nn.functional.interpolate(run_chain(list(self.body), x), scale_factor=2, mode="nearest")
+    with emu_backend() as dev:
+        bench.TEST_RUNTIME = {"device": dev, "backend": "gloo", "seg_factory": TinySeg}
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            bench.main(["--gpus", str(world), "--model", "XceptionTextSegment", "--storage", "bf16", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--size", "32", "--no-cpu-baseline"])
+    open(f"{out}.{rank}", "w").write(buf.getvalue())
+
+
+def test_bench_two_ranks_gloo_bf16_storage_segmentation_step():
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "out")
+        mp.spawn(_rank_seg, args=(2, _free_port(), out), nprocs=2, join=True)
+        texts = [open(f"{out}.{r}").read() for r in range(2)]
+    lines = [ln for ln in texts[0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not any(ln.startswith("{") for ln in texts[1].splitlines())
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["activation_storage"] == "bf16" and rec["dtype"].startswith("bf16 activation")
+    assert rec["config"]["global_batch"] == 4 and rec["value"] > 0 and rec["comm"]["world"] == 2 and rec["comm"]["allreduce_ms"] > 0
+    assert rec["final_loss"] == rec["final_loss"] and rec["final_loss"] > 0          # finite
