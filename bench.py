@@ -28,6 +28,10 @@ PEAK_HBM_TBS = 8.0          # HBM3E spec
 # ImageFill 512^2 forward = 58.8 GFLOP and 2934 MB (train-mode BN) per image; fwd+bwd = 3x
 ALG_GFLOP_PER_IMG = 3 * 58.8
 ALG_GB_PER_IMG = 3 * 2.934
+# the same table for every net / size it lists: (GFLOP forward, GB forward in train mode at 4 bytes per element) per image
+WHOLE_FWD = {("ImageFill", 512): (58.8, 2.934), ("ImageFillOrigin", 512): (75.9, 0.3676), ("ImageFillOriginV2", 512): (78.8, 0.5664),
+             ("TextSegament", 256): (22.7, 0.950), ("TextSegament", 512): (90.6, 3.801), ("TextSegament", 1024): (362.5, 15.205),
+             ("XceptionTextSegment", 256): (37.2, 0.957), ("XceptionTextSegment", 512): (148.7, 3.828), ("XceptionTextSegment", 1024): (594.8, 15.314)}
 PMC_SUMMARY = "r05f_pmc_hbm_traffic_bs32.json"   # tools/collect_profiles.sh -> tools/pmc_summary.py
 
 
@@ -248,7 +252,14 @@ def cpu_baseline(size: int, threads: int):
 TEST_RUNTIME = None
 
 
-def main(argv=None):
+# the secondary BASELINE configs the default line also times (short legs, rank 0, N = 1): name -> argv
+SECONDARY_LEGS = {
+    "cfg5_xceptiontextsegment_1024_bs8_bf16_storage": ["--model", "XceptionTextSegment", "--size", "1024", "--batch", "8", "--storage", "bf16"],
+    "cfg3_textsegament_512_bs64_pixel_shuffle": ["--model", "TextSegament", "--size", "512", "--batch", "64", "--pixel-shuffle"],
+}
+
+
+def main(argv=None, return_line=False):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -270,6 +281,7 @@ def main(argv=None):
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the short run in the bit-exact f32-MFMA arithmetic mode")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU-baseline leg (default: both min(physical cores, 32) and all physical cores, the better one reported)")
     ap.add_argument("--bernoulli-masks", action="store_true", help="stress variant: i.i.d. per-channel masks")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short cfg 5 / cfg 3 legs the default headline run appends (secondary_configs)")
     ap.add_argument("--graph", action="store_true", help="also replay the step from a HIP graph (measured: no gain; off by default)")
     args = ap.parse_args(argv)
 
@@ -315,9 +327,10 @@ def main(argv=None):
     products = _lib.get_gemm_products()
     bf16_storage = args.storage == "bf16"
     if bf16_storage:
-        if args.model not in ("TextSegament", "XceptionTextSegment"):
-            raise SystemExit("--storage bf16 exists for the segmentation nets (the partial-convolution family keeps fp32 storage)")
-        T.set_activation_storage(torch.bfloat16)
+        if args.model != "XceptionTextSegment":
+            raise SystemExit("--storage bf16 exists for XceptionTextSegment (BASELINE config 5): the partial-convolution family keeps fp32 storage, and "
+                             "TextSegament's scSE / global-average-pool / pixel-shuffle layers have no bf16 kernels")
+        T.set_activation_storage("bf16")
         products = 1          # accounting only: the tsii_bf16_* matrix products are one bf16 MFMA product per multiply-add
         args.no_f32_leg = True
     torch.manual_seed(0)  # identical random-init weights on every rank
@@ -326,8 +339,8 @@ def main(argv=None):
         # secondary workloads: logits = net(image), BinaryFocalLoss against the text mask (train.py of the reference); the
         # trainer sees the same (inputs, mask, target) step signature through a one-line adapter
         from text_segmentation_image_inpainting_amd.synthetic import make_seg_batch
-        # (the CPU test of the N > 1 path swaps in a three-layer network: TEST_RUNTIME["seg_factory"])
-        net = ((TEST_RUNTIME or {}).get("seg_factory") or
+        # (the CPU test of the N > 1 path swaps in a three-layer network through the same TEST_RUNTIME["model_factory"] as below)
+        net = ((TEST_RUNTIME or {}).get("model_factory") or
                (lambda: getattr(T, args.model)(**({"pixel_shuffle_head": True} if (args.pixel_shuffle and args.model == "TextSegament") else {}))))()
         if args.checkpoint and hasattr(net, "checkpoint_encoder"):
             net.checkpoint_encoder = True
@@ -367,7 +380,16 @@ def main(argv=None):
     stop_timing = _lib.stop_timing if on_gpu else (lambda: {})
 
     gemm_calls = [n for n, (c, _) in CALLS.items() if c.startswith("gemm")]
-    for _ in range(args.warmup):
+    # the storage type the network ACTUALLY runs in: which family of entry points its first step calls (what the line reports)
+    _lib.count_calls(True)
+    loss = trainer.step(corrupted, mask, clean_nhwc)
+    called = _lib.count_calls(False)
+    seen_dtypes = {"bf16" if n.startswith("tsii_bf16_") else "f32" for n in called if n.startswith(("tsii_bf16_pw", "tsii_bf16_dw", "tsii_bf16_dense", "tsii_pw", "tsii_dw", "tsii_dense"))}
+    storage_seen = "bf16" if "bf16" in seen_dtypes else "f32"
+    if storage_seen != args.storage:
+        raise SystemExit(f"--storage {args.storage} was requested but the network's layers ran the {sorted(seen_dtypes)} convolution kernels: not reporting a line "
+                         "whose dtype the run did not have")
+    for _ in range(args.warmup - 1):
         loss = trainer.step(corrupted, mask, clean_nhwc)
     sync()
     start_timing(gemm_calls)      # HIP events (launch stream) around the GEMM entry points inside the timed region
@@ -497,12 +519,16 @@ def main(argv=None):
                                        else "v_mfma_f32_32x32x2_f32")}
         ms_per_img = elapsed / imgs * world * 1e3  # per-GPU ms per image
         whole = None
-        if args.model == "ImageFill" and args.size == 512:
-            t_hbm = ALG_GB_PER_IMG / (PEAK_HBM_TBS * 1e3) * 1e3
-            t_flop = ALG_GFLOP_PER_IMG / (PEAK_FP32_TFLOPS * 1e3) * 1e3
+        if (args.model, args.size) in WHOLE_FWD:
+            gf, gb = WHOLE_FWD[(args.model, args.size)]
+            gb = gb / 2 if bf16_storage else gb           # bf16 activation storage: the same tensors at 2 bytes per element
+            flop_peak = PEAK_BF16_TFLOPS if (bf16_storage or products == 1) else PEAK_FP32_TFLOPS     # the arithmetic the mode asks for
+            t_hbm = 3 * gb / (PEAK_HBM_TBS * 1e3) * 1e3
+            t_flop = 3 * gf / (flop_peak * 1e3) * 1e3
             fwd_ms_per_img = fwd_elapsed / fwd_steps / args.batch * 1e3
-            whole = {"alg_gflop_per_img": ALG_GFLOP_PER_IMG, "alg_gb_per_img": round(ALG_GB_PER_IMG, 3),
-                     "t_min_ms_per_img_hbm": round(t_hbm, 3), "t_min_ms_per_img_fp32_flop": round(t_flop, 3),
+            whole = {"alg_gflop_per_img": round(3 * gf, 1), "alg_gb_per_img": round(3 * gb, 3),
+                     "t_min_ms_per_img_hbm": round(t_hbm, 3),
+                     ("t_min_ms_per_img_bf16_flop" if flop_peak == PEAK_BF16_TFLOPS else "t_min_ms_per_img_fp32_flop"): round(t_flop, 3),
                      "frac_of_roofline": round(max(t_hbm, t_flop) / ms_per_img, 4),
                      "frac_of_hbm_roofline": round(t_hbm / ms_per_img, 4),
                      "forward_frac_of_roofline": round(max(t_hbm, t_flop) / 3 / fwd_ms_per_img, 4),
@@ -526,7 +552,7 @@ def main(argv=None):
             "dtype": dtype,
             "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * args.batch, "parallelism": f"dp{world}", "gemm_products": products,
-                       "activation_storage": args.storage},
+                       "activation_storage": storage_seen},
             "roofline": roofline, "kernel_classes": classes, "whole_step_roofline": whole, "final_loss": final_loss,
             "launch": "hip_graph_replay" if graphed else "eager", "eager_ms_per_step": round(eager_ms, 3),
             "forward_only": {"value": round(world * args.batch * fwd_steps / fwd_elapsed, 2), "unit": "imgs/s (rank 0 clock)",
@@ -546,10 +572,45 @@ def main(argv=None):
                 line["cpu_baseline"] = best
         elif world == 1:
             line["cpu_baseline"] = None
+        if return_line:
+            return line
+        headline = (args.model == "ImageFill" and args.size == 512 and args.batch == 32 and args.products < 0 and not bf16_storage
+                    and not args.knob and not args.bernoulli_masks)
+        if headline and world == 1 and on_gpu and not args.no_secondary:
+            # BASELINE configs 5 and 3 through the same code path, short legs (like f32_mfma_mode) so that every default run -- the
+            # driver's included -- times them; the headline's tensors are released first
+            import gc
+            del model, trainer, corrupted, mask, clean_nhwc, loss
+            gc.collect()
+            torch.cuda.empty_cache()
+            line["secondary_configs"] = {name: secondary_leg(argv2) for name, argv2 in SECONDARY_LEGS.items()}
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def secondary_leg(argv2, steps=6, warmup=3):
+    """One secondary config as a short run of main() in this process: the fields of its line that say how fast and against which bound."""
+    import gc
+    from text_segmentation_image_inpainting_amd import _lib
+    import text_segmentation_image_inpainting_amd as T
+    torch.cuda.reset_peak_memory_stats()
+    try:
+        rec = main(list(argv2) + ["--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-f32-leg", "--no-secondary"], return_line=True)
+        out = {"argv": " ".join(argv2), "value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"], "steps": steps, "warmup": warmup,
+               "forward_ms_per_step": rec["forward_only"]["ms_per_step"], "dtype": rec["dtype"], "workload": rec["config"]["workload"],
+               "whole_step_roofline": rec["whole_step_roofline"], "roofline": rec["roofline"], "peak_mem_gib": rec["peak_mem_gib"],
+               "kernel_classes": {k: {f: v[f] for f in ("ms_per_step", "hbm_frac", "mfma_frac", "per_launch_roofline_frac") if f in v}
+                                  for k, v in (rec["kernel_classes"] or {}).items()}}
+    except Exception as exc:  # noqa: BLE001 - a secondary leg must never take the headline line down with it
+        out = {"argv": " ".join(argv2), "error": f"{type(exc).__name__}: {exc}"}
+    finally:
+        T.set_activation_storage("f32")
+        _lib.set_gemm_products(None)
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TSII_ABI_VERSION 3
+#define TSII_ABI_VERSION 4
 
 /* activation kinds for the BN/activation kernels */
 #define TSII_ACT_NONE 0

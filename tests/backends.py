@@ -33,7 +33,8 @@ def emu_backend():
         buf[n:] = canary
         guarded.append((buf, n))
         return buf[:n]
-    _lib._LIB, _lib.stream, _lib.check_device, ops._ws = cdll, (lambda: None), (lambda t: None), guarded_ws
+    # host tensors stand in for device tensors; the dtype rule of check_device stays in force
+    _lib._LIB, _lib.stream, _lib.check_device, ops._ws = cdll, (lambda: None), _lib.check_dtype, guarded_ws
     try:
         yield torch.device("cpu")
         for buf, n in guarded:

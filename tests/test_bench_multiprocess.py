@@ -114,7 +114,7 @@ def _rank_seg(rank, world, port, out):
         def forward(self, x):
             return torch.nn.functional.interpolate(run_chain(list(self.body), x), scale_factor=2, mode="nearest")
     with emu_backend() as dev:
-        bench.TEST_RUNTIME = {"device": dev, "backend": "gloo", "seg_factory": TinySeg}
+        bench.TEST_RUNTIME = {"device": dev, "backend": "gloo", "model_factory": TinySeg}
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):
             bench.main(["--gpus", str(world), "--model", "XceptionTextSegment", "--storage", "bf16", "--steps", "2", "--warmup", "1", "--batch", "2",

@@ -187,6 +187,10 @@ def _net_run(m, x, t, storage, products=None, training=True):
             _lib.set_gemm_products(None)
 
 
+COS_AB_RATIO = 1.5      # bf16-storage gradient error <= 1.5x the bf16-operand (fp32 storage) error of the same tensor ...
+COS_MIN = 0.8           # ... and cosine >= 0.8 with the reference's fp64 gradient
+
+
 def _grad_errors(g16, g32):
     gmax = max(float(v.abs().max()) for v in g32.values())
     out = []
@@ -274,16 +278,20 @@ def test_xception_net_bf16_storage_vs_reference_fixture_256_gpu():
                 continue
             kk = k[7:]
             r64 = torch.from_numpy(G[k])
-            rows.append((rel(g16[kk], r64), rel(gp1[kk], r64), kk))
+            cos = float(torch.nn.functional.cosine_similarity(g16[kk].double().flatten().cpu(), r64.double().flatten(), dim=0))
+            rows.append((rel(g16[kk], r64), rel(gp1[kk], r64), kk, cos))
         assert len(rows) >= 20
         rows.sort(reverse=True)
-        print("[bf16 storage] train-mode gradients vs fp64 (bf16 storage | bf16 operands, fp32 storage):")
-        for a_, b_, kk in rows[:6]:
-            print(f"    {kk}: {a_:.3f} | {b_:.3f}")
+        print("[bf16 storage] train-mode gradients vs fp64 (bf16 storage | bf16 operands, fp32 storage | cosine with fp64):")
+        for a_, b_, kk, c_ in rows[:6]:
+            print(f"    {kk}: {a_:.3f} | {b_:.3f} | {c_:.3f}")
         med16, medp1 = rows[len(rows) // 2][0], sorted(r[1] for r in rows)[len(rows) // 2]
-        print(f"    median {med16:.3f} | {medp1:.3f}")
-        for a_, b_, kk in rows:
-            assert a_ <= max(0.15, 3.0 * b_) and a_ <= 1.5, (kk, a_, b_)      # every tensor: bounded, and no worse than 3x the operand-rounding error
+        print(f"    median {med16:.3f} | {medp1:.3f}; worst ratio a/b {max(r[0] / max(r[1], 1e-9) for r in rows):.2f}, lowest cosine {min(r[3] for r in rows):.3f}")
+        for a_, b_, kk, c_ in rows:
+            # every tensor: bounded by what operand rounding alone does to it in the same test (1.5x; round 5 allowed 3x and an absolute
+            # 1.5), and pointing the same way as the fp64 gradient
+            assert a_ <= max(0.15, COS_AB_RATIO * b_), (kk, a_, b_)
+            assert c_ >= COS_MIN, (kk, c_)
         assert med16 <= max(0.1, 2.5 * medp1)
 
 

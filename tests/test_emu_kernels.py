@@ -900,3 +900,76 @@ def test_pointwise_row_scale_split_inside_a_chunk(emu, split, has_r1):
         xs[:, split:] *= r1[:, None]
     ref = xs @ w.astype(np.float64).T
     assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def _act_np(z, act, slope):
+    """(a, da/dz) of the library's activation codes: 0 none, 1 ReLU, 2 LeakyReLU(slope), 3 ReLU6"""
+    if act == 0:
+        return z, np.ones_like(z)
+    if act == 1:
+        return np.maximum(z, 0), (z > 0).astype(z.dtype)
+    if act == 2:
+        return np.where(z > 0, z, slope * z), np.where(z > 0, 1.0, slope)
+    return np.clip(z, 0, 6), ((z > 0) & (z < 6)).astype(z.dtype)
+
+
+@pytest.mark.parametrize("m,c", [(1, 4), (3, 8), (5, 36), (127, 4), (130, 64), (1025, 12), (4099, 32), (257, 5)])
+@pytest.mark.parametrize("act,slope", [(0, 0.0), (2, 0.3), (3, 0.0)])
+def test_batchnorm_apply_and_backward_kernels_row_tails(emu, m, c, act, slope):
+    """tsii_bn_act_fwd / tsii_bn_act_bwd (training and eval) / tsii_bn_act_bwd_pre straight through the C ABI against float64 numpy,
+    at row counts around the apply kernels' rows-per-thread blocking (round 5: a thread owns one channel vector and 4 rows; m % 4 in
+    {1, 2, 3}, fewer rows than one thread's share, channel counts with and without the 16-byte vector path) -- a dense error in these
+    passes would otherwise only show up as 'noise' in whole-network gradient tests."""
+    L = emu
+    rng = np.random.default_rng(m * 131 + c * 7 + act)
+    y = (rng.standard_normal((m, c)) * 1.5 + 0.3).astype(np.float32)
+    res = rng.standard_normal((m, c)).astype(np.float32)
+    dout = rng.standard_normal((m, c)).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, size=c).astype(np.float32)
+    beta = (rng.standard_normal(c) * 0.3).astype(np.float32)
+    eps = 1e-5
+    y64 = y.astype(np.float64)
+    mean = y64.mean(0).astype(np.float32) if m > 1 else y64[0].astype(np.float32)
+    var = (y64.var(0) if m > 1 else np.ones(c)).astype(np.float32)
+    rstd = 1.0 / np.sqrt(var.astype(np.float64) + eps)
+    xhat = (y64 - mean.astype(np.float64)) * rstd
+    z = xhat * gamma + beta
+    # ---- forward apply, with and without the residual
+    for with_res in (False, True):
+        out = np.full((m, c), np.nan, np.float32)
+        assert L.tsii_bn_act_fwd(P(y), m, c, P(mean), P(var), P(gamma), P(beta), eps, act, slope, P(res) if with_res else None, P(out), None) == 0, L.tsii_last_error()
+        # (the residual is added AFTER the activation: out = act(bn(y)) + residual, models/MobileNetV2.py:49 pattern)
+        ref = _act_np(z, act, slope)[0] + (res.astype(np.float64) if with_res else 0.0)
+        assert np.isfinite(out).all() and np.abs(out - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (with_res, np.abs(out - ref).max())
+    # ---- backward: training (batch statistics) and eval
+    a, dadz = _act_np(z, act, slope)
+    # keep the comparison away from the activation kinks: an fp32 z within rounding of a kink legitimately takes either derivative
+    safe = np.ones_like(z, bool) if act == 0 else (np.abs(z) > 1e-4) & ((np.abs(z - 6) > 1e-4) if act == 3 else True)
+    dz = dout.astype(np.float64) * dadz
+    dbeta_r, dgamma_r = dz.sum(0), (dz * xhat).sum(0)
+    dy_train = (dz - dbeta_r / m - xhat * dgamma_r / m) * gamma * rstd
+    dy_eval = dz * gamma * rstd
+    nb = L.tsii_bn_ws_bytes(m, c)
+    for training, dy_r in ((1, dy_train), (0, dy_eval)):
+        dy = np.full((m, c), np.nan, np.float32); dg = np.full(c, np.nan, np.float32); db = np.full(c, np.nan, np.float32)
+        ws = WS(nb)
+        assert L.tsii_bn_act_bwd(P(dout), P(y), m, c, P(mean), P(var), P(gamma), P(beta), eps, act, slope, training, P(dy), P(dg), P(db), P(ws), nb, None) == 0, L.tsii_last_error()
+        if safe.all():
+            scale = max(1.0, np.abs(dy_r).max())
+            assert np.abs(dy - dy_r).max() <= 2e-5 * scale, (training, np.abs(dy - dy_r).max())
+            assert np.abs(dg - dgamma_r).max() <= 2e-5 * max(1.0, np.abs(dgamma_r).max()) and np.abs(db - dbeta_r).max() <= 2e-5 * max(1.0, np.abs(dbeta_r).max())
+        else:
+            assert np.isfinite(dy).all()
+    # ---- the 3-pass form fed with reductions somebody else took (K6c): partial rows that sum to the exact totals
+    rows = 3
+    part = np.zeros((rows, 2, c), np.float32)
+    split = rng.dirichlet(np.ones(rows), size=c).T          # [rows, c] weights summing to 1 per channel
+    part[:, 0, :] = (split * dbeta_r).astype(np.float32)
+    part[:, 1, :] = (split * dgamma_r).astype(np.float32)
+    dy = np.full((m, c), np.nan, np.float32); dg = np.full(c, np.nan, np.float32); db = np.full(c, np.nan, np.float32)
+    ws = WS(nb)
+    assert L.tsii_bn_act_bwd_pre(P(dout), P(y), m, c, P(mean), P(var), P(gamma), P(beta), eps, act, slope, 1, P(part), rows,
+                                 P(dy), P(dg), P(db), P(ws), nb, None) == 0, L.tsii_last_error()
+    if safe.all():
+        assert np.abs(dy - dy_train).max() <= 5e-5 * max(1.0, np.abs(dy_train).max())
+        assert np.abs(dg - dgamma_r).max() <= 5e-5 * max(1.0, np.abs(dgamma_r).max()) and np.abs(db - dbeta_r).max() <= 5e-5 * max(1.0, np.abs(dbeta_r).max())

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TSII_LIBRARY") or os.path.join(_HERE, "libtsii_hip.so")   # TSII_LIBRARY: another BUILD of csrc/ (A/B measurements)
-ABI_VERSION = 3           # TSII_ABI_VERSION of include/tsii_hip.h this binding was written against
+ABI_VERSION = 4           # TSII_ABI_VERSION of include/tsii_hip.h this binding was written against
 
 _p, _i, _l, _f, _z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 _GEOM = [_i] * 8  # kh kw sh sw ph pw dh dw
@@ -155,10 +155,17 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} not found: the MI355X HIP library has not been built "
                 "(python -m text_segmentation_image_inpainting_amd.build_ext). There is no CPU fallback.")
-        _LIB = bind(ctypes.CDLL(LIB_PATH))
-        if _LIB.tsii_version() != ABI_VERSION:
+        cdll = ctypes.CDLL(LIB_PATH)
+        # version first: a stale build lacks the newer symbols, and "rebuild" is a better message than a missing-symbol error
+        try:
+            cdll.tsii_version.restype = ctypes.c_int
+            have = int(cdll.tsii_version())
+        except AttributeError:
+            have = -1
+        if have != ABI_VERSION:
             raise RuntimeError("libtsii_hip.so ABI version mismatch: library %d, binding %d -- rebuild with "
-                               "python -m text_segmentation_image_inpainting_amd.build_ext" % (_LIB.tsii_version(), ABI_VERSION))
+                               "python -m text_segmentation_image_inpainting_amd.build_ext" % (have, ABI_VERSION))
+        _LIB = bind(cdll)
     return _LIB
 
 
@@ -167,12 +174,26 @@ def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def check_device(t: torch.Tensor):
-    if not t.is_cuda:
-        raise RuntimeError("text_segmentation_image_inpainting_amd: tensors must live on a ROCm GPU "
-                           "(MI355X); this implementation has no CPU path")
-    if t.dtype not in (torch.float32, torch.bfloat16):
+def check_dtype(*tensors, bf16_ok=False):
+    """fp32 -- or bf16 for the callers that dispatch to a ``tsii_bf16_*`` kernel themselves (``bf16_ok=True``).  Everything else
+    raises: an fp32 kernel handed a bf16 buffer would read / write twice the bytes the buffer holds."""
+    for t in tensors:
+        if t is None or t.dtype == torch.float32 or (bf16_ok and t.dtype == torch.bfloat16):
+            continue
+        if t.dtype == torch.bfloat16:
+            raise NotImplementedError("text_segmentation_image_inpainting_amd: this op has no bf16 kernel (bf16 activation storage covers the "
+                                      "mask-free convolution / BatchNorm / element-wise layers of the Xception segmentation net only); "
+                                      "got a bf16 tensor of shape %s" % (tuple(t.shape),))
         raise RuntimeError(f"text_segmentation_image_inpainting_amd: fp32 tensors (or bf16 activation storage, ops.set_activation_storage), got {t.dtype}")
+
+
+def check_device(*tensors, bf16_ok=False):
+    """Every given tensor (None entries are skipped) lives on a ROCm GPU and has a type the calling op has a kernel for."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("text_segmentation_image_inpainting_amd: tensors must live on a ROCm GPU "
+                               "(MI355X); this implementation has no CPU path")
+    check_dtype(*tensors, bf16_ok=bf16_ok)
 
 
 def ptr(t):
@@ -197,6 +218,17 @@ def stop_timing():
     rec, _TIMED = _TIMED, None
     torch.cuda.synchronize()
     return {n: [(a.elapsed_time(b), args) for a, b, args in lst] for n, lst in (rec or {}).items()}
+
+
+# Optional census of the entry points called (bench.py: which kernel family -- fp32 or tsii_bf16_* -- a network's step really runs)
+_COUNTS = None
+
+
+def count_calls(on):
+    """count_calls(True) starts counting calls per entry point; count_calls(False) stops and returns {name: calls}."""
+    global _COUNTS
+    rec, _COUNTS = _COUNTS, ({} if on else None)
+    return rec or {}
 
 
 # Arithmetic mode of the matrix products (include/tsii_hip.h: tsii_set_gemm_products).  The library's switch is
@@ -232,6 +264,8 @@ def call(name, *args):
     L = lib()
     if _GEMM_TOUCHED:       # the library's switch is per thread: bring the calling thread (autograd's workers too) in line
         L.tsii_set_gemm_products(-1 if _GEMM_PRODUCTS is None else _GEMM_PRODUCTS)
+    if _COUNTS is not None:
+        _COUNTS[name] = _COUNTS.get(name, 0) + 1
     timed = _TIMED is not None and name in _TIMED
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -74,17 +74,44 @@ BF16 = torch.bfloat16
 _ACT_STORAGE = torch.float32
 
 
+_STORAGE_NAMES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32, "fp32": torch.float32, "float32": torch.float32}
+
+
+def _storage_dtype(dtype):
+    d = _STORAGE_NAMES.get(dtype.lower()) if isinstance(dtype, str) else dtype
+    if d not in (torch.float32, torch.bfloat16):
+        raise ValueError(f"activation storage: torch.float32 / 'f32' or torch.bfloat16 / 'bf16', got {dtype!r}")
+    return d
+
+
 def set_activation_storage(dtype):
-    """torch.float32 (default) or torch.bfloat16: the storage type of activations / activation gradients of the
-    segmentation nets built from now on ... applied by their stems from the next forward pass on."""
+    """torch.float32 / "f32" (default) or torch.bfloat16 / "bf16": the storage type of activations / activation gradients of
+    the mask-free segmentation layers, applied by the network's stem from the next forward pass on."""
     global _ACT_STORAGE
-    if dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError("activation storage: torch.float32 or torch.bfloat16")
-    _ACT_STORAGE = dtype
+    _ACT_STORAGE = _storage_dtype(dtype)
 
 
-def activation_storage():
-    return _ACT_STORAGE
+class _StorageScope:
+    """``with activation_storage("bf16"): ...`` -- sets the storage type and restores the previous one on exit."""
+
+    def __init__(self, dtype):
+        self.dtype, self.prev = _storage_dtype(dtype), None
+
+    def __enter__(self):
+        self.prev = _ACT_STORAGE
+        set_activation_storage(self.dtype)
+        return self.dtype
+
+    def __exit__(self, *exc):
+        set_activation_storage(self.prev)
+        return False
+
+
+def activation_storage(dtype=None):
+    """Without an argument: the current storage type.  With one: a context manager that selects it for the block."""
+    if dtype is None:
+        return _ACT_STORAGE
+    return _StorageScope(dtype)
 
 
 def _h(t) -> bool:
@@ -174,7 +201,7 @@ class _Pointwise(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, r0, r1, denom, keep, inv, split, in_scale, in_shift, in_act, in_slope, want_stats, bn=None, up_add=None):
-        _lib.check_device(x)
+        _lib.check_device(x, bf16_ok=True)
         ctx.bn = bn     # (mean, var, gamma, beta, eps, slot) of the lazily applied producer BatchNorm (K6c) or None
         ctx.pool = None
         ctx.has_up = up_add is not None   # K7b: [n, h/2, w/2, cout] addend, up-sampled x2 onto the accumulator (differentiable)
@@ -345,7 +372,7 @@ class _Depthwise(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, rmask, denom, keep, inv, g, in_scale, in_shift, in_act, in_slope, want_stats, bn=None):
-        _lib.check_device(x)
+        _lib.check_device(x, bf16_ok=True)
         ctx.bn = bn     # (mean, var, gamma, beta, eps, slot) of the lazily applied producer BatchNorm (K6c) or None
         x, w = x.contiguous(), w.contiguous()
         n, h, wd, c = x.shape
@@ -604,7 +631,7 @@ class _DenseH(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, g, want_stats):
-        _lib.check_device(x)
+        _lib.check_device(x, bf16_ok=True)
         x, w = x.contiguous(), w.contiguous()
         n, h, wd, cin = x.shape
         cout = w.shape[0]
@@ -656,7 +683,7 @@ class _StemS2DH(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, g, want_stats):
-        _lib.check_device(x)
+        _lib.check_device(x, bf16_ok=True)
         x, w = x.contiguous(), w.contiguous()
         n, h, wd, cin = x.shape
         cout, k, pad = w.shape[0], g.kh, g.ph
@@ -714,7 +741,7 @@ class _ChannelToF32(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, ch):
-        _lib.check_device(y)
+        _lib.check_device(y, bf16_ok=True)
         y = y.contiguous()
         n, h, w, c = y.shape
         out = torch.empty((n, h, w, 1), dtype=torch.float32, device=y.device)
@@ -736,7 +763,7 @@ class _Cast(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, to_bf16):
-        _lib.check_device(x)
+        _lib.check_device(x, bf16_ok=True)
         x = x.contiguous()
         ctx.to_bf16 = bool(to_bf16)
         out = torch.empty(x.shape, dtype=BF16 if to_bf16 else torch.float32, device=x.device)
@@ -765,7 +792,7 @@ def _dense_bf16(x, w, bias, g: Geom, want_stats):
     to 8 (zero weights) and handed on as an fp32 tensor -- the logits stay fp32."""
     cin, cout = x.shape[-1], w.shape[0]
     if x.dtype == torch.float32:
-        if not _stem_form(x, w, g):
+        if not _bf16_stem_form(x, w, g):
             raise NotImplementedError("bf16 storage: an fp32 input can only enter through a stem (odd k, stride 2, <= 4 channels, no gradient)")
         return _StemS2DH.apply(x, w, bias, g, want_stats)
     if cout % 8 != 0:
@@ -786,9 +813,26 @@ def _stem_form(x, w, g: Geom):
             (x.shape[1] + 2 * g.ph) % 2 == 0 and (x.shape[2] + 2 * g.pw) % 2 == 0)
 
 
+def _bf16_stem_form(x, w, g: Geom):
+    """Geometry of _StemS2DH, the data layer of bf16 activation storage: as _stem_form, but independent of the fp32 path's
+    A/B switch and with the bf16 kernels' channel rule (Cout a multiple of 8)."""
+    cin, cout = x.shape[-1], w.shape[0]
+    return (not x.requires_grad and g.kh == g.kw and g.kh % 2 == 1 and g.kh >= 3 and g.sh == g.sw == 2 and
+            g.ph == g.pw == (g.kh - 1) // 2 and g.dh == g.dw == 1 and cin <= 4 and cout % 8 == 0 and cout >= 16 and
+            (x.shape[1] + 2 * g.ph) % 2 == 0 and (x.shape[2] + 2 * g.pw) % 2 == 0)
+
+
 def pconv_dense(x, w, bias, mfull, r0, split, r1, denom, keep, inv, g: Geom, want_stats=False):
     """With ``want_stats`` returns (y, stat_part or None) -- None when the geometry is not on the implicit-GEMM path."""
-    if _h(x) or (_ACT_STORAGE == BF16 and mfull is None and r0 is None and denom is None and x.dtype == torch.float32 and _stem_form(x, w, g)):
+    data_layer = (_ACT_STORAGE == BF16 and x.dtype == torch.float32 and x.shape[-1] <= 4 and
+                  mfull is None and r0 is None and denom is None)
+    if data_layer and not _bf16_stem_form(x, w, g):
+        # bf16 storage was asked for and this mask-free image-sized input is where it would begin: running the whole net in
+        # fp32 instead would be a silent fallback
+        raise NotImplementedError("bf16 activation storage: the data layer cannot enter it (needs an odd-k stride-2 'same' stem over "
+                                  f"<= 4 channels with Cout % 8 == 0, even padded size and no input gradient; got k={g.kh}x{g.kw} "
+                                  f"stride={g.sh} cin={x.shape[-1]} cout={w.shape[0]} requires_grad={x.requires_grad})")
+    if _h(x) or data_layer:
         _no_masks("dense convolution", mfull, r0, r1, denom, keep)
         out = _dense_bf16(x, w, bias, g, want_stats)
         return (out, None) if (want_stats and not isinstance(out, tuple)) else out
@@ -907,7 +951,7 @@ class _BNLazy(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, part, training, momentum, eps, act, slope, slot, pool=None):
-        _lib.check_device(y)
+        _lib.check_device(y, bf16_ok=True)
         y = y.contiguous()
         c = y.shape[-1]
         m = y.numel() // c
@@ -1054,7 +1098,7 @@ def activation(x, act, slope=0.0):
 class _UpCat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, low, skip):
-        _lib.check_device(low)
+        _lib.check_device(low, skip)
         low, skip = low.contiguous(), skip.contiguous()
         n, h, w, c1 = low.shape
         assert skip.shape[0] == n and skip.shape[1] == 2 * h and skip.shape[2] == 2 * w, "upcat: shape mismatch"
@@ -1111,7 +1155,7 @@ def head_cat_ok(vc: "VirtualCat", cout: int, g) -> bool:
 class _HeadCat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, low, skip, w, bias, r0, r1, denom, keep, inv, r0_low=None):
-        _lib.check_device(low)
+        _lib.check_device(low, skip)
         ctx.r0_low = r0_low      # the low tensor's own mask plane (r0 = its nearest-x2 up-sampling), or None when r0 is None
         low, skip, w = low.contiguous(), skip.contiguous(), w.contiguous()
         n, h, wd, c2 = skip.shape
@@ -1209,7 +1253,7 @@ def upsample2x(x):
 class _MulMask(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mask):
-        _lib.check_device(x)
+        _lib.check_device(x, mask)
         x, mask = x.contiguous(), mask.contiguous()
         assert x.shape == mask.shape
         out = torch.empty_like(x)
@@ -1233,7 +1277,7 @@ def mul_mask(x, mask_full):
 class _L1Mean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
-        _lib.check_device(a)
+        _lib.check_device(a, b)
         a, b = a.contiguous(), b.contiguous()
         assert a.shape == b.shape
         loss = torch.empty(1, dtype=torch.float32, device=a.device)
@@ -1304,7 +1348,7 @@ class _AvgPoolH(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, k):
-        _lib.check_device(x)
+        _lib.check_device(x, bf16_ok=True)
         x = x.contiguous()
         n, h, w, c = x.shape
         y = torch.empty_like(x)
@@ -1324,7 +1368,7 @@ class _AvgPoolH(torch.autograd.Function):
 class _AddAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, act, slope):
-        _lib.check_device(a)
+        _lib.check_device(a, b, bf16_ok=True)
         a, b = a.contiguous(), b.contiguous()
         assert a.shape == b.shape and a.dtype == b.dtype, "add: operands must agree in shape and storage type"
         out = torch.empty_like(a)
@@ -1355,7 +1399,7 @@ def add_act(a, b, act=ACT_NONE, slope=0.0):
 class _Concat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *xs):
-        _lib.check_device(xs[0])
+        _lib.check_device(*xs, bf16_ok=True)
         xs = [x.contiguous() for x in xs]
         lead = xs[0].shape[:-1]
         chans = [x.shape[-1] for x in xs]
@@ -1397,7 +1441,7 @@ def concat(xs):
 class _BilinearUp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, scale):
-        _lib.check_device(x)
+        _lib.check_device(x, bf16_ok=True)
         x = x.contiguous()
         n, h, w, c = x.shape
         y = torch.empty((n, h * scale, w * scale, c), dtype=x.dtype, device=x.device)
@@ -1448,7 +1492,7 @@ def global_avg_pool(x):
 class _SCSE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, cse, sse):
-        _lib.check_device(x)
+        _lib.check_device(x, cse, sse)
         x, cse, sse = x.contiguous(), cse.contiguous(), sse.contiguous()
         n, h, w, c = x.shape
         out = torch.empty_like(x)
@@ -1477,7 +1521,7 @@ def scse_combine(x, cse, sse):
 class _BCEFocal(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, t, gamma, bw, ww):
-        _lib.check_device(x)
+        _lib.check_device(x, t)
         x, t = x.contiguous(), t.contiguous()
         assert x.numel() == t.numel()
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
@@ -1508,7 +1552,7 @@ def bce_focal(x, t, gamma=0.0, background_w=1.0, words_w=2.0):
 class _Compose(torch.autograd.Function):
     @staticmethod
     def forward(ctx, raw, mask, out):
-        _lib.check_device(out)
+        _lib.check_device(raw, mask, out)
         raw, mask, out = raw.contiguous(), mask.contiguous(), out.contiguous()
         assert raw.shape == mask.shape == out.shape
         comp = torch.empty_like(out)
@@ -1533,7 +1577,7 @@ def compose(raw, mask, out):
 class _MaskedL1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, out, gt, mask, wv, wh):
-        _lib.check_device(out)
+        _lib.check_device(out, gt, mask)
         out, gt, mask = out.contiguous(), gt.contiguous(), mask.contiguous()
         assert out.shape == gt.shape == mask.shape
         loss = torch.empty(1, dtype=torch.float32, device=out.device)

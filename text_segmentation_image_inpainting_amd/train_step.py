@@ -10,8 +10,14 @@ iteration: a sum all-reduce of the trainable gradients (RCCL over xGMI through `
 * The gradient buffer is cut into buckets (default 16 MB: ImageFill's 26 MB = 2, ImageFillOrigin / V2's 131 / 149 MB = 9 / 10).
   With more than one rank a bucket's all-reduce starts asynchronously from ``post_accumulate_grad`` hooks as soon as its last
   gradient exists, so the exchange overlaps the rest of backward; ``step()`` waits for what is outstanding (``exposed_ms`` measures
-  that wait) before the update.  A parameter that accumulates twice in one backward (shared across recomputed segments) takes its
-  bucket off the overlapped path for that step.  The mean over ranks is folded into the backward seed.
+  that wait) before the update.  The mean over ranks is folded into the backward seed.
+* Collectives must be issued in the same order on every rank, and nothing guarantees that every rank's backward completes its
+  buckets in the same order (a rank may recompute a stage the others keep, or build two branches in another order).  The FIRST
+  step is therefore a planning step: it exchanges after backward, counts how often each parameter accumulates (a block shared by
+  two recomputed segments accumulates twice) and in which order the buckets completed; the counts are agreed over the ranks (max;
+  a bucket on whose counts the ranks disagree never overlaps) and rank 0's completion order becomes everybody's LAUNCH order.
+  From then on a bucket is complete when each of its parameters has accumulated its planned number of times, and complete buckets
+  go out strictly in the agreed order -- a rank whose backward finishes them in another order only waits a little longer.
 * The update is the SGD-Nesterov the reference trained with (checkpoints/ReadME.md:4) as one fused HIP kernel over the flat
   buffers; parameters without a gradient keep value and momentum, as under ``torch.optim.SGD``.
 * ``capture`` / ``step_graph`` replay forward + backward + packing (+ update on one GPU) from a HIP graph.
@@ -75,7 +81,12 @@ class FlatSGDTrainer:
         self.overlap = bool(overlap) and self.world > 1
         self._pending, self._works, self._launched, self._fired = None, {}, None, None
         self._skipped = []              # parameters without a gradient in the current step (torch.optim.SGD leaves those alone)
-        self.deferred_buckets = 0       # buckets taken off the overlapped path because a gradient was accumulated twice
+        # the exchange plan (see the module docstring): None until the planning step has run
+        self._expected = None           # accumulations per parameter and backward pass, agreed over the ranks
+        self._order = None              # the launch order of the overlapped buckets, rank 0's completion order of the planning step
+        self._static = set()            # buckets that never overlap (no gradient at all, or the ranks disagree on their counts)
+        self._seq, self._last_fire, self._ready, self._next = 0, None, None, 0
+        self.deferred_buckets = 0       # buckets off the overlapped path (len(self._static) once planned)
         self.measure_exposed, self._exposed = False, []
         self._hooks = []
         if self.overlap:
@@ -87,7 +98,7 @@ class FlatSGDTrainer:
         on every backward).  The parameters stay views of ``flat_param``; build the next trainer from the model as usual."""
         for h in self._hooks:
             h.remove()
-        self._hooks, self.overlap, self._pending = [], False, None
+        self._hooks, self.overlap, self._pending, self._fired = [], False, None, None
 
     # ---- replication ---------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src=0):
@@ -117,31 +128,53 @@ class FlatSGDTrainer:
     # ---- gradient exchange ---------------------------------------------------------------------------------------
     def _make_hook(self, i):
         def hook(param):
-            if self._pending is None:          # outside forward_backward (e.g. a user's own backward): nothing to do
+            if self._fired is None:            # outside forward_backward (e.g. a user's own backward): nothing to do
                 return
+            self._fired[i] += 1
             b = self._bucket_of[i]
-            if self._fired[i] or self._pending[b] < 0:
-                # a second accumulation into the same parameter (e.g. one shared by two checkpoint segments, each with its
-                # own autograd.backward): the one-firing-per-parameter count no longer says when the bucket is complete
-                self._defer_bucket(b)
+            if self._expected is None:         # planning step: count, remember when each bucket saw its last accumulation
+                self._seq += 1
+                self._last_fire[b] = self._seq
                 return
-            self._fired[i] = True
+            if self._fired[i] > self._expected[i]:
+                raise RuntimeError("FlatSGDTrainer: a parameter accumulated a gradient more often than in the planning step -- the "
+                                   "autograd graph changed (stage recomputation switched on, a block now shared, a branch newly "
+                                   "used).  Call trainer.replan() on every rank before the next step.")
+            if b in self._static or self._fired[i] < self._expected[i]:
+                return
             self._pending[b] -= 1
             if self._pending[b] == 0:
-                self._launch_bucket(b)
+                self._ready[b] = True
+                self.last_completion_order.append(b)       # (diagnostic: THIS rank's completion order, next to the launch order)
+                # complete buckets leave strictly in the agreed order, whatever order THIS rank's backward completed them in
+                while self._next < len(self._order) and self._ready[self._order[self._next]]:
+                    self._launch_bucket(self._order[self._next])
+                    self._next += 1
         return hook
 
-    def _defer_bucket(self, b):
-        """Take bucket b off the overlapped path for this step: an all-reduce already started on an incomplete gradient is
-        waited for and discarded, and reduce_gradients() packs and reduces the bucket after backward.  Every rank runs the
-        same graph, hence takes the same decision at the same point of the collective sequence."""
-        if self._pending[b] >= 0:
-            self.deferred_buckets += 1
-        self._pending[b] = -1
-        work = self._works.pop(b, None)
-        if work is not None:
-            work.wait()
-        self._launched[b] = False
+    def replan(self):
+        """Forget the exchange plan: the next step is a planning step again (collective: call it on every rank)."""
+        self._expected, self._order, self._static, self.deferred_buckets = None, None, set(), 0
+
+    def _make_plan(self):
+        """After the planning step's backward: agree on the accumulation counts and on the launch order."""
+        dev = self.flat_grad.device
+        counts = torch.tensor(self._fired, dtype=torch.int32, device=dev)
+        hi, lo = counts.clone(), counts.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.pg)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.pg)
+        expected, agreed = hi.tolist(), (hi == lo).tolist()
+        static = set()
+        for b, bk in enumerate(self.buckets):
+            if not all(agreed[i] for i in bk["params"]) or not any(expected[i] for i in bk["params"]):
+                static.add(b)
+        # rank 0's completion order (buckets it never completed go last); broadcast so that every rank launches in that order
+        mine = sorted((b for b in range(len(self.buckets)) if b not in static), key=lambda b: (self._last_fire[b] == 0, self._last_fire[b], b))
+        order = torch.tensor(mine + [-1] * (len(self.buckets) - len(mine)), dtype=torch.int32, device=dev)
+        dist.broadcast(order, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+        self._expected, self._static = expected, static
+        self._order = [int(b) for b in order.tolist() if b >= 0]
+        self.deferred_buckets = len(static)
 
     def _pack_bucket(self, b):
         dst, src = [], []
@@ -170,14 +203,29 @@ class FlatSGDTrainer:
             p.grad = None
         self._works, self._skipped = {}, []
         self._launched = [False] * len(self.buckets)
-        self._pending = [len(bk["params"]) for bk in self.buckets] if self.overlap else None
-        self._fired = [False] * len(self.params)
+        planning = self.overlap and self._expected is None
+        if self.overlap:
+            self._fired = [0] * len(self.params)
+            if planning:
+                self._seq, self._last_fire = 0, [0] * len(self.buckets)
+            else:
+                # a bucket is complete when every parameter the plan expects a gradient for has accumulated its planned count
+                self._pending = [sum(1 for i in bk["params"] if self._expected[i] > 0) for bk in self.buckets]
+                self._ready, self._next = [False] * len(self.buckets), 0
+        self.last_completion_order = []
         with deferred_batch_counters():      # the BatchNorm batch counters: one multi-tensor add instead of one kernel each
             out = self.model((corrupted, mask))
         loss = self.loss_fn(out, clean_nhwc)
         # mean over ranks folded into the backward seed: sum-all-reduce then yields the average
         loss.backward(torch.full((), 1.0 / self.world, dtype=torch.float32, device=loss.device))
-        self._pending = None
+        if planning:
+            self._make_plan()
+        elif self.overlap:
+            short = [i for i in range(len(self.params)) if self._fired[i] < self._expected[i] and self._bucket_of[i] not in self._static]
+            if short:
+                raise RuntimeError(f"FlatSGDTrainer: {len(short)} parameter(s) accumulated fewer gradients than in the planning step -- the "
+                                   "autograd graph changed; call trainer.replan() on every rank before the next step.")
+        self._fired = self._pending = None
         return loss.detach()    # do not hand the autograd graph (and its AccumulateGrad nodes) to the caller
 
     def _pack_gradients(self):
