@@ -298,9 +298,33 @@ def test_dense_conv_gather_gemms(emu, mode, cin, cout, k, s, p, d, h):
 PC_THREADS = 768      # threads per block of the persistent producer / consumer NT kernel (csrc/gemm_pc.hip)
 
 
+@pytest.fixture(params=[(0, 0), (16, 8), (16 + 32, 8), (16 + 64, 3), (32, 0)], ids=["contiguous", "xcd-dealt", "xcd-dealt-lag1", "dealt-lag2", "lag1"])
+def pc_opt(request, emu):
+    """The forms of the persistent kernel's `opt` word (csrc/gemm_pc.hip: bit 4 = tiles dealt round robin with the blocks of an XCD on
+    consecutive tiles, bits 5-6 = the second consumer wave of every SIMD starts that many stages late), on 3 or 8 emulated CUs (8: the
+    XCD remap of the block index is active) -- through emulator-only hooks; the stock library's choice is PC_OPT_DEFAULT."""
+    opt, cus = request.param
+    emu.tsii_emu_set_pc_opt(opt)
+    emu.tsii_emu_set_pc_cus(cus)
+    yield opt
+    emu.tsii_emu_set_pc_opt(-1)
+    emu.tsii_emu_set_pc_cus(0)
+
+
+@pytest.fixture(params=[(0, 0), (16 + 32, 8)], ids=["contiguous", "xcd-dealt-lag1"])
+def pc_opt2(request, emu):
+    """two of pc_opt's forms, for the tests that are parametrised widely already"""
+    opt, cus = request.param
+    emu.tsii_emu_set_pc_opt(opt)
+    emu.tsii_emu_set_pc_cus(cus)
+    yield opt
+    emu.tsii_emu_set_pc_opt(-1)
+    emu.tsii_emu_set_pc_cus(0)
+
+
 @pytest.mark.parametrize("M,K,N", [(768, 64, 256), (512, 40, 128), (512, 96, 384), (256, 32, 128), (1152, 160, 192), (1664, 72, 224), (2560, 128, 128),
-                                   (1280, 32, 256), (640, 224, 512), (512, 256, 32), (512, 256, 48)])
-def test_producer_consumer_gemm(emu, M, K, N):
+                                   (1280, 32, 256), (640, 224, 512), (512, 256, 32), (512, 256, 48), (3072, 64, 384)])
+def test_producer_consumer_gemm(emu, pc_opt, M, K, N):
     """K3p (gemm_pc.hip) at kernel level on the emulator (3 'CUs': several tiles per persistent block, more stages than
     LDS slots, k tails, column blocks past N, both tile shapes): forward with BatchNorm-on-load + statistics, dX with
     and without the K6c BatchNorm-backward reductions, against float64 numpy -- and the 768-thread kernel must be the
@@ -721,7 +745,7 @@ def test_depthwise_stride2_forward_strip_other_paddings(emu, pad):
                                               (1, 16, 32, 64, 256, False),     # producer / consumer kernel, 128 x 256 tiles
                                               (1, 6, 12, 20, 36, True),        # 4-wave kernels, row / column tails
                                               (3, 4, 8, 8, 64, False)])
-def test_pointwise_upsampled_addend(emu, mode, n, h, wd, k, N, stats):
+def test_pointwise_upsampled_addend(emu, pc_opt2, mode, n, h, wd, k, N, stats):
     L = emu
     rng = np.random.default_rng(n * 1000 + h * 10 + k)
     m = n * h * wd

@@ -36,11 +36,15 @@
 #ifndef PC_NT_STORE
 #define PC_NT_STORE 1     // non-temporal stores of the output tile (A/B on the chip: forward 17.88 -> 17.62 ms)
 #endif
+#ifndef PC_OPT_DEFAULT
+#define PC_OPT_DEFAULT 0  // the kernel's `opt` word in the stock library: bit 4 = tiles dealt round robin per XCD, bits 5-6 = consumer lag
+#endif
 
 namespace tsii {
 
 struct PcCursor {      // a k stage of an output tile; wave-uniform
-    unsigned tile;
+    unsigned tile;     // global tile index
+    unsigned ord;      // its position in this block's sequence of tiles
     int ks;
     int64_t m0;
     int n0;
@@ -52,11 +56,12 @@ __device__ __forceinline__ void pc_locate(PcCursor& c, unsigned tile, unsigned n
     c.m0 = (int64_t)(tile / ntn) * BM;
     c.n0 = (int)(tile % ntn) * BN;
 }
-// next stage; past the block's last tile the cursor stays on the last stage (loads issued from it are never used)
+// next stage; past the block's last tile the cursor stays on the last stage (loads issued from it are never used).  A block's tiles
+// are tfirst + i * tstride, i < tcount.
 template <int BM, int BN>
-__device__ __forceinline__ void pc_advance(PcCursor& c, int nst, unsigned ntn, unsigned tlast) {
+__device__ __forceinline__ void pc_advance(PcCursor& c, int nst, unsigned ntn, unsigned tcount, unsigned tstride) {
     if (c.ks + 1 < nst) { ++c.ks; return; }
-    if (c.tile < tlast) { c.ks = 0; pc_locate<BM, BN>(c, c.tile + 1, ntn); }
+    if (c.ord + 1 < tcount) { c.ks = 0; ++c.ord; pc_locate<BM, BN>(c, c.tile + tstride, ntn); }
 }
 
 __device__ __forceinline__ unsigned pc_flag(const unsigned* f) { return __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -226,11 +231,26 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_pc_kernel(const float* __restr
     unsigned* empty = full + 8;                                          // [8]: consumer waves done with the slot, ever
 
     const int tid = threadIdx.x;
-    // this block's tiles: [t0, t1)
-    const unsigned t0 = (unsigned)(((uint64_t)blockIdx.x * tiles) / gridDim.x);
-    const unsigned t1 = (unsigned)(((uint64_t)(blockIdx.x + 1) * tiles) / gridDim.x);
+    // This block's tiles: tfirst + i * tstride, i < tcount.  opt bit 4 clear: a contiguous range of (row block, column block) order.
+    // opt bit 4 set (round 6): dealt round robin over the blocks, with the blocks of one XCD (blockIdx % 8) taking CONSECUTIVE tiles
+    // -- the column tiles of a row block, and the row blocks above / below it, then run at the same time on CUs that share an L2,
+    // so the operand A (and the up-sampled addend rows, shared by two image rows) come from HBM once; in the contiguous order a CU
+    // came back to them a tile (12 us) or three later and they were gone (PMC: 6.2 GB per launch against 3.4 GB algorithmic on
+    // 2M x 64 -> 384).
+    unsigned tfirst, tstride, tcount;
+    if (opt & 16) {
+        const unsigned g = gridDim.x, per = g >> 3;
+        const unsigned lb = (g & 7u) == 0u ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+        tfirst = lb; tstride = g;
+        tcount = (tiles - lb + g - 1) / g;                    // >= 1: the launcher never starts more blocks than tiles
+    } else {
+        tfirst = (unsigned)(((uint64_t)blockIdx.x * tiles) / gridDim.x);
+        tstride = 1u;
+        tcount = (unsigned)(((uint64_t)(blockIdx.x + 1) * tiles) / gridDim.x) - tfirst;
+    }
+    const unsigned t0 = tfirst;
     const int nst = (K + 31) >> 5;
-    const unsigned stages = (t1 - t0) * (unsigned)nst;        // >= 1: the launcher never starts more blocks than tiles
+    const unsigned stages = tcount * (unsigned)nst;
     constexpr bool use_cs = EPI == 2 || EPI == 3;             // dX epilogue: row factors = the two mask planes
 
     if (tid < 16) full[tid] = 0u;
@@ -337,7 +357,15 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_pc_kernel(const float* __restr
         unsigned bl = lane_row(t0);
 #pragma unroll
         for (int p = 0; p < P; ++p) { bx[p] = ldb(Bb, bl, p); by[p] = bx[p]; a3y[p] = bx[p]; }      // k half-step 0 of the first tile
-        for (unsigned tile = t0; tile < t1; ++tile) {
+        // opt bits 5-6 (round 6): the SECOND consumer wave of every SIMD (waves 4-7) starts `lag` stages behind the first, so that
+        // one of a SIMD's two matrix waves is in its epilogue (stores) while the other multiplies instead of both doing either
+        {
+            unsigned lag = ((unsigned)opt >> 5) & 3u;
+            lag = lag < (unsigned)R ? lag : (unsigned)R;          // the first R stages are written without waiting for anybody
+            if (lag != 0u && cw >= 4 && stages > lag) pc_wait_flag(&empty[lag - 1u], 4u);
+        }
+        unsigned tile = t0;
+        for (unsigned ti = 0; ti < tcount; ++ti, tile += tstride) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -345,7 +373,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_pc_kernel(const float* __restr
             int colc = (int)(tile % ntn) * BN + wn * 32 + li;
             colc = colc < N ? colc : N - 1;
             const float bias = ep.bias != nullptr ? ep.bias[colc] : 0.f;                 // needed in the epilogue only: its latency is free here
-            const unsigned bl_next = lane_row(tile + 1 < t1 ? tile + 1 : tile);
+            const unsigned bl_next = lane_row(ti + 1 < tcount ? tile + tstride : tile);
             pc_wait_flag(&full[slot], gen1);                            // first stage of the tile
             load_a_frags(smem + slot * ASTAGE, ch0);
             for (int ks = 0; ks < nst; ++ks) {
@@ -370,13 +398,13 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_pc_kernel(const float* __restr
             if constexpr (!(ABL & 128)) {
                 const int64_t m0 = (int64_t)(tile / ntn) * BM;
                 const int n0 = (int)(tile % ntn) * BN;
-                const float* sx = side + (tile % SLOTS) * (2 * BM) + wm * 128;
+                const float* sx = side + (ti % SLOTS) * (2 * BM) + wm * 128;
                 if (n0 + wn * 32 < N) pc_epilogue<EPI>(acc, C, ldc, N, ep, m0 + wm * 128, n0 + wn * 32, li, hi, sx, sx + BM, bias);
             } else if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.f) {
                 C[tid] = bias;
             }
             if constexpr ((ABL & 32768) != 0) {
-                if (tile + 1 == t1 && lane == 0) {
+                if (ti + 1 == tcount && lane == 0) {
                     const unsigned long long t_all = __builtin_amdgcn_s_memtime() - t_begin;
                     C[(blockIdx.x * 8 + cw) * 2 + 0] = (float)t_wait;
                     C[(blockIdx.x * 8 + cw) * 2 + 1] = (float)t_all;
@@ -391,9 +419,8 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_pc_kernel(const float* __restr
         else if (((opt >> 2) & 3) == 3) __builtin_amdgcn_s_setprio(3);
         const int ptid = tid - 512, plane_lane = ptid & 63;
         const int prow = ptid >> 2, pch = ptid & 3;                     // item i: row prow + 64 i of the tile, chunk pch
-        const unsigned tlast = t1 - 1;
         PcCursor la, wc;                                                // A loads (DA stages ahead), LDS writes
-        pc_locate<BM, BN>(la, t0, ntn); la.ks = 0;
+        pc_locate<BM, BN>(la, t0, ntn); la.ks = 0; la.ord = 0;
         wc = la;
 
         f32x4 ra[DA][NA][2];
@@ -473,7 +500,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_pc_kernel(const float* __restr
         auto store_side = [&](const PcCursor& c, int slotr) {
             if constexpr (!(ABL & (64 | 512 | 1024))) async_wait<DA * LT - 2>(sdx[slotr], sdy[slotr]);
             if (c.ks == 0 && ptid < BM) {
-                float* sx = side + (c.tile % SLOTS) * (2 * BM);
+                float* sx = side + (c.ord % SLOTS) * (2 * BM);
                 const float x = has_sx ? sdx[slotr] : 1.f;
                 sx[ptid] = (!use_cs && has_sx) ? 1.0f / x : x;          // one IEEE division per row
                 sx[BM + ptid] = has_sy ? sdy[slotr] : 1.f;
@@ -486,7 +513,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_pc_kernel(const float* __restr
 #pragma unroll
             for (int i = 0; i < NA; ++i) load_item(la, u, i);
             load_side(la, u);
-            pc_advance<BM, BN>(la, nst, ntn, tlast);
+            pc_advance<BM, BN>(la, nst, ntn, tcount, tstride);
         }
         unsigned long long tp_empty = 0, tp_store = 0, tp_begin = 0, tp_wait = 0, tp_issue = 0;
         if constexpr ((ABL & 32768) != 0) tp_begin = __builtin_amdgcn_s_memtime();
@@ -519,8 +546,8 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_pc_kernel(const float* __restr
                 store_side(wc, u);
                 load_side(la, u);
                 if (plane_lane == 0) pc_bump_flag(&full[slot]);         // release: this wave's LDS stores precede it
-                pc_advance<BM, BN>(la, nst, ntn, tlast);
-                pc_advance<BM, BN>(wc, nst, ntn, tlast);
+                pc_advance<BM, BN>(la, nst, ntn, tcount, tstride);
+                pc_advance<BM, BN>(wc, nst, ntn, tcount, tstride);
                 if (++slot == (unsigned)R) { slot = 0; gen8 += 8u; }
             }
         }
@@ -569,6 +596,10 @@ __global__ void split_w_tiled_kernel(const float* __restrict__ w, int cols_in, i
     }
 }
 
+#ifdef TSII_HIP_EMU
+static int g_emu_cus = 0;        // TEST-ONLY: the grid size of the persistent kernel in the emulator (0: the emulator's default "device")
+extern "C" void tsii_emu_set_pc_cus(int v) { g_emu_cus = v > 0 ? v : 0; }
+#endif
 static int pc_cus() {            // read-only device-properties cache
     static int cus = 0;
     if (cus == 0) {
@@ -576,6 +607,9 @@ static int pc_cus() {            // read-only device-properties cache
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
         cus = v;
     }
+#ifdef TSII_HIP_EMU
+    if (g_emu_cus > 0) return g_emu_cus;
+#endif
     return cus;
 }
 
@@ -583,12 +617,19 @@ static int pc_cus() {            // read-only device-properties cache
 // them from the environment once at load instead (tools/pc_probe.py, tools/gemm_bench.py).
 #ifdef TSII_GEMM_PC_ABLATIONS
 static int g_pc = getenv("TSII_GEMM_PC") ? atoi(getenv("TSII_GEMM_PC")) : 1;              // 0 = 4-wave kernels only
-static int g_pc_opt = getenv("TSII_GEMM_PC_OPT") ? atoi(getenv("TSII_GEMM_PC_OPT")) : 0;   // wave priorities (kernel comment)
+static int g_pc_opt = getenv("TSII_GEMM_PC_OPT") ? atoi(getenv("TSII_GEMM_PC_OPT")) : PC_OPT_DEFAULT;   // wave priorities (kernel comment)
 static int g_pc_abl = getenv("TSII_GEMM_PC_ABL") ? atoi(getenv("TSII_GEMM_PC_ABL")) : 0;   // tools/pc_probe.py ablations
 static int g_pc_bnb_min_k = getenv("TSII_GEMM_PC_BNB_MIN_K") ? atoi(getenv("TSII_GEMM_PC_BNB_MIN_K")) : 32;
 static int g_pc_min_n = getenv("TSII_GEMM_PC_MIN_N") ? atoi(getenv("TSII_GEMM_PC_MIN_N")) : 128;
+#elif defined(TSII_HIP_EMU)
+// TEST-ONLY (emulator build, tests/emu): the kernel's `opt` word (tile dealing, consumer lag), so that the CPU suite walks the forms
+// the stock library does not select
+static constexpr int g_pc = 1;
+static int g_pc_opt = PC_OPT_DEFAULT;
+extern "C" void tsii_emu_set_pc_opt(int v) { g_pc_opt = v >= 0 ? v : PC_OPT_DEFAULT; }
+static constexpr int g_pc_bnb_min_k = 32, g_pc_min_n = 128;
 #else
-static constexpr int g_pc = 1, g_pc_opt = 0;
+static constexpr int g_pc = 1, g_pc_opt = PC_OPT_DEFAULT;
 static constexpr int g_pc_bnb_min_k = 32;   // dX + K6c: shortest reduction the persistent kernel takes (one-stage tiles: 1.57 -> 1.45 ms on 2M x 32 -> 384 since the epilogue prefetches the BatchNorm input; 64 before)
 static constexpr int g_pc_min_n = 128;      // measured: 64-column outputs stay faster on the 4-wave kernel
 #endif
