@@ -490,40 +490,45 @@ def test_depthwise_strip_entry_points(emu, n, h, wd, c, masked, bias, act, targe
         L.tsii_emu_set_strip_target(0)
 
 
-def _strip_entry_points(L, n, h, wd, c, masked, bias, act):
-    rng = np.random.default_rng(h * 100 + wd)
+def _strip_entry_points(L, n, h, wd, c, masked, bias, act, d=1, p=None):
+    """3x3 / stride 1 / dilation d / padding p (default d: a "same" convolution): input grid [h, wd], output grid [ho, wo]"""
+    p = d if p is None else p
+    ho, wo = h + 2 * p - 2 * d, wd + 2 * p - 2 * d
+    assert ho > 0 and wo > 0
+    rng = np.random.default_rng(h * 100 + wd + 7 * d + p)
     slope = 0.3
     x = rng.standard_normal((n, h, wd, c)).astype(np.float32) + 0.5
     w = rng.standard_normal((c, 1, 3, 3)).astype(np.float32)
     b = rng.standard_normal(c).astype(np.float32) if bias else None
     rmask = (rng.uniform(size=(n, h, wd)) > 0.2).astype(np.float32) if masked else None
     cnt = None
-    if masked:
-        pm = np.zeros((n, h + 2, wd + 2)); pm[:, 1:-1, 1:-1] = rmask
-        cnt = sum(pm[:, ky:ky + h, kx:kx + wd] for ky in range(3) for kx in range(3))
+    if masked:      # valid-input count of every output pixel: the same taps over the mask plane
+        cnt = _dw_ref_fwd(rmask[..., None], None, np.ones((1, 1, 3, 3), np.float32), None, None, None, 1, d, p)[..., 0]
     keep = (cnt > 0).astype(np.float32) if masked else None
     denom = (np.where(cnt > 0, cnt, 1.0) * c).astype(np.float32) if masked else None
-    geom = (3, 3, 1, 1, 1, 1, 1, 1)
+    geom = (3, 3, 1, 1, p, p, d, d)
     ws = WS(4 * (9 * c + 16))
     # plain forward
-    y = np.full((n, h, wd, c), np.nan, np.float32)
-    assert L.tsii_dw_fwd(P(x), P(rmask), P(w), P(b), P(denom), P(keep), n, h, wd, c, *geom, h, wd, P(y), P(ws), None) == 0, L.tsii_last_error()
-    yr = _dw_ref_fwd(x, rmask, w, b, denom, keep, 1, 1, 1)
+    y = np.full((n, ho, wo, c), np.nan, np.float32)
+    assert L.tsii_dw_fwd(P(x), P(rmask), P(w), P(b), P(denom), P(keep), n, h, wd, c, *geom, ho, wo, P(y), P(ws), None) == 0, L.tsii_last_error()
+    yr = _dw_ref_fwd(x, rmask, w, b, denom, keep, 1, d, p)
     assert np.abs(y - yr).max() <= 2e-6 * max(1.0, np.abs(yr).max())
     # forward with BatchNorm + activation on load and statistics partials
     sc = (rng.uniform(size=c) + 0.5).astype(np.float32); sh = rng.standard_normal(c).astype(np.float32)
-    rows = L.tsii_dw_stat_rows(n, h, wd, c, 3, 3, 1, 1, 1, 1)
+    rows = L.tsii_dw_stat_rows(n, ho, wo, c, 3, 3, 1, 1, d, d)
     assert rows > 0
     part = WS(4 * rows * 4 * c)
-    y2 = np.full((n, h, wd, c), np.nan, np.float32)
-    assert L.tsii_dw_fwd_bn(P(x), P(rmask), P(w), P(b), P(denom), P(keep), n, h, wd, c, *geom, h, wd, P(sc), P(sh), act, slope,
+    part[:] = np.nan
+    y2 = np.full((n, ho, wo, c), np.nan, np.float32)
+    assert L.tsii_dw_fwd_bn(P(x), P(rmask), P(w), P(b), P(denom), P(keep), n, h, wd, c, *geom, ho, wo, P(sc), P(sh), act, slope,
                             P(part), P(y2), P(ws), None) == 0, L.tsii_last_error()
     xa = _act(x.astype(np.float64) * sc + sh, act, slope)
-    y2r = _dw_ref_fwd(xa, rmask, w, b, denom, keep, 1, 1, 1)
+    y2r = _dw_ref_fwd(xa, rmask, w, b, denom, keep, 1, d, p)
     assert np.abs(y2 - y2r).max() <= 2e-6 * max(1.0, np.abs(y2r).max())
     pr = part[:rows * 4 * c].reshape(rows, 4, c).astype(np.float64)
+    assert np.isfinite(pr).all(), "every partial row the caller sized the buffer for is written"
     cnts, piv, s1, s2 = pr[:, 0], pr[:, 1], pr[:, 2], pr[:, 3]
-    m_tot = n * h * wd
+    m_tot = n * ho * wo
     assert np.all(cnts.sum(0) == m_tot)
     mean = (cnts * piv + s1).sum(0) / m_tot
     ex2 = (s2 + 2 * piv * s1 + cnts * piv * piv).sum(0) / m_tot
@@ -531,29 +536,31 @@ def _strip_entry_points(L, n, h, wd, c, masked, bias, act):
     assert np.abs(mean - y2d.mean(0)).max() <= 1e-5 * max(1.0, np.abs(y2d).max())
     assert np.abs(ex2 - (y2d ** 2).mean(0)).max() <= 1e-5 * max(1.0, (y2d ** 2).max())
     # statistics only (no producer BatchNorm): the identity transform must be exact
-    y3 = np.full((n, h, wd, c), np.nan, np.float32)
-    assert L.tsii_dw_fwd_bn(P(x), P(rmask), P(w), P(b), P(denom), P(keep), n, h, wd, c, *geom, h, wd, None, None, 0, 0.0,
+    y3 = np.full((n, ho, wo, c), np.nan, np.float32)
+    assert L.tsii_dw_fwd_bn(P(x), P(rmask), P(w), P(b), P(denom), P(keep), n, h, wd, c, *geom, ho, wo, None, None, 0, 0.0,
                             P(part), P(y3), P(ws), None) == 0, L.tsii_last_error()
     assert np.array_equal(y3, y)
     # dX (flipped taps, dy * inv staged, rmask applied to the result) and its K6c form
-    dy = rng.standard_normal((n, h, wd, c)).astype(np.float32)
+    dy = rng.standard_normal((n, ho, wo, c)).astype(np.float32)
     inv = (keep / denom).astype(np.float32) if masked else None
     dx = np.full((n, h, wd, c), np.nan, np.float32)
-    assert L.tsii_dw_bwd_dx(P(dy), P(inv), P(w), P(rmask), n, h, wd, c, *geom, h, wd, P(dx), P(ws), None) == 0, L.tsii_last_error()
+    assert L.tsii_dw_bwd_dx(P(dy), P(inv), P(w), P(rmask), n, h, wd, c, *geom, ho, wo, P(dx), P(ws), None) == 0, L.tsii_last_error()
     wf = w[:, :, ::-1, ::-1]
-    dxr = _dw_ref_fwd(dy, inv, wf, None, None, None, 1, 1, 1)
+    dxr = _dw_ref_fwd(dy, inv, wf, None, None, None, 1, d, 2 * d - p)
     if masked:
         dxr = dxr * rmask.astype(np.float64)[..., None]
     assert np.abs(dx - dxr).max() <= 2e-6 * max(1.0, np.abs(dxr).max())
     brows = L.tsii_dw_bwd_stat_rows(n, h, wd, c, *geom)
     assert brows > 0
     bpart = WS(4 * brows * 2 * c)
+    bpart[:] = np.nan
     mean_b = rng.standard_normal(c).astype(np.float32); var_b = (rng.uniform(size=c) + 0.5).astype(np.float32)
     gam = (rng.uniform(size=c) + 0.5).astype(np.float32); bet = rng.standard_normal(c).astype(np.float32)
     dx2 = np.full((n, h, wd, c), np.nan, np.float32)
-    assert L.tsii_dw_bwd_dx_bn(P(dy), P(inv), P(w), P(rmask), n, h, wd, c, *geom, h, wd, P(x), P(mean_b), P(var_b), P(gam), P(bet),
+    assert L.tsii_dw_bwd_dx_bn(P(dy), P(inv), P(w), P(rmask), n, h, wd, c, *geom, ho, wo, P(x), P(mean_b), P(var_b), P(gam), P(bet),
                                1e-5, act, slope, P(dx2), P(bpart), P(ws), None) == 0, L.tsii_last_error()
     assert np.array_equal(dx2, dx)
+    assert np.isfinite(bpart[:brows * 2 * c]).all(), "every K6c partial row is written"
     xh = (x.astype(np.float64) - mean_b) / np.sqrt(var_b.astype(np.float64) + 1e-5)
     z = xh * gam + bet
     g1 = {0: np.ones_like(z), 1: (z > 0) * 1.0, 2: np.where(z > 0, 1.0, slope), 3: ((z > 0) & (z < 6)) * 1.0}[act]
@@ -564,6 +571,28 @@ def _strip_entry_points(L, n, h, wd, c, masked, bias, act):
     slack = (np.abs(dx) * near).reshape(-1, c).sum(0) * 2 + 1e-4 * np.abs(dz).reshape(-1, c).sum(0).max()
     assert np.all(np.abs(bp[0] - dz.reshape(-1, c).sum(0)) <= slack)
     assert np.all(np.abs(bp[1] - (dz * xh).reshape(-1, c).sum(0)) <= slack * max(1.0, np.abs(xh).max()))
+
+
+@pytest.mark.parametrize("n,h,wd,c,d,p,masked,bias,act", [
+    (2, 21, 37, 40, 2, 2, True, True, 2),       # odd sizes: the phases have different row / column counts; channel tail
+    (1, 32, 64, 32, 8, 8, True, False, 3),      # 4 x 8-pixel phase images (half a strip wide, half a step high), ReLU6
+    (1, 33, 70, 8, 4, 4, False, True, 0),       # no mask planes; 70 = 17 full columns + a phase tail
+    (2, 40, 48, 36, 2, 1, True, True, 1),       # padding < dilation: output 2 smaller per side than the input, input phase != output phase
+    (1, 24, 40, 12, 4, 6, True, True, 2),       # padding > dilation: output larger than the input
+    (1, 150, 19, 4, 2, 2, False, False, 2),     # many steps per chunk (both LDS buffers in turn) at target 1
+])
+@pytest.mark.parametrize("target", [1536, 1])
+def test_depthwise_dilated_strips_by_phase(emu, n, h, wd, c, d, p, masked, bias, act, target):
+    """Dilation 2 / 4 / 8 on the lean strip kernel PER PHASE (csrc/dw_lean.h, PH): every entry point of the d = 1 test at a dilated
+    geometry -- forward, BatchNorm on load + statistics partials (all rows of tsii_dw_stat_rows written, counts adding up), dX, dX +
+    K6c -- against float64; geometries too narrow for the phased form (19 columns at d = 2 ... ) take the round-3 ring kernels and
+    must give the same answers."""
+    L = emu
+    L.tsii_emu_set_strip_target(target)
+    try:
+        _strip_entry_points(L, n, h, wd, c, masked, bias, act, d=d, p=p)
+    finally:
+        L.tsii_emu_set_strip_target(0)
 
 
 @pytest.mark.parametrize("n,h,wd,c,masked,bias,act", [

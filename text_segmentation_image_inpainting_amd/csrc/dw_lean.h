@@ -55,7 +55,15 @@ __device__ __forceinline__ f32x4 cat4(f32x2 a, f32x2 b) { return f32x4{a.x, a.y,
 // MODE 0: plain; 1: forward with BatchNorm on load and / or statistics partials (K6b); 2: dX feeding a BatchNorm backward (K6c).
 // DXE: dX epilogue (out = post_mul != 0 ? acc * post_mul : 0) instead of the forward one (acc / denom + bias, zero where keep == 0).
 // PRE: the staged input is multiplied by a per-pixel plane (mask for forward, 1 / count for dX).
-template <int MODE, bool DXE, bool PRE>
+// PH (round 6): DILATION d > 1 BY PHASES.  With dilation d every tap of output pixel (oy, ox) lies d pixels apart, so the outputs with
+// oy = py (mod d), ox = px (mod d) together with the inputs they read form an ordinary dilation-1 3x3 convolution on the sub-image
+// of every d-th row and column -- d^2 independent ones per image.  A block takes a strip chunk of ONE phase: the same kernel, on a
+// "virtual" image whose pixel (r, c) is the real pixel (p_y + d r, p_x + d c), i.e. every pixel offset of the d = 1 kernel times d
+// from the phase's first pixel (one pixel of a 32-channel block is a 128-byte segment either way).  No halo beyond the one
+// sub-pixel of the 3x3 window: a dilation-8 layer reads 18 / 16 of its input like a dilation-1 layer, where the ring of 8 + 2 d
+// rows x (16 + 2 d) columns of the round-3 strip kernel read 2x (64^2 x 1920 at d = 8: 1.7 TB/s).  The grid carries image x phase
+// as its slowest index (nv = n d^2 + phase: the partial-row layout of the fused forms follows it, plan_strip_phased).
+template <int MODE, bool DXE, bool PRE, bool PH = false>
 __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_kernel(
     const float* __restrict__ in, const float* __restrict__ pre, const float* __restrict__ wT, const float* __restrict__ bias,
     const float* __restrict__ denom, const float* __restrict__ keep, const float* __restrict__ post_mul, DtGeom g, int chunk_rows,
@@ -72,20 +80,59 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
     if (LS_ORDER == 1) { sx = b % strips_x; b /= strips_x; cb = b % cblocks; b /= cblocks; }
     else { cb = b % cblocks; b /= cblocks; sx = b % strips_x; b /= strips_x; }
     const unsigned cy = b % chunks_y;
-    const int64_t n = b / chunks_y;
+    const int64_t nv = b / chunks_y;                          // image (x phase): index of the block's partial row
+    int64_t n = nv;
+    // the phase's view: D = pixel pitch, (vhin, vwin) / (vhout, vwout) the sub-image sizes, (pvh, pvw) its padding,
+    // ibase0 / obase0 = first pixel of the phase in the input / output grid (pixel index inside the image)
+    int D = 1, vhin = g.hin, vwin = g.win, vhout = g.hout, vwout = g.wout, pvh = g.pad_h, pvw = g.pad_w;
+    int ipix0 = 0, opix00 = 0;
+    bool have_in = true;
+    if (PH) {
+        D = g.d;
+        const int dd = D * D;
+        n = nv / dd;
+        const int ph = (int)(nv - n * dd);
+        const int py_o = ph / D, px_o = ph - py_o * D;
+        // input row of (virtual output row r, tap ky) = py_o + D r - pad + D ky: the input phase and the padding of the view
+        const int qy = py_o - g.pad_h, qx = px_o - g.pad_w;
+        int py_i = qy % D, px_i = qx % D;
+        py_i = py_i < 0 ? py_i + D : py_i; px_i = px_i < 0 ? px_i + D : px_i;
+        pvh = (py_i - qy) / D; pvw = (px_i - qx) / D;
+        vhout = g.hout > py_o ? (g.hout - py_o + D - 1) / D : 0;
+        vwout = g.wout > px_o ? (g.wout - px_o + D - 1) / D : 0;
+        vhin = g.hin > py_i ? (g.hin - py_i + D - 1) / D : 0;
+        vwin = g.win > px_i ? (g.win - px_i + D - 1) / D : 0;
+        have_in = vhin > 0 && vwin > 0;                        // (a phase without input pixels: every tap is padding)
+        if (!have_in) { py_i = 0; px_i = 0; vhin = 1; vwin = 1; }   // clamped loads stay inside the image; their values are dropped
+        ipix0 = py_i * g.win + px_i;
+        opix00 = py_o * g.wout + px_o;
+    }
+    const unsigned Du = (unsigned)D;
     const int t = threadIdx.x;
     const int cg = t & 7, lane = t >> 3;
     const int C = g.c;
     const int c0 = (int)cb * LS_CB + cg * 4;
     const bool cok = c0 < C;
     const int oy_beg = (int)cy * chunk_rows;
-    const int oy_end = oy_beg + chunk_rows < g.hout ? oy_beg + chunk_rows : g.hout;
+    const int oy_end = oy_beg + chunk_rows < vhout ? oy_beg + chunk_rows : vhout;
     const int ox0 = (int)sx * LS_TW;
-    const int iy_base = oy_beg - g.pad_h, ix0 = ox0 - g.pad_w;      // input row of buffer row 0 at step 0 / input column of slab column 0
+    const int iy_base = oy_beg - pvh, ix0 = ox0 - pvw;        // input row of buffer row 0 at step 0 / input column of slab column 0
     const int nsteps = (oy_end - oy_beg + LS_R - 1) / LS_R;
-    const bool col_interior = ix0 >= 0 && ix0 + LS_PW <= g.win;      // block-uniform
+    const bool col_interior = have_in && ix0 >= 0 && ix0 + LS_PW <= vwin;      // block-uniform
     const float bn_neg = FUSED && ib.sc != nullptr ? ib.neg : 1.f;   // no producer BatchNorm: the identity (scale 1, shift 0, neg 1), exact
     const bool hi_finite = FUSED && ib.sc != nullptr && ib.hi < __builtin_huge_valf();
+    if (PH && (nsteps <= 0 || ox0 >= vwout)) {
+        // a phase with fewer rows / columns than the plan's largest: nothing to compute, but the fused forms' partial rows exist
+        if (t < LS_CB && (int)cb * LS_CB + t < C) {
+            const int64_t prow = (nv * chunks_y + cy) * strips_x + sx;
+            if (BNB) { bb.part[(prow * 2 + 0) * C + (int)cb * LS_CB + t] = 0.f; bb.part[(prow * 2 + 1) * C + (int)cb * LS_CB + t] = 0.f; }
+            else if (FUSED && stats != nullptr) {
+                float* sp = stats + prow * 4 * C + (int)cb * LS_CB + t;
+                sp[0] = 0.f; sp[C] = 0.f; sp[2 * (int64_t)C] = 0.f; sp[3 * (int64_t)C] = 0.f;
+            }
+        }
+        return;
+    }
 
     if (t < LS_CB) {                                          // per-channel constants of this block's 32 channels
         const int ch = (int)cb * LS_CB + t;
@@ -121,7 +168,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
         const int pr = lane + 32 * i;
         const int p = pr < LS_R * LS_PW ? pr : LS_R * LS_PW - 1;   // item 4 of the pixel lanes >= 16: a second load of the slab's last pixel
         const int row = p / LS_PW, px = p - row * LS_PW;
-        poff[i] = (unsigned)(row * g.win + px) * 4u;
+        poff[i] = (unsigned)(row * g.win + px) * 4u * Du;
         rowpk |= (unsigned)row << (4 * i);
         pxpk |= (unsigned)px << (5 * i);
     }
@@ -134,16 +181,16 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
     f32x4 pf[LS_PF];
     float pm[LS_PF];
     unsigned vmask = 0;                                        // edge steps: bit i = item i lies inside the image
-    const int64_t img_pix = n * g.hin * (int64_t)g.win;
-    const char* const ibase = reinterpret_cast<const char*>(in + img_pix * C);      // pixel (0, 0) of this image
+    const int64_t img_pix = n * g.hin * (int64_t)g.win + ipix0;
+    const char* const ibase = reinterpret_cast<const char*>(in + img_pix * C);      // pixel (0, 0) of this image (of its phase)
     const char* const ipre = reinterpret_cast<const char*>(pre + img_pix);
     // running pointers to the first pixel of the NEXT slab to fetch (may point outside the tensor; only used by interior steps)
     int iyb = iy_base + 2;
-    const char* sb = reinterpret_cast<const char*>(in + (img_pix + (int64_t)iyb * g.win + ix0) * C);
-    const char* pb = reinterpret_cast<const char*>(pre + (img_pix + (int64_t)iyb * g.win + ix0));
-    const int64_t sb_step = (int64_t)LS_R * g.win * C * 4, pb_step = (int64_t)LS_R * g.win * 4;
+    const char* sb = reinterpret_cast<const char*>(in + (img_pix + ((int64_t)iyb * g.win + ix0) * D) * C);
+    const char* pb = reinterpret_cast<const char*>(pre + (img_pix + ((int64_t)iyb * g.win + ix0) * D));
+    const int64_t sb_step = (int64_t)LS_R * g.win * C * 4 * D, pb_step = (int64_t)LS_R * g.win * 4 * D;
     auto fetch = [&]() {                                      // global -> registers, slab rows iyb .. iyb + 7
-        const bool interior = col_interior && iyb >= 0 && iyb + LS_R <= g.hin;
+        const bool interior = col_interior && iyb >= 0 && iyb + LS_R <= vhin;
         unsigned po[LS_PF];
         vmask = 31u;
 #pragma unroll
@@ -153,9 +200,9 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
 #pragma unroll
             for (int i = 0; i < LS_PF; ++i) {
                 const int iy = iyb + (int)((rowpk >> (4 * i)) & 15u), ix = ix0 + (int)((pxpk >> (5 * i)) & 31u);
-                if ((unsigned)iy < (unsigned)g.hin && (unsigned)ix < (unsigned)g.win) vmask |= 1u << i;
-                const int iyc = iy < 0 ? 0 : (iy >= g.hin ? g.hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= g.win ? g.win - 1 : ix);
-                po[i] = (unsigned)(iyc * g.win + ixc) * 4u;
+                if (have_in && (unsigned)iy < (unsigned)vhin && (unsigned)ix < (unsigned)vwin) vmask |= 1u << i;
+                const int iyc = iy < 0 ? 0 : (iy >= vhin ? vhin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= vwin ? vwin - 1 : ix);
+                po[i] = (unsigned)(iyc * g.win + ixc) * 4u * Du;
             }
         }
         const char* const ab = interior ? sb : ibase;
@@ -218,8 +265,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
     auto fetch_planes = [&](int s) {
         const int tp = t & (LS_NPX - 1);
         const int oy = oy_beg + LS_R * s + tp / LS_TW, ox = ox0 + tp % LS_TW;
-        const bool ok = oy < oy_end && ox < g.wout;
-        const int64_t q = (n * g.hout + (ok ? oy : oy_beg)) * (int64_t)g.wout + (ok ? ox : ox0);
+        const bool ok = oy < oy_end && ox < vwout;
+        const int64_t q = n * g.hout * (int64_t)g.wout + opix00 + ((int64_t)(ok ? oy : oy_beg) * g.wout + (ok ? ox : ox0)) * D;
         if (DXE) {
             pl0 = post_mul != nullptr ? post_mul[q] : 1.f;
         } else {
@@ -247,9 +294,9 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
             const int p = pr < 2 * LS_PW ? pr : 2 * LS_PW - 1;
             const int row = p / LS_PW, px = p - row * LS_PW;
             const int iy = iy_base + row, ix = ix0 + px;
-            const bool inside = (unsigned)iy < (unsigned)g.hin && (unsigned)ix < (unsigned)g.win;
-            const int iyc = iy < 0 ? 0 : (iy >= g.hin ? g.hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= g.win ? g.win - 1 : ix);
-            const unsigned q = (unsigned)(iyc * g.win + ixc) * 4u;
+            const bool inside = have_in && (unsigned)iy < (unsigned)vhin && (unsigned)ix < (unsigned)vwin;
+            const int iyc = iy < 0 ? 0 : (iy >= vhin ? vhin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= vwin ? vwin - 1 : ix);
+            const unsigned q = (unsigned)(iyc * g.win + ixc) * 4u * Du;
             const f32x4 v = *reinterpret_cast<const f32x4*>(ibase + opq(__umul24(q, (unsigned)C) + c0b));
             const float m = PRE ? *reinterpret_cast<const float*>(ipre + opq(q)) : 1.f;
             const f32x4 sv = stage(v, m, inside, isc, ish);
@@ -264,15 +311,15 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
 
     // this thread's output pixels: column tx, rows 4 th .. 4 th + 3 of the step
     const int tx = lane & 15, th = lane >> 4;
-    const bool xok = cok && ox0 + tx < g.wout;
-    const unsigned orow = (unsigned)g.wout * (unsigned)C * 4u;
-    const unsigned ocol = ((unsigned)tx * (unsigned)C + (unsigned)c0) * 4u;
-    const unsigned ocol_ld = ((unsigned)(ox0 + tx < g.wout ? tx : g.wout - 1 - ox0) * (unsigned)C) * 4u + c0b;   // clamped, for loads
+    const bool xok = cok && ox0 + tx < vwout;
+    const unsigned orow = (unsigned)g.wout * (unsigned)C * 4u * Du;
+    const unsigned ocol = ((unsigned)tx * Du * (unsigned)C + (unsigned)c0) * 4u;
+    const unsigned ocol_ld = ((unsigned)(ox0 + tx < vwout ? tx : vwout - 1 - ox0) * Du * (unsigned)C) * 4u + c0b;   // clamped, for loads
     const char* const rthr = reinterpret_cast<const char*>(lbuf) + ((4 * th) * LS_PW + tx) * LS_PIXB + cg * 16;
-    const int64_t opix0 = (n * g.hout + oy_beg) * (int64_t)g.wout + ox0;
+    const int64_t opix0 = n * g.hout * (int64_t)g.wout + opix00 + ((int64_t)oy_beg * g.wout + ox0) * D;
     char* ob = reinterpret_cast<char*>(out + opix0 * C);                       // running: first output pixel of the step
     const char* const yb = reinterpret_cast<const char*>(bb.y + opix0 * C);
-    const int64_t ob_step = (int64_t)LS_R * g.wout * C * 4;
+    const int64_t ob_step = (int64_t)LS_R * g.wout * C * 4 * D;
 
     f32x4 P = {0.f, 0.f, 0.f, 0.f};                    // K6b: thread-local pivot = its first output
     f32x2 va[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};   // K6b: s1.xy s1.zw s2.xy s2.zw | K6c: sum dz, sum dz*xhat
@@ -389,7 +436,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
             if ((int)cb * LS_CB + ch < C) {
                 float sum = 0.f;
                 for (int l = 0; l < 32; ++l) sum += mrg[(l * 8 + ch / 4) * 8 + which * 4 + ch % 4];
-                const int64_t prow = (n * chunks_y + cy) * strips_x + sx;
+                const int64_t prow = (nv * chunks_y + cy) * strips_x + sx;
                 bb.part[(prow * 2 + which) * C + (int)cb * LS_CB + ch] = sum;
             }
         }
@@ -426,7 +473,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
                     s2 += a2 + dp * (2.f * a1 + n_t * dp);
                     nn += n_t;
                 }
-                const int64_t prow = (n * chunks_y + cy) * strips_x + sx;       // one partial row per strip chunk
+                const int64_t prow = (nv * chunks_y + cy) * strips_x + sx;      // one partial row per strip chunk
                 float* sp = stats + prow * 4 * C + (int)cb * LS_CB + ch;
                 sp[0] = nn;
                 sp[C] = pv;
@@ -446,6 +493,22 @@ static inline bool dw_lean_ok(const DtGeom& g) {
     return LS_ENABLE && g.s == 1 && g.d == 1 && g.c < (1 << 24) && (int64_t)(LS_ROWS * (int64_t)g.win + 64) * 4 < (1ll << 24) &&
            (int64_t)(LS_ROWS * (int64_t)g.win + 64) * g.c * 4 < (1ll << 31) &&
            (int64_t)(LS_ROWS * (int64_t)g.wout + 64) * g.c * 4 < (1ll << 31);
+}
+// dilation by phases (PH): dilations 2 / 4 / 8 whose phase sub-images are at least half a strip wide; every offset of the d = 1
+// form times d stays inside the same 24 / 31-bit limits
+#ifndef LS_PHASED
+#define LS_PHASED 1              // A/B: 0 keeps dilations 2 / 4 / 8 on the round-3 ring kernels
+#endif
+// (a function of the OUTPUT grid only: the partial-row counts the callers size their buffers with -- tsii_dw_stat_rows /
+// tsii_dw_bwd_stat_rows -- do not see the input size; the input is at most 2 d larger per side)
+static inline bool dw_phased_dims_ok(int hout, int wout, int c, int s, int d) {
+    if (!(LS_PHASED && LS_ENABLE && s == 1 && (d == 2 || d == 4 || d == 8) && c % 4 == 0 && wout >= 8 * d && hout >= 4 * d)) return false;
+    const int64_t wmax = (int64_t)wout + 2 * d, hmax = (int64_t)hout + 2 * d;
+    return c < (1 << 24) && hmax * wmax * 4 < (1ll << 24) && hmax * wmax * c * 4 < (1ll << 32) &&
+           (LS_ROWS * wmax + 64) * c * 4 * d < (1ll << 31);
+}
+static inline bool dw_lean_phased_ok(const DtGeom& g) {
+    return dw_phased_dims_ok(g.hout, g.wout, g.c, g.s, g.d) && g.win <= g.wout + 2 * g.d && g.hin <= g.hout + 2 * g.d && g.pad_h >= 0 && g.pad_w >= 0;
 }
 
 }  // namespace tsii

@@ -766,6 +766,28 @@ static StripPlan plan_strip(int n, int hout, int wout, int c, int s, int d) {
 // row counts the callers size their buffers with (tsii_dw_stat_rows / tsii_dw_bwd_stat_rows)
 static inline unsigned strip_rows_per_image(const StripPlan& sp) { return sp.ok ? sp.chunks_y * sp.strips_x : 0u; }
 
+// The plan of a stride-1 layer's forward / dX strips over the OUTPUT grid [hout, wout]: dilations 2 / 4 / 8 run the lean kernel per
+// phase (dw_lean.h, PH) -- d^2 sub-images of every d-th row and column per image, planned as n d^2 images of ceil(h / d) x ceil(w / d)
+// pixels; `phases` = d^2 then, else 1.  rows per (real) image = phases * chunks_y * strips_x.
+struct FusedPlan {
+    StripPlan sp;
+    unsigned phases;
+};
+static FusedPlan plan_fwd_strips(int n, int hout, int wout, int c, int s, int d) {
+    FusedPlan fp;
+    if (dw_phased_dims_ok(hout, wout, c, s, d)) {
+        fp.phases = (unsigned)(d * d);
+        if ((int64_t)n * d * d < (1ll << 24)) {
+            fp.sp = plan_strip(n * d * d, cdiv(hout, d), cdiv(wout, d), c, 1, 1);
+            return fp;
+        }
+    }
+    fp.phases = 1u;
+    fp.sp = plan_strip(n, hout, wout, c, s, d);
+    return fp;
+}
+static inline unsigned fused_rows_per_image(const FusedPlan& fp) { return fp.phases * strip_rows_per_image(fp.sp); }
+
 // -> 0 launched, 1 not applicable (caller falls back to the direct kernel), <0 error
 static const DwBN kNoDwBN = {nullptr, nullptr, 1.f, 0.f};
 static const DwBnBwd kNoBnBwd = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
@@ -778,14 +800,15 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
                                DwBN ib = kNoDwBN, float* stats = nullptr, DwBnBwd bb = kNoBnBwd) {
     if (g.c % 4 != 0 || !aligned16(in) || !aligned16(out) || !aligned16(wT)) return 1;
     if (ib.sc != nullptr && (!aligned16(ib.sc) || !aligned16(ib.sh))) return 1;
-    const StripPlan sp = plan_strip(g.n, g.hout, g.wout, g.c, g.s, g.d);
+    const FusedPlan fp = plan_fwd_strips(g.n, g.hout, g.wout, g.c, g.s, g.d);
+    const StripPlan sp = fp.sp;
     const bool fused_any = ib.sc != nullptr || stats != nullptr || bb.y != nullptr;
     // small maps: the whole map of a channel block in LDS (any dilation; the fused forms where the strip plan defines the partial rows)
     if (dw_small_ok(g) && !(post_mul != nullptr && (denom != nullptr || keep != nullptr || bias != nullptr)) && (!fused_any || (sp.ok && dw_fused_ok(g.s, g.d))) &&
         !(fused_any && bb.y == nullptr && post_mul != nullptr)) {
         const bool dxe = denom == nullptr && keep == nullptr && bias == nullptr;
         if (bb.y == nullptr || dxe) {
-            const unsigned scb = (unsigned)cdiv(g.c, SM_CB), rpi = sp.ok ? strip_rows_per_image(sp) : 1u;
+            const unsigned scb = (unsigned)cdiv(g.c, SM_CB), rpi = sp.ok ? fused_rows_per_image(fp) : 1u;
             const dim3 sgrid((unsigned)g.n * scb);
 #define TSII_DW_SMALL(MODE, DXE) do { \
             if (pre != nullptr) hipLaunchKernelGGL((dw_small_kernel<MODE, DXE, true>), sgrid, dim3(SM_THREADS), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, scb, rpi, ib, stats, bb, out); \
@@ -799,11 +822,33 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
         }
     }
     if (!sp.ok) return 1;
-    const int64_t nblk = (int64_t)sp.strips_x * sp.chunks_y * sp.cblocks * g.n;
+    const int64_t nblk = (int64_t)sp.strips_x * sp.chunks_y * sp.cblocks * g.n * fp.phases;
+    if (nblk >= (1ll << 31)) return fp.phases > 1 ? -1 : 1;
     const dim3 grid((unsigned)nblk);
     const bool fused = ib.sc != nullptr || stats != nullptr || bb.y != nullptr;
     if (fused && !dw_fused_ok(g.s, g.d)) return 1;
     if (bb.y != nullptr && g.s != 1) return 1;
+    if (fp.phases > 1) {
+        // dilation by phases: the partial rows of the fused forms follow THIS plan (tsii_dw_stat_rows / tsii_dw_bwd_stat_rows), so a
+        // geometry the phased kernel cannot take is an error for them, not a fall-through to a kernel with another row layout
+        const bool takes = dw_lean_phased_ok(g) && !(post_mul != nullptr && (denom != nullptr || keep != nullptr || bias != nullptr));
+        const bool dxe = denom == nullptr && keep == nullptr && bias == nullptr;
+        if (!takes || (bb.y != nullptr && !dxe) || (fused && bb.y == nullptr && post_mul != nullptr)) {
+            TSII_REQUIRE(!fused, "depth-wise strips: this dilated geometry has no fused BatchNorm form (input more than 2 d larger than the output per side?)");
+            return 1;
+        }
+#define TSII_DW_LEAN_PH(MODE, DXE) do { \
+            if (pre != nullptr) hipLaunchKernelGGL((dw_lean_kernel<MODE, DXE, true, true>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, \
+                                                   sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out); \
+            else hipLaunchKernelGGL((dw_lean_kernel<MODE, DXE, false, true>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, \
+                                    sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out); } while (0)
+        if (bb.y != nullptr) TSII_DW_LEAN_PH(2, true);
+        else if (fused) TSII_DW_LEAN_PH(1, false);
+        else if (dxe) TSII_DW_LEAN_PH(0, true);
+        else TSII_DW_LEAN_PH(0, false);
+#undef TSII_DW_LEAN_PH
+        return check_launch("dw_lean_phased");
+    }
     if (dw_lean_ok(g) && !(post_mul != nullptr && (denom != nullptr || keep != nullptr || bias != nullptr))) {
         const bool dxe = denom == nullptr && keep == nullptr && bias == nullptr;
 #define TSII_DW_LEAN(MODE, DXE) do { \
@@ -1130,18 +1175,18 @@ extern "C" int tsii_dw_fwd(const float* x, const float* rmask, const float* w, c
 extern "C" int64_t tsii_dw_stat_rows(int n, int ho, int wo, int c, int kh, int kw, int sh, int sw, int dh, int dw) {
     if (n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || c % 4 != 0) return 0;
     if (!(kh == 3 && kw == 3 && sh == sw && dh == dw) || !dw_fused_ok(sh, dh)) return 0;
-    const StripPlan sp = plan_strip(n, ho, wo, c, sh, dh);
-    return (int64_t)n * strip_rows_per_image(sp);          // one partial row per strip chunk
+    const FusedPlan fp = plan_fwd_strips(n, ho, wo, c, sh, dh);
+    return (int64_t)n * fused_rows_per_image(fp);          // one partial row per strip chunk (of every phase)
 }
 
 // rows of the partials tsii_dw_bwd_dx_bn writes (0: that geometry has no fused form): strip chunks of the dX (= input) grid
 extern "C" int64_t tsii_dw_bwd_stat_rows(int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw) {
     if (n <= 0 || h <= 0 || wd <= 0 || c <= 0 || c % 4 != 0 || !(kh == 3 && kw == 3 && sh == sw && dh == dw)) return 0;
-    StripPlan sp;
-    if (sh == 1 && (dh == 1 || dh == 2 || dh == 4 || dh == 8)) sp = plan_strip(n, h, wd, c, 1, dh);
-    else if (sh == 2 && dh == 1 && ph == 1 && pw == 1) sp = plan_strip(n, h, wd, c, 1, 1);
+    FusedPlan fp;
+    if (sh == 1 && (dh == 1 || dh == 2 || dh == 4 || dh == 8)) fp = plan_fwd_strips(n, h, wd, c, 1, dh);
+    else if (sh == 2 && dh == 1 && ph == 1 && pw == 1) fp = plan_fwd_strips(n, h, wd, c, 1, 1);
     else return 0;
-    return (int64_t)n * strip_rows_per_image(sp);
+    return (int64_t)n * fused_rows_per_image(fp);
 }
 
 extern "C" int tsii_dw_fwd_bn(const float* x, const float* rmask, const float* w, const float* bias,

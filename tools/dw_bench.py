@@ -14,11 +14,20 @@ def timeit(fn, it=5):
     for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it
-for (n, h, w, c, s, d) in [(32, 256, 256, 384, 1, 1), (32, 128, 128, 768, 1, 1), (32, 64, 64, 1024, 1, 1), (32, 256, 256, 256, 2, 1)]:
+# default: ImageFill's largest layers (mask planes); "cfg3": TextSegament 512^2 bs 64's dilated layers (no mask planes); "dil": ImageFill's
+# dilated encoder levels
+SETS = {"": [(32, 256, 256, 384, 1, 1), (32, 128, 128, 768, 1, 1), (32, 64, 64, 1024, 1, 1), (32, 256, 256, 256, 2, 1)],
+        "cfg3": [(64, 64, 64, 1920, 1, 8), (64, 64, 64, 1152, 1, 8), (64, 64, 64, 1152, 1, 4), (64, 64, 64, 768, 1, 4), (64, 64, 64, 768, 1, 2), (64, 128, 128, 384, 1, 2), (64, 64, 64, 384, 1, 1)],
+        "dil": [(32, 64, 64, 1024, 1, 2), (32, 64, 64, 1024, 1, 4), (32, 64, 64, 1024, 1, 8)]}
+WHICH = sys.argv[1] if len(sys.argv) > 1 else ""
+MASKED = WHICH != "cfg3"
+for (n, h, w, c, s, d) in SETS[WHICH]:
     ho, wo = (h + 2 * d - 2 * d - 1) // s + 1, (w + 2 * d - 2 * d - 1) // s + 1
     x = torch.randn(n, h, w, c, device=dev); wt = torch.randn(c, 1, 3, 3, device=dev)
-    m = (torch.rand(n, h, w, device=dev) > 0.05).float()
-    den = torch.full((n, ho, wo), 9.0 * c, device=dev); keep = torch.ones(n, ho, wo, device=dev); inv = 1 / den
+    m = (torch.rand(n, h, w, device=dev) > 0.05).float() if MASKED else None
+    den = torch.full((n, ho, wo), 9.0 * c, device=dev) if MASKED else None
+    keep = torch.ones(n, ho, wo, device=dev) if MASKED else None
+    inv = 1 / den if MASKED else None
     y = torch.empty(n, ho, wo, c, device=dev); dy = torch.randn(n, ho, wo, c, device=dev); dx = torch.empty_like(x)
     ws = torch.empty(c * 9 + 16, device=dev)
     g = (3, 3, s, s, d, d, d, d)

@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--model", default="ImageFill")
+    ap.add_argument("--pixel-shuffle", action="store_true")
+    ap.add_argument("--storage", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--rows", type=int, default=70)
     ap.add_argument("--forward", action="store_true", help="time the forward pass only (train-mode BatchNorm + L1 loss under no_grad: bench.py's forward_only leg)")
     args = ap.parse_args()
     import text_segmentation_image_inpainting_amd as T
@@ -29,10 +32,29 @@ def main():
     from text_segmentation_image_inpainting_amd.train_step import FlatSGDTrainer
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    model = getattr(T, args.model)().to(dev).train()
-    tr = FlatSGDTrainer(model, lr=1e-3)
-    c, m, cl = make_batch(args.batch, args.size)
-    c, m, cl = c.to(dev), m.to(dev), to_nhwc(cl.to(dev))
+    seg = args.model in ("TextSegament", "XceptionTextSegment")
+    if seg:
+        from text_segmentation_image_inpainting_amd.synthetic import make_seg_batch
+        T.set_activation_storage(args.storage)
+        net = getattr(T, args.model)(**({"pixel_shuffle_head": True} if (args.pixel_shuffle and args.model == "TextSegament") else {}))
+
+        class SegStep(torch.nn.Module):
+            def __init__(self, net):
+                super().__init__()
+                self.net = net
+
+            def forward(self, a):
+                return self.net(a[0])
+        model = SegStep(net).to(dev).train()
+        focal = T.BinaryFocalLoss(0, 1, 2)
+        tr = FlatSGDTrainer(model, lr=1e-3, loss_fn=lambda out, tgt: focal(out, tgt))
+        c, cl = (v.to(dev) for v in make_seg_batch(args.batch, args.size, seed0=0))
+        m = None
+    else:
+        model = getattr(T, args.model)().to(dev).train()
+        tr = FlatSGDTrainer(model, lr=1e-3)
+        c, m, cl = make_batch(args.batch, args.size)
+        c, m, cl = c.to(dev), m.to(dev), to_nhwc(cl.to(dev))
     for _ in range(2):
         tr.step(c, m, cl)
     torch.cuda.synchronize()
@@ -62,7 +84,7 @@ def main():
     for name, ms in by_name.most_common():
         print(f"  {name:28s} {ms:8.2f} ms")
     print("--- per shape ---")
-    for (name, a), (cnt, ms) in rows[:(200 if args.forward else 70)]:
+    for (name, a), (cnt, ms) in rows[:(200 if args.forward else args.rows)]:
         extra = ""
         if name in ("tsii_pw_fwd", "tsii_pw_bwd_dx", "tsii_pw_bwd_dw"):
             mm, p, q = a[0], a[1], a[2]
