@@ -582,17 +582,21 @@ def _strip_entry_points(L, n, h, wd, c, masked, bias, act, d=1, p=None):
     (1, 150, 19, 4, 2, 2, False, False, 2),     # many steps per chunk (both LDS buffers in turn) at target 1
 ])
 @pytest.mark.parametrize("target", [1536, 1])
-def test_depthwise_dilated_strips_by_phase(emu, n, h, wd, c, d, p, masked, bias, act, target):
+@pytest.mark.parametrize("phased", [1, 0])
+def test_depthwise_dilated_strips_by_phase(emu, n, h, wd, c, d, p, masked, bias, act, target, phased):
     """Dilation 2 / 4 / 8 on the lean strip kernel PER PHASE (csrc/dw_lean.h, PH): every entry point of the d = 1 test at a dilated
     geometry -- forward, BatchNorm on load + statistics partials (all rows of tsii_dw_stat_rows written, counts adding up), dX, dX +
-    K6c -- against float64; geometries too narrow for the phased form (19 columns at d = 2 ... ) take the round-3 ring kernels and
-    must give the same answers."""
+    K6c -- against float64.  The stock library keeps these geometries on the round-3 ring kernels (measured, dw_lean.h: the phased
+    form only wins without mask planes and below dilation 8); phased = 1 selects it through an emulator-only switch, phased = 0 is
+    the product's path at the same geometries."""
     L = emu
     L.tsii_emu_set_strip_target(target)
+    L.tsii_emu_set_ls_phased(phased)
     try:
         _strip_entry_points(L, n, h, wd, c, masked, bias, act, d=d, p=p)
     finally:
         L.tsii_emu_set_strip_target(0)
+        L.tsii_emu_set_ls_phased(0)
 
 
 @pytest.mark.parametrize("n,h,wd,c,masked,bias,act", [

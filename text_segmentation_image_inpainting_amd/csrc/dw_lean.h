@@ -496,8 +496,21 @@ static inline bool dw_lean_ok(const DtGeom& g) {
 }
 // dilation by phases (PH): dilations 2 / 4 / 8 whose phase sub-images are at least half a strip wide; every offset of the d = 1
 // form times d stays inside the same 24 / 31-bit limits
+// Measured (round 6, tools/dw_bench.py cfg3 / dil, profiles/r06e_dw_bench_*.log; phased vs the ring kernels): without mask planes
+// dilation 2 forward + K6b 0.321 vs 0.435 ms (64^2 x 768 x 64) and 0.564 vs 0.809 ms (128^2 x 384), dilation 4 0.596 vs 0.681 ms,
+// dX + K6c 6-11 % faster -- but dilation 8 on 64^2 maps (8 x 8-pixel phase images: one marching step per block, nothing to
+// pipeline) 2.50 vs 2.20 ms, and with mask planes (ImageFill's dilated levels: per-pixel planes read d pixels apart) 10-30 % SLOWER.
+// The partial-row layout of the fused forms has to follow from the output grid alone (the row-count entry points see neither the
+// mask planes nor the dilation's effect), so the form cannot be chosen per call site: OFF in the stock library (TextSegament's step
+// as a whole: 253.4 vs 254.1 ms).  -DLS_PHASED=1 builds it (tools/variants); the CPU suite runs it through an emulator-only switch.
+#ifdef TSII_HIP_EMU
+static int g_ls_phased = 0;
+extern "C" void tsii_emu_set_ls_phased(int v) { g_ls_phased = v; }
+#define LS_PHASED g_ls_phased
+#else
 #ifndef LS_PHASED
-#define LS_PHASED 1              // A/B: 0 keeps dilations 2 / 4 / 8 on the round-3 ring kernels
+#define LS_PHASED 0
+#endif
 #endif
 // (a function of the OUTPUT grid only: the partial-row counts the callers size their buffers with -- tsii_dw_stat_rows /
 // tsii_dw_bwd_stat_rows -- do not see the input size; the input is at most 2 d larger per side)
