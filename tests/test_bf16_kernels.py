@@ -364,9 +364,25 @@ def dw_dw_ref(dy, a, s, p, d):
 @pytest.mark.parametrize("n,h,wd,c,s,d,act,bias", [
     (2, 20, 19, 64, 1, 1, 2, False), (1, 33, 17, 24, 1, 2, None, True), (2, 24, 40, 128, 1, 4, 2, False),
     (2, 22, 21, 40, 2, 1, 2, False), (1, 16, 16, 8, 2, 1, None, True), (1, 9, 300, 16, 1, 1, 1, False),
-    (3, 70, 6, 256, 1, 2, 3, False)])
-def test_depthwise_forward_dx_dw(emu, n, h, wd, c, s, d, act, bias):
+    (3, 70, 6, 256, 1, 2, 3, False), (1, 40, 36, 32, 1, 4, 3, True), (2, 21, 37, 16, 1, 2, 1, True)])
+@pytest.mark.parametrize("lean", [1, 0], ids=["strip", "column"])
+def test_depthwise_forward_dx_dw(emu, n, h, wd, c, s, d, act, bias, lean):
+    """lean = 0: the marching-column kernels of bf16_dw.hip -- the product's path; lean = 1: the stride-1 layers with dilation 1 / 2 / 4
+    on the LDS-slab strip kernel in its bf16-storage form (csrc/dw_lean.h H16, dilation by phases), which measured slower on the chip
+    (csrc/dwconv.hip) and is kept as a tested A/B form behind an emulator-only switch.  Same contract, same tolerances."""
     L = emu
+    if hasattr(L, "tsii_emu_set_hdw_lean"):
+        L.tsii_emu_set_hdw_lean(lean)
+    elif lean == 1:
+        pytest.skip("the stock library has one path per geometry (the switch exists in the emulator build only)")
+    try:
+        _depthwise_forward_dx_dw(L, n, h, wd, c, s, d, act, bias)
+    finally:
+        if hasattr(L, "tsii_emu_set_hdw_lean"):
+            L.tsii_emu_set_hdw_lean(0)
+
+
+def _depthwise_forward_dx_dw(L, n, h, wd, c, s, d, act, bias):
     p = d
     geom = (3, 3, s, s, p, p, d, d)
     ho = (h + 2 * p - 2 * d - 1) // s + 1

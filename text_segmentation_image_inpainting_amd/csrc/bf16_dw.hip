@@ -17,6 +17,7 @@
 //   hdw_dx_s2_kernel  dX of the two stride-2 layers (gather form)
 //   havgpool_kernel   k x k / stride 1 / count_include_pad average pool (its own adjoint): ring of k horizontal sums
 #include "bf16_common.h"
+#include "dw_lean_api.h"
 
 namespace tsii {
 
@@ -596,6 +597,7 @@ using namespace tsii;
 
 extern "C" int64_t tsii_bf16_dw_stat_rows(int n, int ho, int wo, int c, int kh, int kw, int sh, int sw, int dh, int dw) {
     if (n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || c % 8 != 0 || kh != 3 || kw != 3 || sh != sw || (sh != 1 && sh != 2) || dh != dw || dh < 1 || (sh == 2 && dh != 1)) return 0;
+    if (hdw_lean_ok(ho, wo, c, sh, dh)) return hdw_lean_rows(n, ho, wo, c, sh, dh);        // the lean strip kernel's layout (dw_lean_api.h)
     return hdw_rows(hdw_plan(n, 1, 1, c, ho, wo, sh, 0, dh, 0, 1));
 }
 
@@ -611,6 +613,12 @@ extern "C" int tsii_bf16_dw_fwd(const uint16_t* x, const float* w, const float* 
     if (in_scale != nullptr) {
         TSII_REQUIRE(in_shift != nullptr, "bf16_dw_fwd: in_scale / in_shift go together");
         TSII_REQUIRE(make_in_bn(in_scale, in_shift, in_act, in_slope, &ib) == 0, "bf16_dw_fwd: activation %d has no load-time form", in_act);
+    }
+    if (hdw_lean_ok(ho, wo, c, sh, dh)) {      // stride 1, dilation 1 / 2 / 4: the LDS-slab strip kernel (round 6)
+        const int rc = launch_hdw_lean(x, w, bias, n, h, wd, c, dh, ph, pw, ho, wo, 0, ib.sc, ib.sh, ib.neg, ib.hi, stat_part,
+                                       nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 1.f, 0.f, nullptr, y, st);
+        if (rc <= 0) return rc;
+        TSII_REQUIRE(stat_part == nullptr, "bf16_dw_fwd: this geometry is outside the strip kernel's limits but its partial rows were sized for it");
     }
     const HDwPlan g = hdw_plan(n, h, wd, c, ho, wo, sh, ph, dh, 0, 1);
     const dim3 grid((unsigned)hdw_blocks(g));
@@ -629,6 +637,7 @@ extern "C" int tsii_bf16_dw_fwd(const uint16_t* x, const float* w, const float* 
 
 extern "C" int64_t tsii_bf16_dw_bwd_stat_rows(int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw) {
     if (n <= 0 || h <= 0 || wd <= 0 || c <= 0 || c % 8 != 0 || kh != 3 || kw != 3 || sh != 1 || sw != 1 || dh != dw || dh < 1 || ph != pw) return 0;
+    if (hdw_lean_ok(h, wd, c, 1, dh)) return hdw_lean_rows(n, h, wd, c, 1, dh);
     return hdw_rows(hdw_plan(n, 1, 1, c, h, wd, 1, 0, dh, 1, 2));
 }
 
@@ -650,6 +659,19 @@ extern "C" int tsii_bf16_dw_bwd_dx(const uint16_t* dy, const float* w, int n, in
         return check_launch("bf16_dw_bwd_dx (stride 2)");
     }
     // stride 1: the adjoint is the same stencil with flipped taps and padding 2 d - p over dy [n, ho, wo, c] -> dx [n, h, wd, c]
+    if (hdw_lean_ok(h, wd, c, 1, dh) && 2 * dh - ph >= 0) {
+        float neg = 1.f, hi = 0.f;
+        if (bn_y != nullptr) {
+            TSII_REQUIRE(bn_mean && bn_var && bn_gamma && bn_beta && aligned16(bn_y), "bf16_dw_bwd_dx: BatchNorm parameters missing");
+            InBN tmp;
+            TSII_REQUIRE(make_in_bn(bn_mean, bn_var, bn_act, bn_slope, &tmp) == 0, "bf16_dw_bwd_dx: activation %d has no load-time form", bn_act);
+            neg = tmp.neg; hi = tmp.hi;
+        }
+        const int rc = launch_hdw_lean(dy, w, nullptr, n, ho, wo, c, dh, 2 * dh - ph, 2 * dw - pw, h, wd, 1, nullptr, nullptr, 1.f, __builtin_huge_valf(), nullptr,
+                                       bn_y, bn_mean, bn_var, bn_gamma, bn_beta, bn_eps, neg, hi, bwd_part, dx, st);
+        if (rc <= 0) return rc;
+        TSII_REQUIRE(bn_y == nullptr, "bf16_dw_bwd_dx: this geometry is outside the strip kernel's limits but its partial rows were sized for it");
+    }
     const HDwPlan g = hdw_plan(n, ho, wo, c, h, wd, 1, 2 * dh - ph, dh, 1, bn_y != nullptr ? 2 : 1);
     const dim3 grid((unsigned)hdw_blocks(g));
     InBN ib = {nullptr, nullptr, 1.f, __builtin_huge_valf()};

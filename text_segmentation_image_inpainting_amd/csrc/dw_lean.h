@@ -63,13 +63,19 @@ __device__ __forceinline__ f32x4 cat4(f32x2 a, f32x2 b) { return f32x4{a.x, a.y,
 // sub-pixel of the 3x3 window: a dilation-8 layer reads 18 / 16 of its input like a dilation-1 layer, where the ring of 8 + 2 d
 // rows x (16 + 2 d) columns of the round-3 strip kernel read 2x (64^2 x 1920 at d = 8: 1.7 TB/s).  The grid carries image x phase
 // as its slowest index (nv = n d^2 + phase: the partial-row layout of the fused forms follows it, plan_strip_phased).
-template <int MODE, bool DXE, bool PRE, bool PH = false>
+// H16 (round 6): bf16 ACTIVATION STORAGE on the same kernel (bf16_dw.hip's contract: read bf16, compute in fp32, ONE rounding per
+// stored value, statistics over the rounded values): `in`, `out` and `bb.y` point at bf16 tensors, a thread moves its 4 channels as
+// 8 bytes, the staged slab in LDS is fp32 (an activation the producer's BatchNorm forms on load is rounded to bf16 first -- where it
+// would have been stored), `wT` is the reference layout [C][9] (the bf16 entry points carry no workspace for a transposed copy).
+template <int MODE, bool DXE, bool PRE, bool PH = false, bool H16 = false>
 __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_kernel(
     const float* __restrict__ in, const float* __restrict__ pre, const float* __restrict__ wT, const float* __restrict__ bias,
     const float* __restrict__ denom, const float* __restrict__ keep, const float* __restrict__ post_mul, DtGeom g, int chunk_rows,
     unsigned strips_x, unsigned chunks_y, unsigned cblocks, DwBN ib, float* __restrict__ stats, DwBnBwd bb,
     float* __restrict__ out) {
     constexpr bool FUSED = (MODE == 1), BNB = (MODE == 2);
+    constexpr unsigned ES = H16 ? 2u : 4u;                   // bytes per activation element
+    static_assert(!H16 || !PRE, "bf16 activation storage carries no mask planes");
     static_assert(!BNB || DXE, "K6c rides on the dX epilogue");
     static_assert(!FUSED || !DXE, "K6b rides on the forward epilogue");
     __shared__ __attribute__((aligned(16))) float lbuf[2 * LS_BUFB / 4];
@@ -153,7 +159,11 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
     for (int k = 0; k < 9; ++k) w[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (cok) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const f32x4*>(wT + (g.flip ? 8 - k : k) * C + c0);
+        for (int k = 0; k < 9; ++k) {
+            const int kk = g.flip ? 8 - k : k;
+            if (H16) w[k] = f32x4{wT[(c0 + 0) * 9 + kk], wT[(c0 + 1) * 9 + kk], wT[(c0 + 2) * 9 + kk], wT[(c0 + 3) * 9 + kk]};
+            else w[k] = *reinterpret_cast<const f32x4*>(wT + kk * C + c0);
+        }
     }
 
     // ---- slab staging: 8 rows x 18 pixels per step; slab pixel p = lane + 32 i of thread t sits at byte (t + 256 i) * 16 ----
@@ -173,22 +183,41 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
         pxpk |= (unsigned)px << (5 * i);
     }
     const bool item4 = lane < LS_R * LS_PW - 128;             // item 4 exists for the first 16 pixel lanes only
-    const unsigned c0b = (unsigned)(cok ? c0 : C - 4) * 4u;   // channel offset for loads (clamped: the channel tail of the last block)
+    const unsigned c0b = (unsigned)(cok ? c0 : C - 4) * ES;   // channel offset for loads (clamped: the channel tail of the last block)
     // Offsets pass through an opaque copy right before their use: the zero-extension then sits next to the access and hipcc
     // selects the `global_load v, v_off, s[base]` form instead of 64-bit vector address pairs
     auto opq = [](unsigned o) { TSII_OPAQUE_U32(o); return o; };
+    // 4 channels of an activation tensor at byte address p: 16 bytes of fp32, or 8 bytes of bf16 widened (exact)
+    auto ld4 = [](const char* p) {
+        if constexpr (H16) {
+            const unsigned long long u = *reinterpret_cast<const unsigned long long*>(p);
+            const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+            return f32x4{__builtin_bit_cast(float, lo << 16), __builtin_bit_cast(float, lo & 0xffff0000u),
+                         __builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+        } else {
+            return *reinterpret_cast<const f32x4*>(p);
+        }
+    };
+    // byte offset of 4 channels from a plane byte offset po (= 4 x pixel index): po x C elements of ES bytes
+    auto aoff = [&](unsigned po) { return H16 ? (__umul24(po, (unsigned)C) >> 1) : __umul24(po, (unsigned)C); };
+    // round-to-nearest-even through bf16 (v_cvt_pk_bf16_f32), as a stored value would be
+    auto rnd2 = [](f32x2 v) {
+        typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+        const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b16x2));
+        return f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+    };
 
     f32x4 pf[LS_PF];
     float pm[LS_PF];
     unsigned vmask = 0;                                        // edge steps: bit i = item i lies inside the image
     const int64_t img_pix = n * g.hin * (int64_t)g.win + ipix0;
-    const char* const ibase = reinterpret_cast<const char*>(in + img_pix * C);      // pixel (0, 0) of this image (of its phase)
+    const char* const ibase = reinterpret_cast<const char*>(in) + img_pix * C * ES;      // pixel (0, 0) of this image (of its phase)
     const char* const ipre = reinterpret_cast<const char*>(pre + img_pix);
     // running pointers to the first pixel of the NEXT slab to fetch (may point outside the tensor; only used by interior steps)
     int iyb = iy_base + 2;
-    const char* sb = reinterpret_cast<const char*>(in + (img_pix + ((int64_t)iyb * g.win + ix0) * D) * C);
+    const char* sb = reinterpret_cast<const char*>(in) + (img_pix + ((int64_t)iyb * g.win + ix0) * D) * C * ES;
     const char* pb = reinterpret_cast<const char*>(pre + (img_pix + ((int64_t)iyb * g.win + ix0) * D));
-    const int64_t sb_step = (int64_t)LS_R * g.win * C * 4 * D, pb_step = (int64_t)LS_R * g.win * 4 * D;
+    const int64_t sb_step = (int64_t)LS_R * g.win * C * ES * D, pb_step = (int64_t)LS_R * g.win * 4 * D;
     auto fetch = [&]() {                                      // global -> registers, slab rows iyb .. iyb + 7
         const bool interior = col_interior && iyb >= 0 && iyb + LS_R <= vhin;
         unsigned po[LS_PF];
@@ -209,8 +238,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
         const char* const mb = interior ? pb : ipre;
 #pragma unroll
         for (int i = 0; i < LS_PF; ++i) {
-            pf[i] = LS_NT_LOAD ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ab + opq(__umul24(po[i], (unsigned)C) + c0b)))
-                               : *reinterpret_cast<const f32x4*>(ab + opq(__umul24(po[i], (unsigned)C) + c0b));
+            pf[i] = (LS_NT_LOAD && !H16) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ab + opq(aoff(po[i]) + c0b)))
+                                         : ld4(ab + opq(aoff(po[i]) + c0b));
             pm[i] = PRE ? *reinterpret_cast<const float*>(mb + opq(po[i])) : 1.f;
         }
         iyb += LS_R; sb += sb_step; pb += pb_step;
@@ -224,6 +253,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
             f32x2 z0 = fma2(v.xy, isc.xy, ish.xy), z1 = fma2(v.zw, isc.zw, ish.zw);
             z0 = max2(z0, z0 * bn_neg); z1 = max2(z1, z1 * bn_neg);
             if (hi_finite) { z0 = min2(z0, f32x2{ib.hi, ib.hi}); z1 = min2(z1, f32x2{ib.hi, ib.hi}); }
+            if (H16 && ib.sc != nullptr) { z0 = rnd2(z0); z1 = rnd2(z1); }      // the virtual activation is a bf16 tensor
             v = cat4(z0, z1);
         }
         v *= m;
@@ -297,7 +327,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
             const bool inside = have_in && (unsigned)iy < (unsigned)vhin && (unsigned)ix < (unsigned)vwin;
             const int iyc = iy < 0 ? 0 : (iy >= vhin ? vhin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= vwin ? vwin - 1 : ix);
             const unsigned q = (unsigned)(iyc * g.win + ixc) * 4u * Du;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ibase + opq(__umul24(q, (unsigned)C) + c0b));
+            const f32x4 v = ld4(ibase + opq(aoff(q) + c0b));
             const float m = PRE ? *reinterpret_cast<const float*>(ipre + opq(q)) : 1.f;
             const f32x4 sv = stage(v, m, inside, isc, ish);
             if (pr < 2 * LS_PW) *reinterpret_cast<f32x4*>(lthr + 256 * i * 16) = sv;
@@ -312,14 +342,14 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
     // this thread's output pixels: column tx, rows 4 th .. 4 th + 3 of the step
     const int tx = lane & 15, th = lane >> 4;
     const bool xok = cok && ox0 + tx < vwout;
-    const unsigned orow = (unsigned)g.wout * (unsigned)C * 4u * Du;
-    const unsigned ocol = ((unsigned)tx * Du * (unsigned)C + (unsigned)c0) * 4u;
-    const unsigned ocol_ld = ((unsigned)(ox0 + tx < vwout ? tx : vwout - 1 - ox0) * Du * (unsigned)C) * 4u + c0b;   // clamped, for loads
+    const unsigned orow = (unsigned)g.wout * (unsigned)C * ES * Du;
+    const unsigned ocol = ((unsigned)tx * Du * (unsigned)C + (unsigned)c0) * ES;
+    const unsigned ocol_ld = ((unsigned)(ox0 + tx < vwout ? tx : vwout - 1 - ox0) * Du * (unsigned)C) * ES + c0b;   // clamped, for loads
     const char* const rthr = reinterpret_cast<const char*>(lbuf) + ((4 * th) * LS_PW + tx) * LS_PIXB + cg * 16;
     const int64_t opix0 = n * g.hout * (int64_t)g.wout + opix00 + ((int64_t)oy_beg * g.wout + ox0) * D;
-    char* ob = reinterpret_cast<char*>(out + opix0 * C);                       // running: first output pixel of the step
-    const char* const yb = reinterpret_cast<const char*>(bb.y + opix0 * C);
-    const int64_t ob_step = (int64_t)LS_R * g.wout * C * 4 * D;
+    char* ob = reinterpret_cast<char*>(out) + opix0 * C * ES;                  // running: first output pixel of the step
+    const char* const yb = reinterpret_cast<const char*>(bb.y) + opix0 * C * ES;
+    const int64_t ob_step = (int64_t)LS_R * g.wout * C * ES * D;
 
     f32x4 P = {0.f, 0.f, 0.f, 0.f};                    // K6b: thread-local pivot = its first output
     f32x2 va[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};   // K6b: s1.xy s1.zw s2.xy s2.zw | K6c: sum dz, sum dz*xhat
@@ -333,7 +363,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int ry = 4 * th + k < rows_left ? 4 * th + k : rows_left - 1;
-            yv[k] = *reinterpret_cast<const f32x4*>(ybs + opq((unsigned)ry * orow + ocol_ld));
+            yv[k] = ld4(ybs + opq((unsigned)ry * orow + ocol_ld));
         }
     };
     if (BNB) fetch_y(0);
@@ -384,8 +414,18 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
                 a0 += bq.xy; a1 += bq.zw;
                 if (pq.y == 0.f) { a0 = f32x2{0.f, 0.f}; a1 = a0; }
             }
+            if (H16) { a0 = rnd2(a0); a1 = rnd2(a1); }        // the stored value: statistics / K6c reductions see what memory holds
             a[k][0] = a0; a[k][1] = a1;
             if (xok && 4 * th + k < rows_left) {
+                if constexpr (H16) {
+                    // two dwords of four bf16: the rounded values are exact in their high halves.  (Scalars first: __builtin_bit_cast
+                    // of a vector ELEMENT expression reads element 0 with this clang.)
+                    const float e0 = a0.x, e1 = a0.y, e2 = a1.x, e3 = a1.y;
+                    const unsigned d0 = (__builtin_bit_cast(unsigned, e0) >> 16) | (__builtin_bit_cast(unsigned, e1) & 0xffff0000u);
+                    const unsigned d1 = (__builtin_bit_cast(unsigned, e2) >> 16) | (__builtin_bit_cast(unsigned, e3) & 0xffff0000u);
+                    const unsigned long long pk = (unsigned long long)d0 | ((unsigned long long)d1 << 32);
+                    __builtin_nontemporal_store(pk, reinterpret_cast<unsigned long long*>(ob + opq((unsigned)(4 * th + k) * orow + ocol)));
+                } else
                 if (LS_NT_STORE) __builtin_nontemporal_store(cat4(a0, a1), reinterpret_cast<f32x4*>(ob + opq((unsigned)(4 * th + k) * orow + ocol)));
                 else *reinterpret_cast<f32x4*>(ob + opq((unsigned)(4 * th + k) * orow + ocol)) = cat4(a0, a1);
                 if (FUSED) {

@@ -7,6 +7,7 @@
 // zeroing (:72) are fused, so x is read once (taps re-hit L1/L2) and y is written once.
 // The valid count comes from K1 (mask.hip) as the `denom`/`keep`/`inv` planes.
 #include "tsii_common.h"
+#include "dw_lean_api.h"
 
 #include <stdlib.h>
 
@@ -893,6 +894,72 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
     else hipLaunchKernelGGL((dw_strip_kernel<1, 1, 0>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
                             sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out);
     return check_launch("dw_strip");
+}
+
+// ---- bf16 activation storage on the lean strip kernel (dw_lean_api.h; round 6) -----------------------------------------------
+// The marching-column kernels of bf16_dw.hip request one row ahead at two waves per SIMD (231 VGPRs in the fused forms) and apply the
+// producer's BatchNorm once per THREAD that loads an element (2-3x per element): 3.3 TB/s fused.  The lean kernel stages a slab
+// once, applies the transform once per element and keeps a slab in flight across a whole step at three waves per SIMD -- and
+// MEASURED SLOWER (round 6, tools/bf16_bench.py, profiles/r06f_bf16_bench_dw_*.log; 8 x 128^2 x 512, strip vs column kernel):
+// forward + K6b 87.5 vs 81.4 us, plain forward 54.9 vs 49.8, dX + K6c 106.0 vs 110.4; 8 x 512^2 x 64 plain 115.6 vs 89.3; cfg 5's
+// step 63.1 vs 60.4 ms.  The strip kernel is bound by its ELEMENT rate (LDS traffic and issue slots per element are those of the
+// fp32 form, ~1.5e12 elements/s), which 4 bytes per element hide behind HBM and 2 bytes do not; its 64-byte pixel segments (4
+// channels x 2 bytes per thread) also coalesce worse than the column kernels' 16-byte octets.  OFF in the stock library; the CPU
+// suite keeps the form tested through an emulator-only switch.
+#ifdef TSII_HIP_EMU
+static int g_hdw_lean = 0;       // TEST-ONLY: 1 = the strip form, 0 = the marching-column kernels (the CPU suite runs both)
+extern "C" void tsii_emu_set_hdw_lean(int v) { g_hdw_lean = v; }
+#define HDW_LEAN g_hdw_lean
+#else
+#ifndef HDW_LEAN
+#define HDW_LEAN 0               // A/B (tools/variants): 1 puts bf16 storage's stride-1 depth-wise layers on the strip kernel
+#endif
+#endif
+bool hdw_lean_ok(int hout, int wout, int c, int s, int d) {
+    if (!HDW_LEAN || !LS_ENABLE || s != 1 || c % 8 != 0 || hout < 1 || wout < 1) return false;
+    if (d == 1) {
+        const int64_t wmax = (int64_t)wout + 2, hmax = (int64_t)hout + 2;
+        return c < (1 << 24) && hmax * wmax * 4 < (1ll << 24) && hmax * wmax * c * 4 < (1ll << 32) && (LS_ROWS * wmax + 64) * c * 4 < (1ll << 31);
+    }
+    if (!(d == 2 || d == 4) || wout < 8 * d || hout < 4 * d) return false;
+    const int64_t wmax = (int64_t)wout + 2 * d, hmax = (int64_t)hout + 2 * d;
+    return c < (1 << 24) && hmax * wmax * 4 < (1ll << 24) && hmax * wmax * c * 4 < (1ll << 32) && (LS_ROWS * wmax + 64) * c * 4 * d < (1ll << 31);
+}
+static FusedPlan hdw_lean_plan(int n, int hout, int wout, int c, int d) {
+    FusedPlan fp;
+    fp.phases = (unsigned)(d * d);
+    fp.sp = plan_strip(n * d * d, cdiv(hout, d), cdiv(wout, d), c, 1, 1);
+    return fp;
+}
+int64_t hdw_lean_rows(int n, int hout, int wout, int c, int s, int d) {
+    if (!hdw_lean_ok(hout, wout, c, s, d) || (int64_t)n * d * d >= (1ll << 24)) return 0;
+    const FusedPlan fp = hdw_lean_plan(n, hout, wout, c, d);
+    return fp.sp.ok ? (int64_t)n * fused_rows_per_image(fp) : 0;
+}
+int launch_hdw_lean(const void* in, const float* w, const float* bias, int n, int hin, int win, int c, int d, int pad_h, int pad_w,
+                    int hout, int wout, int flip, const float* in_sc, const float* in_sh, float in_neg, float in_hi, float* stats,
+                    const void* bn_y, const float* bn_mean, const float* bn_var, const float* bn_gamma, const float* bn_beta,
+                    float bn_eps, float bn_neg, float bn_hi, float* bn_part, void* out, hipStream_t st) {
+    if (hdw_lean_rows(n, hout, wout, c, 1, d) <= 0) return 1;
+    if (win > wout + 2 * d || hin > hout + 2 * d || pad_h < 0 || pad_w < 0) return 1;
+    DtGeom g = {n, hin, win, c, 1, d, pad_h, pad_w, hout, wout, flip};
+    const FusedPlan fp = hdw_lean_plan(n, hout, wout, c, d);
+    const StripPlan sp = fp.sp;
+    const int64_t nblk = (int64_t)sp.strips_x * sp.chunks_y * sp.cblocks * n * fp.phases;
+    if (nblk >= (1ll << 31)) return 1;
+    const dim3 grid((unsigned)nblk);
+    const DwBN ib = {in_sc, in_sh, in_neg, in_hi};
+    const DwBnBwd bb = {reinterpret_cast<const float*>(bn_y), bn_mean, bn_var, bn_gamma, bn_beta, bn_eps, bn_neg, bn_hi, bn_part};
+    const float* inf = reinterpret_cast<const float*>(in);
+    float* outf = reinterpret_cast<float*>(out);
+    const float* none = nullptr;
+#define TSII_HDW_LEAN(MODE, DXE, PHV) hipLaunchKernelGGL((dw_lean_kernel<MODE, DXE, false, PHV, true>), grid, dim3(256), 0, st, inf, none, w, bias, none, none, none, g, \
+                                                         sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, outf)
+    if (bn_y != nullptr) { if (d > 1) TSII_HDW_LEAN(2, true, true); else TSII_HDW_LEAN(2, true, false); }
+    else if (in_sc != nullptr || stats != nullptr) { if (d > 1) TSII_HDW_LEAN(1, false, true); else TSII_HDW_LEAN(1, false, false); }
+    else { if (d > 1) TSII_HDW_LEAN(0, false, true); else TSII_HDW_LEAN(0, false, false); }
+#undef TSII_HDW_LEAN
+    return check_launch("dw_lean (bf16 storage)");
 }
 
 // ---- marching-strip dW (stride 1): same ring of x rows as dw_strip_kernel, the 9 taps x 4 channels (+ bias)
