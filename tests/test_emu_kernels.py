@@ -298,28 +298,27 @@ def test_dense_conv_gather_gemms(emu, mode, cin, cout, k, s, p, d, h):
 PC_THREADS = 768      # threads per block of the persistent producer / consumer NT kernel (csrc/gemm_pc.hip)
 
 
-@pytest.fixture(params=[(0, 0), (16, 8), (16 + 32, 8), (16 + 64, 3), (32, 0)], ids=["contiguous", "xcd-dealt", "xcd-dealt-lag1", "dealt-lag2", "lag1"])
+def _set_pc(emu, opt, cus):
+    emu.tsii_emu_set_pc_opt(opt)
+    emu.tsii_emu_set_pc_cus(cus)
+
+
+@pytest.fixture(params=[(16, 8), (0, 0)], ids=["xcd-dealt", "contiguous"])
 def pc_opt(request, emu):
-    """The forms of the persistent kernel's `opt` word (csrc/gemm_pc.hip: bit 4 = tiles dealt round robin with the blocks of an XCD on
-    consecutive tiles, bits 5-6 = the second consumer wave of every SIMD starts that many stages late), on 3 or 8 emulated CUs (8: the
-    XCD remap of the block index is active) -- through emulator-only hooks; the stock library's choice is PC_OPT_DEFAULT."""
-    opt, cus = request.param
-    emu.tsii_emu_set_pc_opt(opt)
-    emu.tsii_emu_set_pc_cus(cus)
-    yield opt
-    emu.tsii_emu_set_pc_opt(-1)
-    emu.tsii_emu_set_pc_cus(0)
+    """The two tile orders of the persistent kernel (csrc/gemm_pc.hip `opt` bit 4): dealt round robin with the blocks of an XCD on
+    consecutive tiles (the stock library's PC_OPT_DEFAULT; 8 emulated CUs, so the XCD remap of the block index is active) and the
+    contiguous ranges of rounds 3-5 (3 CUs) -- through emulator-only hooks."""
+    _set_pc(emu, *request.param)
+    yield request.param[0]
+    _set_pc(emu, -1, 0)
 
 
-@pytest.fixture(params=[(0, 0), (16 + 32, 8)], ids=["contiguous", "xcd-dealt-lag1"])
+@pytest.fixture(params=[(16, 8)], ids=["xcd-dealt"])
 def pc_opt2(request, emu):
-    """two of pc_opt's forms, for the tests that are parametrised widely already"""
-    opt, cus = request.param
-    emu.tsii_emu_set_pc_opt(opt)
-    emu.tsii_emu_set_pc_cus(cus)
-    yield opt
-    emu.tsii_emu_set_pc_opt(-1)
-    emu.tsii_emu_set_pc_cus(0)
+    """the stock tile order on 8 emulated CUs (XCD remap active), for the tests that are parametrised widely already"""
+    _set_pc(emu, *request.param)
+    yield request.param[0]
+    _set_pc(emu, -1, 0)
 
 
 @pytest.mark.parametrize("M,K,N", [(768, 64, 256), (512, 40, 128), (512, 96, 384), (256, 32, 128), (1152, 160, 192), (1664, 72, 224), (2560, 128, 128),
@@ -408,6 +407,36 @@ def test_producer_consumer_gemm(emu, pc_opt, M, K, N):
         s2 = bpart[:, 1].astype(np.float64).sum(0)
         assert np.abs(s1 - dz.sum(0)).max() <= 2e-5 * np.abs(dz).sum(0).max()
         assert np.abs(s2 - (dz * xh).sum(0)).max() <= 2e-5 * np.abs(dz * xh).sum(0).max()
+
+
+@pytest.mark.parametrize("opt,cus", [(16 + 32, 8), (16 + 64, 3), (32, 0)], ids=["xcd-dealt-lag1", "dealt-lag2", "lag1"])
+@pytest.mark.parametrize("M,K,N", [(768, 64, 256), (1152, 160, 192), (3072, 64, 384)])
+def test_producer_consumer_gemm_consumer_lag(emu, opt, cus, M, K, N):
+    """`opt` bits 5-6: the second consumer wave of every SIMD starts 1 / 2 stages behind the first (an A/B form, measured without
+    effect on the chip): same results, no deadlock with 2-5 LDS stages, with and without the XCD dealing."""
+    _set_pc(emu, opt, cus)
+    try:
+        L = emu
+        assert L.tsii_set_gemm_products(6) == 0
+        rng = np.random.default_rng(M + K + N + opt)
+        x = rng.standard_normal((M, K)).astype(np.float32)
+        w = rng.standard_normal((N, K)).astype(np.float32)
+        sc = rng.uniform(0.5, 1.5, K).astype(np.float32); sh = rng.standard_normal(K).astype(np.float32)
+        wws = WS(L.tsii_pw_ws_bytes(N, K))
+        y = np.zeros((M, N), np.float32)
+        part = np.zeros((L.tsii_pw_stat_rows(M), 4, N), np.float32)
+        assert L.tsii_pw_fwd_bn(P(x), M, K, P(w), N, None, None, 0, None, None, None, P(sc), P(sh), 2, 0.3, P(part), P(y), P(wws), wws.nbytes, None) == 0, L.tsii_last_error()
+        z = x.astype(np.float64) * sc + sh
+        ref = np.where(z > 0, z, 0.3 * z) @ w.T.astype(np.float64)
+        assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max()
+        dy = rng.standard_normal((M, N)).astype(np.float32)
+        dx = np.zeros((M, K), np.float32)
+        wt = WS(L.tsii_pw_ws_bytes(N, K))
+        assert L.tsii_pw_bwd_dx(P(dy), M, N, P(w), K, None, None, 0, None, P(dx), P(wt), None) == 0, L.tsii_last_error()
+        rdx = dy.astype(np.float64) @ w.astype(np.float64)
+        assert np.abs(dx - rdx).max() <= 1e-5 * np.abs(rdx).max()
+    finally:
+        _set_pc(emu, -1, 0)
 
 
 def test_split_modes_non_finite_operands(emu):

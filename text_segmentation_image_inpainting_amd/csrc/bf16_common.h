@@ -65,23 +65,9 @@ __device__ __forceinline__ void load_inbn8(const InBN& ib, int c, InBN8& o) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { o.sc[i] = a.v[i]; o.sc[4 + i] = b.v[i]; o.sh[i] = d.v[i]; o.sh[4 + i] = e.v[i]; }
 }
-// hi == +inf (every activation but ReLU6; wave-uniform): the upper clamp is the identity and its v_min_f32 per element is left out --
-// the load-time transform is VALU work on the critical path of every fused bf16 kernel (round 6: 4 -> 3 instructions per element)
-__device__ __forceinline__ float bn_act_load_noclamp(float v, float sc, float sh, float neg) {
-    const float z = fmaf(v, sc, sh);
-    return fmaxf(z, neg * z);
-}
-#ifndef HBN_NOCLAMP
-#define HBN_NOCLAMP 0    // 1: a second copy of the transform without the v_min_f32 when hi = +inf (round 6 A/B, profiles/r06d_bf16_bench_*.log: NT forms equal, the register-transposing TN kernel 86.7 vs 66.6 us and 310.8 vs 226.7 us -- the duplicated body costs it its occupancy; not taken)
-#endif
 __device__ __forceinline__ void apply_inbn8(float (&v)[8], const InBN8& c, float neg, float hi) {
-    if (!HBN_NOCLAMP || hi < __builtin_huge_valf()) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = bn_act_load(v[i], c.sc[i], c.sh[i], neg, hi);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = bn_act_load_noclamp(v[i], c.sc[i], c.sh[i], neg);
-    }
+    for (int i = 0; i < 8; ++i) v[i] = bn_act_load(v[i], c.sc[i], c.sh[i], neg, hi);
 }
 
 // derivative of the load-time activation min(max(z, neg z), hi) at pre-activation z (torch semantics, like act_grad)

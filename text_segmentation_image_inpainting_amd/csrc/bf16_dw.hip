@@ -121,63 +121,27 @@ __device__ __forceinline__ void hdw_load_row(const HDwWin<NC>& wn, int q, hu32x4
     ok = rv ? wn.xmask : 0u;
 }
 // the producer's BatchNorm + activation (the virtual activation is a bf16 tensor: rounded like a stored one), zero padding
-template <bool CLAMP, int NC>
-__device__ __forceinline__ void hdw_bn8(hu32x4 (&r)[NC], const float* __restrict__ lsc, const float* __restrict__ lsh, float neg, float hi) {
-    hf32x2 sc[4], sh[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { sc[q] = *reinterpret_cast<const hf32x2*>(lsc + 2 * q); sh[q] = *reinterpret_cast<const hf32x2*>(lsh + 2 * q); }
-    const hf32x2 ng = {neg, neg};
-#pragma unroll
-    for (int kc = 0; kc < NC; ++kc) {
-        hu32x4 o;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const hf32x2 x = {bf16_lo(r[kc][q]), bf16_hi(r[kc][q])};
-            const hf32x2 z = __builtin_elementwise_fma(x, sc[q], sh[q]);
-            const hf32x2 nz = ng * z;
-            float a0 = fmaxf(z[0], nz[0]), a1 = fmaxf(z[1], nz[1]);
-            if constexpr (CLAMP) { a0 = fminf(a0, hi); a1 = fminf(a1, hi); }
-            o[q] = bf16_pack2(a0, a1);
-        }
-        r[kc] = o;
-    }
-}
-// the producer's BatchNorm + activation (the virtual activation is a bf16 tensor: rounded like a stored one), zero padding.
-// Round 6: the transform runs on float2 pairs (v_pk_fma_f32 / v_pk_mul_f32: this file keeps packed math, there is no MFMA around) and
-// WITHOUT the upper clamp when there is none (hi = +inf: every activation but ReLU6; a wave-uniform branch between two copies of the
-// body -- as a select the compiler kept the v_min_f32 and added a v_cndmask): 2 instead of 4 vector instructions per element on
-// kernels whose bound is the vector ALU; same operations in the same order, results bit-identical.
-#ifndef HDW_BN_PK
-#define HDW_BN_PK 0      // 1: float2 pairs + no upper clamp when hi = +inf (round 6 A/B, profiles/r06d_bf16_bench_*.log: forward 80.6 vs 79.4 us -- no gain --, weight gradient 115.8 vs 100.9 us: 178 VGPRs = 2 waves per SIMD; not taken)
-#endif
-#ifndef HDW_DW_LB3
-#define HDW_DW_LB3 0     // 1: hold the stride-1 weight-gradient kernel at 3 waves per SIMD (A/B: 168 VGPRs + 44 bytes of scratch against 178 / 2 waves)
-#endif
 template <bool BNIN, int NC>
 __device__ __forceinline__ void hdw_commit(hu32x4 (&r)[NC], unsigned ok, const float* __restrict__ lsc, const float* __restrict__ lsh, float neg, float hi) {
-    if constexpr (BNIN && HDW_BN_PK != 0) {
-        if (hi < __builtin_huge_valf()) hdw_bn8<true, NC>(r, lsc, lsh, neg, hi);
-        else hdw_bn8<false, NC>(r, lsc, lsh, neg, hi);
-    } else if constexpr (BNIN) {
 #pragma unroll
-        for (int kc = 0; kc < NC; ++kc) {
+    for (int kc = 0; kc < NC; ++kc) {
+        if constexpr (BNIN) {
             float v[8];
             unpack8(r[kc], v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = bn_act_load(v[e], lsc[e], lsh[e], neg, hi);
             r[kc] = pack8(v);
         }
+        const hu32x4 z = {0u, 0u, 0u, 0u};
+        r[kc] = ((ok >> kc) & 1u) ? r[kc] : z;
     }
-    const hu32x4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int kc = 0; kc < NC; ++kc) r[kc] = ((ok >> kc) & 1u) ? r[kc] : z;
 }
 
 // LDS of the marching kernels: [0, 9*128) weights [tap][octet*8+e]; then 4 x 128 constants; then the reduction scratch
 static constexpr int HDW_W = 0, HDW_C0 = 9 * 128, HDW_RED = HDW_C0 + 4 * 128;
 
 template <int S, bool BNIN, int EPI, int NX>
-__global__ __launch_bounds__(256, (S == 1 && NX == 1 && EPI == 0) ? 4 : 1) void hdw_conv_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) void hdw_conv_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                        HDwPlan g, InBN ib, float* __restrict__ part, HDwBn kb, bf16_t* __restrict__ y) {
     static_assert(NX == 1 || S == 1, "two output columns per thread at stride 1 only");
     constexpr int NC = NX + 2;
@@ -371,7 +335,7 @@ __global__ __launch_bounds__(256, (S == 1 && NX == 1 && EPI == 0) ? 4 : 1) void 
 
 // ---- weight gradient: dw[c][ky][kx] = sum dy[n,yo,xo,c] * a[n, yo*S - p + ky*d, xo*S - p + kx*d, c] ------------------------
 template <int S, bool BNIN, int NX>
-__global__ __launch_bounds__(256, (HDW_DW_LB3 && S == 1 && NX == 1) ? 3 : 1) void hdw_dw_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, HDwPlan g, InBN ib,
+__global__ __launch_bounds__(256) void hdw_dw_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, HDwPlan g, InBN ib,
                                                      float* __restrict__ part) {
     static_assert(NX == 1 || S == 1, "two output columns per thread at stride 1 only");
     constexpr int NC = NX + 2;

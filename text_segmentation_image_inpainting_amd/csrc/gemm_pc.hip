@@ -36,6 +36,9 @@
 #ifndef PC_NT_STORE
 #define PC_NT_STORE 1     // non-temporal stores of the output tile (A/B on the chip: forward 17.88 -> 17.62 ms)
 #endif
+#ifndef PC_WIDE_K
+#define PC_WIDE_K 0       // A/B: reductions up to this length run 128 x 256 tiles for every N (fewer column tiles = fewer passes over A)
+#endif
 #ifndef PC_OPT_DEFAULT
 #define PC_OPT_DEFAULT 16 // the kernel's `opt` word in the stock library: bit 4 = tiles dealt round robin per XCD, bits 5-6 = consumer lag
 #endif
@@ -621,17 +624,19 @@ static int g_pc_opt = getenv("TSII_GEMM_PC_OPT") ? atoi(getenv("TSII_GEMM_PC_OPT
 static int g_pc_abl = getenv("TSII_GEMM_PC_ABL") ? atoi(getenv("TSII_GEMM_PC_ABL")) : 0;   // tools/pc_probe.py ablations
 static int g_pc_bnb_min_k = getenv("TSII_GEMM_PC_BNB_MIN_K") ? atoi(getenv("TSII_GEMM_PC_BNB_MIN_K")) : 32;
 static int g_pc_min_n = getenv("TSII_GEMM_PC_MIN_N") ? atoi(getenv("TSII_GEMM_PC_MIN_N")) : 128;
+static int g_pc_wide_k = getenv("TSII_GEMM_PC_WIDE_K") ? atoi(getenv("TSII_GEMM_PC_WIDE_K")) : PC_WIDE_K;   // reductions up to this length take 128 x 256 tiles whatever N
 #elif defined(TSII_HIP_EMU)
 // TEST-ONLY (emulator build, tests/emu): the kernel's `opt` word (tile dealing, consumer lag), so that the CPU suite walks the forms
 // the stock library does not select
 static constexpr int g_pc = 1;
 static int g_pc_opt = PC_OPT_DEFAULT;
 extern "C" void tsii_emu_set_pc_opt(int v) { g_pc_opt = v >= 0 ? v : PC_OPT_DEFAULT; }
-static constexpr int g_pc_bnb_min_k = 32, g_pc_min_n = 128;
+static constexpr int g_pc_bnb_min_k = 32, g_pc_min_n = 128, g_pc_wide_k = PC_WIDE_K;
 #else
 static constexpr int g_pc = 1, g_pc_opt = PC_OPT_DEFAULT;
 static constexpr int g_pc_bnb_min_k = 32;   // dX + K6c: shortest reduction the persistent kernel takes (one-stage tiles: 1.57 -> 1.45 ms on 2M x 32 -> 384 since the epilogue prefetches the BatchNorm input; 64 before)
 static constexpr int g_pc_min_n = 128;      // measured: 64-column outputs stay faster on the 4-wave kernel
+static constexpr int g_pc_wide_k = PC_WIDE_K;
 #endif
 
 size_t nt_pc_ws_bytes(int n, int k) { return (size_t)3 * n * ((k + 31) & ~31) * sizeof(unsigned short) + 16; }
@@ -709,7 +714,7 @@ int launch_nt_pc(const float* A, int64_t lda, RowScale as, const float* B, int64
     hipLaunchKernelGGL(split_w_tiled_kernel<3>, dim3(stream_grid((int64_t)nhalf * N * 16, 256)), dim3(256), 0, stream, B, (int)ldb, b_transposed ? 1 : 0, N, K, nhalf, planes);
     int rc = check_launch("split_w_tiled");
     if (rc) return rc;
-    if (pc_wide(N)) return launch_nt_pc_cfg<1, 8>(A, lda, as, planes, C, ldc, M, N, K, ep, ib, stream);
+    if (pc_wide(N) || (K <= g_pc_wide_k && M % 128 == 0)) return launch_nt_pc_cfg<1, 8>(A, lda, as, planes, C, ldc, M, N, K, ep, ib, stream);
     return launch_nt_pc_cfg<2, 4>(A, lda, as, planes, C, ldc, M, N, K, ep, ib, stream);
 }
 
