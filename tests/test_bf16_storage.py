@@ -345,8 +345,8 @@ def test_xception_1024_bs8_bf16_storage_properties_gpu():
 
 
 # band of the training-curve test below, set from the chip's own print-out (profiles/r06h_gputests_bf16_curve.log)
-CURVE_REL_BAND = 0.05        # |loss_bf16 - loss_fp32| <= 5 % of the fp32-storage loss at every step ...
-CURVE_END_BAND = 0.03        # ... and 3 % averaged over the last 10 steps
+CURVE_REL_BAND = 0.02        # |loss_bf16 - loss_fp32| <= 2 % of the fp32-storage loss at every step (measured worst 0.64 %) ...
+CURVE_END_BAND = 0.01        # ... and 1 % averaged over the last 10 steps (measured 0.11 %)
 
 
 @pytest.mark.gpu

@@ -628,6 +628,65 @@ def test_depthwise_dilated_strips_by_phase(emu, n, h, wd, c, d, p, masked, bias,
         L.tsii_emu_set_ls_phased(0)
 
 
+def _dw_ref_dw(x, dy, d, p):
+    """float64 weight gradient [c, 3, 3] and bias gradient [c] of the stride-1 depth-wise 3x3 convolution (NHWC arrays)"""
+    n, h, wd, c = x.shape
+    ho, wo = dy.shape[1], dy.shape[2]
+    xp = np.zeros((n, h + 2 * p, wd + 2 * p, c))
+    xp[:, p:p + h, p:p + wd] = x
+    g = np.zeros((c, 3, 3))
+    for ky in range(3):
+        for kx in range(3):
+            g[:, ky, kx] = (dy.astype(np.float64) * xp[:, ky * d:ky * d + ho, kx * d:kx * d + wo]).sum((0, 1, 2))
+    return g, dy.astype(np.float64).sum((0, 1, 2))
+
+
+@pytest.mark.parametrize("n,h,wd,c,d,masked,bias,act", [
+    (2, 40, 48, 40, 8, False, True, 2),      # 5-row phases, 48 columns (16 idle column lanes), channel tail
+    (1, 64, 64, 32, 8, False, False, 3),     # the cfg-3 geometry: 8 x 64 phases exactly, ReLU6
+    (1, 48, 30, 8, 16, False, True, 1),      # dilation 16: no strip form existed; 3-row phases
+    (1, 60, 33, 36, 17, False, False, 2),    # RFB's dilation 17: phases of 4 and 3 rows
+    (1, 64, 64, 16, 29, False, True, 0),     # dilation 29: most tap columns outside the image
+    (2, 40, 48, 40, 8, True, True, 2),       # mask planes: the strip kernels, SAME partial-row layout
+])
+@pytest.mark.parametrize("rows", [1, 0], ids=["row-phase", "strips"])
+def test_depthwise_large_dilation_row_phase(emu, n, h, wd, c, d, masked, bias, act, rows):
+    """Dilation >= 8 on maps of more than 1024 pixels and at most 64 columns (csrc/dw_rows.h: one row phase of a 32-channel block in
+    LDS, no halo): forward, BatchNorm on load + statistics partials, dX, dX + K6c through the C ABI against float64 -- at dilations
+    16 / 17 / 29 the fused forms exist ONLY on this kernel -- and the weight gradient with and without BatchNorm on load.  rows = 0
+    keeps the geometries on the strip / direct kernels (emulator-only switch): same answers, and for dilation 8 the same row count."""
+    L = emu
+    L.tsii_emu_set_dw_rows(rows)
+    try:
+        fused = rows == 1 or d == 8
+        if fused and not (masked and d != 8):
+            _strip_entry_points(L, n, h, wd, c, masked, bias, act, d=d, p=d)
+        else:
+            assert L.tsii_dw_stat_rows(n, h, wd, c, 3, 3, 1, 1, d, d) == 0        # no fused form without the row-phase kernel
+        if masked:
+            return
+        rng = np.random.default_rng(n + h + wd + c + d)
+        x = rng.standard_normal((n, h, wd, c)).astype(np.float32)
+        dy = rng.standard_normal((n, h, wd, c)).astype(np.float32)
+        geom = (3, 3, 1, 1, d, d, d, d)
+        nb = L.tsii_dw_bwd_dw_ws_bytes(n, h, wd, c, 3, 3)
+        ws = WS(nb)
+        dwg = np.full((c, 1, 3, 3), np.nan, np.float32); db = np.full(c, np.nan, np.float32)
+        assert L.tsii_dw_bwd_dw(P(dy), None, None, P(x), None, n, h, wd, c, *geom, h, wd, P(dwg), P(db), P(ws), nb, None) == 0, L.tsii_last_error()
+        gr, br = _dw_ref_dw(x.astype(np.float64), dy, d, d)
+        assert np.abs(dwg[:, 0] - gr).max() <= 2e-5 * max(1.0, np.abs(gr).max()) and np.abs(db - br).max() <= 2e-5 * max(1.0, np.abs(br).max())
+        if fused:
+            sc = (rng.uniform(size=c) + 0.5).astype(np.float32); sh = rng.standard_normal(c).astype(np.float32)
+            dwg2 = np.full((c, 1, 3, 3), np.nan, np.float32)
+            ws2 = WS(nb)
+            assert L.tsii_dw_bwd_dw_bn(P(dy), None, None, P(x), None, n, h, wd, c, *geom, h, wd, P(sc), P(sh), act, 0.3, P(dwg2), None, P(ws2), nb, None) == 0, L.tsii_last_error()
+            xa = _act(x.astype(np.float64) * sc + sh, act, 0.3)
+            gr2, _ = _dw_ref_dw(xa, dy, d, d)
+            assert np.abs(dwg2[:, 0] - gr2).max() <= 2e-5 * max(1.0, np.abs(gr2).max())
+    finally:
+        L.tsii_emu_set_dw_rows(1)
+
+
 @pytest.mark.parametrize("n,h,wd,c,masked,bias,act", [
     (2, 21, 37, 40, True, True, 2),      # odd sizes: row / column / channel tails
     (1, 16, 32, 32, True, False, 3),     # two steps, two strips exactly, ReLU6
@@ -1059,3 +1118,40 @@ def test_batchnorm_apply_and_backward_kernels_row_tails(emu, m, c, act, slope):
     if safe.all():
         assert np.abs(dy - dy_train).max() <= 5e-5 * max(1.0, np.abs(dy_train).max())
         assert np.abs(dg - dgamma_r).max() <= 5e-5 * max(1.0, np.abs(dgamma_r).max()) and np.abs(db - dbeta_r).max() <= 5e-5 * max(1.0, np.abs(dbeta_r).max())
+
+
+@pytest.mark.parametrize("n,hw,c", [(2, 37, 128), (1, 300, 48), (2, 64, 320), (1, 50, 32), (3, 1000, 192), (1, 20, 640), (1, 9, 2052), (1, 33, 6)])
+def test_scse_backward_one_pass(emu, n, hw, c):
+    """tsii_scse_bwd (models/common.py:38-43): dx = g (cse + sse), dcse[n, c] = sum_hw g x, dsse[n, hw] = sum_c g x against float64 --
+    the one-pass kernel (channel quads of a pixel in a lane group, channel sums through LDS) on the shapes it takes (c % 4 == 0, up to
+    2048 channels) and the three-kernel form on the rest (2052, 6 channels); pixel ranges that do not fill the last iteration."""
+    L = emu
+    rng = np.random.default_rng(n * 1000 + hw + c)
+    g = rng.standard_normal((n, hw, c)).astype(np.float32)
+    x = rng.standard_normal((n, hw, c)).astype(np.float32)
+    cse = rng.uniform(size=(n, c)).astype(np.float32)
+    sse = rng.uniform(size=(n, hw)).astype(np.float32)
+    dx = np.full((n, hw, c), np.nan, np.float32); dcse = np.full((n, c), np.nan, np.float32); dsse = np.full((n, hw), np.nan, np.float32)
+    nb = L.tsii_gap_ws_bytes(n, hw, c)
+    ws = WS(nb)
+    assert L.tsii_scse_bwd(P(g), P(x), P(cse), P(sse), n, hw, c, P(dx), P(dcse), P(dsse), P(ws), nb, None) == 0, L.tsii_last_error()
+    g64, x64 = g.astype(np.float64), x.astype(np.float64)
+    rdx = g64 * (cse.astype(np.float64)[:, None, :] + sse.astype(np.float64)[:, :, None])
+    assert np.abs(dx - rdx).max() <= 2e-6 * max(1.0, np.abs(rdx).max())
+    rc = (g64 * x64).sum(1); rs = (g64 * x64).sum(2)
+    assert np.abs(dcse - rc).max() <= 1e-5 * max(1.0, np.abs(rc).max()) and np.abs(dsse - rs).max() <= 1e-5 * max(1.0, np.abs(rs).max())
+
+
+@pytest.mark.parametrize("n,hw,c", [(2, 37, 128), (1, 300, 48), (2, 600, 320), (1, 50, 32), (1, 20, 1920), (1, 9, 2052), (1, 33, 6), (2, 5, 4)])
+def test_global_average_pool_forward(emu, n, hw, c):
+    """tsii_gap_fwd (the squeeze of scSE, models/common.py:13-27): mean over the pixels of every (image, channel) against float64 --
+    16-byte loads when c % 4 == 0 (two rows in flight per thread, odd row counts, more channel quads than threads), else the scalar form."""
+    L = emu
+    rng = np.random.default_rng(n * 77 + hw + c)
+    x = (rng.standard_normal((n, hw, c)) + 0.25).astype(np.float32)
+    out = np.full((n, c), np.nan, np.float32)
+    nb = L.tsii_gap_ws_bytes(n, hw, c)
+    ws = WS(nb)
+    assert L.tsii_gap_fwd(P(x), n, hw, c, P(out), P(ws), nb, None) == 0, L.tsii_last_error()
+    ref = x.astype(np.float64).mean(1)
+    assert np.abs(out - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())

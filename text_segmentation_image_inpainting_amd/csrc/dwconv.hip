@@ -730,6 +730,7 @@ __global__ __launch_bounds__(256, 3) void dw_strip_dx2_kernel(const float* __res
 #include "dw_lean.h"
 #include "dw_lean_s2.h"
 #include "dw_small.h"
+#include "dw_rows.h"
 namespace tsii {
 
 struct StripPlan {
@@ -773,9 +774,11 @@ static inline unsigned strip_rows_per_image(const StripPlan& sp) { return sp.ok 
 struct FusedPlan {
     StripPlan sp;
     unsigned phases;
+    bool rows_only;      // no strip kernel for this dilation: the plan only sizes the row-phase kernel's partial rows (dw_rows.h)
 };
 static FusedPlan plan_fwd_strips(int n, int hout, int wout, int c, int s, int d) {
     FusedPlan fp;
+    fp.rows_only = false;
     if (dw_phased_dims_ok(hout, wout, c, s, d)) {
         fp.phases = (unsigned)(d * d);
         if ((int64_t)n * d * d < (1ll << 24)) {
@@ -785,6 +788,11 @@ static FusedPlan plan_fwd_strips(int n, int hout, int wout, int c, int s, int d)
     }
     fp.phases = 1u;
     fp.sp = plan_strip(n, hout, wout, c, s, d);
+    if (!fp.sp.ok && dw_rows_dims_ok(hout, wout, c, s, d)) {
+        // a dilation without strip form (16, 17, 29 ...) on a map the row-phase kernel takes (dw_rows.h): one partial row per image
+        fp.sp.ok = true; fp.sp.chunk_rows = hout; fp.sp.strips_x = 1; fp.sp.chunks_y = 1; fp.sp.cblocks = (unsigned)cdiv(c, ST_CB);
+        fp.rows_only = true;
+    }
     return fp;
 }
 static inline unsigned fused_rows_per_image(const FusedPlan& fp) { return fp.phases * strip_rows_per_image(fp.sp); }
@@ -804,6 +812,20 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
     const FusedPlan fp = plan_fwd_strips(g.n, g.hout, g.wout, g.c, g.s, g.d);
     const StripPlan sp = fp.sp;
     const bool fused_any = ib.sc != nullptr || stats != nullptr || bb.y != nullptr;
+    // large dilation on mid-sized maps, no mask planes: one row phase of a channel block in LDS (dw_rows.h)
+    if (dw_rows_ok(g) && pre == nullptr && denom == nullptr && keep == nullptr && post_mul == nullptr && sp.ok &&
+        (int64_t)g.n * cdiv(g.c, DR_CB) < (1ll << 31)) {
+        const unsigned rcb = (unsigned)cdiv(g.c, DR_CB), rpi = fused_rows_per_image(fp);
+        const dim3 rgrid((unsigned)g.n * rcb);
+        if (bb.y != nullptr) hipLaunchKernelGGL((dw_rows_kernel<2>), rgrid, dim3(DR_THREADS), 0, st, in, wT, bias, g, rcb, rpi, ib, stats, bb, out);
+        else if (fused_any) hipLaunchKernelGGL((dw_rows_kernel<1>), rgrid, dim3(DR_THREADS), 0, st, in, wT, bias, g, rcb, rpi, ib, stats, bb, out);
+        else hipLaunchKernelGGL((dw_rows_kernel<0>), rgrid, dim3(DR_THREADS), 0, st, in, wT, bias, g, rcb, rpi, ib, stats, bb, out);
+        return check_launch("dw_rows");
+    }
+    if (fp.rows_only) {          // mask planes / another padding at a dilation without strip kernels: the direct kernels, unfused only
+        TSII_REQUIRE(!fused_any, "depth-wise strips: dilation %d has a fused BatchNorm form on the row-phase kernel only (no mask planes, padding = dilation)", g.d);
+        return 1;
+    }
     // small maps: the whole map of a channel block in LDS (any dilation; the fused forms where the strip plan defines the partial rows)
     if (dw_small_ok(g) && !(post_mul != nullptr && (denom != nullptr || keep != nullptr || bias != nullptr)) && (!fused_any || (sp.ok && dw_fused_ok(g.s, g.d))) &&
         !(fused_any && bb.y == nullptr && post_mul != nullptr)) {
@@ -827,7 +849,11 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
     if (nblk >= (1ll << 31)) return fp.phases > 1 ? -1 : 1;
     const dim3 grid((unsigned)nblk);
     const bool fused = ib.sc != nullptr || stats != nullptr || bb.y != nullptr;
-    if (fused && !dw_fused_ok(g.s, g.d)) return 1;
+    if (!dw_fused_ok(g.s, g.d)) {
+        // (a dilation whose only fused form is the row-phase kernel above, called with mask planes or another padding)
+        TSII_REQUIRE(!fused, "depth-wise strips: dilation %d has a fused BatchNorm form on the row-phase kernel only (no mask planes, padding = dilation)", g.d);
+        return 1;
+    }
     if (bb.y != nullptr && g.s != 1) return 1;
     if (fp.phases > 1) {
         // dilation by phases: the partial rows of the fused forms follow THIS plan (tsii_dw_stat_rows / tsii_dw_bwd_stat_rows), so a
@@ -927,6 +953,7 @@ bool hdw_lean_ok(int hout, int wout, int c, int s, int d) {
 }
 static FusedPlan hdw_lean_plan(int n, int hout, int wout, int c, int d) {
     FusedPlan fp;
+    fp.rows_only = false;
     fp.phases = (unsigned)(d * d);
     fp.sp = plan_strip(n * d * d, cdiv(hout, d), cdiv(wout, d), c, 1, 1);
     return fp;
@@ -1241,7 +1268,7 @@ extern "C" int tsii_dw_fwd(const float* x, const float* rmask, const float* w, c
 
 extern "C" int64_t tsii_dw_stat_rows(int n, int ho, int wo, int c, int kh, int kw, int sh, int sw, int dh, int dw) {
     if (n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || c % 4 != 0) return 0;
-    if (!(kh == 3 && kw == 3 && sh == sw && dh == dw) || !dw_fused_ok(sh, dh)) return 0;
+    if (!(kh == 3 && kw == 3 && sh == sw && dh == dw) || !(dw_fused_ok(sh, dh) || dw_rows_dims_ok(ho, wo, c, sh, dh))) return 0;
     const FusedPlan fp = plan_fwd_strips(n, ho, wo, c, sh, dh);
     return (int64_t)n * fused_rows_per_image(fp);          // one partial row per strip chunk (of every phase)
 }
@@ -1250,7 +1277,7 @@ extern "C" int64_t tsii_dw_stat_rows(int n, int ho, int wo, int c, int kh, int k
 extern "C" int64_t tsii_dw_bwd_stat_rows(int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw) {
     if (n <= 0 || h <= 0 || wd <= 0 || c <= 0 || c % 4 != 0 || !(kh == 3 && kw == 3 && sh == sw && dh == dw)) return 0;
     FusedPlan fp;
-    if (sh == 1 && (dh == 1 || dh == 2 || dh == 4 || dh == 8)) fp = plan_fwd_strips(n, h, wd, c, 1, dh);
+    if (sh == 1 && (dh == 1 || dh == 2 || dh == 4 || dh == 8 || (ph == dh && pw == dw && dw_rows_dims_ok(h, wd, c, 1, dh)))) fp = plan_fwd_strips(n, h, wd, c, 1, dh);
     else if (sh == 2 && dh == 1 && ph == 1 && pw == 1) fp = plan_fwd_strips(n, h, wd, c, 1, 1);
     else return 0;
     return (int64_t)n * fused_rows_per_image(fp);
@@ -1356,6 +1383,18 @@ static int dw_bwd_dw_impl(const float* dy, const float* inv, const float* keep, 
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (c % 4 == 0) && aligned16(dy) && aligned16(x) && (ib.sc == nullptr || (aligned16(ib.sc) && aligned16(ib.sh)));
     float* part = (float*)ws;
+    if (vec && kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == dw && inv == nullptr && keep == nullptr && rmask == nullptr) {
+        DtGeom rg = {n, h, wd, c, 1, dh, ph, pw, ho, wo, 0};
+        if (dw_rows_ok(rg) && (int64_t)n * cdiv(c, DR_CB) < (1ll << 31)) {        // large dilation, mid-sized map, no planes: dw_rows.h
+            const unsigned rcb = (unsigned)cdiv(c, DR_CB);
+            if (ib.sc != nullptr) hipLaunchKernelGGL((dw_rows_dw_kernel<true>), dim3((unsigned)n * rcb), dim3(DR_THREADS), 0, st, dy, x, rg, rcb, ib, part);
+            else hipLaunchKernelGGL((dw_rows_dw_kernel<false>), dim3((unsigned)n * rcb), dim3(DR_THREADS), 0, st, dy, x, rg, rcb, ib, part);
+            int rc0 = check_launch("dw_rows_dw");
+            if (rc0) return rc0;
+            hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)cdiv64((int64_t)10 * c, 32)), dim3(256), 0, st, part, n, 9, c, dwgt, dbias);
+            return check_launch("dw_reduce");
+        }
+    }
     if (vec && kh == 3 && kw == 3 && sh == sw && dh == dw &&
         ((sh == 1 && (dh == 1 || dh == 2 || dh == 4 || dh == 8)) || (sh == 2 && dh == 1))) {
         const StripPlan sp = plan_strip(n, ho, wo, c, sh, dh);   // marching strips

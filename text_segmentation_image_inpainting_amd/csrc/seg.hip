@@ -144,11 +144,57 @@ __global__ void sample_colsum_final_kernel(const float* __restrict__ part, int n
         out[i] = (float)(s * (double)scale);
     }
 }
+// the same partial sums with 16-byte loads (c % 4 == 0, 16-byte aligned operands; round 6): a thread owns one channel quad of NB4
+// <= 256 quads and every L-th row of the chunk, two rows in flight -- the 4-byte form above ran at 3 TB/s on the pooling of scSE
+template <bool HASB>
+__global__ __launch_bounds__(256) void sample_colsum4_kernel(const float* __restrict__ a, const float* __restrict__ b, int hw, int c, int NB4, int L,
+                                                             int rows_per_block, int chunks, float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float sh[256 * 4];
+    const int n = blockIdx.z, chunk = blockIdx.x;
+    const int cl = threadIdx.x % NB4, lane = threadIdx.x / NB4;
+    const int cq = blockIdx.y * NB4 + cl;
+    const int r0 = chunk * rows_per_block;
+    const int r1 = r0 + rows_per_block < hw ? r0 + rows_per_block : hw;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    const bool act = lane < L && cq * 4 < c;
+    if (act) {
+        const float* pa = a + (int64_t)n * hw * c + cq * 4;
+        const float* pb = HASB ? b + (int64_t)n * hw * c + cq * 4 : nullptr;
+        int r = r0 + lane;
+        for (; r + L < r1; r += 2 * L) {
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(pa + (int64_t)r * c), v1 = *reinterpret_cast<const f32x4*>(pa + (int64_t)(r + L) * c);
+            if (HASB) { v0 *= *reinterpret_cast<const f32x4*>(pb + (int64_t)r * c); v1 *= *reinterpret_cast<const f32x4*>(pb + (int64_t)(r + L) * c); }
+            s0 += v0; s1 += v1;
+        }
+        if (r < r1) {
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(pa + (int64_t)r * c);
+            if (HASB) v0 *= *reinterpret_cast<const f32x4*>(pb + (int64_t)r * c);
+            s0 += v0;
+        }
+    }
+    *reinterpret_cast<f32x4*>(sh + threadIdx.x * 4) = s0 + s1;
+    __syncthreads();
+    if (lane == 0 && cq * 4 < c) {
+        f32x4 tsum = {0.f, 0.f, 0.f, 0.f};
+        for (int l = 0; l < L; ++l) tsum += *reinterpret_cast<const f32x4*>(sh + (l * NB4 + cl) * 4);
+        *reinterpret_cast<f32x4*>(part + ((int64_t)n * chunks + chunk) * c + cq * 4) = tsum;
+    }
+}
 static inline int sc_chunks(int hw) { int k = (hw + 255) / 256; return k > 64 ? 64 : (k < 1 ? 1 : k); }
 static int launch_sample_colsum(const float* a, const float* b, int n, int hw, int c, float scale, float* out, float* ws,
                                 hipStream_t st) {
     const int chunks = sc_chunks(hw);
     const int rpb = cdiv(hw, chunks);
+    if (c % 4 == 0 && aligned16(a) && (b == nullptr || aligned16(b)) && aligned16(ws)) {
+        const int CG = c / 4, NB4 = CG < 256 ? CG : 256, L4 = 256 / NB4;
+        const dim3 grid4(chunks, cdiv(CG, NB4), n);
+        if (b != nullptr) hipLaunchKernelGGL((sample_colsum4_kernel<true>), grid4, dim3(256), 0, st, a, b, hw, c, NB4, L4, rpb, chunks, ws);
+        else hipLaunchKernelGGL((sample_colsum4_kernel<false>), grid4, dim3(256), 0, st, a, b, hw, c, NB4, L4, rpb, chunks, ws);
+        int rc4 = check_launch("sample_colsum4");
+        if (rc4) return rc4;
+        hipLaunchKernelGGL(sample_colsum_final_kernel, dim3(cdiv(n * c, 256)), dim3(256), 0, st, ws, n, chunks, c, scale, out);
+        return check_launch("sample_colsum_final");
+    }
     const int NB = c < 256 ? c : 256, L = 256 / NB;
     hipLaunchKernelGGL(sample_colsum_kernel, dim3(chunks, cdiv(c, NB), n), dim3(256), 0, st, a, b, hw, c, NB, L, rpb, chunks, ws);
     int rc = check_launch("sample_colsum");
@@ -202,6 +248,72 @@ __global__ __launch_bounds__(256) void scse_dsse_kernel(const float* __restrict_
         for (int k = lane; k < c; k += 64) s = fmaf(g[pix * c + k], x[pix * c + k], s);
         s = wave_sum(s);
         if (lane == 0) dsse[pix] = s;
+    }
+}
+
+// scSE backward in ONE pass (round 6): dx = g * (cse + sse), dsse[pix] = sum_c g x, dcse[n, c] = sum_pix g x.  The three-kernel form
+// above reads g three times and x twice (dsse with 4-byte loads, one wave per pixel): 2.5 TB/s of algorithmic traffic, 7.8 ms of
+// TextSegament's 512^2 bs-64 step.  Here a group of G lanes (G = the channel quads of a pixel rounded up to a power of two, at most
+// 64) owns a pixel at a time: 16-byte loads of g and x, the pixel's sum by shuffles inside the group, the channel sums in registers
+// (Q quads per lane) over the block's pixel range, combined through LDS into one partial row per (image, chunk) -- the layout
+// sample_colsum_final_kernel reduces.
+template <int Q>
+__global__ __launch_bounds__(256) void scse_bwd_fused_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ cse,
+                                                             const float* __restrict__ sse, int hw, int c, int G, int rows_per_block, int chunks,
+                                                             float* __restrict__ dx, float* __restrict__ dsse, float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float sh[8192];
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane % G, gp = lane / G, PPW = 64 / G, SLOTS = 4 * PPW;
+    const int CG = c >> 2;
+    const int r0 = chunk * rows_per_block;
+    const int r1 = r0 + rows_per_block < hw ? r0 + rows_per_block : hw;
+    const int64_t base = (int64_t)n * hw;
+    f32x4 cs[Q], acc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int cq = gl + q * G;
+        cs[q] = cq < CG ? *reinterpret_cast<const f32x4*>(cse + (int64_t)n * c + cq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int iters = (r1 - r0 + SLOTS - 1) / SLOTS;             // block-uniform: every lane takes part in every shuffle
+    for (int it = 0; it < iters; ++it) {
+        const int p = r0 + it * SLOTS + wave * PPW + gp;
+        const bool ok = p < r1;
+        const int64_t pix = base + (ok ? p : r1 - 1);
+        const float ss = sse[pix];
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int cq = gl + q * G;
+            if (cq < CG) {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(g + pix * c + cq * 4), xv = *reinterpret_cast<const f32x4*>(x + pix * c + cq * 4);
+                f32x4 pr = gv * xv;
+                if (!ok) pr = f32x4{0.f, 0.f, 0.f, 0.f};
+                s += (pr.x + pr.y) + (pr.z + pr.w);
+                acc[q] += pr;
+                if (ok) {
+                    const f32x4 o = gv * cs[q] + gv * ss;            // mul, mul, add like the reference (and scse_scale_kernel)
+                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dx + pix * c + cq * 4));
+                }
+            }
+        }
+        for (int m = 1; m < G; m <<= 1) s += __shfl_xor(s, m, 64);
+        if (gl == 0 && ok) dsse[pix] = s;
+    }
+    // channel sums of the block: [slot][c] through LDS
+    const int slot = wave * PPW + gp;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int cq = gl + q * G;
+        if (cq < CG) *reinterpret_cast<f32x4*>(sh + slot * c + cq * 4) = acc[q];
+    }
+    __syncthreads();
+    float* prow = part + ((int64_t)n * chunks + chunk) * c;
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        float sum = 0.f;
+        for (int sl = 0; sl < SLOTS; ++sl) sum += sh[sl * c + ch];
+        prow[ch] = sum;
     }
 }
 
@@ -350,6 +462,25 @@ extern "C" int tsii_scse_bwd(const float* g, const float* x, const float* cse, c
     TSII_REQUIRE(g && x && cse && sse && dx && dcse && dsse && ws && n > 0 && hw > 0 && c > 0, "scse_bwd: bad arguments");
     TSII_REQUIRE(ws_bytes >= tsii_gap_ws_bytes(n, hw, c) && n <= 65535, "scse_bwd: workspace too small / batch too large");
     hipStream_t st = (hipStream_t)stream;
+    // one pass over g and x (scse_bwd_fused_kernel) when the channel quads of a pixel fit 64 lanes x 8 and the block's channel sums
+    // fit its LDS buffer; else the three-kernel form
+    {
+        const int CG = c / 4;
+        int G = 1;
+        while (G < CG && G < 64) G <<= 1;
+        const int Q = cdiv(CG, G), slots = 4 * (64 / G);
+        if (c % 4 == 0 && Q <= 8 && (int64_t)slots * c <= 8192 && aligned16(g) && aligned16(x) && aligned16(cse) && aligned16(dx)) {
+            const int chunks = sc_chunks(hw), rpb = cdiv(hw, chunks);
+            const dim3 grid(chunks, n);
+#define TSII_SCSE_BWD(QV) hipLaunchKernelGGL((scse_bwd_fused_kernel<QV>), grid, dim3(256), 0, st, g, x, cse, sse, hw, c, G, rpb, chunks, dx, dsse, (float*)ws)
+            if (Q <= 1) TSII_SCSE_BWD(1); else if (Q <= 2) TSII_SCSE_BWD(2); else if (Q <= 4) TSII_SCSE_BWD(4); else TSII_SCSE_BWD(8);
+#undef TSII_SCSE_BWD
+            int rcf = check_launch("scse_bwd_fused");
+            if (rcf) return rcf;
+            hipLaunchKernelGGL(sample_colsum_final_kernel, dim3(cdiv(n * c, 256)), dim3(256), 0, st, (const float*)ws, n, chunks, c, 1.f, dcse);
+            return check_launch("sample_colsum_final");
+        }
+    }
     int rc = tsii_scse_fwd(g, cse, sse, n, hw, c, dx, stream);   // dx = g*cse + g*sse
     if (rc) return rc;
     rc = launch_sample_colsum(g, x, n, hw, c, 1.f, dcse, (float*)ws, st);

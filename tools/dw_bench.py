@@ -17,7 +17,7 @@ def timeit(fn, it=5):
 # default: ImageFill's largest layers (mask planes); "cfg3": TextSegament 512^2 bs 64's dilated layers (no mask planes); "dil": ImageFill's
 # dilated encoder levels
 SETS = {"": [(32, 256, 256, 384, 1, 1), (32, 128, 128, 768, 1, 1), (32, 64, 64, 1024, 1, 1), (32, 256, 256, 256, 2, 1)],
-        "cfg3": [(64, 64, 64, 1920, 1, 8), (64, 64, 64, 1152, 1, 8), (64, 64, 64, 1152, 1, 4), (64, 64, 64, 768, 1, 4), (64, 64, 64, 768, 1, 2), (64, 128, 128, 384, 1, 2), (64, 64, 64, 384, 1, 1)],
+        "cfg3": [(64, 64, 64, 1920, 1, 16), (64, 64, 64, 1920, 1, 8), (64, 64, 64, 1152, 1, 8), (64, 64, 64, 1152, 1, 4), (64, 64, 64, 768, 1, 4), (64, 64, 64, 768, 1, 2), (64, 128, 128, 384, 1, 2), (64, 64, 64, 384, 1, 1)],
         "dil": [(32, 64, 64, 1024, 1, 2), (32, 64, 64, 1024, 1, 4), (32, 64, 64, 1024, 1, 8)]}
 WHICH = sys.argv[1] if len(sys.argv) > 1 else ""
 MASKED = WHICH != "cfg3"
