@@ -1058,7 +1058,7 @@ def _act_np(z, act, slope):
     return np.clip(z, 0, 6), ((z > 0) & (z < 6)).astype(z.dtype)
 
 
-@pytest.mark.parametrize("m,c", [(1, 4), (3, 8), (5, 36), (127, 4), (130, 64), (1025, 12), (4099, 32), (257, 5)])
+@pytest.mark.parametrize("m,c", [(1, 4), (3, 8), (5, 36), (127, 4), (130, 64), (1025, 12), (4099, 32), (257, 5), (4099, 1024), (40003, 64)])      # the last two: several rows per reduction lane (the 4-rows-in-flight loops and their tails)
 @pytest.mark.parametrize("act,slope", [(0, 0.0), (2, 0.3), (3, 0.0)])
 def test_batchnorm_apply_and_backward_kernels_row_tails(emu, m, c, act, slope):
     """tsii_bn_act_fwd / tsii_bn_act_bwd (training and eval) / tsii_bn_act_bwd_pre straight through the C ABI against float64 numpy,

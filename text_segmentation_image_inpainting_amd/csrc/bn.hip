@@ -21,7 +21,23 @@ __global__ void bn_stats_partial_kernel(const float* __restrict__ y, int64_t M, 
         float s1[W], s2[W];
 #pragma unroll
         for (int i = 0; i < W; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-        for (int64_t m = r; m < M; m += R) {
+        // four rows requested before the first is used (round 6): narrow tensors have few tasks -- 4096 row lanes x C / 4 quads: two
+        // waves per CU at 32 channels -- and one load in flight per thread ran them at 1.8 TB/s; same summation order as before
+        int64_t m = r;
+        for (; m + 3 * (int64_t)R < M; m += 4 * (int64_t)R) {
+            VecF<W> v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = vload<W>(y + (m + u * (int64_t)R) * C + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < W; ++i) {
+                    const float d = v[u].v[i] - piv.v[i];
+                    s1[i] += d;
+                    s2[i] = fmaf(d, d, s2[i]);
+                }
+        }
+        for (; m < M; m += R) {
             const VecF<W> v = vload<W>(y + m * C + c);
 #pragma unroll
             for (int i = 0; i < W; ++i) {
@@ -313,7 +329,24 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ dout, const floa
             mu[i] = mean[c + i]; istd[i] = 1.0f / sqrtf(var[c + i] + eps);
             ga[i] = gamma[c + i]; be[i] = beta[c + i]; s1[i] = 0.f; s2[i] = 0.f;
         }
-        for (int64_t m = r; m < M; m += R) {
+        // four rows (8 loads) requested before the first is used, same summation order (see bn_stats_partial_kernel)
+        int64_t m = r;
+        for (; m + 3 * (int64_t)R < M; m += 4 * (int64_t)R) {
+            VecF<W> yv[4], dv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { yv[u] = vload<W>(y + (m + u * (int64_t)R) * C + c); dv[u] = vload<W>(dout + (m + u * (int64_t)R) * C + c); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < W; ++i) {
+                    const float xh = (yv[u].v[i] - mu[i]) * istd[i];
+                    const float z = xh * ga[i] + be[i];
+                    const float dz = dv[u].v[i] * act_grad(z, act, slope);
+                    s1[i] += dz;
+                    s2[i] = fmaf(dz, xh, s2[i]);
+                }
+        }
+        for (; m < M; m += R) {
             const VecF<W> yv = vload<W>(y + m * C + c);
             const VecF<W> dv = vload<W>(dout + m * C + c);
 #pragma unroll

@@ -455,7 +455,13 @@ static TnPlan plan_tn(int64_t M, int P, int Q, bool allow_narrow = false) {
     if (TSII_TN_NARROW64 && allow_narrow && P >= 128 && Q > 32 && Q <= 64) { pl.narrow = true; pl.bm = 128; }
     if (pl.narrow) pl.bn = 64;
     const int tiles = cdiv(P, pl.bm) * cdiv(Q, pl.bn);
-    int64_t want = 1024 / tiles;
+    // split M so that the grid is ONE full wave of resident blocks: the TN kernels hold 3 blocks per CU (48 KB of LDS each), 768 on
+    // the part.  Rounds 2-5 aimed at 1024 blocks -- a full wave plus a third of one, whose blocks run while two thirds of the slots
+    // idle (round 6, TN_SLOTS: 1024 restores that)
+#ifndef TN_SLOTS
+#define TN_SLOTS 768
+#endif
+    int64_t want = TN_SLOTS / tiles;
     if (want < 1) want = 1;
     int64_t chunk = cdiv64(M, want);
     if (chunk < 256) chunk = 256;

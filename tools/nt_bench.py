@@ -16,9 +16,10 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 NAMES = ("tsii_pw_fwd", "tsii_pw_fwd_bn", "tsii_pw_fwd_up", "tsii_pw_bwd_dx", "tsii_pw_bwd_dx_bn")
+NAMES_TN = ("tsii_pw_bwd_dw", "tsii_pw_bwd_dw_bn")      # --tn: the weight-gradient launches (class gemm_tn) instead
 
 
-def record(batch, size):
+def record(batch, size, names=NAMES):
     import text_segmentation_image_inpainting_amd as T
     from text_segmentation_image_inpainting_amd import _lib
     from text_segmentation_image_inpainting_amd.BaseModels import to_nhwc
@@ -34,7 +35,7 @@ def record(batch, size):
     calls, real = [], _lib.call
 
     def spy(name, *args):
-        if name in NAMES:
+        if name in names:
             calls.append((name, tuple((a if isinstance(a, (int, float)) else (a is not None and getattr(a, "value", 1) is not None)) for a in args)))
         return real(name, *args)
     _lib.call = spy
@@ -62,7 +63,24 @@ def replay(name, a, iters):
     st = _lib.stream()
     R = lambda *s: torch.randn(*s, device=dev)
     opt = lambda on, t: t if on else None
-    if name in ("tsii_pw_fwd", "tsii_pw_fwd_bn", "tsii_pw_fwd_up"):
+    if name in NAMES_TN:
+        # (gy, x, m, cout, k, inv, keep, r0, split, r1, [in_scale, in_shift, act, slope,] dw, db, ws, nbytes, stream)
+        m, cout, k = a[2], a[3], a[4]
+        gy, x = R(m, cout), R(m, k)
+        inv = opt(a[5], torch.full((m,), 1.0 / cout, device=dev)); keep = opt(a[6], torch.ones(m, device=dev))
+        r0 = opt(a[7], (torch.rand(m, device=dev) > 0.05).float()); split = a[8]; r1 = opt(a[9], torch.ones(m, device=dev))
+        bn = name.endswith("_bn")
+        o = 4 if bn else 0
+        dw = torch.empty(cout, k, device=dev); db = opt(a[11 + o], torch.empty(cout, device=dev))
+        nb = L.tsii_pw_bwd_dw_ws_bytes(m, cout, k)
+        ws = torch.empty(nb // 4 + 4, device=dev)
+        if bn:
+            sc, sh = torch.rand(k, device=dev) + 0.5, R(k)
+            fn = lambda: call(name, ptr(gy), ptr(x), m, cout, k, ptr(inv), ptr(keep), ptr(r0), split, ptr(r1), ptr(sc), ptr(sh), a[12], a[13], ptr(dw), ptr(db), ptr(ws), nb, st)
+        else:
+            fn = lambda: call(name, ptr(gy), ptr(x), m, cout, k, ptr(inv), ptr(keep), ptr(r0), split, ptr(r1), ptr(dw), ptr(db), ptr(ws), nb, st)
+        by, label, n = 4.0 * m * (k + cout), f"P={cout:4d} Q={k:4d}" + (" inBN" if bn else ""), cout
+    elif name in ("tsii_pw_fwd", "tsii_pw_fwd_bn", "tsii_pw_fwd_up"):
         m, k, n = a[1], a[2], a[4]
         x, w, y = R(m, k), R(n, k) * 0.05, torch.empty(m, n, device=dev)
         bias = opt(a[5], R(n))
@@ -123,15 +141,17 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--only", default="", help="comma list of substrings of the entry-point names")
+    ap.add_argument("--tn", action="store_true", help="the weight-gradient launches (tsii_pw_bwd_dw / _dw_bn) instead of forward / dX")
+    ap.add_argument("--model", default="ImageFill")
     ap.add_argument("--min-k", type=int, default=0)
     ap.add_argument("--max-k", type=int, default=1 << 30, help="reduction length (the entry point's contraction dimension)")
     args = ap.parse_args()
-    uniq = record(args.batch, args.size)
+    uniq = record(args.batch, args.size, NAMES_TN if args.tn else NAMES)
     rows, tot, tot_floor = [], 0.0, 0.0
     for (name, a), cnt in uniq.items():
         if args.only and not any(s in name for s in args.only.split(",")):
             continue
-        kk = a[2]
+        kk = a[4] if name in NAMES_TN else a[2]
         if not (args.min_k <= kk <= args.max_k):
             continue
         ms, by, macs, label = replay(name, a, args.iters)
