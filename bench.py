@@ -91,6 +91,7 @@ CALLS = {
     "tsii_dw_fwd": ("dw_stencil", lambda a: _dw(a, (1, 1))), "tsii_dw_fwd_bn": ("dw_stencil", lambda a: _dw(a, (1, 1))),
     "tsii_dw_bwd_dx": ("dw_stencil", lambda a: _dw(a, (1, 1))),
     "tsii_dw_bwd_dx_bn": ("dw_stencil", lambda a: _dw(a, (2, 1))),      # + the raw BatchNorm input read alongside (K6c)
+    "tsii_dw_bwd_dxdw_bn": ("dw_stencil", lambda a: _dw(a, (2, 1))),    # K6d: the same pass also leaves the weight gradient ([C][9]: no traffic to speak of)
     "tsii_dw_bwd_dw": ("dw_stencil", lambda a: _dw(a, (1, 1))), "tsii_dw_bwd_dw_bn": ("dw_stencil", lambda a: _dw(a, (1, 1))),
     "tsii_bn_act_fwd": ("bn_act", lambda a: _bn(a, 2)), "tsii_bn_stats": ("bn_act", lambda a: _bn(a, 1)),
     "tsii_bn_act_bwd": ("bn_bwd", lambda a: _bn(a, 3)), "tsii_bn_act_bwd_pre": ("bn_bwd", lambda a: _bn(a, 3)),

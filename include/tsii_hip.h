@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TSII_ABI_VERSION 4
+#define TSII_ABI_VERSION 5
 
 /* activation kinds for the BN/activation kernels */
 #define TSII_ACT_NONE 0
@@ -279,6 +279,17 @@ int tsii_dw_bwd_dx_bn(const float* dy, const float* inv, const float* w, const f
                       int ho, int wo, const float* bn_y, const float* bn_mean, const float* bn_var,
                       const float* bn_gamma, const float* bn_beta, float bn_eps, int bn_act, float bn_slope,
                       float* dx, float* bwd_part, float* ws, void* stream);
+/* K6d: tsii_dw_bwd_dx_bn that ALSO returns the layer's weight gradient dwgt[c][1][3][3] (no bias gradient: the layer has no bias) --
+ * the dX pass holds dy * inv with its halo in LDS and forms the layer's input act(BN(bn_y)) * rmask at its own pixels for the K6c
+ * sums, i.e. both operands of dW; tsii_dw_bwd_dw_bn's second pass over (dy, bn_y) is not run.  3x3 / stride 1 / dilation 1 only:
+ * ws_dw of tsii_dw_bwd_dxdw_ws_bytes(...) bytes, 0 = no such form for this geometry (call the two separate entry points).
+ * Replaces the autograd of F.conv2d(groups=C) in models/partial_convolution.py:49-51 for dX and dW together. */
+size_t tsii_dw_bwd_dxdw_ws_bytes(int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw);
+int tsii_dw_bwd_dxdw_bn(const float* dy, const float* inv, const float* w, const float* rmask,
+                        int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                        int ho, int wo, const float* bn_y, const float* bn_mean, const float* bn_var,
+                        const float* bn_gamma, const float* bn_beta, float bn_eps, int bn_act, float bn_slope,
+                        float* dx, float* bwd_part, float* dwgt, float* ws, void* ws_dw, size_t ws_dw_bytes, void* stream);
 /* same for the point-wise dX (N = k % 4 == 0): dx is the gradient w.r.t. a = act(BN(bn_y)), bn_y raw [m,k];
  * bwd_part[tsii_pw_stat_rows(m)][2][k] */
 int tsii_pw_bwd_dx_bn(const float* dy, int64_t m, int n, const float* w, int k, const float* inv,

@@ -600,6 +600,40 @@ def _strip_entry_points(L, n, h, wd, c, masked, bias, act, d=1, p=None):
     slack = (np.abs(dx) * near).reshape(-1, c).sum(0) * 2 + 1e-4 * np.abs(dz).reshape(-1, c).sum(0).max()
     assert np.all(np.abs(bp[0] - dz.reshape(-1, c).sum(0)) <= slack)
     assert np.all(np.abs(bp[1] - (dz * xh).reshape(-1, c).sum(0)) <= slack * max(1.0, np.abs(xh).max()))
+    # K6d: the same pass also returns the weight gradient -- dX and the K6c partials bit for bit those above, dW against float64 and
+    # against the separate entry point it replaces
+    dwb = L.tsii_dw_bwd_dxdw_ws_bytes(n, h, wd, c, *geom)
+    if d != 1:
+        assert dwb == 0, "K6d exists for dilation 1 only"
+        return
+    assert dwb == 4 * brows * 9 * c
+    wsd = WS(dwb); wsd[:] = np.nan
+    bpart3 = WS(4 * brows * 2 * c); bpart3[:] = np.nan
+    dx3 = np.full((n, h, wd, c), np.nan, np.float32)
+    dw3 = np.full((c, 1, 3, 3), np.nan, np.float32)
+    assert L.tsii_dw_bwd_dxdw_bn(P(dy), P(inv), P(w), P(rmask), n, h, wd, c, *geom, ho, wo, P(x), P(mean_b), P(var_b), P(gam), P(bet),
+                                 1e-5, act, slope, P(dx3), P(bpart3), P(dw3), P(ws), P(wsd), dwb, None) == 0, L.tsii_last_error()
+    assert np.array_equal(dx3, dx)
+    assert np.array_equal(bpart3[:brows * 2 * c], bpart[:brows * 2 * c])
+    am = _act(z, act, slope) * (1.0 if rmask is None else rmask.astype(np.float64)[..., None])    # the layer's input
+    gfull = dy.astype(np.float64) * (1.0 if inv is None else inv.astype(np.float64)[..., None])
+    ap = np.zeros((n, h + 2 * p, wd + 2 * p, c)); ap[:, p:p + h, p:p + wd] = am
+    dwr = np.zeros((c, 1, 3, 3)); dwabs = np.zeros((c, 1, 3, 3))
+    for ky in range(3):
+        for kx in range(3):
+            prod = ap[:, ky:ky + ho, kx:kx + wo] * gfull
+            dwr[:, 0, ky, kx] = prod.reshape(-1, c).sum(0)
+            dwabs[:, 0, ky, kx] = np.abs(prod).reshape(-1, c).sum(0)
+    assert np.all(np.abs(dw3 - dwr) <= 2e-6 * dwabs + 1e-6), np.abs(dw3 - dwr).max()
+    # the separate weight-gradient entry point (BatchNorm on load with the equivalent scale / shift): same sums, another order
+    isig = 1.0 / np.sqrt(var_b.astype(np.float64) + 1e-5)
+    sc2 = (gam * isig).astype(np.float32); sh2 = (bet - mean_b * gam * isig).astype(np.float32)
+    nb = L.tsii_dw_bwd_dw_ws_bytes(n, ho, wo, c, 3, 3)
+    wsw = WS(nb)
+    dw4 = np.full((c, 1, 3, 3), np.nan, np.float32)
+    assert L.tsii_dw_bwd_dw_bn(P(dy), P(inv), P(keep), P(x), P(rmask), n, h, wd, c, *geom, ho, wo, P(sc2), P(sh2), act, slope,
+                               P(dw4), None, P(wsw), nb, None) == 0, L.tsii_last_error()
+    assert np.all(np.abs(dw3 - dw4) <= 2e-5 * dwabs + 1e-5), np.abs(dw3 - dw4).max()
 
 
 @pytest.mark.parametrize("n,h,wd,c,d,p,masked,bias,act", [

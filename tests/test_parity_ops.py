@@ -98,6 +98,23 @@ def test_golden_pir_blocks_all_batchnorm_fusions(backend, monkeypatch):
     test_golden_pir_blocks.__wrapped__(backend) if hasattr(test_golden_pir_blocks, "__wrapped__") else test_golden_pir_blocks(backend)
 
 
+@both_backends
+def test_golden_pir_blocks_weight_gradient_in_the_dx_pass(backend, monkeypatch):
+    """K6d (the depth-wise dX + K6c pass also takes the weight gradient, the default for stride 1 / dilation 1) really runs on the
+    PartialInvertedResidual fixtures -- and the same fixtures with it switched off (the separate tsii_dw_bwd_dw_bn pass)."""
+    from text_segmentation_image_inpainting_amd import ops
+    calls = []
+    real = ops.call
+    monkeypatch.setattr(ops, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+    run = test_golden_pir_blocks.__wrapped__ if hasattr(test_golden_pir_blocks, "__wrapped__") else test_golden_pir_blocks
+    run(backend)
+    assert "tsii_dw_bwd_dxdw_bn" in calls, sorted(set(calls))
+    del calls[:]
+    monkeypatch.setattr(ops, "FUSE_DW_DXDW", False)
+    run(backend)
+    assert "tsii_dw_bwd_dxdw_bn" not in calls and "tsii_dw_bwd_dw_bn" in calls, sorted(set(calls))
+
+
 def _imagefill_case(dev, size, batch, seed, per_channel_mask, hole_frac=0.12):
     from oracle.filler import seeded_input
     keys = json.load(open(os.path.join(GOLD, "state_dict_keys.json")))

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TSII_LIBRARY") or os.path.join(_HERE, "libtsii_hip.so")   # TSII_LIBRARY: another BUILD of csrc/ (A/B measurements)
-ABI_VERSION = 4           # TSII_ABI_VERSION of include/tsii_hip.h this binding was written against
+ABI_VERSION = 5           # TSII_ABI_VERSION of include/tsii_hip.h this binding was written against
 
 _p, _i, _l, _f, _z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 _GEOM = [_i] * 8  # kh kw sh sw ph pw dh dw
@@ -70,6 +70,8 @@ SIGNATURES = {
     "tsii_bn_finalize_ws_bytes": (_z, [_l, _i]),
     "tsii_bn_finalize": (_i, [_p, _l, _i, _l, _p, _p, _p, _p, _f, _p, _p, _f, _p, _p, _p, _z, _p]),
     "tsii_dw_bwd_dx_bn": (_i, [_p, _p, _p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p]),
+    "tsii_dw_bwd_dxdw_ws_bytes": (_z, [_i, _i, _i, _i] + _GEOM),
+    "tsii_dw_bwd_dxdw_bn": (_i, [_p, _p, _p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p, _p, _z, _p]),
     "tsii_pw_bwd_dx_bn": (_i, [_p, _l, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p]),
     "tsii_bn_act_bwd_pre": (_i, [_p, _p, _l, _i, _p, _p, _p, _p, _f, _i, _f, _i, _p, _l, _p, _p, _p, _p, _z, _p]),
     "tsii_bn_act_bwd_pre_pool": (_i, [_p, _p, _l, _i, _p, _p, _p, _p, _f, _i, _f, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),

@@ -52,7 +52,15 @@ __device__ __forceinline__ f32x2 max2(f32x2 a, f32x2 b) { return f32x2{fmaxf(a.x
 __device__ __forceinline__ f32x2 min2(f32x2 a, f32x2 b) { return f32x2{fminf(a.x, b.x), fminf(a.y, b.y)}; }
 __device__ __forceinline__ f32x4 cat4(f32x2 a, f32x2 b) { return f32x4{a.x, a.y, b.x, b.y}; }
 
-// MODE 0: plain; 1: forward with BatchNorm on load and / or statistics partials (K6b); 2: dX feeding a BatchNorm backward (K6c).
+// MODE 0: plain; 1: forward with BatchNorm on load and / or statistics partials (K6b); 2: dX feeding a BatchNorm backward (K6c);
+// 3 (K6d, round 6): MODE 2 that ALSO takes the layer's weight gradient.  The dX pass already holds both operands of dW on chip:
+// the staged slab is G = dy * inv with its halo, and the raw BatchNorm input y it reads for the K6c reductions at its own output
+// pixels q gives the convolution's input a(q) = act(BatchNorm(y(q))) * rmask(q) for three more instructions per element --
+//     dW[t] = sum_q a(q) G(q + pad - t)        dX(q) = rmask(q) sum_t W[t] G(q + pad - t)
+// walk the same 3x3 window of G around q.  A second sweep over the step's 18 LDS reads (after the stores, when y has landed)
+// accumulates 9 taps x 4 channels per thread over the whole strip chunk; one partial row [9][C] per block in `stats`, combined
+// by dw_reduce_kernel.  The separate weight-gradient kernel (dw_strip_dw_kernel<1, 1>: dy and y streamed once more, 6.4 GB on
+// the 32 x 256^2 x 384 layer) is not launched.  36 more accumulators: 2 waves per SIMD.
 // DXE: dX epilogue (out = post_mul != 0 ? acc * post_mul : 0) instead of the forward one (acc / denom + bias, zero where keep == 0).
 // PRE: the staged input is multiplied by a per-pixel plane (mask for forward, 1 / count for dX).
 // PH (round 6): DILATION d > 1 BY PHASES.  With dilation d every tap of output pixel (oy, ox) lies d pixels apart, so the outputs with
@@ -68,12 +76,13 @@ __device__ __forceinline__ f32x4 cat4(f32x2 a, f32x2 b) { return f32x4{a.x, a.y,
 // 8 bytes, the staged slab in LDS is fp32 (an activation the producer's BatchNorm forms on load is rounded to bf16 first -- where it
 // would have been stored), `wT` is the reference layout [C][9] (the bf16 entry points carry no workspace for a transposed copy).
 template <int MODE, bool DXE, bool PRE, bool PH = false, bool H16 = false>
-__global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_kernel(
+__global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 2 : LS_WAVES_FUSED)) void dw_lean_kernel(
     const float* __restrict__ in, const float* __restrict__ pre, const float* __restrict__ wT, const float* __restrict__ bias,
     const float* __restrict__ denom, const float* __restrict__ keep, const float* __restrict__ post_mul, DtGeom g, int chunk_rows,
     unsigned strips_x, unsigned chunks_y, unsigned cblocks, DwBN ib, float* __restrict__ stats, DwBnBwd bb,
     float* __restrict__ out) {
-    constexpr bool FUSED = (MODE == 1), BNB = (MODE == 2);
+    constexpr bool FUSED = (MODE == 1), BNB = (MODE == 2 || MODE == 3), DWG = (MODE == 3);
+    static_assert(!DWG || (!PH && !H16), "K6d: the fp32 dilation-1 strips only");
     constexpr unsigned ES = H16 ? 2u : 4u;                   // bytes per activation element
     static_assert(!H16 || !PRE, "bf16 activation storage carries no mask planes");
     static_assert(!BNB || DXE, "K6c rides on the dX epilogue");
@@ -354,6 +363,10 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
     f32x4 P = {0.f, 0.f, 0.f, 0.f};                    // K6b: thread-local pivot = its first output
     f32x2 va[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};   // K6b: s1.xy s1.zw s2.xy s2.zw | K6c: sum dz, sum dz*xhat
 
+    f32x4 dwa[DWG ? 9 : 1];                              // K6d: weight-gradient accumulators, tap (ky, kx) of the (flipped) window
+#pragma unroll
+    for (int k = 0; k < (DWG ? 9 : 1); ++k) dwa[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
     // K6c: raw BatchNorm input at this thread's output pixels of step s (clamped rows / columns: the loads are unconditional),
     // requested one step ahead like the slab and used after the step's stores
     f32x4 yv[4];
@@ -401,11 +414,13 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
         const float* pls = &lplanes[s & 1][(4 * th) * LS_TW + tx][0];
         f32x4 bq = {0.f, 0.f, 0.f, 0.f};
         if (!DXE) bq = *reinterpret_cast<const f32x4*>(cthr + 2 * LS_PIXB);
+        float rmk[4] = {0.f, 0.f, 0.f, 0.f};          // K6d: rmask at the thread's pixels (0 for a pixel outside the chunk)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             f32x2 a0 = a[k][0], a1 = a[k][1];
             if (DXE) {
                 const float pmk = pls[k * LS_TW * 2];
+                if (DWG) rmk[k] = (xok && 4 * th + k < rows_left) ? pmk : 0.f;
                 a0 *= pmk; a1 *= pmk;
                 if (pmk == 0.f) { a0 = f32x2{0.f, 0.f}; a1 = a0; }
             } else {
@@ -453,6 +468,33 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
                     va[0] += d0; va[1] += d1;
                     va[2] = fma2(d0, h0, va[2]); va[3] = fma2(d1, h1, va[3]);
                 }
+                if (DWG) {
+                    // the convolution's input at this pixel: act(z) * rmask (exact zero outside the chunk: y was a clamped load)
+                    f32x2 e0 = min2(max2(z0, z0 * bb.neg), f32x2{bb.hi, bb.hi}), e1 = min2(max2(z1, z1 * bb.neg), f32x2{bb.hi, bb.hi});
+                    e0 *= rmk[k]; e1 *= rmk[k];
+                    if (rmk[k] == 0.f) { e0 = f32x2{0.f, 0.f}; e1 = e0; }
+                    yv[k] = cat4(e0, e1);
+                }
+            }
+            if (DWG) {
+                // second sweep over the step's window: dwa[ky * 3 + kx] += a(q_k) * G(q_k - pad' + (ky, kx)), rows r = k + ky
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    f32x4 v[3];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) v[kx] = *reinterpret_cast<const f32x4*>(rb + (r * LS_PW + kx) * LS_PIXB);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int k = r - ky;
+                        if (k < 0 || k > 3) continue;
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            f32x2 lo = dwa[ky * 3 + kx].xy, hi2 = dwa[ky * 3 + kx].zw;
+                            lo = fma2(v[kx].xy, yv[k].xy, lo); hi2 = fma2(v[kx].zw, yv[k].zw, hi2);
+                            dwa[ky * 3 + kx] = cat4(lo, hi2);
+                        }
+                    }
+                }
             }
         }
         if (more) { commit((s + 1) & 1); commit_planes(s + 1); }   // into the buffer nobody reads during this step
@@ -478,6 +520,26 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : LS_WAVES_FUSED) void dw_lean_k
                 for (int l = 0; l < 32; ++l) sum += mrg[(l * 8 + ch / 4) * 8 + which * 4 + ch % 4];
                 const int64_t prow = (nv * chunks_y + cy) * strips_x + sx;
                 bb.part[(prow * 2 + which) * C + (int)cb * LS_CB + ch] = sum;
+            }
+        }
+        if (DWG) {
+            // K6d: merge the 32 pixel lanes of every channel, tap by tap: [9][256] float4 through the buffers
+            static_assert(9 * 256 * 16 <= 2 * LS_BUFB, "weight-gradient merge buffer fits the LDS buffers");
+            __syncthreads();
+            f32x4* m4 = reinterpret_cast<f32x4*>(lbuf);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) m4[k * 256 + t] = dwa[k];
+            __syncthreads();
+            const int64_t prow = (nv * chunks_y + cy) * strips_x + sx;
+            for (int j = t; j < 9 * LS_CB; j += 256) {
+                const int k = j / LS_CB, ch = j % LS_CB;
+                if ((int)cb * LS_CB + ch >= C) continue;
+                const float* col = lbuf + ((k * 256 + ch / 4) * 4 + ch % 4);
+                float sum = 0.f;
+#pragma unroll 8
+                for (int l = 0; l < 32; ++l) sum += col[l * 32];
+                const int tap = g.flip ? 8 - k : k;               // the window is the flipped one: tap index of the forward weight
+                stats[(prow * 9 + tap) * C + (int)cb * LS_CB + ch] = sum;
             }
         }
     } else if (FUSED) {

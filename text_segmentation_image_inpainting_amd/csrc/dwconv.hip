@@ -804,13 +804,21 @@ static const DwBnBwd kNoBnBwd = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.
 // geometries with the K6b / K6c strip variants (stride 2: forward only here; its dX has its own kernel)
 static bool dw_fused_ok(int s, int d) { return (s == 2 && d == 1) || (s == 1 && (d == 1 || d == 2 || d == 4 || d == 8)); }
 
+// K6d: the geometry (of the dX grid: g.hout x g.wout = the layer's input) the lean kernel takes before any other strip path does
+static bool dw_dxdw_geom_ok(const DtGeom& g) {
+    return g.s == 1 && g.d == 1 && g.flip == 1 && g.pad_h >= 0 && g.pad_w >= 0 && dw_lean_ok(g) && !dw_rows_ok(g) && !dw_small_ok(g);
+}
+
 static int try_launch_dw_strip(const float* in, const float* pre, const float* wT, const float* bias, const float* denom,
                                const float* keep, const float* post_mul, DtGeom g, float* out, hipStream_t st,
-                               DwBN ib = kNoDwBN, float* stats = nullptr, DwBnBwd bb = kNoBnBwd) {
+                               DwBN ib = kNoDwBN, float* stats = nullptr, DwBnBwd bb = kNoBnBwd, float* dwpart = nullptr) {
     if (g.c % 4 != 0 || !aligned16(in) || !aligned16(out) || !aligned16(wT)) return 1;
     if (ib.sc != nullptr && (!aligned16(ib.sc) || !aligned16(ib.sh))) return 1;
     const FusedPlan fp = plan_fwd_strips(g.n, g.hout, g.wout, g.c, g.s, g.d);
     const StripPlan sp = fp.sp;
+    // K6d (dX + K6c + the weight gradient in one pass, dwpart = [partial rows][9][C]) exists on the lean kernel only
+    if (dwpart != nullptr && !(dw_dxdw_geom_ok(g) && sp.ok && fp.phases == 1 && !fp.rows_only && bb.y != nullptr && stats == nullptr &&
+                               ib.sc == nullptr && denom == nullptr && keep == nullptr && bias == nullptr)) return 1;
     const bool fused_any = ib.sc != nullptr || stats != nullptr || bb.y != nullptr;
     // large dilation on mid-sized maps, no mask planes: one row phase of a channel block in LDS (dw_rows.h)
     if (dw_rows_ok(g) && pre == nullptr && denom == nullptr && keep == nullptr && post_mul == nullptr && sp.ok &&
@@ -885,6 +893,13 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
                                     sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out); } while (0)
         if (bb.y != nullptr) {
             if (!dxe) return 1;
+            if (dwpart != nullptr) {
+                if (pre != nullptr) hipLaunchKernelGGL((dw_lean_kernel<3, true, true>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                                       sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, dwpart, bb, out);
+                else hipLaunchKernelGGL((dw_lean_kernel<3, true, false>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                        sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, dwpart, bb, out);
+                return check_launch("dw_lean (dX + dW)");
+            }
             TSII_DW_LEAN(2, true);
         } else if (fused) {
             if (post_mul != nullptr) return 1;
@@ -1166,9 +1181,9 @@ __global__ __launch_bounds__(256, 2) void dw_strip_dw_kernel(const float* __rest
 // sum the R partial rows (block = 32 columns x 8 row lanes, 4 loads in flight) and scatter back to the
 // reference layout dw[c][t], db[c]
 __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ part, int R, int T, int C,
-                                                        float* __restrict__ dwgt, float* __restrict__ dbias) {
+                                                        float* __restrict__ dwgt, float* __restrict__ dbias, int TP = 0) {
     __shared__ double sh[8][33];
-    const int64_t len = (int64_t)(T + 1) * C;
+    const int64_t len = (int64_t)(TP > 0 ? TP : T + 1) * C;    // TP: sub-rows of a partial row (default: the taps + the bias row)
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int64_t j = (int64_t)blockIdx.x * 32 + tx;
     double a[4] = {0, 0, 0, 0};
@@ -1297,7 +1312,7 @@ extern "C" int tsii_dw_fwd_bn(const float* x, const float* rmask, const float* w
 
 static int dw_bwd_dx_impl(const float* dy, const float* inv, const float* w, const float* rmask,
                           int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw,
-                          int dh, int dw, int ho, int wo, DwBnBwd bb, float* dx, float* ws, void* stream) {
+                          int dh, int dw, int ho, int wo, DwBnBwd bb, float* dx, float* ws, void* stream, float* dwpart = nullptr) {
     TSII_REQUIRE(dy && w && dx && ws, "dw_bwd_dx: null pointer");
     DW_GEOM();
     if (check_geom(g, "dw_bwd_dx")) return -1;
@@ -1308,9 +1323,10 @@ static int dw_bwd_dx_impl(const float* dy, const float* inv, const float* w, con
     if (kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == dw) {
         // stride 1: dx[i] = rmask[i] * sum_t w[t] * (dy*inv)[i + pad - t*d] -- the forward stencil with flipped taps
         DtGeom tg = {n, ho, wo, c, 1, dh, 2 * dh - ph, 2 * dw - pw, h, wd, 1};
-        rc = try_launch_dw_strip(dy, inv, ws, nullptr, nullptr, nullptr, rmask, tg, dx, st, kNoDwBN, nullptr, bb);
+        rc = try_launch_dw_strip(dy, inv, ws, nullptr, nullptr, nullptr, rmask, tg, dx, st, kNoDwBN, nullptr, bb, dwpart);
         if (rc <= 0) return rc;
     }
+    TSII_REQUIRE(dwpart == nullptr, "dw_bwd_dxdw_bn: this geometry has no fused dX + dW form (tsii_dw_bwd_dxdw_ws_bytes() == 0)");
     if (vec && kh == 3 && kw == 3 && sh == 2 && sw == 2 && dh == 1 && dw == 1 && ph == 1 && pw == 1) {   // marching strips
         const StripPlan sp = plan_strip(n, h, wd, c, 1, 1);     // strips of the input grid
         if (sp.ok) {
@@ -1357,6 +1373,46 @@ extern "C" int tsii_dw_bwd_dx_bn(const float* dy, const float* inv, const float*
     return dw_bwd_dx_impl(dy, inv, w, rmask, n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo, bb, dx, ws, stream);
 }
 
+// K6d: dX + K6c + the layer's weight gradient in ONE pass over (dy, y) -- the lean strip kernel's MODE 3 (dw_lean.h).
+// -> bytes of the weight-gradient partial rows, 0 when the geometry has no such form (3x3, stride 1, dilation 1, c % 4 == 0, the
+// sizes dw_lean_ok() takes); the K6c partial rows are those of tsii_dw_bwd_stat_rows().
+extern "C" size_t tsii_dw_bwd_dxdw_ws_bytes(int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw) {
+    if (n <= 0 || h <= 0 || wd <= 0 || c <= 0 || c % 4 != 0 || !(kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == 1 && dw == 1)) return 0;
+    if (ph < 0 || pw < 0 || ph > 2 || pw > 2) return 0;
+    const int ho = h + 2 * ph - 2, wo = wd + 2 * pw - 2;
+    if (ho <= 0 || wo <= 0) return 0;
+    const DtGeom tg = {n, ho, wo, c, 1, 1, 2 - ph, 2 - pw, h, wd, 1};
+    if (!dw_dxdw_geom_ok(tg)) return 0;
+    const FusedPlan fp = plan_fwd_strips(n, h, wd, c, 1, 1);
+    if (!fp.sp.ok || fp.phases != 1 || fp.rows_only) return 0;
+    const int64_t rows = (int64_t)n * fused_rows_per_image(fp);
+    if (rows <= 0 || rows >= (1ll << 31)) return 0;
+    return (size_t)rows * 9 * (size_t)c * sizeof(float);
+}
+
+extern "C" int tsii_dw_bwd_dxdw_bn(const float* dy, const float* inv, const float* w, const float* rmask,
+                                   int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw,
+                                   int dh, int dw, int ho, int wo,
+                                   const float* bn_y, const float* bn_mean, const float* bn_var, const float* bn_gamma,
+                                   const float* bn_beta, float bn_eps, int bn_act, float bn_slope,
+                                   float* dx, float* bwd_part, float* dwgt, float* ws, void* ws_dw, size_t ws_dw_bytes, void* stream) {
+    TSII_REQUIRE(bn_y && bn_mean && bn_var && bn_gamma && bn_beta && bwd_part && dwgt && ws_dw, "dw_bwd_dxdw_bn: null pointer");
+    TSII_REQUIRE(aligned16(bn_y) && aligned16(bn_mean) && aligned16(bn_var) && aligned16(bn_gamma) && aligned16(bn_beta) && aligned16(ws_dw),
+                 "dw_bwd_dxdw_bn: BatchNorm operands and the workspace must be 16-byte aligned");
+    const size_t need = tsii_dw_bwd_dxdw_ws_bytes(n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw);
+    TSII_REQUIRE(need > 0, "dw_bwd_dxdw_bn: this geometry has no fused dX + dW form (tsii_dw_bwd_dxdw_ws_bytes() == 0)");
+    TSII_REQUIRE(ws_dw_bytes >= need, "dw_bwd_dxdw_bn: weight-gradient workspace too small");
+    InBN tmp;
+    TSII_REQUIRE(make_in_bn(bn_mean, bn_var, bn_act, bn_slope, &tmp) == 0, "dw_bwd_dxdw_bn: activation %d has no load-time form", bn_act);
+    const DwBnBwd bb = {bn_y, bn_mean, bn_var, bn_gamma, bn_beta, bn_eps, tmp.neg, tmp.hi, bwd_part};
+    int rc = dw_bwd_dx_impl(dy, inv, w, rmask, n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo, bb, dx, ws, stream, (float*)ws_dw);
+    if (rc) return rc;
+    const int rows = (int)(need / ((size_t)9 * c * sizeof(float)));
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)cdiv64((int64_t)9 * c, 32)), dim3(256), 0, (hipStream_t)stream, (const float*)ws_dw, rows, 9, c, dwgt,
+                       (float*)nullptr, 9);
+    return check_launch("dw_reduce");
+}
+
 extern "C" size_t tsii_dw_bwd_dw_ws_bytes(int n, int ho, int wo, int c, int kh, int kw) {
     if (n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || kh <= 0 || kw <= 0) return 0;
     // the scalar plan (taken when c % 4 != 0 or a pointer is unaligned) never needs more rows
@@ -1391,7 +1447,7 @@ static int dw_bwd_dw_impl(const float* dy, const float* inv, const float* keep, 
             else hipLaunchKernelGGL((dw_rows_dw_kernel<false>), dim3((unsigned)n * rcb), dim3(DR_THREADS), 0, st, dy, x, rg, rcb, ib, part);
             int rc0 = check_launch("dw_rows_dw");
             if (rc0) return rc0;
-            hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)cdiv64((int64_t)10 * c, 32)), dim3(256), 0, st, part, n, 9, c, dwgt, dbias);
+            hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)cdiv64((int64_t)10 * c, 32)), dim3(256), 0, st, part, n, 9, c, dwgt, dbias, 0);
             return check_launch("dw_reduce");
         }
     }
@@ -1414,7 +1470,7 @@ static int dw_bwd_dw_impl(const float* dy, const float* inv, const float* keep, 
                                     sp.strips_x, sp.chunks_y, sp.cblocks, ib, part);
             int rc0 = check_launch("dw_strip_dw");
             if (rc0) return rc0;
-            hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)cdiv64((int64_t)10 * c, 32)), dim3(256), 0, st, part, (int)rows, 9, c, dwgt, dbias);
+            hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)cdiv64((int64_t)10 * c, 32)), dim3(256), 0, st, part, (int)rows, 9, c, dwgt, dbias, 0);
             return check_launch("dw_reduce");
         }
     }
@@ -1428,7 +1484,7 @@ static int dw_bwd_dw_impl(const float* dy, const float* inv, const float* keep, 
     int rc = check_launch("dw_bwd_dw");
     if (rc) return rc;
     const int T = kh * kw;
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)cdiv64((int64_t)(T + 1) * c, 32)), dim3(256), 0, st, part, p.R, T, c, dwgt, dbias);
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)cdiv64((int64_t)(T + 1) * c, 32)), dim3(256), 0, st, part, p.R, T, c, dwgt, dbias, 0);
     return check_launch("dw_reduce");
 }
 

@@ -24,6 +24,8 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3, 4
 # GEMMs): PW on vs off = BatchNorm backward 19.9 -> 16.3 ms for +2.0 ms of GEMM epilogue: 90.5 -> 89.3 ms per step.
 FUSE_BN_BWD = True
 FUSE_BN_BWD_PW = True
+# K6d: the depth-wise dX + K6c pass also takes the layer's weight gradient (tsii_dw_bwd_dxdw_bn; stride 1 / dilation 1, bias-free)
+FUSE_DW_DXDW = True
 # bf16 storage: where the PLAIN dX product runs on the 256 x 256 direct-to-LDS kernel (k, cout >= 256) the K6c epilogue (register-staged
 # 128 x 256 tiles) costs more in a microbenchmark than that kernel plus the stand-alone reduction pass (131072 x 512 x 512: 153-165 us against 88 + 52) --
 # in the cfg 5 step it does not (profiles/r05x_k6c_unfuse.log: 60.2 ms fused, 61.0 unfused: the reduction pass reads dx and y cold), so: off
@@ -454,6 +456,20 @@ class _Depthwise(torch.autograd.Function):
             rows = 0
             if ctx.bn is not None and FUSE_BN_BWD and load_time_act(*ctx.in_cfg) and _al16(gy, x):   # K6c: strip paths of the dX grid
                 rows = int(_lib.lib().tsii_dw_bwd_stat_rows(n, h, wd, c, *g))
+            # K6d: the dX pass also takes the weight gradient (both of its operands are on chip there); bias-free layers only
+            dwb = 0
+            if rows > 0 and FUSE_DW_DXDW and ctx.needs_input_grad[1] and not ctx.has_bias and in_scale is not None:
+                dwb = int(_lib.lib().tsii_dw_bwd_dxdw_ws_bytes(n, h, wd, c, *g))
+            if dwb > 0:
+                mean, var, gamma, beta, eps, slot = ctx.bn
+                part = torch.empty((rows, 2, c), dtype=torch.float32, device=x.device)
+                dw = torch.empty_like(w)
+                wsd = _ws(dwb, x)
+                call("tsii_dw_bwd_dxdw_bn", ptr(gy), ptr(inv), ptr(w), ptr(rmask), n, h, wd, c, *g, ho, wo,
+                     ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ctx.in_cfg[0], ctx.in_cfg[1],
+                     ptr(dx), ptr(part), ptr(dw), ptr(ws), ptr(wsd), dwb, st)
+                slot.part = part
+                return (dx, dw, None) + (None,) * 11
             if rows > 0:
                 mean, var, gamma, beta, eps, slot = ctx.bn
                 part = torch.empty((rows, 2, c), dtype=torch.float32, device=x.device)
