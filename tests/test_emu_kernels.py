@@ -865,6 +865,74 @@ def test_depthwise_small_map_dilated(emu, n, h, wd, c, d, masked, bias, act):
         assert np.all(np.abs(bp[1] - (dz * xh).reshape(-1, c).sum(0)) <= slack * max(1.0, np.abs(xh).max()))
 
 
+@pytest.mark.parametrize("n,h,wd,c,masked,act", [
+    (2, 21, 37, 40, True, 2),        # odd sizes, row / column / channel tails
+    (1, 16, 32, 32, False, 3),       # whole steps and strips, no mask planes, ReLU6
+    (3, 45, 18, 36, True, 1),        # several steps per chunk, a strip tail of 2 columns
+    (1, 6, 5, 4, True, 0),           # smaller than a step and a strip
+])
+@pytest.mark.parametrize("target", [1536, 1])
+def test_depthwise_stride2_dx_with_weight_gradient(emu, n, h, wd, c, masked, act, target):
+    """K6d on the stride-2 dX strips (3x3 / stride 2 / padding 1): tsii_dw_bwd_dxdw_bn returns tsii_dw_bwd_dx_bn's dX and K6c partial
+    rows bit for bit plus the weight gradient -- against float64 and against the separate tsii_dw_bwd_dw_bn pass."""
+    L = emu
+    L.tsii_emu_set_strip_target(target)
+    try:
+        rng = np.random.default_rng(h * 100 + wd + 13)
+        slope = 0.3
+        ho, wo = (h - 1) // 2 + 1, (wd - 1) // 2 + 1
+        x = rng.standard_normal((n, h, wd, c)).astype(np.float32) + 0.5       # raw BatchNorm input of the layer
+        w = rng.standard_normal((c, 1, 3, 3)).astype(np.float32)
+        dy = rng.standard_normal((n, ho, wo, c)).astype(np.float32)
+        rmask = (rng.uniform(size=(n, h, wd)) > 0.2).astype(np.float32) if masked else None
+        keep = inv = None
+        if masked:
+            cnt = _dw_ref_fwd(rmask[..., None], None, np.ones((1, 1, 3, 3), np.float32), None, None, None, 2, 1, 1)[..., 0]
+            keep = (cnt > 0).astype(np.float32)
+            inv = (keep / (np.where(cnt > 0, cnt, 1.0) * c)).astype(np.float32)
+        geom = (3, 3, 2, 2, 1, 1, 1, 1)
+        ws = WS(4 * (9 * c + 16))
+        brows = L.tsii_dw_bwd_stat_rows(n, h, wd, c, *geom)
+        assert brows > 0
+        mean_b = rng.standard_normal(c).astype(np.float32); var_b = (rng.uniform(size=c) + 0.5).astype(np.float32)
+        gam = (rng.uniform(size=c) + 0.5).astype(np.float32); bet = rng.standard_normal(c).astype(np.float32)
+        bpart = WS(4 * brows * 2 * c); bpart[:] = np.nan
+        dx = np.full((n, h, wd, c), np.nan, np.float32)
+        assert L.tsii_dw_bwd_dx_bn(P(dy), P(inv), P(w), P(rmask), n, h, wd, c, *geom, ho, wo, P(x), P(mean_b), P(var_b), P(gam), P(bet),
+                                   1e-5, act, slope, P(dx), P(bpart), P(ws), None) == 0, L.tsii_last_error()
+        dwb = L.tsii_dw_bwd_dxdw_ws_bytes(n, h, wd, c, *geom)
+        assert dwb == 4 * brows * 9 * c
+        wsd = WS(dwb); wsd[:] = np.nan
+        bpart3 = WS(4 * brows * 2 * c); bpart3[:] = np.nan
+        dx3 = np.full((n, h, wd, c), np.nan, np.float32)
+        dw3 = np.full((c, 1, 3, 3), np.nan, np.float32)
+        assert L.tsii_dw_bwd_dxdw_bn(P(dy), P(inv), P(w), P(rmask), n, h, wd, c, *geom, ho, wo, P(x), P(mean_b), P(var_b), P(gam), P(bet),
+                                     1e-5, act, slope, P(dx3), P(bpart3), P(dw3), P(ws), P(wsd), dwb, None) == 0, L.tsii_last_error()
+        assert np.array_equal(dx3, dx)
+        assert np.array_equal(bpart3[:brows * 2 * c], bpart[:brows * 2 * c])
+        xh = (x.astype(np.float64) - mean_b) / np.sqrt(var_b.astype(np.float64) + 1e-5)
+        am = _act(xh * gam + bet, act, slope) * (1.0 if rmask is None else rmask.astype(np.float64)[..., None])
+        gfull = dy.astype(np.float64) * (1.0 if inv is None else inv.astype(np.float64)[..., None])
+        ap = np.zeros((n, h + 3, wd + 3, c)); ap[:, 1:1 + h, 1:1 + wd] = am
+        dwr = np.zeros((c, 1, 3, 3)); dwabs = np.zeros((c, 1, 3, 3))
+        for ky in range(3):
+            for kx in range(3):
+                prod = ap[:, ky:ky + 2 * (ho - 1) + 1:2, kx:kx + 2 * (wo - 1) + 1:2] * gfull
+                dwr[:, 0, ky, kx] = prod.reshape(-1, c).sum(0)
+                dwabs[:, 0, ky, kx] = np.abs(prod).reshape(-1, c).sum(0)
+        assert np.all(np.abs(dw3 - dwr) <= 2e-6 * dwabs + 1e-6), np.abs(dw3 - dwr).max()
+        isig = 1.0 / np.sqrt(var_b.astype(np.float64) + 1e-5)
+        sc2 = (gam * isig).astype(np.float32); sh2 = (bet - mean_b * gam * isig).astype(np.float32)
+        nb = L.tsii_dw_bwd_dw_ws_bytes(n, ho, wo, c, 3, 3)
+        wsw = WS(nb)
+        dw4 = np.full((c, 1, 3, 3), np.nan, np.float32)
+        assert L.tsii_dw_bwd_dw_bn(P(dy), P(inv), P(keep), P(x), P(rmask), n, h, wd, c, *geom, ho, wo, P(sc2), P(sh2), act, slope,
+                                   P(dw4), None, P(wsw), nb, None) == 0, L.tsii_last_error()
+        assert np.all(np.abs(dw3 - dw4) <= 2e-5 * dwabs + 1e-5), np.abs(dw3 - dw4).max()
+    finally:
+        L.tsii_emu_set_strip_target(0)
+
+
 @pytest.mark.parametrize("pad", [0, 2])
 def test_depthwise_stride2_forward_strip_other_paddings(emu, pad):
     """The stride-2 strip with padding 0 (valid) and 2: the kernel's buffer geometry (9 rows, 17 columns per 4 x 8 outputs) does not

@@ -545,17 +545,26 @@ __global__ __launch_bounds__(256, MODE != 0 ? (S == 2 ? ST_S2_WAVES : 2) : 3) vo
 // candidate taps per axis, the second one zero-weighted where the parity admits a single tap.
 // BNB (K6c): dx is the gradient w.r.t. act(bn(y)) of the raw tensor y on the same grid; sum(dz), sum(dz*xhat) per strip
 // chunk go to bb.part like in the stride-1 strip kernel.
-template <bool BNB>
+// DWG (K6d, round 6): the pass also takes the layer's weight gradient.  A thread's (up to) four candidate taps are fixed by its
+// parity and their dy*inv values are the ones it has just read for dX; the layer's input at its pixel, act(bn(y)) * rmask, comes
+// with the K6c arithmetic: dW[tap] += a(q) * G -- 4 x 4 accumulators, merged per parity class at the end into one partial row
+// [9][C] per block (dwpart), instead of dw_strip_dw_kernel<2, 1>'s second pass over (dy, y).
+template <bool BNB, bool DWG = false>
 __global__ __launch_bounds__(256, 3) void dw_strip_dx2_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
                                                               const float* __restrict__ wT, const float* __restrict__ rmask,
                                                               int n_img, int h, int w_in, int c_all, int ho, int wo, int chunk_rows,
                                                               unsigned strips_x, unsigned chunks_y, unsigned cblocks, DwBnBwd bb,
-                                                              float* __restrict__ dx) {
+                                                              float* __restrict__ dx, float* __restrict__ dwpart = nullptr) {
+    static_assert(!DWG || BNB, "K6d rides on the K6c form");
     constexpr int R = 8, TW = 16, NEW = 4, PRO = 1, NR = 5, PW = 9;
     constexpr int CGS = ST_CB / 4, LANES = 256 / CGS, NP = R * TW / LANES, PF = (NEW * PW + LANES - 1) / LANES;
     constexpr int NPX = R * TW;
     __shared__ __attribute__((aligned(16))) float ring[NR * PW * ST_CB];
     __shared__ float planes[2][NPX];                             // rmask of a step's pixels, double buffered
+    __shared__ __attribute__((aligned(16))) float dwm[DWG ? 4 * 256 * 4 : 4];   // K6d: the final merge of the weight-gradient accumulators
+    float4 dwa[DWG ? 4 : 1];                                     // K6d: candidates AA, AB, BA, BB
+#pragma unroll
+    for (int i = 0; i < (DWG ? 4 : 1); ++i) dwa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned b = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned cb = b % cblocks; b /= cblocks;
     const unsigned sx = b % strips_x; b /= strips_x;
@@ -694,6 +703,17 @@ __global__ __launch_bounds__(256, 3) void dw_strip_dx2_kernel(const float* __res
                 vals[0] += gx; vals[1] += gy; vals[2] += gz; vals[3] += gw;
                 vals[4] = fmaf(gx, hx, vals[4]); vals[5] = fmaf(gy, hy, vals[5]);
                 vals[6] = fmaf(gz, hz, vals[6]); vals[7] = fmaf(gw, hw, vals[7]);
+                if constexpr (DWG) {
+                    float4 e = make_float4(0.f, 0.f, 0.f, 0.f);      // the layer's input at this pixel: act(z) * rmask
+                    if (pmk != 0.f) {
+                        e.x = fminf(fmaxf(zx, zx * bb.neg), bb.hi) * pmk; e.y = fminf(fmaxf(zy, zy * bb.neg), bb.hi) * pmk;
+                        e.z = fminf(fmaxf(zz, zz * bb.neg), bb.hi) * pmk; e.w = fminf(fmaxf(zw, zw * bb.neg), bb.hi) * pmk;
+                    }
+                    dwa[0].x = fmaf(e.x, vAA.x, dwa[0].x); dwa[0].y = fmaf(e.y, vAA.y, dwa[0].y); dwa[0].z = fmaf(e.z, vAA.z, dwa[0].z); dwa[0].w = fmaf(e.w, vAA.w, dwa[0].w);
+                    dwa[1].x = fmaf(e.x, vAB.x, dwa[1].x); dwa[1].y = fmaf(e.y, vAB.y, dwa[1].y); dwa[1].z = fmaf(e.z, vAB.z, dwa[1].z); dwa[1].w = fmaf(e.w, vAB.w, dwa[1].w);
+                    dwa[2].x = fmaf(e.x, vBA.x, dwa[2].x); dwa[2].y = fmaf(e.y, vBA.y, dwa[2].y); dwa[2].z = fmaf(e.z, vBA.z, dwa[2].z); dwa[2].w = fmaf(e.w, vBA.w, dwa[2].w);
+                    dwa[3].x = fmaf(e.x, vBB.x, dwa[3].x); dwa[3].y = fmaf(e.y, vBB.y, dwa[3].y); dwa[3].z = fmaf(e.z, vBB.z, dwa[3].z); dwa[3].w = fmaf(e.w, vBB.w, dwa[3].w);
+                }
             }
         }
         lds_barrier();
@@ -722,6 +742,30 @@ __global__ __launch_bounds__(256, 3) void dw_strip_dx2_kernel(const float* __res
                 const int64_t prow = (n * chunks_y + cy) * strips_x + sx;
                 bb.part[(prow * 2 + which) * c_all + (int)cb * ST_CB + ch] = sum;
             }
+        }
+    }
+    if constexpr (DWG) {
+        // tap (ky, kx) collects the candidate slot (ky == 2 ? B : A, kx == 2 ? B : A) of the 8 pixel lanes whose parity admits it:
+        // rows ty0 = (ky == 1 ? 0 : 1), columns tx even for kx == 1, odd otherwise (a thread without the second candidate on an axis
+        // holds a duplicate of the first in that slot: never read)
+        float4* m4 = reinterpret_cast<float4*>(dwm);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m4[i * 256 + threadIdx.x] = dwa[i];
+        __syncthreads();
+        const int64_t prow = (n * chunks_y + cy) * strips_x + sx;
+        for (int j = threadIdx.x; j < 9 * ST_CB; j += 256) {
+            const int tap = j / ST_CB, ch = j % ST_CB;
+            if ((int)cb * ST_CB + ch >= c_all) continue;
+            const int ky = tap / 3, kx = tap % 3;
+            const int slot = (ky == 2 ? 2 : 0) + (kx == 2 ? 1 : 0);
+            const int ty_sel = ky == 1 ? 0 : 1, tx_par = kx == 1 ? 0 : 1;
+            float sum = 0.f;
+#pragma unroll
+            for (int l = 0; l < TW / 2; ++l) {
+                const int ln = ty_sel * TW + 2 * l + tx_par;          // pixel lane
+                sum += dwm[((slot * 256 + ln * CGS + ch / 4) * 4) + ch % 4];
+            }
+            dwpart[(prow * 9 + tap) * c_all + (int)cb * ST_CB + ch] = sum;
         }
     }
 }
@@ -1326,20 +1370,23 @@ static int dw_bwd_dx_impl(const float* dy, const float* inv, const float* w, con
         rc = try_launch_dw_strip(dy, inv, ws, nullptr, nullptr, nullptr, rmask, tg, dx, st, kNoDwBN, nullptr, bb, dwpart);
         if (rc <= 0) return rc;
     }
-    TSII_REQUIRE(dwpart == nullptr, "dw_bwd_dxdw_bn: this geometry has no fused dX + dW form (tsii_dw_bwd_dxdw_ws_bytes() == 0)");
     if (vec && kh == 3 && kw == 3 && sh == 2 && sw == 2 && dh == 1 && dw == 1 && ph == 1 && pw == 1) {   // marching strips
         const StripPlan sp = plan_strip(n, h, wd, c, 1, 1);     // strips of the input grid
         if (sp.ok) {
             const int64_t nblk2 = (int64_t)sp.strips_x * sp.chunks_y * sp.cblocks * n;
-            if (bb.y != nullptr)
-                hipLaunchKernelGGL(dw_strip_dx2_kernel<true>, dim3((unsigned)nblk2), dim3(256), 0, st, dy, inv, ws, rmask, n, h, wd, c, ho, wo,
-                                   sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, bb, dx);
+            if (bb.y != nullptr && dwpart != nullptr)
+                hipLaunchKernelGGL((dw_strip_dx2_kernel<true, true>), dim3((unsigned)nblk2), dim3(256), 0, st, dy, inv, ws, rmask, n, h, wd, c, ho, wo,
+                                   sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, bb, dx, dwpart);
+            else if (bb.y != nullptr)
+                hipLaunchKernelGGL((dw_strip_dx2_kernel<true, false>), dim3((unsigned)nblk2), dim3(256), 0, st, dy, inv, ws, rmask, n, h, wd, c, ho, wo,
+                                   sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, bb, dx, (float*)nullptr);
             else
-                hipLaunchKernelGGL(dw_strip_dx2_kernel<false>, dim3((unsigned)nblk2), dim3(256), 0, st, dy, inv, ws, rmask, n, h, wd, c, ho, wo,
-                                   sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, bb, dx);
+                hipLaunchKernelGGL((dw_strip_dx2_kernel<false, false>), dim3((unsigned)nblk2), dim3(256), 0, st, dy, inv, ws, rmask, n, h, wd, c, ho, wo,
+                                   sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, bb, dx, (float*)nullptr);
             return check_launch("dw_strip_dx2");
         }
     }
+    TSII_REQUIRE(dwpart == nullptr, "dw_bwd_dxdw_bn: this geometry has no fused dX + dW form (tsii_dw_bwd_dxdw_ws_bytes() == 0)");
     TSII_REQUIRE(bb.y == nullptr, "dw_bwd_dx_bn: the BatchNorm-backward form needs a marching-strip path (tsii_dw_bwd_stat_rows() > 0)");
     const bool k3 = false;  // see dw_fwd
     const int px = (vec && k3) ? DwPx<true>::value : DwPx<false>::value;
@@ -1377,7 +1424,14 @@ extern "C" int tsii_dw_bwd_dx_bn(const float* dy, const float* inv, const float*
 // -> bytes of the weight-gradient partial rows, 0 when the geometry has no such form (3x3, stride 1, dilation 1, c % 4 == 0, the
 // sizes dw_lean_ok() takes); the K6c partial rows are those of tsii_dw_bwd_stat_rows().
 extern "C" size_t tsii_dw_bwd_dxdw_ws_bytes(int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw) {
-    if (n <= 0 || h <= 0 || wd <= 0 || c <= 0 || c % 4 != 0 || !(kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == 1 && dw == 1)) return 0;
+    if (n <= 0 || h <= 0 || wd <= 0 || c <= 0 || c % 4 != 0 || !(kh == 3 && kw == 3 && dh == 1 && dw == 1)) return 0;
+    if (sh == 2 && sw == 2 && ph == 1 && pw == 1) {          // the stride-2 dX strips (dw_strip_dx2_kernel<true, true>)
+        const StripPlan sp = plan_strip(n, h, wd, c, 1, 1);
+        const int64_t rows = (int64_t)n * strip_rows_per_image(sp);
+        if (!sp.ok || rows <= 0 || rows >= (1ll << 31) || (int64_t)sp.strips_x * sp.chunks_y * sp.cblocks * n >= (1ll << 31)) return 0;
+        return (size_t)rows * 9 * (size_t)c * sizeof(float);
+    }
+    if (sh != 1 || sw != 1) return 0;
     if (ph < 0 || pw < 0 || ph > 2 || pw > 2) return 0;
     const int ho = h + 2 * ph - 2, wo = wd + 2 * pw - 2;
     if (ho <= 0 || wo <= 0) return 0;
