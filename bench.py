@@ -92,6 +92,9 @@ CALLS = {
     "tsii_dw_bwd_dx": ("dw_stencil", lambda a: _dw(a, (1, 1))),
     "tsii_dw_bwd_dx_bn": ("dw_stencil", lambda a: _dw(a, (2, 1))),      # + the raw BatchNorm input read alongside (K6c)
     "tsii_dw_bwd_dxdw_bn": ("dw_stencil", lambda a: _dw(a, (2, 1))),    # K6d: the same pass also leaves the weight gradient ([C][9]: no traffic to speak of)
+    # K6e: (bn2_act, bn2_slope, n, h, ...): reads the gradient and the raw input of the FOLLOWING BatchNorm on the output grid (its apply
+    # pass rides here), the layer's raw input on the input grid; writes dX
+    "tsii_dw_bwd_dxdw_bn2": ("dw_stencil", lambda a: _dw(a[2:], (2, 2))),
     "tsii_dw_bwd_dw": ("dw_stencil", lambda a: _dw(a, (1, 1))), "tsii_dw_bwd_dw_bn": ("dw_stencil", lambda a: _dw(a, (1, 1))),
     "tsii_bn_act_fwd": ("bn_act", lambda a: _bn(a, 2)), "tsii_bn_stats": ("bn_act", lambda a: _bn(a, 1)),
     "tsii_bn_act_bwd": ("bn_bwd", lambda a: _bn(a, 3)), "tsii_bn_act_bwd_pre": ("bn_bwd", lambda a: _bn(a, 3)),

@@ -290,6 +290,27 @@ int tsii_dw_bwd_dxdw_bn(const float* dy, const float* inv, const float* w, const
                         int ho, int wo, const float* bn_y, const float* bn_mean, const float* bn_var,
                         const float* bn_gamma, const float* bn_beta, float bn_eps, int bn_act, float bn_slope,
                         float* dx, float* bwd_part, float* dwgt, float* ws, void* ws_dw, size_t ws_dw_bytes, void* stream);
+/* K6e: tsii_dw_bwd_dxdw_bn fed with the gradient w.r.t. the ACTIVATION that follows the layer: da2 = d loss / d act2(BN2(y2)), y2 = the
+ * layer's raw output (bn2_y, same [n,ho,wo,c] layout), bn2_coef[6][c] = (mean, 1/std, gamma, beta, dbeta/m, dgamma/m) of BN2 as
+ * tsii_bn_bwd_reduce leaves it -- BN2's backward is applied while the kernel stages its slab, so tsii_bn_act_bwd_pre's pass over
+ * (da2, y2) -> dy2 and this kernel's read of dy2 become this kernel's reads of da2 and y2.  Stride 1 only
+ * (tsii_dw_bwd_dxdw_fold_ok() == 1); everything else as tsii_dw_bwd_dxdw_bn.
+ * tsii_bn_bwd_reduce / tsii_bn_bwd_apply: the two halves of tsii_bn_act_bwd_pre (reduction of the K6c partial rows to dgamma, dbeta
+ * and the table; the stand-alone apply pass over the table: dy = ((dout act'(z) - coef[4]) - xhat coef[5]) gamma / std).
+ * Together they replace the autograd of nn.BatchNorm2d + activation in models/partial_convolution.py:176-180 (bn_act). */
+int tsii_dw_bwd_dxdw_fold_ok(int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw);
+int tsii_dw_bwd_dxdw_bn2(const float* da2, const float* bn2_y, const float* bn2_coef, int bn2_act, float bn2_slope,
+                         const float* inv, const float* w, const float* rmask,
+                         int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                         int ho, int wo, const float* bn_y, const float* bn_mean, const float* bn_var,
+                         const float* bn_gamma, const float* bn_beta, float bn_eps, int bn_act, float bn_slope,
+                         float* dx, float* bwd_part, float* dwgt, float* ws, void* ws_dw, size_t ws_dw_bytes, void* stream);
+size_t tsii_bn_bwd_reduce_ws_bytes(int64_t rows, int c);
+int tsii_bn_bwd_reduce(const float* mean, const float* var, const float* gamma, const float* beta, float eps, int training,
+                       const float* bwd_part, int64_t rows, int64_t m, int c, float* dgamma, float* dbeta, float* coef,
+                       void* ws, size_t ws_bytes, void* stream);
+int tsii_bn_bwd_apply(const float* dout, const float* y, int64_t m, int c, const float* coef, int act, float slope, float* dy,
+                      void* stream);
 /* same for the point-wise dX (N = k % 4 == 0): dx is the gradient w.r.t. a = act(BN(bn_y)), bn_y raw [m,k];
  * bwd_part[tsii_pw_stat_rows(m)][2][k] */
 int tsii_pw_bwd_dx_bn(const float* dy, int64_t m, int n, const float* w, int k, const float* inv,

@@ -634,6 +634,66 @@ def _strip_entry_points(L, n, h, wd, c, masked, bias, act, d=1, p=None):
     assert L.tsii_dw_bwd_dw_bn(P(dy), P(inv), P(keep), P(x), P(rmask), n, h, wd, c, *geom, ho, wo, P(sc2), P(sh2), act, slope,
                                P(dw4), None, P(wsw), nb, None) == 0, L.tsii_last_error()
     assert np.all(np.abs(dw3 - dw4) <= 2e-5 * dwabs + 1e-5), np.abs(dw3 - dw4).max()
+    # K6e: the same pass fed with the gradient w.r.t. the activation of the BatchNorm that FOLLOWS the layer (da2, its raw input y2 and
+    # the constants' table of tsii_bn_bwd_reduce): that BatchNorm's backward is applied on load.  Against the two-step route
+    # (tsii_bn_bwd_apply, then tsii_dw_bwd_dxdw_bn) and the pieces against float64.
+    assert L.tsii_dw_bwd_dxdw_fold_ok(n, h, wd, c, *geom) == 1
+    m2 = n * ho * wo
+    da2 = rng.standard_normal((n, ho, wo, c)).astype(np.float32)
+    y2 = (rng.standard_normal((n, ho, wo, c)) * 1.5 + 0.3).astype(np.float32)
+    mean2 = rng.standard_normal(c).astype(np.float32) * 0.2; var2 = (rng.uniform(size=c) + 0.5).astype(np.float32)
+    gam2 = (rng.uniform(size=c) + 0.5).astype(np.float32); bet2 = rng.standard_normal(c).astype(np.float32) * 0.3
+    act2 = {0: 2, 1: 3, 2: 1, 3: 0}[act]            # another activation than the layer's input BatchNorm has
+    xh2 = (y2.astype(np.float64) - mean2) / np.sqrt(var2.astype(np.float64) + 1e-5)
+    z2 = xh2 * gam2 + bet2
+    g2 = {0: np.ones_like(z2), 1: (z2 > 0) * 1.0, 2: np.where(z2 > 0, 1.0, slope), 3: ((z2 > 0) & (z2 < 6)) * 1.0}[act2]
+    dz2 = da2.astype(np.float64) * g2
+    # K6c partial rows of that BatchNorm as a producer would leave them: 3 rows that sum to the totals
+    rows2 = 3
+    tot = np.stack([dz2.reshape(-1, c).sum(0), (dz2 * xh2).reshape(-1, c).sum(0)])        # [2][c]
+    split = rng.uniform(size=(rows2, 1, 1)); split /= split.sum(0)
+    part2 = (split * tot[None]).astype(np.float32)
+    coef = np.full(6 * c, np.nan, np.float32); dgam2 = np.full(c, np.nan, np.float32); dbet2 = np.full(c, np.nan, np.float32)
+    rb = L.tsii_bn_bwd_reduce_ws_bytes(rows2, c)
+    wsr = WS(rb)
+    assert L.tsii_bn_bwd_reduce(P(mean2), P(var2), P(gam2), P(bet2), 1e-5, 1, P(part2), rows2, m2, c, P(dgam2), P(dbet2), P(coef),
+                                P(wsr), rb, None) == 0, L.tsii_last_error()
+    tot32 = part2.astype(np.float64).sum(0)
+    assert np.allclose(dbet2, tot32[0], rtol=1e-6, atol=1e-6) and np.allclose(dgam2, tot32[1], rtol=1e-6, atol=1e-6)
+    cf = coef.reshape(6, c).astype(np.float64)
+    assert np.allclose(cf[0], mean2) and np.allclose(cf[1], 1 / np.sqrt(var2.astype(np.float64) + 1e-5), rtol=1e-6)
+    assert np.allclose(cf[4], tot32[0] / m2, rtol=1e-5, atol=1e-7) and np.allclose(cf[5], tot32[1] / m2, rtol=1e-5, atol=1e-7)
+    dy2 = np.full((n, ho, wo, c), np.nan, np.float32)
+    assert L.tsii_bn_bwd_apply(P(da2), P(y2), m2, c, P(coef), act2, slope, P(dy2), None) == 0, L.tsii_last_error()
+    dy2r = (dz2 - cf[4] - xh2 * cf[5]) * gam2 / np.sqrt(var2.astype(np.float64) + 1e-5)
+    near2 = (np.abs(z2) < 1e-5) | (np.abs(z2 - 6) < 1e-5)
+    assert np.all((np.abs(dy2 - dy2r) <= 1e-5 * max(1.0, np.abs(dy2r).max())) | near2)
+    # two-step route
+    dxA = np.full((n, h, wd, c), np.nan, np.float32); dwA = np.full((c, 1, 3, 3), np.nan, np.float32)
+    bpA = WS(4 * brows * 2 * c); bpA[:] = np.nan
+    assert L.tsii_dw_bwd_dxdw_bn(P(dy2), P(inv), P(w), P(rmask), n, h, wd, c, *geom, ho, wo, P(x), P(mean_b), P(var_b), P(gam), P(bet),
+                                 1e-5, act, slope, P(dxA), P(bpA), P(dwA), P(ws), P(wsd), dwb, None) == 0, L.tsii_last_error()
+    # folded
+    dxB = np.full((n, h, wd, c), np.nan, np.float32); dwB = np.full((c, 1, 3, 3), np.nan, np.float32)
+    bpB = WS(4 * brows * 2 * c); bpB[:] = np.nan
+    wsd2 = WS(dwb); wsd2[:] = np.nan
+    assert L.tsii_dw_bwd_dxdw_bn2(P(da2), P(y2), P(coef), act2, slope, P(inv), P(w), P(rmask), n, h, wd, c, *geom, ho, wo,
+                                  P(x), P(mean_b), P(var_b), P(gam), P(bet), 1e-5, act, slope, P(dxB), P(bpB), P(dwB), P(ws), P(wsd2), dwb,
+                                  None) == 0, L.tsii_last_error()
+    sA = max(1.0, np.abs(dxA).max())
+    assert np.abs(dxB - dxA).max() <= 2e-6 * sA, np.abs(dxB - dxA).max()
+    gA = np.abs(dy2.astype(np.float64) * (1.0 if inv is None else inv.astype(np.float64)[..., None]))
+    apA = np.zeros((n, h + 2 * p, wd + 2 * p, c)); apA[:, p:p + h, p:p + wd] = np.abs(am)
+    dwabsA = np.zeros((c, 1, 3, 3))
+    for ky in range(3):
+        for kx in range(3):
+            dwabsA[:, 0, ky, kx] = (apA[:, ky:ky + ho, kx:kx + wo] * gA).reshape(-1, c).sum(0)
+    assert np.all(np.abs(dwB - dwA) <= 4e-6 * dwabsA + 1e-6), np.abs(dwB - dwA).max()
+    pA = bpA[:brows * 2 * c].reshape(brows, 2, c).astype(np.float64).sum(0); pB = bpB[:brows * 2 * c].reshape(brows, 2, c).astype(np.float64).sum(0)
+    assert np.isfinite(bpB[:brows * 2 * c]).all()
+    # (a value within rounding of the input BatchNorm's kink may take the other slope in one of the two routes)
+    slackB = (np.abs(dxA) * near).reshape(-1, c).sum(0) * 2 + 1e-4 * np.abs(dxA).reshape(-1, c).sum(0).max()
+    assert np.all(np.abs(pB[0] - pA[0]) <= slackB) and np.all(np.abs(pB[1] - pA[1]) <= slackB * max(1.0, np.abs(xh).max()))
 
 
 @pytest.mark.parametrize("n,h,wd,c,d,p,masked,bias,act", [

@@ -108,7 +108,12 @@ def test_golden_pir_blocks_weight_gradient_in_the_dx_pass(backend, monkeypatch):
     monkeypatch.setattr(ops, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
     run = test_golden_pir_blocks.__wrapped__ if hasattr(test_golden_pir_blocks, "__wrapped__") else test_golden_pir_blocks
     run(backend)
-    assert "tsii_dw_bwd_dxdw_bn" in calls, sorted(set(calls))
+    # stride-1 layers: K6e, the one-pass kernel also applies the following BatchNorm's backward on load (that BatchNorm only reduces)
+    assert "tsii_dw_bwd_dxdw_bn2" in calls and "tsii_bn_bwd_reduce" in calls, sorted(set(calls))
+    del calls[:]
+    monkeypatch.setattr(ops, "FUSE_DW_BN2_FOLD", False)
+    run(backend)
+    assert "tsii_dw_bwd_dxdw_bn" in calls and "tsii_dw_bwd_dxdw_bn2" not in calls and "tsii_bn_bwd_reduce" not in calls, sorted(set(calls))
     del calls[:]
     monkeypatch.setattr(ops, "FUSE_DW_DXDW", False)
     run(backend)

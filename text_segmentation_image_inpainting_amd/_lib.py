@@ -72,6 +72,11 @@ SIGNATURES = {
     "tsii_dw_bwd_dx_bn": (_i, [_p, _p, _p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p]),
     "tsii_dw_bwd_dxdw_ws_bytes": (_z, [_i, _i, _i, _i] + _GEOM),
     "tsii_dw_bwd_dxdw_bn": (_i, [_p, _p, _p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p, _p, _z, _p]),
+    "tsii_dw_bwd_dxdw_fold_ok": (_i, [_i, _i, _i, _i] + _GEOM),
+    "tsii_dw_bwd_dxdw_bn2": (_i, [_p, _p, _p, _i, _f, _p, _p, _p, _i, _i, _i, _i] + _GEOM + [_i, _i, _p, _p, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p, _p, _z, _p]),
+    "tsii_bn_bwd_reduce_ws_bytes": (_z, [_l, _i]),
+    "tsii_bn_bwd_reduce": (_i, [_p, _p, _p, _p, _f, _i, _p, _l, _l, _i, _p, _p, _p, _p, _z, _p]),
+    "tsii_bn_bwd_apply": (_i, [_p, _p, _l, _i, _p, _i, _f, _p, _p]),
     "tsii_pw_bwd_dx_bn": (_i, [_p, _l, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p]),
     "tsii_bn_act_bwd_pre": (_i, [_p, _p, _l, _i, _p, _p, _p, _p, _f, _i, _f, _i, _p, _l, _p, _p, _p, _p, _z, _p]),
     "tsii_bn_act_bwd_pre_pool": (_i, [_p, _p, _l, _i, _p, _p, _p, _p, _f, _i, _f, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),

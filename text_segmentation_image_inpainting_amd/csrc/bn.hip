@@ -705,6 +705,31 @@ extern "C" int tsii_bn_act_bwd_pre(const float* dout, const float* y, int64_t m,
     return launch_bn_bwd_apply(dout, y, m, c, act, slope, dy, coef, st);
 }
 
+// K6e: the two halves of tsii_bn_act_bwd_pre as entry points of their own.  tsii_bn_bwd_reduce: the K6c partial rows -> dgamma, dbeta
+// and the apply pass's table coef[6][c] = (mean, 1/std, gamma, beta, dbeta/m, dgamma/m) (zeros in the last two in eval mode) -- the
+// consumer that applies the BatchNorm backward while it loads (tsii_dw_bwd_dxdw_bn2) takes the table; tsii_bn_bwd_apply: the
+// stand-alone apply pass over that table (what a consumer without such a form falls back to).
+extern "C" size_t tsii_bn_bwd_reduce_ws_bytes(int64_t rows, int c) {
+    if (rows <= 0 || c <= 0) return 0;
+    return bn_bwd_reduce_ws_bytes(rows, c);
+}
+
+extern "C" int tsii_bn_bwd_reduce(const float* mean, const float* var, const float* gamma, const float* beta, float eps, int training,
+                                  const float* bwd_part, int64_t rows, int64_t m, int c, float* dgamma, float* dbeta, float* coef,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    TSII_REQUIRE(mean && var && gamma && beta && bwd_part && dgamma && dbeta && coef && ws, "bn_bwd_reduce: null pointer");
+    TSII_REQUIRE(m > 0 && c > 0 && rows > 0 && rows < (1ll << 31), "bn_bwd_reduce: bad shape");
+    TSII_REQUIRE(ws_bytes >= bn_bwd_reduce_ws_bytes(rows, c), "bn_bwd_reduce: workspace too small (tsii_bn_bwd_reduce_ws_bytes)");
+    return bn_bwd_pre_reduce(mean, var, gamma, beta, eps, training, bwd_part, rows, m, c, dgamma, dbeta, ws, coef, (hipStream_t)stream);
+}
+
+extern "C" int tsii_bn_bwd_apply(const float* dout, const float* y, int64_t m, int c, const float* coef, int act, float slope, float* dy,
+                                 void* stream) {
+    TSII_REQUIRE(dout && y && coef && dy, "bn_bwd_apply: null pointer");
+    TSII_REQUIRE(m > 0 && c > 0, "bn_bwd_apply: bad shape");
+    return launch_bn_bwd_apply(dout, y, m, c, act, slope, dy, coef, (hipStream_t)stream);
+}
+
 extern "C" int tsii_bn_act_bwd_pre_pool(const float* dout, const float* y, int64_t m, int c, const float* mean,
                                         const float* var, const float* gamma, const float* beta, float eps, int act,
                                         float slope, int training, const float* bwd_part, int64_t rows,

@@ -61,6 +61,13 @@ __device__ __forceinline__ f32x4 cat4(f32x2 a, f32x2 b) { return f32x4{a.x, a.y,
 // accumulates 9 taps x 4 channels per thread over the whole strip chunk; one partial row [9][C] per block in `stats`, combined
 // by dw_reduce_kernel.  The separate weight-gradient kernel (dw_strip_dw_kernel<1, 1>: dy and y streamed once more, 6.4 GB on
 // the 32 x 256^2 x 384 layer) is not launched.  36 more accumulators: 2 waves per SIMD.
+// 4 (K6e, round 6): MODE 3 whose staged slab is FORMED from the gradient w.r.t. the layer's OUTPUT activation: the BatchNorm
+// that follows the layer (its output y2 -> act(BatchNorm(y2))) is differentiated while the slab is staged,
+//     G = (dz - k1 - xhat k2) gamma istd * inv,   dz = da * act'(z),  xhat = (y2 - mu) istd,  z = xhat gamma + beta
+// from the two tensors (da, y2) and the per-channel table coef[6][C] = (mu, istd, gamma, beta, k1, k2) the reduction kernel
+// leaves (bn.hip: bn_bwd_final_kernel) -- the stand-alone apply pass (tsii_bn_act_bwd_pre: read da, read y2, write dy; 9.7 GB
+// on the 32 x 256^2 x 384 layer) and this kernel's read of its result are replaced by this kernel reading da and y2.
+// The operands ride in `ib`: ib.sc = y2 (same grid and pitch as `in` = da), ib.sh = coef, ib.neg / ib.hi = that activation's.
 // DXE: dX epilogue (out = post_mul != 0 ? acc * post_mul : 0) instead of the forward one (acc / denom + bias, zero where keep == 0).
 // PRE: the staged input is multiplied by a per-pixel plane (mask for forward, 1 / count for dX).
 // PH (round 6): DILATION d > 1 BY PHASES.  With dilation d every tap of output pixel (oy, ox) lies d pixels apart, so the outputs with
@@ -76,12 +83,12 @@ __device__ __forceinline__ f32x4 cat4(f32x2 a, f32x2 b) { return f32x4{a.x, a.y,
 // 8 bytes, the staged slab in LDS is fp32 (an activation the producer's BatchNorm forms on load is rounded to bf16 first -- where it
 // would have been stored), `wT` is the reference layout [C][9] (the bf16 entry points carry no workspace for a transposed copy).
 template <int MODE, bool DXE, bool PRE, bool PH = false, bool H16 = false>
-__global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 2 : LS_WAVES_FUSED)) void dw_lean_kernel(
+__global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE >= 3 ? 2 : LS_WAVES_FUSED)) void dw_lean_kernel(
     const float* __restrict__ in, const float* __restrict__ pre, const float* __restrict__ wT, const float* __restrict__ bias,
     const float* __restrict__ denom, const float* __restrict__ keep, const float* __restrict__ post_mul, DtGeom g, int chunk_rows,
     unsigned strips_x, unsigned chunks_y, unsigned cblocks, DwBN ib, float* __restrict__ stats, DwBnBwd bb,
     float* __restrict__ out) {
-    constexpr bool FUSED = (MODE == 1), BNB = (MODE == 2 || MODE == 3), DWG = (MODE == 3);
+    constexpr bool FUSED = (MODE == 1), BNB = (MODE >= 2), DWG = (MODE >= 3), APL = (MODE == 4);
     static_assert(!DWG || (!PH && !H16), "K6d: the fp32 dilation-1 strips only");
     constexpr unsigned ES = H16 ? 2u : 4u;                   // bytes per activation element
     static_assert(!H16 || !PRE, "bf16 activation storage carries no mask planes");
@@ -90,6 +97,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 2 : LS_WAVES_FUSE
     __shared__ __attribute__((aligned(16))) float lbuf[2 * LS_BUFB / 4];
     __shared__ __attribute__((aligned(8))) float lplanes[2][LS_NPX][2];
     __shared__ __attribute__((aligned(16))) float lconst[4][LS_CB];   // K6b: scale, shift, bias | K6c: mean, 1/sigma, gamma, beta
+    __shared__ __attribute__((aligned(16))) float lapl[APL ? 6 : 1][LS_CB];   // K6e: mu, istd, gamma, beta, k1, k2 of the folded BatchNorm
     unsigned b = xcd_remap(blockIdx.x, gridDim.x);
     unsigned cb, sx;
     if (LS_ORDER == 1) { sx = b % strips_x; b /= strips_x; cb = b % cblocks; b /= cblocks; }
@@ -152,6 +160,11 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 2 : LS_WAVES_FUSE
     if (t < LS_CB) {                                          // per-channel constants of this block's 32 channels
         const int ch = (int)cb * LS_CB + t;
         const bool ok = ch < C;
+        if (APL) {
+            const float* cf = ib.sh;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) lapl[j][t] = ok ? cf[(int64_t)j * C + ch] : 0.f;
+        }
         if (BNB) {
             lconst[0][t] = ok ? bb.mean[ch] : 0.f;
             lconst[1][t] = ok ? 1.0f / sqrtf(bb.var[ch] + bb.eps) : 0.f;
@@ -163,10 +176,20 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 2 : LS_WAVES_FUSE
             lconst[2][t] = (!DXE && bias != nullptr && ok) ? bias[ch] : 0.f;
         }
     }
-    f32x4 w[9];
+    // K6e keeps the 9 x 4 weights in LDS and walks the window tap row by tap row (3 weight vectors and one slab row live at a time
+    // instead of 9 + 9: the second input stream's registers have to come from somewhere at 2 waves per SIMD); everything else
+    // holds them in registers
+    constexpr bool WL = APL;
+    __shared__ __attribute__((aligned(16))) float lw[WL ? 9 : 1][LS_CB];
+    f32x4 w[WL ? 1 : 9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) w[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (cok) {
+    for (int k = 0; k < (WL ? 1 : 9); ++k) w[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (WL) {
+        for (int j = t; j < 9 * LS_CB; j += 256) {
+            const int k = j / LS_CB, ch = (int)cb * LS_CB + j % LS_CB;
+            lw[k][j % LS_CB] = ch < C ? wT[(g.flip ? 8 - k : k) * C + ch] : 0.f;
+        }
+    } else if (cok) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const int kk = g.flip ? 8 - k : k;
@@ -217,10 +240,12 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 2 : LS_WAVES_FUSE
     };
 
     f32x4 pf[LS_PF];
+    f32x4 pf2[APL ? LS_PF : 1];                                // K6e: the folded BatchNorm's raw input at the same pixels
     float pm[LS_PF];
     unsigned vmask = 0;                                        // edge steps: bit i = item i lies inside the image
     const int64_t img_pix = n * g.hin * (int64_t)g.win + ipix0;
     const char* const ibase = reinterpret_cast<const char*>(in) + img_pix * C * ES;      // pixel (0, 0) of this image (of its phase)
+    const int64_t y2d = APL ? reinterpret_cast<const char*>(ib.sc) - reinterpret_cast<const char*>(in) : 0;   // K6e: y2 - da, in bytes (same layout)
     const char* const ipre = reinterpret_cast<const char*>(pre + img_pix);
     // running pointers to the first pixel of the NEXT slab to fetch (may point outside the tensor; only used by interior steps)
     int iyb = iy_base + 2;
@@ -249,6 +274,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 2 : LS_WAVES_FUSE
         for (int i = 0; i < LS_PF; ++i) {
             pf[i] = (LS_NT_LOAD && !H16) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ab + opq(aoff(po[i]) + c0b)))
                                          : ld4(ab + opq(aoff(po[i]) + c0b));
+            if (APL) pf2[i] = ld4(ab + y2d + opq(aoff(po[i]) + c0b));
             pm[i] = PRE ? *reinterpret_cast<const float*>(mb + opq(po[i])) : 1.f;
         }
         iyb += LS_R; sb += sb_step; pb += pb_step;
@@ -257,6 +283,23 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 2 : LS_WAVES_FUSE
     // `x * 0`: the clamped address may hold NaN / Inf) -- zero padding pads the ACTIVATED tensor
     char* const lthr = reinterpret_cast<char*>(lbuf) + t * 16;
     const char* const cthr = reinterpret_cast<const char*>(&lconst[0][0]) + cg * 16;
+    // K6e: the folded BatchNorm's backward on one element quad: da, y2 -> dy (constants from LDS at the point of use)
+    const char* const athr = reinterpret_cast<const char*>(&lapl[0][0]) + cg * 16;
+    auto bn_apply = [&](f32x4 da, f32x4 y2) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(athr), is = *reinterpret_cast<const f32x4*>(athr + LS_PIXB);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(athr + 2 * LS_PIXB), be = *reinterpret_cast<const f32x4*>(athr + 3 * LS_PIXB);
+        const f32x4 k1 = *reinterpret_cast<const f32x4*>(athr + 4 * LS_PIXB), k2 = *reinterpret_cast<const f32x4*>(athr + 5 * LS_PIXB);
+        const f32x2 h0 = (y2.xy - mu.xy) * is.xy, h1 = (y2.zw - mu.zw) * is.zw;
+        const f32x2 z0 = fma2(h0, ga.xy, be.xy), z1 = fma2(h1, ga.zw, be.zw);
+        f32x2 d0 = da.xy, d1 = da.zw;
+        d0.x *= (z0.x > 0.f && z0.x < ib.hi) ? 1.f : (z0.x > 0.f ? 0.f : ib.neg);
+        d0.y *= (z0.y > 0.f && z0.y < ib.hi) ? 1.f : (z0.y > 0.f ? 0.f : ib.neg);
+        d1.x *= (z1.x > 0.f && z1.x < ib.hi) ? 1.f : (z1.x > 0.f ? 0.f : ib.neg);
+        d1.y *= (z1.y > 0.f && z1.y < ib.hi) ? 1.f : (z1.y > 0.f ? 0.f : ib.neg);
+        // the stand-alone pass's order: ((dz - k1) - xhat k2) * gamma * istd  (bn_bwd_apply_kernel)
+        d0 = (d0 - k1.xy) - h0 * k2.xy; d1 = (d1 - k1.zw) - h1 * k2.zw;
+        return cat4((d0 * ga.xy) * is.xy, (d1 * ga.zw) * is.zw);
+    };
     auto stage = [&](f32x4 v, float m, bool inside, const f32x4& isc, const f32x4& ish) {
         if (FUSED) {
             f32x2 z0 = fma2(v.xy, isc.xy, ish.xy), z1 = fma2(v.zw, isc.zw, ish.zw);
@@ -275,13 +318,14 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 2 : LS_WAVES_FUSE
         if (vmask == 31u) {                                    // interior step (wave-uniform in practice; any mix is handled below)
 #pragma unroll
             for (int i = 0; i < LS_PF; ++i) {
-                const f32x4 v = stage(pf[i], pm[i], true, isc, ish);
+                const f32x4 v = stage(APL ? bn_apply(pf[i], pf2[APL ? i : 0]) : pf[i], pm[i], true, isc, ish);
                 if (i < 4 || item4) *reinterpret_cast<f32x4*>(T + 256 * i * 16) = v;
+                if (APL) __builtin_amdgcn_sched_barrier(0);        // K6e: one item's transform at a time (VGPR budget)
             }
         } else {
 #pragma unroll
             for (int i = 0; i < LS_PF; ++i) {
-                const f32x4 v = stage(pf[i], pm[i], (vmask >> i) & 1u, isc, ish);
+                const f32x4 v = stage(APL ? bn_apply(pf[i], pf2[APL ? i : 0]) : pf[i], pm[i], (vmask >> i) & 1u, isc, ish);
                 if (i < 4 || item4) *reinterpret_cast<f32x4*>(T + 256 * i * 16) = v;
             }
         }
@@ -336,7 +380,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 2 : LS_WAVES_FUSE
             const bool inside = have_in && (unsigned)iy < (unsigned)vhin && (unsigned)ix < (unsigned)vwin;
             const int iyc = iy < 0 ? 0 : (iy >= vhin ? vhin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= vwin ? vwin - 1 : ix);
             const unsigned q = (unsigned)(iyc * g.win + ixc) * 4u * Du;
-            const f32x4 v = ld4(ibase + opq(aoff(q) + c0b));
+            f32x4 v = ld4(ibase + opq(aoff(q) + c0b));
+            if (APL) v = bn_apply(v, ld4(ibase + y2d + opq(aoff(q) + c0b)));
             const float m = PRE ? *reinterpret_cast<const float*>(ipre + opq(q)) : 1.f;
             const f32x4 sv = stage(v, m, inside, isc, ish);
             if (pr < 2 * LS_PW) *reinterpret_cast<f32x4*>(lthr + 256 * i * 16) = sv;
@@ -391,6 +436,27 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 2 : LS_WAVES_FUSE
         for (int k = 0; k < 4; ++k) { a[k][0] = f32x2{0.f, 0.f}; a[k][1] = f32x2{0.f, 0.f}; }
         // two batches of three input rows: 9 reads in flight (the VGPR budget of 3 waves per SIMD).  The accumulators pass through
         // an opaque copy after the first batch so that its FMAs are issued there and not sunk below the second batch's reads.
+        if (WL) {
+            // tap row by tap row (the same summation order per output: ky, then kx): 3 weight vectors + one slab row at a time
+            const char* const wthr = reinterpret_cast<const char*>(&lw[0][0]) + cg * 16;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                f32x4 wr[3];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) wr[kx] = *reinterpret_cast<const f32x4*>(wthr + (ky * 3 + kx) * LS_PIXB);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    f32x4 v[3];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) v[kx] = *reinterpret_cast<const f32x4*>(rb + ((k + ky) * LS_PW + kx) * LS_PIXB);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        a[k][0] = fma2(v[kx].xy, wr[kx].xy, a[k][0]);
+                        a[k][1] = fma2(v[kx].zw, wr[kx].zw, a[k][1]);
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             f32x4 v[3];
@@ -494,6 +560,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : (MODE == 3 ? 2 : LS_WAVES_FUSE
                             dwa[ky * 3 + kx] = cat4(lo, hi2);
                         }
                     }
+                    if (APL && (r & 1)) __builtin_amdgcn_sched_barrier(0);     // K6e: at most two slab rows of the sweep in flight (VGPR budget)
                 }
             }
         }

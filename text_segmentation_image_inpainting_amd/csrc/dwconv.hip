@@ -549,8 +549,11 @@ __global__ __launch_bounds__(256, MODE != 0 ? (S == 2 ? ST_S2_WAVES : 2) : 3) vo
 // parity and their dy*inv values are the ones it has just read for dX; the layer's input at its pixel, act(bn(y)) * rmask, comes
 // with the K6c arithmetic: dW[tap] += a(q) * G -- 4 x 4 accumulators, merged per parity class at the end into one partial row
 // [9][C] per block (dwpart), instead of dw_strip_dw_kernel<2, 1>'s second pass over (dy, y).
+#ifndef DX2_DWG_WAVES
+#define DX2_DWG_WAVES 2          // A/B (tools/variants): waves per SIMD the K6d form is compiled for (3: 8 spilled registers; same-box step 60.12 vs 60.36-60.43 ms)
+#endif
 template <bool BNB, bool DWG = false>
-__global__ __launch_bounds__(256, 3) void dw_strip_dx2_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
+__global__ __launch_bounds__(256, DWG ? DX2_DWG_WAVES : 3) void dw_strip_dx2_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
                                                               const float* __restrict__ wT, const float* __restrict__ rmask,
                                                               int n_img, int h, int w_in, int c_all, int ho, int wo, int chunk_rows,
                                                               unsigned strips_x, unsigned chunks_y, unsigned cblocks, DwBnBwd bb,
@@ -855,15 +858,18 @@ static bool dw_dxdw_geom_ok(const DtGeom& g) {
 
 static int try_launch_dw_strip(const float* in, const float* pre, const float* wT, const float* bias, const float* denom,
                                const float* keep, const float* post_mul, DtGeom g, float* out, hipStream_t st,
-                               DwBN ib = kNoDwBN, float* stats = nullptr, DwBnBwd bb = kNoBnBwd, float* dwpart = nullptr) {
+                               DwBN ib = kNoDwBN, float* stats = nullptr, DwBnBwd bb = kNoBnBwd, float* dwpart = nullptr, bool fold = false) {
     if (g.c % 4 != 0 || !aligned16(in) || !aligned16(out) || !aligned16(wT)) return 1;
     if (ib.sc != nullptr && (!aligned16(ib.sc) || !aligned16(ib.sh))) return 1;
     const FusedPlan fp = plan_fwd_strips(g.n, g.hout, g.wout, g.c, g.s, g.d);
     const StripPlan sp = fp.sp;
     // K6d (dX + K6c + the weight gradient in one pass, dwpart = [partial rows][9][C]) exists on the lean kernel only
+    // (K6e, fold: `in` is the gradient w.r.t. the activation of the BatchNorm that FOLLOWS the layer; ib carries that BatchNorm's raw
+    // input, its constants' table and its activation -- dw_lean.h MODE 4)
     if (dwpart != nullptr && !(dw_dxdw_geom_ok(g) && sp.ok && fp.phases == 1 && !fp.rows_only && bb.y != nullptr && stats == nullptr &&
-                               ib.sc == nullptr && denom == nullptr && keep == nullptr && bias == nullptr)) return 1;
-    const bool fused_any = ib.sc != nullptr || stats != nullptr || bb.y != nullptr;
+                               (ib.sc == nullptr) == !fold && denom == nullptr && keep == nullptr && bias == nullptr)) return 1;
+    if (fold && dwpart == nullptr) return 1;
+    const bool fused_any = ib.sc != nullptr || stats != nullptr || bb.y != nullptr;      // (fold: bb.y is set anyway)
     // large dilation on mid-sized maps, no mask planes: one row phase of a channel block in LDS (dw_rows.h)
     if (dw_rows_ok(g) && pre == nullptr && denom == nullptr && keep == nullptr && post_mul == nullptr && sp.ok &&
         (int64_t)g.n * cdiv(g.c, DR_CB) < (1ll << 31)) {
@@ -937,6 +943,13 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
                                     sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out); } while (0)
         if (bb.y != nullptr) {
             if (!dxe) return 1;
+            if (dwpart != nullptr && fold) {
+                if (pre != nullptr) hipLaunchKernelGGL((dw_lean_kernel<4, true, true>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                                       sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, dwpart, bb, out);
+                else hipLaunchKernelGGL((dw_lean_kernel<4, true, false>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
+                                        sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, dwpart, bb, out);
+                return check_launch("dw_lean (BatchNorm backward on load + dX + dW)");
+            }
             if (dwpart != nullptr) {
                 if (pre != nullptr) hipLaunchKernelGGL((dw_lean_kernel<3, true, true>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g,
                                                        sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, dwpart, bb, out);
@@ -1356,7 +1369,8 @@ extern "C" int tsii_dw_fwd_bn(const float* x, const float* rmask, const float* w
 
 static int dw_bwd_dx_impl(const float* dy, const float* inv, const float* w, const float* rmask,
                           int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw,
-                          int dh, int dw, int ho, int wo, DwBnBwd bb, float* dx, float* ws, void* stream, float* dwpart = nullptr) {
+                          int dh, int dw, int ho, int wo, DwBnBwd bb, float* dx, float* ws, void* stream, float* dwpart = nullptr,
+                          DwBN fold_ib = kNoDwBN) {
     TSII_REQUIRE(dy && w && dx && ws, "dw_bwd_dx: null pointer");
     DW_GEOM();
     if (check_geom(g, "dw_bwd_dx")) return -1;
@@ -1367,9 +1381,10 @@ static int dw_bwd_dx_impl(const float* dy, const float* inv, const float* w, con
     if (kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == dw) {
         // stride 1: dx[i] = rmask[i] * sum_t w[t] * (dy*inv)[i + pad - t*d] -- the forward stencil with flipped taps
         DtGeom tg = {n, ho, wo, c, 1, dh, 2 * dh - ph, 2 * dw - pw, h, wd, 1};
-        rc = try_launch_dw_strip(dy, inv, ws, nullptr, nullptr, nullptr, rmask, tg, dx, st, kNoDwBN, nullptr, bb, dwpart);
+        rc = try_launch_dw_strip(dy, inv, ws, nullptr, nullptr, nullptr, rmask, tg, dx, st, fold_ib, nullptr, bb, dwpart, fold_ib.sc != nullptr);
         if (rc <= 0) return rc;
     }
+    TSII_REQUIRE(fold_ib.sc == nullptr, "dw_bwd_dxdw_bn2: this geometry has no form with the BatchNorm backward on load (tsii_dw_bwd_dxdw_fold_ok() == 0)");
     if (vec && kh == 3 && kw == 3 && sh == 2 && sw == 2 && dh == 1 && dw == 1 && ph == 1 && pw == 1) {   // marching strips
         const StripPlan sp = plan_strip(n, h, wd, c, 1, 1);     // strips of the input grid
         if (sp.ok) {
@@ -1460,6 +1475,39 @@ extern "C" int tsii_dw_bwd_dxdw_bn(const float* dy, const float* inv, const floa
     TSII_REQUIRE(make_in_bn(bn_mean, bn_var, bn_act, bn_slope, &tmp) == 0, "dw_bwd_dxdw_bn: activation %d has no load-time form", bn_act);
     const DwBnBwd bb = {bn_y, bn_mean, bn_var, bn_gamma, bn_beta, bn_eps, tmp.neg, tmp.hi, bwd_part};
     int rc = dw_bwd_dx_impl(dy, inv, w, rmask, n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo, bb, dx, ws, stream, (float*)ws_dw);
+    if (rc) return rc;
+    const int rows = (int)(need / ((size_t)9 * c * sizeof(float)));
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)cdiv64((int64_t)9 * c, 32)), dim3(256), 0, (hipStream_t)stream, (const float*)ws_dw, rows, 9, c, dwgt,
+                       (float*)nullptr, 9);
+    return check_launch("dw_reduce");
+}
+
+// K6e: tsii_dw_bwd_dxdw_bn whose incoming gradient is still the gradient w.r.t. the ACTIVATION of the BatchNorm that follows the
+// layer (da2; bn2_y = the layer's raw output y2, bn2_coef = the [6][c] table tsii_bn_bwd_reduce leaves): that BatchNorm's backward
+// is applied while the slab is staged (dw_lean.h MODE 4) -- 1 when the geometry has the form (3x3 / stride 1 / dilation 1).
+extern "C" int tsii_dw_bwd_dxdw_fold_ok(int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw) {
+    return (sh == 1 && sw == 1 && tsii_dw_bwd_dxdw_ws_bytes(n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw) > 0) ? 1 : 0;
+}
+
+extern "C" int tsii_dw_bwd_dxdw_bn2(const float* da2, const float* bn2_y, const float* bn2_coef, int bn2_act, float bn2_slope,
+                                    const float* inv, const float* w, const float* rmask,
+                                    int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw,
+                                    int dh, int dw, int ho, int wo,
+                                    const float* bn_y, const float* bn_mean, const float* bn_var, const float* bn_gamma,
+                                    const float* bn_beta, float bn_eps, int bn_act, float bn_slope,
+                                    float* dx, float* bwd_part, float* dwgt, float* ws, void* ws_dw, size_t ws_dw_bytes, void* stream) {
+    TSII_REQUIRE(da2 && bn2_y && bn2_coef && bn_y && bn_mean && bn_var && bn_gamma && bn_beta && bwd_part && dwgt && ws_dw, "dw_bwd_dxdw_bn2: null pointer");
+    TSII_REQUIRE(aligned16(bn_y) && aligned16(bn_mean) && aligned16(bn_var) && aligned16(bn_gamma) && aligned16(bn_beta) && aligned16(ws_dw) &&
+                 aligned16(bn2_y) && aligned16(da2), "dw_bwd_dxdw_bn2: tensors and the workspace must be 16-byte aligned");
+    TSII_REQUIRE(tsii_dw_bwd_dxdw_fold_ok(n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw), "dw_bwd_dxdw_bn2: this geometry has no form with the BatchNorm backward on load");
+    const size_t need = tsii_dw_bwd_dxdw_ws_bytes(n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw);
+    TSII_REQUIRE(ws_dw_bytes >= need, "dw_bwd_dxdw_bn2: weight-gradient workspace too small");
+    InBN tmp, tmp2;
+    TSII_REQUIRE(make_in_bn(bn_mean, bn_var, bn_act, bn_slope, &tmp) == 0, "dw_bwd_dxdw_bn2: activation %d has no load-time form", bn_act);
+    TSII_REQUIRE(make_in_bn(bn2_y, bn2_coef, bn2_act, bn2_slope, &tmp2) == 0, "dw_bwd_dxdw_bn2: activation %d has no load-time form", bn2_act);
+    const DwBnBwd bb = {bn_y, bn_mean, bn_var, bn_gamma, bn_beta, bn_eps, tmp.neg, tmp.hi, bwd_part};
+    const DwBN fold_ib = {bn2_y, bn2_coef, tmp2.neg, tmp2.hi};
+    int rc = dw_bwd_dx_impl(da2, inv, w, rmask, n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw, ho, wo, bb, dx, ws, stream, (float*)ws_dw, fold_ib);
     if (rc) return rc;
     const int rows = (int)(need / ((size_t)9 * c * sizeof(float)));
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)cdiv64((int64_t)9 * c, 32)), dim3(256), 0, (hipStream_t)stream, (const float*)ws_dw, rows, 9, c, dwgt,

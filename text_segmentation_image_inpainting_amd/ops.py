@@ -26,6 +26,9 @@ FUSE_BN_BWD = True
 FUSE_BN_BWD_PW = True
 # K6d: the depth-wise dX + K6c pass also takes the layer's weight gradient (tsii_dw_bwd_dxdw_bn; stride 1 / dilation 1, bias-free)
 FUSE_DW_DXDW = True
+# K6e: ... and applies the backward of the BatchNorm that FOLLOWS the layer while it loads (tsii_dw_bwd_dxdw_bn2): that BatchNorm's
+# backward only reduces its K6c partial rows (tsii_bn_bwd_reduce) and hands (gradient, raw input, constants) over; stride 1
+FUSE_DW_BN2_FOLD = True
 # bf16 storage: where the PLAIN dX product runs on the 256 x 256 direct-to-LDS kernel (k, cout >= 256) the K6c epilogue (register-staged
 # 128 x 256 tiles) costs more in a microbenchmark than that kernel plus the stand-alone reduction pass (131072 x 512 x 512: 153-165 us against 88 + 52) --
 # in the cfg 5 step it does not (profiles/r05x_k6c_unfuse.log: 60.2 ms fused, 61.0 unfused: the reduction pass reads dx and y cold), so: off
@@ -194,6 +197,36 @@ class _PoolHandOver:
         if dy is not None and dy.data_ptr() == gy.data_ptr() and dy.shape == gy.shape:
             return dz
         return None
+
+
+class _FoldHandOver:
+    """K6e hand-over: the BatchNorm that follows a depth-wise layer defers its backward APPLY pass to that layer's dX + dW kernel, which
+    forms dy = BatchNorm-backward(da, y) while it stages its slab.  _BNLazy.backward leaves (da, y, coef, act, slope) here and returns da
+    unchanged as the "gradient" of the conv output; _Depthwise.backward takes it if the gradient it receives is that very tensor --
+    anything else (autograd summed a second consumer's gradient into it) cannot be undone and raises."""
+
+    __slots__ = ("pending",)
+
+    def __init__(self):
+        self.pending = None
+
+    def take(self, gy):
+        pend, self.pending = self.pending, None
+        if pend is None:
+            return None
+        if pend[0].data_ptr() != gy.data_ptr() or pend[0].shape != gy.shape:
+            raise RuntimeError("deferred BatchNorm backward (K6e): the depth-wise layer's output has another consumer than its BatchNorm; "
+                               "set ops.FUSE_DW_BN2_FOLD = False for this network")
+        return pend
+
+
+def _apply_deferred_bn(pend):
+    """The stand-alone apply pass of a deferred BatchNorm backward: dy from (da, y, coef)."""
+    da, y, coef, act, slope = pend
+    c = y.shape[-1]
+    dy = torch.empty_like(y)
+    call("tsii_bn_bwd_apply", ptr(da), ptr(y), y.numel() // c, c, ptr(coef), int(act), float(slope), ptr(dy), _lib.stream())
+    return dy
 
 
 class _Pointwise(torch.autograd.Function):
@@ -408,6 +441,13 @@ class _Depthwise(torch.autograd.Function):
         ctx.save_for_backward(x, w, rmask, inv, keep, in_scale, in_shift)
         ctx.g, ctx.has_bias, ctx.in_cfg = g, bias is not None, (int(in_act), float(in_slope))
         ctx.set_materialize_grads(False)
+        # K6e: will this layer's backward be the one-pass dX + K6c + dW kernel with a form that applies the FOLLOWING BatchNorm's
+        # backward on load?  Decided here, where everything it depends on is known; pconv_depthwise hangs the hand-over on y
+        ctx.fold = None
+        if (FUSE_DW_BN2_FOLD and FUSE_DW_DXDW and FUSE_BN_BWD and bn is not None and bias is None and in_scale is not None
+                and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and load_time_act(int(in_act), float(in_slope)) and _al16(x, y)
+                and int(_lib.lib().tsii_dw_bwd_stat_rows(n, h, wd, c, *g)) > 0 and int(_lib.lib().tsii_dw_bwd_dxdw_fold_ok(n, h, wd, c, *g)) == 1):
+            ctx.fold = _FoldHandOver()
         if want_stats:
             ctx.mark_non_differentiable(part)
             return y, part
@@ -420,6 +460,17 @@ class _Depthwise(torch.autograd.Function):
         x, w, rmask, inv, keep, in_scale, in_shift = ctx.saved_tensors
         g = ctx.g
         gy = gy.contiguous()
+        pend = ctx.fold.take(gy) if getattr(ctx, "fold", None) is not None else None
+        if pend is not None:
+            # the following BatchNorm deferred its apply pass to this backward (K6e); if the one-pass kernel cannot run after all (a
+            # switch changed between forward and backward), the stand-alone apply pass runs here
+            L = _lib.lib()
+            can = (FUSE_DW_DXDW and FUSE_BN_BWD and ctx.bn is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+                   and not ctx.has_bias and in_scale is not None and load_time_act(*ctx.in_cfg) and _al16(gy, x)
+                   and int(L.tsii_dw_bwd_stat_rows(x.shape[0], x.shape[1], x.shape[2], x.shape[3], *g)) > 0
+                   and int(L.tsii_dw_bwd_dxdw_fold_ok(x.shape[0], x.shape[1], x.shape[2], x.shape[3], *g)) == 1)
+            if not can:
+                gy, pend = _apply_deferred_bn(pend), None
         n, h, wd, c = x.shape
         ho, wo = g.out_hw(h, wd)
         st = _lib.stream()
@@ -465,11 +516,19 @@ class _Depthwise(torch.autograd.Function):
                 part = torch.empty((rows, 2, c), dtype=torch.float32, device=x.device)
                 dw = torch.empty_like(w)
                 wsd = _ws(dwb, x)
+                if pend is not None:
+                    _, y2, coef, act2, slope2 = pend      # K6e: gy is still the gradient w.r.t. act2(BatchNorm2(y2))
+                    call("tsii_dw_bwd_dxdw_bn2", ptr(gy), ptr(y2), ptr(coef), int(act2), float(slope2), ptr(inv), ptr(w), ptr(rmask),
+                         n, h, wd, c, *g, ho, wo, ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ctx.in_cfg[0], ctx.in_cfg[1],
+                         ptr(dx), ptr(part), ptr(dw), ptr(ws), ptr(wsd), dwb, st)
+                    slot.part = part
+                    return (dx, dw, None) + (None,) * 11
                 call("tsii_dw_bwd_dxdw_bn", ptr(gy), ptr(inv), ptr(w), ptr(rmask), n, h, wd, c, *g, ho, wo,
                      ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ctx.in_cfg[0], ctx.in_cfg[1],
                      ptr(dx), ptr(part), ptr(dw), ptr(ws), ptr(wsd), dwb, st)
                 slot.part = part
                 return (dx, dw, None) + (None,) * 11
+            assert pend is None, "K6e: a deferred BatchNorm backward reached a path without the one-pass kernel"
             if rows > 0:
                 mean, var, gamma, beta, eps, slot = ctx.bn
                 part = torch.empty((rows, 2, c), dtype=torch.float32, device=x.device)
@@ -510,6 +569,10 @@ def pconv_depthwise(x, w, bias, rmask, denom, keep, inv, g: Geom, want_stats=Fal
         x.consumed()
         bn = (x.mean, x.var, x.gamma, x.beta, x.eps, x.slot) if x.slot is not None else None
         out = _Depthwise.apply(x.token, w, bias, rmask, denom, keep, inv, g, x.scale, x.shift, x.act, x.slope, stats, bn)
+        y = out[0] if stats else out
+        fold = getattr(y.grad_fn, "fold", None)
+        if fold is not None:
+            y._tsii_fold = fold      # read by bn_lazy: the BatchNorm over y may leave its backward apply pass to this layer's dX kernel (K6e)
     else:
         out = _Depthwise.apply(x, w, bias, rmask, denom, keep, inv, g, None, None, 0, 0.0, stats)
     if want_stats and not stats:
@@ -966,7 +1029,7 @@ class _BNLazy(torch.autograd.Function):
     backward receives the gradient w.r.t. the normalised activation and is the full BatchNorm(+act) backward."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, part, training, momentum, eps, act, slope, slot, pool=None):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, part, training, momentum, eps, act, slope, slot, pool=None, fold=None):
         _lib.check_device(y, bf16_ok=True)
         y = y.contiguous()
         c = y.shape[-1]
@@ -975,6 +1038,7 @@ class _BNLazy(torch.autograd.Function):
         dev = y.device
         ctx.slot = slot
         ctx.pool = pool     # _PoolHandOver of the conv that produced y (K7b) or None
+        ctx.fold = fold     # _FoldHandOver of the depth-wise conv that produced y (K6e) or None
         scale = torch.empty(c, dtype=torch.float32, device=dev)
         shift = torch.empty(c, dtype=torch.float32, device=dev)
         if training:
@@ -1010,13 +1074,12 @@ class _BNLazy(torch.autograd.Function):
     @staticmethod
     def backward(ctx, ga, *_):
         if ga is None:
-            return (None,) * 13
+            return (None,) * 14
         y, mean, var, gamma, beta = ctx.saved_tensors
         training, eps, act, slope = ctx.cfg
         ga = ga.contiguous()
         c = y.shape[-1]
         m = y.numel() // c
-        dy = torch.empty_like(y)
         dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
         dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
         slot = ctx.slot
@@ -1026,14 +1089,29 @@ class _BNLazy(torch.autograd.Function):
         if _h(y):
             if ga.dtype != BF16:
                 raise RuntimeError("bf16 storage: the incoming gradient of a bf16 BatchNorm must be bf16")
+            dy = torch.empty_like(y)
             nbytes = _lib.lib().tsii_bf16_bn_ws_bytes(m, c)
             ws = _ws(nbytes, y)
             call("tsii_bf16_bn_act_bwd", ptr(ga), ptr(y), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), eps, act, slope, int(training),
                  ptr(part), 0 if part is None else part.shape[0], ptr(dy), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _lib.stream())
-            return (dy, dgamma, dbeta) + (None,) * 10
+            return (dy, dgamma, dbeta) + (None,) * 11
+        pool = ctx.pool
+        fold = ctx.fold
+        if (fold is not None and part is not None and FUSE_DW_BN2_FOLD and load_time_act(act, slope) and c % 4 == 0 and _al16(ga, y)
+                and not (pool is not None and pool.want)):
+            # K6e: only the reduction of the K6c partial rows runs here (dgamma, dbeta, the constants' table); the apply pass rides in the
+            # producing depth-wise layer's dX + dW kernel, which receives ga itself
+            L = _lib.lib()
+            coef = torch.empty((6, c), dtype=torch.float32, device=y.device)
+            rbytes = L.tsii_bn_bwd_reduce_ws_bytes(part.shape[0], c)
+            wsr = _ws(rbytes, y)
+            call("tsii_bn_bwd_reduce", ptr(mean), ptr(var), ptr(gamma), ptr(beta), eps, int(training), ptr(part), part.shape[0], m, c,
+                 ptr(dgamma), ptr(dbeta), ptr(coef), ptr(wsr), rbytes, _lib.stream())
+            fold.pending = (ga, y, coef, act, slope)
+            return (ga, dgamma, dbeta) + (None,) * 11
+        dy = torch.empty_like(y)
         nbytes = _lib.lib().tsii_bn_ws_bytes(m, c)
         ws = _ws(nbytes, y)
-        pool = ctx.pool
         if part is not None and pool is not None and pool.want and y.dim() == 4 and (y.shape[1], y.shape[2]) == (pool.h, pool.w):
             dz = torch.empty((y.shape[0], pool.h // 2, pool.w // 2, c), dtype=torch.float32, device=y.device)
             call("tsii_bn_act_bwd_pre_pool", ptr(ga), ptr(y), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), eps, act,
@@ -1047,7 +1125,7 @@ class _BNLazy(torch.autograd.Function):
         else:
             call("tsii_bn_act_bwd", ptr(ga), ptr(y), m, c, ptr(mean), ptr(var), ptr(gamma), ptr(beta), eps, act,
                  slope, int(training), ptr(dy), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, _lib.stream())
-        return (dy, dgamma, dbeta) + (None,) * 10
+        return (dy, dgamma, dbeta) + (None,) * 11
 
 
 class _LazyApply(torch.autograd.Function):
@@ -1080,7 +1158,8 @@ def bn_lazy(y, gamma, beta, running_mean, running_var, training, momentum=0.1, e
     """BatchNorm(+act) of a conv output as a LazyBN; ``part``: the statistics partials the conv left behind."""
     slot = _BwdSlot()
     token, scale, shift, mean, var = _BNLazy.apply(y, gamma, beta, running_mean, running_var, part, training,
-                                                   momentum, eps, act, slope, slot, getattr(y, "_tsii_pool", None))
+                                                   momentum, eps, act, slope, slot, getattr(y, "_tsii_pool", None),
+                                                   getattr(y, "_tsii_fold", None))
     return LazyBN(token, scale, shift, act, slope, mean, var, gamma.detach(), beta.detach(), eps, slot)
 
 
