@@ -60,7 +60,9 @@ def mode(request, emu):
 @pytest.mark.parametrize("M,K,N,bias,masked", [(300, 64, 128, True, True), (257, 96, 192, True, False),
                                                (130, 40, 32, False, True), (70, 6, 5, True, True),
                                                (260, 128, 256, False, False), (200, 36, 136, True, True),
-                                               (300, 192, 128, True, True), (210, 132, 256, False, True)])
+                                               (300, 192, 128, True, True), (210, 132, 256, False, True),
+                                               # weight gradient on the 32 x 128 tiles (<= 32 output channels, wide reduction side)
+                                               (300, 384, 32, True, True), (1000, 160, 16, False, True), (515, 132, 24, True, False)])
 def test_pointwise_gemms(emu, mode, M, K, N, bias, masked):
     L = emu
     tol = MODE_TOL[mode]
@@ -113,7 +115,7 @@ def test_pointwise_gemms(emu, mode, M, K, N, bias, masked):
 
 
 @pytest.mark.parametrize("M,K,N,act,slope", [(300, 64, 128, 2, 0.3), (257, 192, 192, 1, 0.0), (140, 36, 40, 3, 0.0),
-                                             (260, 128, 256, 0, 0.0)])
+                                             (260, 128, 256, 0, 0.0), (300, 384, 32, 2, 0.3), (700, 160, 24, 3, 0.0)])
 def test_pointwise_fused_batchnorm(emu, mode, M, K, N, act, slope):
     """K6b at kernel level: BatchNorm(+act) of the producer applied on operand load (forward and dW) and the
     statistics partials of the output (-> tsii_bn_finalize) against float64 numpy."""

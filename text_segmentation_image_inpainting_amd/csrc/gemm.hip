@@ -441,11 +441,29 @@ struct TnPlan {
     int bm, bn;
     int splits;
     int64_t chunk;
+    bool thin;      // 32 x 128 tiles (split-bf16 kernel only)
 };
-static TnPlan plan_tn(int64_t M, int P, int Q, bool allow_narrow = false) {
+static TnPlan plan_tn(int64_t M, int P, int Q, bool allow_narrow = false, bool allow_thin = false) {
     TnPlan pl;
     pl.big = (P >= 128 && Q >= 128);
     pl.bm = pl.bn = pl.big ? 128 : 64;
+    pl.thin = false;
+#ifndef TSII_TN_THIN32
+#define TSII_TN_THIN32 1
+#endif
+    // <= 32 x wide products (the first block's project layer: 2M x 32 x 384): 32 x 128 tiles on the split-bf16 kernel -- the 64 x 64
+    // tiles gave two of the four waves rows of padding to multiply and split the 32-channel panel once per 64 columns (round 6)
+    if (TSII_TN_THIN32 && allow_thin && allow_narrow && P <= 32 && Q >= 128) {
+        pl.thin = true; pl.bm = 32; pl.bn = 128;
+        const int tiles_t = cdiv(Q, 128);
+        int64_t want_t = 768 / tiles_t;
+        if (want_t < 1) want_t = 1;
+        int64_t chunk_t = cdiv64(M, want_t);
+        if (chunk_t < 256) chunk_t = 256;
+        chunk_t = cdiv64(chunk_t, GEMM_BK) * GEMM_BK;
+        pl.chunk = chunk_t; pl.splits = (int)cdiv64(M, chunk_t); pl.narrow = false;
+        return pl;
+    }
     pl.narrow = allow_narrow && pl.big && (Q % 128) >= 1 && (Q % 128) <= 64;
 #ifndef TSII_TN_NARROW64
 #define TSII_TN_NARROW64 1
@@ -697,8 +715,9 @@ extern "C" int tsii_pw_bwd_dx_bn(const float* dy, int64_t m, int n, const float*
 
 extern "C" size_t tsii_pw_bwd_dw_ws_bytes(int64_t m, int n, int k) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    const TnPlan a = plan_tn(m, n, k, true), b = plan_tn(m, n, k, false);   // the call picks one by operand alignment
-    const int splits = a.splits > b.splits ? a.splits : b.splits;
+    const TnPlan a = plan_tn(m, n, k, true), b = plan_tn(m, n, k, false), t = plan_tn(m, n, k, true, true);   // the call picks one by operand alignment / arithmetic mode
+    int splits = a.splits > b.splits ? a.splits : b.splits;
+    splits = t.splits > splits ? t.splits : splits;
     return ((size_t)splits * n * k + colsum_ws_floats(m, n)) * sizeof(float);
 }
 
@@ -710,12 +729,13 @@ static int pw_bwd_dw_impl(const float* dy, const float* x, int64_t m, int n, int
     TSII_REQUIRE(ws_bytes >= tsii_pw_bwd_dw_ws_bytes(m, n, k), "pw_bwd_dw: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (n % 4 == 0) && (k % 4 == 0) && aligned16(dy) && aligned16(x);
-    TnPlan pl = plan_tn(m, n, k, vec);
+    const bool split_path = tn_split_ok(dy, n, x, k, n, k);
+    TnPlan pl = plan_tn(m, n, k, vec, split_path);
     float* part = (float*)ws;
     RowScale sb = {r0, r1, split};
     dim3 grid(cdiv(k, pl.bn), cdiv(n, pl.bm), pl.splits);
-    if (tn_split_ok(dy, n, x, k, n, k)) {     // split-bf16 MFMA (gemm_split.hip): same partial-slab workspace + row reduce
-        int rc = launch_tn_split(dy, n, inv, x, k, sb, part, m, n, k, pl.chunk, pl.splits, pl.narrow ? 1 : (pl.big ? 0 : 2), ib, st);
+    if (split_path) {     // split-bf16 MFMA (gemm_split.hip): same partial-slab workspace + row reduce
+        int rc = launch_tn_split(dy, n, inv, x, k, sb, part, m, n, k, pl.chunk, pl.splits, pl.thin ? 3 : (pl.narrow ? 1 : (pl.big ? 0 : 2)), ib, st);
         if (rc) return rc;
         rc = launch_reduce_rows(part, pl.splits, (int64_t)n * k, dw, st);
         if (rc) return rc;

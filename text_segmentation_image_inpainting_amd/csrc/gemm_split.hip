@@ -415,7 +415,11 @@ __global__ __launch_bounds__(256, (BNB || (BNIN && BPRE)) ? 2 : 3) void gemm_nt_
 // Thread -> micro-tile: cq = (lane & 7) | ((lane >> 4) << 3), mq = ((lane >> 3) & 1) | (wave << 1): one global load
 // instruction reads 2 rows x 4 full 128-byte lines per wave.
 template <int CH>
-__device__ __forceinline__ int tn_atom(int c, int ch) { return c * CH + (ch & 3) * (CH / 4) + ((ch >> 2) ^ (4 * (ch & 3))); }
+__device__ __forceinline__ int tn_atom(int c, int ch) {
+    // (32 channels: 8 atoms per residue class, the swizzle stays inside them; stores and fragment reads conflict-free like the wider forms)
+    if (CH == 32) return c * CH + (ch & 3) * 8 + ((ch >> 2) ^ (2 * (ch & 3)));
+    return c * CH + (ch & 3) * (CH / 4) + ((ch >> 2) ^ (4 * (ch & 3)));
+}
 
 template <int CH>
 __device__ __forceinline__ void tn_split_load(const float* __restrict__ Pm, int64_t ld, int64_t m0, int64_t mend, int c0, int ncols,
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_split_kernel(const float* __re
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(!BCONV || !BNIN, "the gathered B operand has no BatchNorm-on-load form");
-    static_assert((BM == 128 || BM == 64) && (BN == 128 || BN == 64), "micro-tile mapping: 32 (16) channel quads x 8 m quads");
+    static_assert((BM == 128 || BM == 64 || BM == 32) && (BN == 128 || BN == 64), "micro-tile mapping: 32 (16, 8) channel quads x 8 m quads");
     __shared__ __attribute__((aligned(16))) unsigned char smem[P * (BM + BN) * 64];
     unsigned char* As = smem;
     unsigned char* Bs = smem + P * BM * 64;
@@ -834,17 +838,18 @@ bool tn_split_ok(const float* A, int64_t lda, const float* B, int64_t ldb, int P
     return g_products != 0 && Pn % 4 == 0 && Q % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) && aligned16(B);
 }
 
-// tile = 0: 128x128, 1: 128x64 (narrow), 2: 64x64 (P or Q below 128); one partial [P,Q] slab per m-chunk in Cws
+// tile = 0: 128x128, 1: 128x64 (narrow), 2: 64x64 (P or Q below 128), 3: 32x128 (P <= 32, one wave row); one partial [P,Q] slab per m-chunk in Cws
 int launch_tn_split(const float* A, int64_t lda, const float* sa, const float* B, int64_t ldb, RowScale sb, float* Cws,
                     int64_t M, int Pn, int Q, int64_t chunk, int splits, int tile, InBN ib, hipStream_t stream) {
-    const int bm = tile == 2 ? 64 : 128, bn = tile == 0 ? 128 : 64;
+    const int bm = tile == 3 ? 32 : (tile == 2 ? 64 : 128), bn = (tile == 0 || tile == 3) ? 128 : 64;
     const unsigned qt = (unsigned)cdiv(Q, bn), pt = (unsigned)cdiv(Pn, bm);
     const int64_t nblocks = (int64_t)qt * pt * splits;
     TSII_REQUIRE(nblocks < (1ll << 31), "gemm_tn_split: grid too large");
     const dim3 grid((unsigned)nblocks);
     if (ib.sc != nullptr) TSII_REQUIRE(aligned16(ib.sc) && aligned16(ib.sh), "gemm_tn_split: input BatchNorm needs 16-byte aligned scale / shift");
 #define TSII_TN_SPLIT(TMV, TNV, PR, BNV) hipLaunchKernelGGL((gemm_tn_split_kernel<2, 2, TMV, TNV, PR, BNV>), grid, dim3(256), 0, stream, A, lda, sa, B, ldb, sb, Cws, M, Pn, Q, chunk, ib, qt, pt, kNoGather)
-#define TSII_TN_SPLIT_T(PR, BNV) do { if (tile == 0) TSII_TN_SPLIT(2, 2, PR, BNV); else if (tile == 1) TSII_TN_SPLIT(2, 1, PR, BNV); else TSII_TN_SPLIT(1, 1, PR, BNV); } while (0)
+#define TSII_TN_SPLIT_THIN(PR, BNV) hipLaunchKernelGGL((gemm_tn_split_kernel<1, 4, 1, 1, PR, BNV>), grid, dim3(256), 0, stream, A, lda, sa, B, ldb, sb, Cws, M, Pn, Q, chunk, ib, qt, pt, kNoGather)
+#define TSII_TN_SPLIT_T(PR, BNV) do { if (tile == 0) TSII_TN_SPLIT(2, 2, PR, BNV); else if (tile == 1) TSII_TN_SPLIT(2, 1, PR, BNV); else if (tile == 3) TSII_TN_SPLIT_THIN(PR, BNV); else TSII_TN_SPLIT(1, 1, PR, BNV); } while (0)
     if (ib.sc != nullptr) { if (g_products == 1) TSII_TN_SPLIT_T(1, true); else if (g_products == 8) TSII_TN_SPLIT_T(8, true); else if (g_products == 3) TSII_TN_SPLIT_T(3, true); else TSII_TN_SPLIT_T(6, true); }
     else { if (g_products == 1) TSII_TN_SPLIT_T(1, false); else if (g_products == 8) TSII_TN_SPLIT_T(8, false); else if (g_products == 3) TSII_TN_SPLIT_T(3, false); else TSII_TN_SPLIT_T(6, false); }
 #undef TSII_TN_SPLIT_T
