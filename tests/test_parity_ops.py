@@ -120,6 +120,58 @@ def test_golden_pir_blocks_weight_gradient_in_the_dx_pass(backend, monkeypatch):
     assert "tsii_dw_bwd_dxdw_bn" not in calls and "tsii_dw_bwd_dw_bn" in calls, sorted(set(calls))
 
 
+@both_backends
+def test_deferred_batchnorm_backward_falls_back_and_refuses(backend, monkeypatch):
+    """K6e's hand-over between the BatchNorm that follows a depth-wise layer and that layer's backward: (1) a switch flipped BETWEEN
+    forward and backward (the one-pass kernel is no longer allowed) -> the stand-alone apply pass runs inside the layer's backward and
+    the fixture gradients still hold; (2) a second consumer of the layer's raw output -> the deferral cannot be undone: RuntimeError."""
+    from text_segmentation_image_inpainting_amd import ops
+    meta = json.load(open(os.path.join(GOLD, "pir_blocks.json")))
+    G = np.load(os.path.join(GOLD, "pir_blocks.npz"))
+    c = next(c for c in meta if c["s"] == 1 and c["d"] == 1)
+    i = c["idx"]
+    pre = f"pir{i}."
+    calls = []
+    real = ops.call
+    monkeypatch.setattr(ops, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+    with BACKENDS[backend]() as dev:
+        m = T.PartialInvertedResidual(c["in_c"], c["out_c"], c["k"], c["s"], c["p"], c["d"], c["t"], bias=False, BN=True,
+                                      activation=torch.nn.LeakyReLU(0.3), use_1_conv=c["use_1_conv"],
+                                      no_holes_1_conv=c["no_holes_1_conv"], same_holes=c["same_holes"])
+        fill_state_dict_(m.state_dict(), seed=100 + i)
+        m = m.to(dev).train()
+        x = torch.from_numpy(G[pre + "x"]).to(dev).requires_grad_(True)
+        y, _ = m((x, torch.from_numpy(G[pre + "mask"]).to(dev)))
+        monkeypatch.setattr(ops, "FUSE_DW_DXDW", False)          # after the forward decided to defer
+        y.backward(torch.from_numpy(G[pre + "gy"]).to(dev))
+        assert "tsii_bn_bwd_reduce" in calls and "tsii_bn_bwd_apply" in calls and "tsii_dw_bwd_dxdw_bn2" not in calls, sorted(set(calls))
+        assert_close(x.grad, G[pre + "dx"], TOL, f"pir{i} dx (fallback)")
+        params = dict(m.named_parameters())
+        for k in G.files:
+            if k.startswith(pre + "grad."):
+                assert_close(params[k[len(pre) + 5:]].grad, G[k], TOL, k + " (fallback)")
+        monkeypatch.setattr(ops, "FUSE_DW_DXDW", True)
+        # (2) the layer's raw output consumed by its BatchNorm AND directly
+        cch = 8
+        g = ops.make_geom(3, 1, 1, 1)
+        rng = np.random.default_rng(5)
+        t = lambda *sh: torch.from_numpy(rng.standard_normal(sh).astype(np.float32)).to(dev)
+        ones = lambda n: torch.ones(n, device=dev)
+        x0 = t(1, 6, 7, cch).requires_grad_(True)
+        lz = ops.bn_lazy(x0 * 1.0, ones(cch).requires_grad_(True), torch.zeros(cch, device=dev).requires_grad_(True), torch.zeros(cch, device=dev), ones(cch),
+                         True, act=ops.ACT_LEAKY, slope=0.3)
+        w = t(cch, 1, 3, 3).requires_grad_(True)
+        yraw = ops.pconv_depthwise(lz, w, None, None, None, None, None, g)
+        assert getattr(yraw, "_tsii_fold", None) is not None, "the layer offers the deferral for this geometry"
+        lz2 = ops.bn_lazy(yraw, ones(cch).requires_grad_(True), torch.zeros(cch, device=dev).requires_grad_(True), torch.zeros(cch, device=dev), ones(cch),
+                          True, act=ops.ACT_LEAKY, slope=0.3)
+        w2 = t(4, cch, 1, 1).requires_grad_(True)
+        out = ops.pconv_pointwise(lz2, w2)
+        loss = out.sum() + yraw.sum()          # the second consumer
+        with pytest.raises(RuntimeError, match="another consumer"):
+            loss.backward()
+
+
 def _imagefill_case(dev, size, batch, seed, per_channel_mask, hole_frac=0.12):
     from oracle.filler import seeded_input
     keys = json.load(open(os.path.join(GOLD, "state_dict_keys.json")))
