@@ -164,6 +164,9 @@ SCRATCH_ALLOWED = {
     # K6e with mask planes (round 6): 2-4 registers at the 256-register limit of 2 waves per SIMD; the form was measured WITH them
     # (profiles/r06r_bench_k6e_ab.log: step 58.4-58.6 ms with the kernel, 60.4 without)
     "_ZN4tsii14dw_lean_kernelILi4ELb1ELb1E": 24,
+    # K6d on the dilated ring kernels (dilation 2 / 4; ImageFill's 32 x 32 levels, 0.2 ms per step each): 14-18 registers at the
+    # 256-register limit; the form was measured WITH them (profiles/r06v_bench_dil_ab.log: 56.9-57.1 vs 57.45-57.48 ms without the forms)
+    "_ZN4tsii15dw_strip_kernelILi1ELi2ELi3E": 80, "_ZN4tsii15dw_strip_kernelILi1ELi4ELi3E": 64,
     "_ZN4tsii17gemm_nt_pc_kernelILi2ELi4ELi6ELb1E": 8,
     "_ZN4tsii20gemm_nt_split_kernelILi2ELi2ELi2ELi2E": 16, "_ZN4tsii20gemm_tn_split_kernelILi2ELi2ELi2ELi2E": 16,
     "_ZN4tsii23head_cat_dw_mfma_kernelILi2ELb0ELb1E": 96, "_ZN4tsii23head_cat_dw_mfma_kernelILi2ELb1ELb0ELb0E": 52,

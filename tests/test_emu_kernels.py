@@ -605,8 +605,8 @@ def _strip_entry_points(L, n, h, wd, c, masked, bias, act, d=1, p=None):
     # K6d: the same pass also returns the weight gradient -- dX and the K6c partials bit for bit those above, dW against float64 and
     # against the separate entry point it replaces
     dwb = L.tsii_dw_bwd_dxdw_ws_bytes(n, h, wd, c, *geom)
-    if d != 1:
-        assert dwb == 0, "K6d exists for dilation 1 only"
+    if dwb == 0:
+        assert d != 1, "K6d always exists at dilation 1; at dilation 2 / 4 / 8 on the ring kernels only (not by phases, not on the small-map kernel)"
         return
     assert dwb == 4 * brows * 9 * c
     wsd = WS(dwb); wsd[:] = np.nan
@@ -623,7 +623,7 @@ def _strip_entry_points(L, n, h, wd, c, masked, bias, act, d=1, p=None):
     dwr = np.zeros((c, 1, 3, 3)); dwabs = np.zeros((c, 1, 3, 3))
     for ky in range(3):
         for kx in range(3):
-            prod = ap[:, ky:ky + ho, kx:kx + wo] * gfull
+            prod = ap[:, ky * d:ky * d + ho, kx * d:kx * d + wo] * gfull
             dwr[:, 0, ky, kx] = prod.reshape(-1, c).sum(0)
             dwabs[:, 0, ky, kx] = np.abs(prod).reshape(-1, c).sum(0)
     assert np.all(np.abs(dw3 - dwr) <= 2e-6 * dwabs + 1e-6), np.abs(dw3 - dwr).max()
@@ -639,6 +639,9 @@ def _strip_entry_points(L, n, h, wd, c, masked, bias, act, d=1, p=None):
     # K6e: the same pass fed with the gradient w.r.t. the activation of the BatchNorm that FOLLOWS the layer (da2, its raw input y2 and
     # the constants' table of tsii_bn_bwd_reduce): that BatchNorm's backward is applied on load.  Against the two-step route
     # (tsii_bn_bwd_apply, then tsii_dw_bwd_dxdw_bn) and the pieces against float64.
+    if d != 1:
+        assert L.tsii_dw_bwd_dxdw_fold_ok(n, h, wd, c, *geom) == 0, "K6e: dilation 1 only"
+        return
     assert L.tsii_dw_bwd_dxdw_fold_ok(n, h, wd, c, *geom) == 1
     m2 = n * ho * wo
     da2 = rng.standard_normal((n, ho, wo, c)).astype(np.float32)
@@ -925,6 +928,28 @@ def test_depthwise_small_map_dilated(emu, n, h, wd, c, d, masked, bias, act):
         slack = (np.abs(dx) * near).reshape(-1, c).sum(0) * 2 + 1e-4 * np.abs(dz).reshape(-1, c).sum(0).max()
         assert np.all(np.abs(bp[0] - dz.reshape(-1, c).sum(0)) <= slack)
         assert np.all(np.abs(bp[1] - (dz * xh).reshape(-1, c).sum(0)) <= slack * max(1.0, np.abs(xh).max()))
+        # K6d on the small-map kernel (dilation 8): the same pass also returns the weight gradient
+        dwb = L.tsii_dw_bwd_dxdw_ws_bytes(n, h, wd, c, *geom)
+        assert (dwb > 0) == (d == 8), "the small-map kernel has the K6c / K6d forms where the strip plan defines the partial rows"
+        if dwb > 0:
+            assert dwb == 4 * brows * 9 * c
+            wsd = WS(dwb); wsd[:] = np.nan
+            bpart3 = WS(4 * brows * 2 * c); bpart3[:] = np.nan
+            dx3 = np.full((n, h, wd, c), np.nan, np.float32)
+            dw3 = np.full((c, 1, 3, 3), np.nan, np.float32)
+            assert L.tsii_dw_bwd_dxdw_bn(P(dy), P(inv), P(w), P(rmask), n, h, wd, c, *geom, h, wd, P(x), P(mean_b), P(var_b), P(gam), P(bet),
+                                         1e-5, act, slope, P(dx3), P(bpart3), P(dw3), P(ws), P(wsd), dwb, None) == 0, L.tsii_last_error()
+            assert np.array_equal(dx3, dx)
+            assert np.array_equal(bpart3[:brows * 2 * c], bpart[:brows * 2 * c])
+            assert np.isfinite(wsd[:dwb // 4]).all(), "every weight-gradient partial row is written (an image's other rows: zeros)"
+            am = _act(z, act, slope) * (1.0 if rmask is None else rmask.astype(np.float64)[..., None])
+            gfull = dy.astype(np.float64) * (1.0 if inv is None else inv.astype(np.float64)[..., None])
+            ap = np.zeros((n, h + 2 * d, wd + 2 * d, c)); ap[:, d:d + h, d:d + wd] = am
+            for ky in range(3):
+                for kx in range(3):
+                    prod = ap[:, ky * d:ky * d + h, kx * d:kx * d + wd] * gfull
+                    ref = prod.reshape(-1, c).sum(0)
+                    assert np.all(np.abs(dw3[:, 0, ky, kx] - ref) <= 2e-6 * np.abs(prod).reshape(-1, c).sum(0) + 1e-6), (ky, kx)
 
 
 @pytest.mark.parametrize("n,h,wd,c,masked,act", [

@@ -8,7 +8,9 @@
 // flight per thread, and computes every output from LDS with per-tap bounds predicates -- no halo traffic at any dilation.  The
 // two blocks that share the 128-byte lines of a pixel (channels 16 c .. 16 c + 31) carry consecutive logical ids, i.e. run on the
 // same XCD at the same time (xcd_remap).
-//   MODE 0 plain | 1 forward with BatchNorm on load and / or statistics partials (K6b) | 2 dX feeding a BatchNorm backward (K6c);
+//   MODE 0 plain | 1 forward with BatchNorm on load and / or statistics partials (K6b) | 2 dX feeding a BatchNorm backward (K6c) |
+//   3 (K6d, round 6) MODE 2 that also takes the layer's weight gradient: the 9 tap values of a pixel times the layer's input there
+//   (act(bn(y)) * rmask) accumulate in 9 x 4 registers per thread over its 16 pixels; partial rows [9][C] in `stats`, strip layout;
 //   DXE: dX epilogue (out = acc * post_mul, zero where post_mul == 0); PRE: staged input x per-pixel plane.
 // Partial rows keep the strip plan's layout (the callers size them by tsii_dw_stat_rows / tsii_dw_bwd_stat_rows): an image's first
 // row carries its sums, its other rows are written empty (count 0 / zeros).
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(SM_THREADS, 2) void dw_small_kernel(
     const float* __restrict__ in, const float* __restrict__ pre, const float* __restrict__ wT, const float* __restrict__ bias,
     const float* __restrict__ denom, const float* __restrict__ keep, const float* __restrict__ post_mul, DtGeom g,
     unsigned cblocks, unsigned rows_per_image, DwBN ib, float* __restrict__ stats, DwBnBwd bb, float* __restrict__ out) {
-    constexpr bool FUSED = (MODE == 1), BNB = (MODE == 2);
+    constexpr bool FUSED = (MODE == 1), BNB = (MODE >= 2), DWG = (MODE == 3);
     static_assert(!BNB || DXE, "K6c rides on the dX epilogue");
     static_assert(!FUSED || !DXE, "K6b rides on the forward epilogue");
     static_assert((SM_MAXPIX + 1) * SM_CB * sizeof(float) <= 160 * 1024, "the whole-map tile must fit gfx950's 160 KB of LDS per CU (65.6 KB: more than the 64 KB of earlier parts)");
@@ -113,6 +115,9 @@ __global__ __launch_bounds__(SM_THREADS, 2) void dw_small_kernel(
     f32x4 P = {0.f, 0.f, 0.f, 0.f};
     f32x2 va[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
     int cnt = 0;
+    f32x4 dwa[DWG ? 9 : 1];                                        // K6d: weight-gradient accumulators per (flipped) window tap
+#pragma unroll
+    for (int k = 0; k < (DWG ? 9 : 1); ++k) dwa[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     const unsigned wmagic = (unsigned)(((1 << 20) + W - 1) / W);    // p / W for p < 1024, W <= 1024: (p * magic) >> 20 is exact
 #pragma unroll 2
     for (int j = 0; j < SM_NP; ++j) {
@@ -127,6 +132,12 @@ __global__ __launch_bounds__(SM_THREADS, 2) void dw_small_kernel(
         f32x4 yv = {0.f, 0.f, 0.f, 0.f};
         if (BNB) yv = *reinterpret_cast<const f32x4*>(ybase + opq(__umul24((unsigned)pc * 4u, (unsigned)C) + c0b));
         f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+        f32x4 ein = {0.f, 0.f, 0.f, 0.f};                          // K6d: the layer's input at this pixel, act(bn(y)) * rmask
+        if (DWG && pok && e0 != 0.f) {
+            const f32x2 g0 = fma2((yv.xy - bmu.xy) * bis.xy, bga.xy, bbe.xy), g1 = fma2((yv.zw - bmu.zw) * bis.zw, bga.zw, bbe.zw);
+            const f32x2 q0 = min2(max2(g0, g0 * bb.neg), f32x2{bb.hi, bb.hi}) * e0, q1 = min2(max2(g1, g1 * bb.neg), f32x2{bb.hi, bb.hi}) * e0;
+            ein = cat4(q0, q1);
+        }
         // a tap outside the map reads the zero pixel (one select on the index, none on the data)
         int qrow[3], qcol[3];
         bool rok[3], cokx[3];
@@ -144,6 +155,10 @@ __global__ __launch_bounds__(SM_THREADS, 2) void dw_small_kernel(
                 const f32x4 v = *reinterpret_cast<const f32x4*>(rthr + q * (SM_CB * 4));
                 a0 = fma2(v.xy, w[ky * 3 + kx].xy, a0);
                 a1 = fma2(v.zw, w[ky * 3 + kx].zw, a1);
+                if (DWG) {
+                    f32x4& q = dwa[DWG ? ky * 3 + kx : 0];
+                    q = cat4(fma2(v.xy, ein.xy, q.xy), fma2(v.zw, ein.zw, q.zw));
+                }
             }
         }
         if (DXE) {
@@ -195,6 +210,32 @@ __global__ __launch_bounds__(SM_THREADS, 2) void dw_small_kernel(
                 for (int l = 0; l < SM_LANES; ++l) sum += mrg[(l * 4 + ch / 4) * 13 + 5 + which * 4 + ch % 4];
                 bb.part[(n * rows_per_image * 2 + which) * C + (int)cb * SM_CB + ch] = sum;
                 for (unsigned r = 1; r < rows_per_image; ++r) bb.part[((n * rows_per_image + r) * 2 + which) * C + (int)cb * SM_CB + ch] = 0.f;
+            }
+        }
+        if (DWG) {
+            // K6d: the 128 pixel lanes of every channel, 5 + 4 taps at a time through the tile ([5][512] float4 = 40 KB)
+            static_assert(5 * SM_THREADS * 16 <= (SM_MAXPIX + 1) * SM_CB * 4, "weight-gradient merge buffer fits the tile");
+            f32x4* m4 = reinterpret_cast<f32x4*>(tile);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    if (half * 5 + k < 9) m4[k * SM_THREADS + t] = dwa[half * 5 + k < 9 ? half * 5 + k : 0];
+                __syncthreads();
+                const int nt = half == 0 ? 5 : 4;
+                if (t < nt * SM_CB) {
+                    const int k = t / SM_CB, ch = t % SM_CB;
+                    if ((int)cb * SM_CB + ch < C) {
+                        const float* col = tile + (k * SM_THREADS + ch / 4) * 4 + ch % 4;
+                        float sum = 0.f;
+#pragma unroll 8
+                        for (int l = 0; l < SM_LANES; ++l) sum += col[l * 16];
+                        const int kk = half * 5 + k, tap = g.flip ? 8 - kk : kk;
+                        stats[((n * rows_per_image) * 9 + tap) * C + (int)cb * SM_CB + ch] = sum;
+                        for (unsigned r = 1; r < rows_per_image; ++r) stats[((n * rows_per_image + r) * 9 + tap) * C + (int)cb * SM_CB + ch] = 0.f;
+                    }
+                }
             }
         }
     } else if (t < SM_CB && (int)cb * SM_CB + t < C) {

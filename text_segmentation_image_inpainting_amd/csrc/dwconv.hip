@@ -268,7 +268,10 @@ static constexpr int ST_UNROLL_K = ST_UNROLL;
 #endif   // pixels of a thread processed together (all 4: ~150 VGPRs of LDS data in flight)
 
 // MODE 0: plain; 1: forward with BatchNorm on load and / or statistics partials (K6b; either may be off at run time);
-// 2: dX feeding a BatchNorm backward (K6c).  MODE 1 / 2 need ~210 VGPRs = 2 waves per SIMD.  (Tried for MODE 1: a build capped
+// 2: dX feeding a BatchNorm backward (K6c); 3 (K6d, round 6): MODE 2 that also takes the layer's weight gradient -- the 9 tap values a
+// pixel's dX reads from the ring times the layer's input at that pixel (act(bn(y)) * rmask, from the K6c arithmetic) accumulate in
+// 9 x 4 registers over the strip chunk, one partial row [9][C] per block in `stats` (see dw_lean.h MODE 3; here for the dilated
+// strips, dilation 2 / 4 / 8).  MODE 1 / 2 need ~210 VGPRs = 2 waves per SIMD.  (Tried for MODE 1: a build capped
 // at 3 waves per SIMD with the 9 x 4 weights read from LDS per tap and one pixel in flight -- 18-20 spilled registers and
 // 17.2 -> 20.4 ms over the depth-wise kernels of a step: the plain-register form stays.)
 template <int S, int D, int MODE>
@@ -277,7 +280,8 @@ __global__ __launch_bounds__(256, MODE != 0 ? (S == 2 ? ST_S2_WAVES : 2) : 3) vo
     const float* __restrict__ denom, const float* __restrict__ keep, const float* __restrict__ post_mul, DtGeom g, int chunk_rows,
     unsigned strips_x, unsigned chunks_y, unsigned cblocks, DwBN ib, float* __restrict__ stats, DwBnBwd bb,
     float* __restrict__ out) {
-    constexpr bool FUSED = (MODE == 1), BNB = (MODE == 2);
+    constexpr bool FUSED = (MODE == 1), BNB = (MODE >= 2), DWG = (MODE == 3);
+    static_assert(!DWG || S == 1, "K6d on the ring kernel: stride 1");
     constexpr int R = ST_R / S, TW = ST_TW / S;                 // output rows x columns per step: 8 x 16 at stride 1, 4 x 8 at stride 2
     constexpr int PW = (TW - 1) * S + 2 * D + 1, NR = (R - 1) * S + 2 * D + 1;
     constexpr int NEW = R * S, PRO = NR - NEW;                 // input rows a step brings in / rows the prologue adds first
@@ -401,6 +405,9 @@ __global__ __launch_bounds__(256, MODE != 0 ? (S == 2 ? ST_S2_WAVES : 2) : 3) vo
     float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
     float vals[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int cnt = 0;
+    float4 dwa[DWG ? 9 : 1];                                 // K6d: weight-gradient accumulators per (flipped) window tap
+#pragma unroll
+    for (int t = 0; t < (DWG ? 9 : 1); ++t) dwa[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     // one step: fetch slab `fstep` into the (fpf, fpm) set, compute step s, commit slab s + 1 from the (cpf, cpm) set
     // The two barriers of a step guard the LDS ring only and are lds_barrier()s: __syncthreads() also waits for vmcnt(0), i.e. for
     // the slab(s) just requested and for this step's stores -- the prefetch would be over before the compute had begun.
@@ -428,6 +435,18 @@ __global__ __launch_bounds__(256, MODE != 0 ? (S == 2 ? ST_S2_WAVES : 2) : 3) vo
             const int ty = ty0 + TYS * k;
             if (!(xok && oyb + ty < oy_end)) continue;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int pp = ty * TW + tx;
+            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);      // K6d: the layer's input at this pixel, act(bn(y)) * rmask
+            if (DWG) {
+                const float pmk = post_mul != nullptr ? pls[2 * NPX + pp] : 1.f;
+                if (pmk != 0.f) {
+                    const float4 yq = yv[k];
+                    const float zx = fmaf((yq.x - bmu.x) * bis.x, bga.x, bbe.x), zy = fmaf((yq.y - bmu.y) * bis.y, bga.y, bbe.y);
+                    const float zz = fmaf((yq.z - bmu.z) * bis.z, bga.z, bbe.z), zw = fmaf((yq.w - bmu.w) * bis.w, bga.w, bbe.w);
+                    e.x = fminf(fmaxf(zx, zx * bb.neg), bb.hi) * pmk; e.y = fminf(fmaxf(zy, zy * bb.neg), bb.hi) * pmk;
+                    e.z = fminf(fmaxf(zz, zz * bb.neg), bb.hi) * pmk; e.w = fminf(fmaxf(zw, zw * bb.neg), bb.hi) * pmk;
+                }
+            }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const float* rp = ring + ((((R * s + ty) * S + ky * D) % NR) * PW + tx * S) * ST_CB + cg * 4;
@@ -436,9 +455,12 @@ __global__ __launch_bounds__(256, MODE != 0 ? (S == 2 ? ST_S2_WAVES : 2) : 3) vo
                     const float4 v = *reinterpret_cast<const float4*>(rp + kx * D * ST_CB);
                     const float4 ww = w[ky * 3 + kx];
                     a.x = fmaf(v.x, ww.x, a.x); a.y = fmaf(v.y, ww.y, a.y); a.z = fmaf(v.z, ww.z, a.z); a.w = fmaf(v.w, ww.w, a.w);
+                    if (DWG) {
+                        float4& q = dwa[DWG ? ky * 3 + kx : 0];
+                        q.x = fmaf(e.x, v.x, q.x); q.y = fmaf(e.y, v.y, q.y); q.z = fmaf(e.z, v.z, q.z); q.w = fmaf(e.w, v.w, q.w);
+                    }
                 }
             }
-            const int pp = ty * TW + tx;
             if (denom != nullptr) { const float rd = 1.0f / pls[NPX + pp]; a.x *= rd; a.y *= rd; a.z *= rd; a.w *= rd; }   // one IEEE division per pixel, then multiplies (<= 1 ulp apart)
             a.x += bq.x; a.y += bq.y; a.z += bq.z; a.w += bq.w;
             if (post_mul != nullptr) {
@@ -495,6 +517,31 @@ __global__ __launch_bounds__(256, MODE != 0 ? (S == 2 ? ST_S2_WAVES : 2) : 3) vo
                 for (int l = 0; l < LANES; ++l) sum += mrg[(l * CGS + ch / 4) * 8 + which * 4 + ch % 4];
                 const int64_t prow = (n * chunks_y + cy) * strips_x + sx;
                 bb.part[(prow * 2 + which) * g.c + (int)cb * ST_CB + ch] = sum;
+            }
+        }
+        if constexpr (DWG) {
+            // K6d: the 32 pixel lanes of every channel, 5 + 4 taps at a time through the ring ([5][256] float4)
+            static_assert(5 * 256 * 4 <= NR * PW * ST_CB, "weight-gradient merge buffer fits the ring");
+            float4* m4 = reinterpret_cast<float4*>(ring);
+            const int64_t prow = (n * chunks_y + cy) * strips_x + sx;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < 5; ++t)
+                    if (half * 5 + t < 9) m4[t * 256 + threadIdx.x] = dwa[half * 5 + t < 9 ? half * 5 + t : 0];
+                __syncthreads();
+                const int nt = half == 0 ? 5 : 4;
+                for (int j = threadIdx.x; j < nt * ST_CB; j += 256) {
+                    const int t = j / ST_CB, ch = j % ST_CB;
+                    if ((int)cb * ST_CB + ch >= g.c) continue;
+                    const float* col = ring + (t * 256 + ch / 4) * 4 + ch % 4;
+                    float sum = 0.f;
+#pragma unroll 8
+                    for (int l = 0; l < LANES; ++l) sum += col[l * CGS * 4];
+                    const int k = half * 5 + t;
+                    stats[(prow * 9 + (g.flip ? 8 - k : k)) * g.c + (int)cb * ST_CB + ch] = sum;
+                }
             }
         }
     } else if (FUSED && stats != nullptr) {
@@ -852,8 +899,17 @@ static const DwBnBwd kNoBnBwd = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.
 static bool dw_fused_ok(int s, int d) { return (s == 2 && d == 1) || (s == 1 && (d == 1 || d == 2 || d == 4 || d == 8)); }
 
 // K6d: the geometry (of the dX grid: g.hout x g.wout = the layer's input) the lean kernel takes before any other strip path does
+#ifndef ST_DWG
+#define ST_DWG 1                 // A/B (tools/variants): 0 = no K6d on the dilated ring kernels
+#endif
+#ifndef SM_DWG
+#define SM_DWG 1                 // A/B (tools/variants): 0 = no K6d on the small-map kernel
+#endif
 static bool dw_dxdw_geom_ok(const DtGeom& g) {
-    return g.s == 1 && g.d == 1 && g.flip == 1 && g.pad_h >= 0 && g.pad_w >= 0 && dw_lean_ok(g) && !dw_rows_ok(g) && !dw_small_ok(g);
+    if (g.s != 1 || g.flip != 1 || g.pad_h < 0 || g.pad_w < 0 || g.c % 4 != 0 || dw_rows_ok(g)) return false;
+    if (dw_small_ok(g)) return SM_DWG && dw_fused_ok(g.s, g.d);          // the small-map kernel (dw_small_kernel<3>) where it has the K6c form
+    if (g.d == 1) return dw_lean_ok(g);
+    return ST_DWG && (g.d == 2 || g.d == 4 || g.d == 8);          // the ring kernels (dw_strip_kernel<1, D, 3>)
 }
 
 static int try_launch_dw_strip(const float* in, const float* pre, const float* wT, const float* bias, const float* denom,
@@ -894,7 +950,11 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
 #define TSII_DW_SMALL(MODE, DXE) do { \
             if (pre != nullptr) hipLaunchKernelGGL((dw_small_kernel<MODE, DXE, true>), sgrid, dim3(SM_THREADS), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, scb, rpi, ib, stats, bb, out); \
             else hipLaunchKernelGGL((dw_small_kernel<MODE, DXE, false>), sgrid, dim3(SM_THREADS), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, scb, rpi, ib, stats, bb, out); } while (0)
-            if (bb.y != nullptr) TSII_DW_SMALL(2, true);
+            if (bb.y != nullptr && dwpart != nullptr) {
+                if (pre != nullptr) hipLaunchKernelGGL((dw_small_kernel<3, true, true>), sgrid, dim3(SM_THREADS), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, scb, rpi, ib, dwpart, bb, out);
+                else hipLaunchKernelGGL((dw_small_kernel<3, true, false>), sgrid, dim3(SM_THREADS), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, scb, rpi, ib, dwpart, bb, out);
+            }
+            else if (bb.y != nullptr) TSII_DW_SMALL(2, true);
             else if (fused_any) TSII_DW_SMALL(1, false);
             else if (dxe) TSII_DW_SMALL(0, true);
             else TSII_DW_SMALL(0, false);
@@ -979,7 +1039,9 @@ static int try_launch_dw_strip(const float* in, const float* pre, const float* w
     }
 #define TSII_DW_STRIP(S, D, MODE) hipLaunchKernelGGL((dw_strip_kernel<S, D, MODE>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, \
                                                      sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, stats, bb, out)
-#define TSII_DW_STRIP_D(D) do { if (bb.y != nullptr) TSII_DW_STRIP(1, D, 2); else if (fused) TSII_DW_STRIP(1, D, 1); else TSII_DW_STRIP(1, D, 0); } while (0)
+#define TSII_DW_STRIP_D(D) do { if (bb.y != nullptr && dwpart != nullptr) hipLaunchKernelGGL((dw_strip_kernel<1, D, 3>), grid, dim3(256), 0, st, in, pre, wT, bias, denom, keep, post_mul, g, \
+                                                                                          sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, ib, dwpart, bb, out); \
+                                else if (bb.y != nullptr) TSII_DW_STRIP(1, D, 2); else if (fused) TSII_DW_STRIP(1, D, 1); else TSII_DW_STRIP(1, D, 0); } while (0)
     if (g.s == 2 && fused) TSII_DW_STRIP(2, 1, 1);
     else if (g.s == 2) TSII_DW_STRIP(2, 1, 0);
     else if (g.d == 2) TSII_DW_STRIP_D(2);
@@ -1439,20 +1501,21 @@ extern "C" int tsii_dw_bwd_dx_bn(const float* dy, const float* inv, const float*
 // -> bytes of the weight-gradient partial rows, 0 when the geometry has no such form (3x3, stride 1, dilation 1, c % 4 == 0, the
 // sizes dw_lean_ok() takes); the K6c partial rows are those of tsii_dw_bwd_stat_rows().
 extern "C" size_t tsii_dw_bwd_dxdw_ws_bytes(int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw) {
-    if (n <= 0 || h <= 0 || wd <= 0 || c <= 0 || c % 4 != 0 || !(kh == 3 && kw == 3 && dh == 1 && dw == 1)) return 0;
-    if (sh == 2 && sw == 2 && ph == 1 && pw == 1) {          // the stride-2 dX strips (dw_strip_dx2_kernel<true, true>)
+    if (n <= 0 || h <= 0 || wd <= 0 || c <= 0 || c % 4 != 0 || !(kh == 3 && kw == 3 && dh == dw && dh >= 1)) return 0;
+    if (sh == 2 && sw == 2 && ph == 1 && pw == 1 && dh == 1) {          // the stride-2 dX strips (dw_strip_dx2_kernel<true, true>)
         const StripPlan sp = plan_strip(n, h, wd, c, 1, 1);
         const int64_t rows = (int64_t)n * strip_rows_per_image(sp);
         if (!sp.ok || rows <= 0 || rows >= (1ll << 31) || (int64_t)sp.strips_x * sp.chunks_y * sp.cblocks * n >= (1ll << 31)) return 0;
         return (size_t)rows * 9 * (size_t)c * sizeof(float);
     }
     if (sh != 1 || sw != 1) return 0;
-    if (ph < 0 || pw < 0 || ph > 2 || pw > 2) return 0;
-    const int ho = h + 2 * ph - 2, wo = wd + 2 * pw - 2;
+    const int d = dh;
+    if (ph < 0 || pw < 0 || ph > 2 * d || pw > 2 * d) return 0;
+    const int ho = h + 2 * ph - 2 * d, wo = wd + 2 * pw - 2 * d;
     if (ho <= 0 || wo <= 0) return 0;
-    const DtGeom tg = {n, ho, wo, c, 1, 1, 2 - ph, 2 - pw, h, wd, 1};
+    const DtGeom tg = {n, ho, wo, c, 1, d, 2 * d - ph, 2 * d - pw, h, wd, 1};
     if (!dw_dxdw_geom_ok(tg)) return 0;
-    const FusedPlan fp = plan_fwd_strips(n, h, wd, c, 1, 1);
+    const FusedPlan fp = plan_fwd_strips(n, h, wd, c, 1, d);
     if (!fp.sp.ok || fp.phases != 1 || fp.rows_only) return 0;
     const int64_t rows = (int64_t)n * fused_rows_per_image(fp);
     if (rows <= 0 || rows >= (1ll << 31)) return 0;
@@ -1486,7 +1549,7 @@ extern "C" int tsii_dw_bwd_dxdw_bn(const float* dy, const float* inv, const floa
 // layer (da2; bn2_y = the layer's raw output y2, bn2_coef = the [6][c] table tsii_bn_bwd_reduce leaves): that BatchNorm's backward
 // is applied while the slab is staged (dw_lean.h MODE 4) -- 1 when the geometry has the form (3x3 / stride 1 / dilation 1).
 extern "C" int tsii_dw_bwd_dxdw_fold_ok(int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw) {
-    return (sh == 1 && sw == 1 && tsii_dw_bwd_dxdw_ws_bytes(n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw) > 0) ? 1 : 0;
+    return (sh == 1 && sw == 1 && dh == 1 && dw == 1 && tsii_dw_bwd_dxdw_ws_bytes(n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw) > 0) ? 1 : 0;
 }
 
 extern "C" int tsii_dw_bwd_dxdw_bn2(const float* da2, const float* bn2_y, const float* bn2_coef, int bn2_act, float bn2_slope,
