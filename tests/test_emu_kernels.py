@@ -1139,6 +1139,33 @@ def test_batchnorm_backward_with_pooled_addend_gradient(emu, n, h, wd, c, act, r
     assert b"bn_act_bwd_pre_pool" in L.tsii_last_error()
 
 
+@pytest.mark.parametrize("rows", [1, 3, 64, 65, 600, 2048, 2049, 5000])
+@pytest.mark.parametrize("c,training", [(8, 1), (40, 1), (33, 0)])
+def test_batchnorm_backward_reduction_of_partial_rows(emu, rows, c, training):
+    """tsii_bn_bwd_reduce over every row-count regime (<= 64 rows: one launch of the final kernel; 65 .. 2048: the one-launch fp64 kernel of
+    round 6; above: level-1 fold + final): dgamma, dbeta and the constants' table against float64."""
+    L = emu
+    rng = np.random.default_rng(rows * 7 + c)
+    m = 12345
+    part = rng.standard_normal((rows, 2, c)).astype(np.float32)
+    mean = rng.standard_normal(c).astype(np.float32); var = (rng.uniform(size=c) + 0.5).astype(np.float32)
+    gam = (rng.uniform(size=c) + 0.5).astype(np.float32); bet = rng.standard_normal(c).astype(np.float32)
+    coef = np.full(6 * c + 4, np.nan, np.float32)[:6 * c]; dg = np.full(c, np.nan, np.float32); db = np.full(c, np.nan, np.float32)
+    nb = L.tsii_bn_bwd_reduce_ws_bytes(rows, c)
+    ws = WS(nb)
+    assert L.tsii_bn_bwd_reduce(P(mean), P(var), P(gam), P(bet), 1e-5, training, P(part), rows, m, c, P(dg), P(db), P(coef), P(ws), nb, None) == 0, L.tsii_last_error()
+    tot = part.astype(np.float64).sum(0)
+    scale = np.abs(part).astype(np.float64).sum(0)
+    assert np.all(np.abs(db - tot[0]) <= 1e-6 * scale[0] + 1e-7) and np.all(np.abs(dg - tot[1]) <= 1e-6 * scale[1] + 1e-7)
+    cf = coef.reshape(6, c).astype(np.float64)
+    assert np.array_equal(cf[0], mean.astype(np.float64)) and np.array_equal(cf[2], gam.astype(np.float64)) and np.array_equal(cf[3], bet.astype(np.float64))
+    assert np.allclose(cf[1], 1 / np.sqrt(var.astype(np.float64) + 1e-5), rtol=1e-6)
+    if training:
+        assert np.all(np.abs(cf[4] - tot[0] / m) <= 1e-6 * scale[0] / m + 1e-9) and np.all(np.abs(cf[5] - tot[1] / m) <= 1e-6 * scale[1] / m + 1e-9)
+    else:
+        assert not cf[4].any() and not cf[5].any()
+
+
 def test_pointwise_upsampled_addend_rejects_bad_geometry(emu):
     L = emu
     x = np.zeros((48, 8), np.float32); w = np.zeros((8, 8), np.float32); z = np.zeros((12, 8), np.float32); y = np.zeros((48, 8), np.float32)

@@ -393,6 +393,49 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const T* __restrict__
     }
 }
 
+// 65 .. 2048 partial rows in ONE launch (round 6): 32 channels x 32 row lanes per block, <= 64 rows per lane in batches of 8 in flight,
+// fp64 sums -- instead of the level-1 fold + final pair (two launches of 5-6 us behind every BatchNorm backward whose K6c partial rows
+// come from a GEMM epilogue or a strip kernel; ~35 per ImageFill step).  Same outputs as bn_bwd_final_kernel.
+static constexpr int BN_BWD_SMALL_ROWS = 2048;
+__global__ __launch_bounds__(1024) void bn_bwd_small_kernel(const float* __restrict__ part, int R, int C, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int64_t M, const float* __restrict__ mean,
+                                                            const float* __restrict__ var, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, int training, float* __restrict__ coef) {
+    __shared__ double sh[2][32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        for (int rb = ty; rb < R; rb += 32 * 8) {
+            float v[8][2];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = rb + 32 * u;
+                const float* pr = part + (int64_t)(r < R ? r : 0) * 2 * C + c;
+                v[u][0] = pr[0]; v[u][1] = pr[C];
+                if (r >= R) { v[u][0] = 0.f; v[u][1] = 0.f; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s1 += (double)v[u][0]; s2 += (double)v[u][1]; }
+        }
+    }
+    sh[0][ty][tx] = s1; sh[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        s1 = 0.0; s2 = 0.0;
+        for (int j = 0; j < 32; ++j) { s1 += sh[0][j][tx]; s2 += sh[1][j][tx]; }
+        dbeta[c] = (float)s1;
+        dgamma[c] = (float)s2;
+        const float invM = 1.0f / (float)M;
+        coef[c] = mean[c];
+        coef[C + c] = 1.0f / sqrtf(var[c] + eps);
+        coef[2 * C + c] = gamma[c];
+        coef[3 * C + c] = beta[c];
+        coef[4 * C + c] = training ? (float)s1 * invM : 0.f;
+        coef[5 * C + c] = training ? (float)s2 * invM : 0.f;
+    }
+}
+
 // backward pass 2: dy = gamma*istd*(dz - s1/M - xhat*s2/M)   (training)  |  gamma*istd*dz  (eval)
 // A thread owns one channel vector and RPT consecutive rows (flat grid over row blocks x channel vectors): the six per-channel
 // constants come from the table bn_bwd_final_kernel leaves behind (coef[j][C], j = mean, 1/std, gamma, beta, dbeta/M, dgamma/M) --
@@ -643,6 +686,12 @@ extern "C" int tsii_bn_act_bwd(const float* dout, const float* y, int64_t m, int
     else hipLaunchKernelGGL((bn_bwd_partial_kernel<1>), dim3(stream_grid(tasks, 256)), dim3(256), 0, st, dout, y, m, c, mean, var, gamma, beta, eps, act, slope, R, part);
     int rc = check_launch("bn_bwd_partial");
     if (rc) return rc;
+    if (R > BN_L1_ROWS && R <= BN_BWD_SMALL_ROWS) {
+        hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(cdiv(c, 32)), dim3(1024), 0, st, (const float*)part, R, c, dgamma, dbeta, m, mean, var, gamma, beta, eps, training, coef);
+        rc = check_launch("bn_bwd_small");
+        if (rc) return rc;
+        return launch_bn_bwd_apply(dout, y, m, c, act, slope, dy, coef, st);
+    }
     if (R > BN_L1_ROWS) {
         double* l1 = bn_l1_buffer(ws, R, c);
         const int chunks = cdiv(R, BN_L1_ROWS);
@@ -665,6 +714,10 @@ static int bn_bwd_pre_reduce(const float* mean, const float* var, const float* g
                              const float* bwd_part, int64_t rows, int64_t m, int c, float* dgamma, float* dbeta, void* ws, float* coef, hipStream_t st) {
     const int R = (int)rows;
     int rc;
+    if (R > BN_L1_ROWS && R <= BN_BWD_SMALL_ROWS) {
+        hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(cdiv(c, 32)), dim3(1024), 0, st, bwd_part, R, c, dgamma, dbeta, m, mean, var, gamma, beta, eps, training, coef);
+        return check_launch("bn_bwd_small");
+    }
     if (R > BN_L1_ROWS) {
         double* l1 = (double*)(((uintptr_t)ws + 7) & ~(uintptr_t)7);
         const int chunks = cdiv(R, BN_L1_ROWS);
