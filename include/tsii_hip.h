@@ -281,7 +281,7 @@ int tsii_dw_bwd_dx_bn(const float* dy, const float* inv, const float* w, const f
                       float* dx, float* bwd_part, float* ws, void* stream);
 /* K6d: tsii_dw_bwd_dx_bn that ALSO returns the layer's weight gradient dwgt[c][1][3][3] (no bias gradient: the layer has no bias) --
  * the dX pass holds dy * inv with its halo in LDS and forms the layer's input act(BN(bn_y)) * rmask at its own pixels for the K6c
- * sums, i.e. both operands of dW; tsii_dw_bwd_dw_bn's second pass over (dy, bn_y) is not run.  3x3 / dilation 1, stride 1 (padding 0..2) or stride 2 / padding 1:
+ * sums, i.e. both operands of dW; tsii_dw_bwd_dw_bn's second pass over (dy, bn_y) is not run.  3x3; stride 1 at dilation 1 / 2 / 4 / 8 (padding 0..2d; not the row-phase kernel's geometries) or stride 2 / padding 1 / dilation 1:
  * ws_dw of tsii_dw_bwd_dxdw_ws_bytes(...) bytes, 0 = no such form for this geometry (call the two separate entry points).
  * Replaces the autograd of F.conv2d(groups=C) in models/partial_convolution.py:49-51 for dX and dW together. */
 size_t tsii_dw_bwd_dxdw_ws_bytes(int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw);
