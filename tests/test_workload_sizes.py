@@ -49,6 +49,83 @@ def test_imagefill_bs32_batch_independence_and_masks_gpu():
                     assert torch.equal(a.as_tensor()[:, :1], b[i:i + 1]), f"mask level {lvl}, image {i}"
 
 
+@pytest.mark.parametrize("n,h,wd,c,stride,masked", [(8, 256, 256, 384, 1, True), (8, 256, 256, 256, 2, True), (16, 128, 128, 768, 1, False)])
+def test_depthwise_one_pass_backward_at_the_headline_shapes_gpu(n, h, wd, c, stride, masked):
+    """K6d / K6e at ImageFill's first-level layer shapes (a quarter of the bench batch) through the C ABI on the chip: the one-pass
+    entry points against the passes they replace -- dX and the K6c partial rows bit for bit, the weight gradient to summation order,
+    the folded BatchNorm backward (stride 1) to rounding.  Random hole masks (the plane the 3x3 count leaves)."""
+    from text_segmentation_image_inpainting_amd import _lib, ops
+    from text_segmentation_image_inpainting_amd.ops import call, ptr
+    with BACKENDS["gpu"]() as dev:
+        L = _lib.lib()
+        g = ops.make_geom(3, stride, 1, 1)
+        ho, wo = g.out_hw(h, wd)
+        gen = torch.Generator(device="cpu").manual_seed(n * 1000 + c + stride)
+        rnd = lambda *sh: torch.randn(*sh, generator=gen).to(dev)
+        y1 = rnd(n, h, wd, c) * 1.3 + 0.2                       # raw input of the layer's input BatchNorm
+        w = rnd(c, 1, 3, 3)
+        rmask = inv = None
+        if masked:
+            rmask = (torch.rand(n, h, wd, generator=gen) > 0.15).float().to(dev)
+            denom, new_mask, inv = ops.mask_update(rmask, 1.0, None, 0.0, g, float(c), True)
+        mean1, var1 = rnd(c) * 0.2, torch.rand(c, generator=gen).to(dev) + 0.5
+        gam1, bet1 = torch.rand(c, generator=gen).to(dev) + 0.5, rnd(c) * 0.3
+        st = _lib.stream()
+        ws = torch.empty(9 * c + 16, device=dev)
+        rows = int(L.tsii_dw_bwd_stat_rows(n, h, wd, c, *g))
+        dwb = int(L.tsii_dw_bwd_dxdw_ws_bytes(n, h, wd, c, *g))
+        assert rows > 0 and dwb == 4 * rows * 9 * c
+        dy = rnd(n, ho, wo, c)
+        # the separate passes
+        dx0, part0 = torch.empty(n, h, wd, c, device=dev), torch.empty(rows, 2, c, device=dev)
+        call("tsii_dw_bwd_dx_bn", ptr(dy), ptr(inv), ptr(w), ptr(rmask), n, h, wd, c, *g, ho, wo, ptr(y1), ptr(mean1), ptr(var1), ptr(gam1), ptr(bet1),
+             1e-5, 2, 0.3, ptr(dx0), ptr(part0), ptr(ws), st)
+        sc1 = gam1 / torch.sqrt(var1 + 1e-5); sh1 = bet1 - mean1 * sc1
+        nb = int(L.tsii_dw_bwd_dw_ws_bytes(n, ho, wo, c, 3, 3))
+        wsw = torch.empty(nb // 4 + 4, device=dev)
+        dw0 = torch.empty_like(w)
+        keep = new_mask if masked else None
+        call("tsii_dw_bwd_dw_bn", ptr(dy), ptr(inv), ptr(keep), ptr(y1), ptr(rmask), n, h, wd, c, *g, ho, wo, ptr(sc1), ptr(sh1), 2, 0.3, ptr(dw0), None,
+             ptr(wsw), nb, st)
+        # K6d
+        dx1, part1, dw1 = torch.full_like(dx0, float("nan")), torch.full_like(part0, float("nan")), torch.full_like(dw0, float("nan"))
+        wsd = torch.empty(dwb // 4, device=dev)
+        call("tsii_dw_bwd_dxdw_bn", ptr(dy), ptr(inv), ptr(w), ptr(rmask), n, h, wd, c, *g, ho, wo, ptr(y1), ptr(mean1), ptr(var1), ptr(gam1), ptr(bet1),
+             1e-5, 2, 0.3, ptr(dx1), ptr(part1), ptr(dw1), ptr(ws), ptr(wsd), dwb, st)
+        assert torch.equal(dx1, dx0) and torch.equal(part1, part0)
+        scale = float(dw0.abs().max())
+        assert float((dw1 - dw0).abs().max()) <= 2e-5 * scale, (float((dw1 - dw0).abs().max()), scale)
+        if stride != 1:
+            assert int(L.tsii_dw_bwd_dxdw_fold_ok(n, h, wd, c, *g)) == 0
+            return
+        # K6e: the same with dy = BatchNorm2-backward(da2, y2) applied on load
+        assert int(L.tsii_dw_bwd_dxdw_fold_ok(n, h, wd, c, *g)) == 1
+        m2 = n * ho * wo
+        da2, y2 = rnd(n, ho, wo, c), rnd(n, ho, wo, c) * 1.5 + 0.1
+        mean2, var2 = rnd(c) * 0.2, torch.rand(c, generator=gen).to(dev) + 0.5
+        gam2, bet2 = torch.rand(c, generator=gen).to(dev) + 0.5, rnd(c) * 0.3
+        xh2 = (y2 - mean2) / torch.sqrt(var2 + 1e-5)
+        dz2 = da2 * torch.where(xh2 * gam2 + bet2 > 0, 1.0, 0.3)
+        part2 = torch.stack([dz2.reshape(-1, c).sum(0), (dz2 * xh2).reshape(-1, c).sum(0)]).reshape(1, 2, c).contiguous()
+        coef = torch.empty(6, c, device=dev); dg2, db2 = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        rb = int(L.tsii_bn_bwd_reduce_ws_bytes(1, c))
+        wsr = torch.empty(rb // 4 + 4, device=dev)
+        call("tsii_bn_bwd_reduce", ptr(mean2), ptr(var2), ptr(gam2), ptr(bet2), 1e-5, 1, ptr(part2), 1, m2, c, ptr(dg2), ptr(db2), ptr(coef), ptr(wsr), rb, st)
+        dy2 = torch.empty_like(da2)
+        call("tsii_bn_bwd_apply", ptr(da2), ptr(y2), m2, c, ptr(coef), 2, 0.3, ptr(dy2), st)
+        dxA, partA, dwA = torch.empty_like(dx0), torch.empty_like(part0), torch.empty_like(dw0)
+        call("tsii_dw_bwd_dxdw_bn", ptr(dy2), ptr(inv), ptr(w), ptr(rmask), n, h, wd, c, *g, ho, wo, ptr(y1), ptr(mean1), ptr(var1), ptr(gam1), ptr(bet1),
+             1e-5, 2, 0.3, ptr(dxA), ptr(partA), ptr(dwA), ptr(ws), ptr(wsd), dwb, st)
+        dxB, partB, dwB = torch.full_like(dx0, float("nan")), torch.full_like(part0, float("nan")), torch.full_like(dw0, float("nan"))
+        call("tsii_dw_bwd_dxdw_bn2", ptr(da2), ptr(y2), ptr(coef), 2, 0.3, ptr(inv), ptr(w), ptr(rmask), n, h, wd, c, *g, ho, wo,
+             ptr(y1), ptr(mean1), ptr(var1), ptr(gam1), ptr(bet1), 1e-5, 2, 0.3, ptr(dxB), ptr(partB), ptr(dwB), ptr(ws), ptr(wsd), dwb, st)
+        assert bool(torch.isfinite(dxB).all()) and bool(torch.isfinite(partB).all())
+        assert float((dxB - dxA).abs().max()) <= 4e-6 * max(1.0, float(dxA.abs().max()))
+        assert float((dwB - dwA).abs().max()) <= 2e-5 * float(dwA.abs().max())
+        pa, pb = partA.sum(0), partB.sum(0)
+        assert float((pb - pa).abs().max()) <= 1e-4 * float(dxA.abs().reshape(-1, c).sum(0).max())
+
+
 def test_imagefill_bs32_split_resolution_decoder_equals_concat_gpu(monkeypatch):
     """K7b at the bench size: the decoder's 1x1 expand convolutions with their low half at low resolution (no concatenated tensor)
     against the same network with the concatenation materialised (K7 + one product), train mode, batch 32: output, loss, running
