@@ -708,21 +708,37 @@ __global__ __launch_bounds__(256, DWG ? DX2_DWG_WAVES : 3) void dw_strip_dx2_ker
     commit_planes(0);
     __syncthreads();
 
+#ifndef DX2_Y_AHEAD
+#define DX2_Y_AHEAD 1            // A/B (tools/variants): the K6c input of step s + 1 requested during step s (0: at the top of its own step)
+#endif
+    // K6c: raw BatchNorm input at this thread's pixels, requested one step ahead like the slab (round 6: requested at the top of its own
+    // step it was a memory round trip per step that only the step's 4 pixels of arithmetic could hide)
+    float4 yn[BNB ? NP : 1];
+    auto fetch_y = [&](int s) {
+        if constexpr (BNB) {
+            const int iyb = iy_beg + R * s;
+            const float* __restrict__ y_b = bb.y + ((n * h + iyb) * (int64_t)w_in + ix0) * c_all + c;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int ty = ty0 + 2 * k;
+                yn[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (xok && iyb + ty < iy_end) yn[k] = *reinterpret_cast<const float4*>(y_b + (ty * w_in + tx) * c_all);
+            }
+        }
+    };
+    if (DX2_Y_AHEAD) fetch_y(0);
     for (int s = 0; s < nsteps; ++s) {
         const bool more = s + 1 < nsteps;
         if (more) { fetch(PRO + NEW * (s + 1), NEW); fetch_planes(s + 1); }
         const int iyb = iy_beg + R * s;
         float* __restrict__ out_b = dx + ((n * h + iyb) * (int64_t)w_in + ix0) * c_all + c;
         const float* __restrict__ pls = &planes[s & 1][0];
-        float4 yv[BNB ? NP : 1];                              // K6c: raw BatchNorm input at this thread's pixels
+        float4 yv[BNB ? NP : 1];
         if constexpr (BNB) {
-            const float* __restrict__ y_b = bb.y + ((n * h + iyb) * (int64_t)w_in + ix0) * c_all + c;
+            if (!DX2_Y_AHEAD) fetch_y(s);
 #pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                const int ty = ty0 + 2 * k;
-                yv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (xok && iyb + ty < iy_end) yv[k] = *reinterpret_cast<const float4*>(y_b + (ty * w_in + tx) * c_all);
-            }
+            for (int k = 0; k < NP; ++k) yv[k] = yn[k];
+            if (DX2_Y_AHEAD && more) fetch_y(s + 1);
         }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
