@@ -293,7 +293,7 @@ int tsii_dw_bwd_dxdw_bn(const float* dy, const float* inv, const float* w, const
 /* K6e: tsii_dw_bwd_dxdw_bn fed with the gradient w.r.t. the ACTIVATION that follows the layer: da2 = d loss / d act2(BN2(y2)), y2 = the
  * layer's raw output (bn2_y, same [n,ho,wo,c] layout), bn2_coef[6][c] = (mean, 1/std, gamma, beta, dbeta/m, dgamma/m) of BN2 as
  * tsii_bn_bwd_reduce leaves it -- BN2's backward is applied while the kernel stages its slab, so tsii_bn_act_bwd_pre's pass over
- * (da2, y2) -> dy2 and this kernel's read of dy2 become this kernel's reads of da2 and y2.  Stride 1 only
+ * (da2, y2) -> dy2 and this kernel's read of dy2 become this kernel's reads of da2 and y2.  Stride 1 / dilation 1 and stride 2 / padding 1
  * (tsii_dw_bwd_dxdw_fold_ok() == 1); everything else as tsii_dw_bwd_dxdw_bn.
  * tsii_bn_bwd_reduce / tsii_bn_bwd_apply: the two halves of tsii_bn_act_bwd_pre (reduction of the K6c partial rows to dgamma, dbeta
  * and the table; the stand-alone apply pass over the table: dy = ((dout act'(z) - coef[4]) - xhat coef[5]) gamma / std).

@@ -1016,6 +1016,48 @@ def test_depthwise_stride2_dx_with_weight_gradient(emu, n, h, wd, c, masked, act
         assert L.tsii_dw_bwd_dw_bn(P(dy), P(inv), P(keep), P(x), P(rmask), n, h, wd, c, *geom, ho, wo, P(sc2), P(sh2), act, slope,
                                    P(dw4), None, P(wsw), nb, None) == 0, L.tsii_last_error()
         assert np.all(np.abs(dw3 - dw4) <= 2e-5 * dwabs + 1e-5), np.abs(dw3 - dw4).max()
+        # K6e on the stride-2 strips: the following BatchNorm's backward applied while the slab is committed, against the two-step route
+        assert L.tsii_dw_bwd_dxdw_fold_ok(n, h, wd, c, *geom) == 1
+        m2 = n * ho * wo
+        da2 = rng.standard_normal((n, ho, wo, c)).astype(np.float32)
+        y2 = (rng.standard_normal((n, ho, wo, c)) * 1.5 + 0.3).astype(np.float32)
+        mean2 = rng.standard_normal(c).astype(np.float32) * 0.2; var2 = (rng.uniform(size=c) + 0.5).astype(np.float32)
+        gam2 = (rng.uniform(size=c) + 0.5).astype(np.float32); bet2 = rng.standard_normal(c).astype(np.float32) * 0.3
+        act2 = {0: 2, 1: 3, 2: 1, 3: 0}[act]
+        xh2 = (y2.astype(np.float64) - mean2) / np.sqrt(var2.astype(np.float64) + 1e-5)
+        z2 = xh2 * gam2 + bet2
+        g2 = {0: np.ones_like(z2), 1: (z2 > 0) * 1.0, 2: np.where(z2 > 0, 1.0, slope), 3: ((z2 > 0) & (z2 < 6)) * 1.0}[act2]
+        dz2 = da2.astype(np.float64) * g2
+        part2 = np.stack([dz2.reshape(-1, c).sum(0), (dz2 * xh2).reshape(-1, c).sum(0)]).astype(np.float32).reshape(1, 2, c)
+        coef = np.full(6 * c, np.nan, np.float32); dgam2 = np.full(c, np.nan, np.float32); dbet2 = np.full(c, np.nan, np.float32)
+        rb = L.tsii_bn_bwd_reduce_ws_bytes(1, c)
+        wsr = WS(rb)
+        assert L.tsii_bn_bwd_reduce(P(mean2), P(var2), P(gam2), P(bet2), 1e-5, 1, P(part2), 1, m2, c, P(dgam2), P(dbet2), P(coef), P(wsr), rb, None) == 0, L.tsii_last_error()
+        dy2 = np.full((n, ho, wo, c), np.nan, np.float32)
+        assert L.tsii_bn_bwd_apply(P(da2), P(y2), m2, c, P(coef), act2, slope, P(dy2), None) == 0, L.tsii_last_error()
+        dxA = np.full((n, h, wd, c), np.nan, np.float32); dwA = np.full((c, 1, 3, 3), np.nan, np.float32)
+        bpA = WS(4 * brows * 2 * c); bpA[:] = np.nan
+        assert L.tsii_dw_bwd_dxdw_bn(P(dy2), P(inv), P(w), P(rmask), n, h, wd, c, *geom, ho, wo, P(x), P(mean_b), P(var_b), P(gam), P(bet),
+                                     1e-5, act, slope, P(dxA), P(bpA), P(dwA), P(ws), P(wsd), dwb, None) == 0, L.tsii_last_error()
+        dxB = np.full((n, h, wd, c), np.nan, np.float32); dwB = np.full((c, 1, 3, 3), np.nan, np.float32)
+        bpB = WS(4 * brows * 2 * c); bpB[:] = np.nan
+        wsd2 = WS(dwb); wsd2[:] = np.nan
+        assert L.tsii_dw_bwd_dxdw_bn2(P(da2), P(y2), P(coef), act2, slope, P(inv), P(w), P(rmask), n, h, wd, c, *geom, ho, wo,
+                                      P(x), P(mean_b), P(var_b), P(gam), P(bet), 1e-5, act, slope, P(dxB), P(bpB), P(dwB), P(ws), P(wsd2), dwb,
+                                      None) == 0, L.tsii_last_error()
+        assert np.abs(dxB - dxA).max() <= 2e-6 * max(1.0, np.abs(dxA).max()), np.abs(dxB - dxA).max()
+        gA = np.abs(dy2.astype(np.float64) * (1.0 if inv is None else inv.astype(np.float64)[..., None]))
+        apA = np.zeros((n, h + 3, wd + 3, c)); apA[:, 1:1 + h, 1:1 + wd] = np.abs(am)
+        for ky in range(3):
+            for kx in range(3):
+                bound = (apA[:, ky:ky + 2 * (ho - 1) + 1:2, kx:kx + 2 * (wo - 1) + 1:2] * gA).reshape(-1, c).sum(0)
+                assert np.all(np.abs(dwB[:, 0, ky, kx] - dwA[:, 0, ky, kx]) <= 4e-6 * bound + 1e-6), (ky, kx)
+        pA = bpA[:brows * 2 * c].reshape(brows, 2, c).astype(np.float64).sum(0); pB = bpB[:brows * 2 * c].reshape(brows, 2, c).astype(np.float64).sum(0)
+        assert np.isfinite(bpB[:brows * 2 * c]).all()
+        zz = xh * gam + bet
+        nearB = (np.abs(zz) < 1e-5) | (np.abs(zz - 6) < 1e-5)
+        slackB = (np.abs(dxA) * nearB).reshape(-1, c).sum(0) * 2 + 1e-4 * np.abs(dxA).reshape(-1, c).sum(0).max()
+        assert np.all(np.abs(pB[0] - pA[0]) <= slackB) and np.all(np.abs(pB[1] - pA[1]) <= slackB * max(1.0, np.abs(xh).max()))
     finally:
         L.tsii_emu_set_strip_target(0)
 

@@ -599,13 +599,17 @@ __global__ __launch_bounds__(256, MODE != 0 ? (S == 2 ? ST_S2_WAVES : 2) : 3) vo
 #ifndef DX2_DWG_WAVES
 #define DX2_DWG_WAVES 2          // A/B (tools/variants): waves per SIMD the K6d form is compiled for (3: 8 spilled registers; same-box step 60.12 vs 60.36-60.43 ms)
 #endif
-template <bool BNB, bool DWG = false>
+// APL (K6e, round 6): `dy` is the gradient w.r.t. the ACTIVATION of the BatchNorm that follows the layer (da2), ap.sc that BatchNorm's raw
+// input y2 (the layer's output, same [n, ho, wo, c] layout), ap.sh its constants' table coef[6][C], ap.neg / ap.hi its activation: the
+// BatchNorm backward is applied while the slab is committed (dw_lean.h MODE 4 has the stride-1 form), outside the tensor the slab stays 0.
+template <bool BNB, bool DWG = false, bool APL = false>
 __global__ __launch_bounds__(256, DWG ? DX2_DWG_WAVES : 3) void dw_strip_dx2_kernel(const float* __restrict__ dy, const float* __restrict__ inv,
                                                               const float* __restrict__ wT, const float* __restrict__ rmask,
                                                               int n_img, int h, int w_in, int c_all, int ho, int wo, int chunk_rows,
                                                               unsigned strips_x, unsigned chunks_y, unsigned cblocks, DwBnBwd bb,
-                                                              float* __restrict__ dx, float* __restrict__ dwpart = nullptr) {
+                                                              float* __restrict__ dx, float* __restrict__ dwpart = nullptr, DwBN ap = DwBN{nullptr, nullptr, 1.f, 0.f}) {
     static_assert(!DWG || BNB, "K6d rides on the K6c form");
+    static_assert(!APL || DWG, "K6e rides on the K6d form");
     constexpr int R = 8, TW = 16, NEW = 4, PRO = 1, NR = 5, PW = 9;
     constexpr int CGS = ST_CB / 4, LANES = 256 / CGS, NP = R * TW / LANES, PF = (NEW * PW + LANES - 1) / LANES;
     constexpr int NPX = R * TW;
@@ -630,12 +634,22 @@ __global__ __launch_bounds__(256, DWG ? DX2_DWG_WAVES : 3) void dw_strip_dx2_ker
     const int oy_base = iy_beg / 2, ox_base = ix0 / 2;          // dy pixel of ring row 0 / slab column 0
     const int nsteps = (iy_end - iy_beg + R - 1) / R;
 
-    float4 pf[PF];
+    float4 pf[PF], pf2[APL ? PF : 1];
     float pm[PF];
+    float4 amu = make_float4(0.f, 0.f, 0.f, 0.f), ais = amu, aga = amu, abe = amu, ak1 = amu, ak2 = amu;   // K6e: the folded BatchNorm's constants
+    if constexpr (APL) {
+        if (cok) {
+            const float* cf = ap.sh + c;
+            amu = *reinterpret_cast<const float4*>(cf); ais = *reinterpret_cast<const float4*>(cf + c_all);
+            aga = *reinterpret_cast<const float4*>(cf + 2 * (int64_t)c_all); abe = *reinterpret_cast<const float4*>(cf + 3 * (int64_t)c_all);
+            ak1 = *reinterpret_cast<const float4*>(cf + 4 * (int64_t)c_all); ak2 = *reinterpret_cast<const float4*>(cf + 5 * (int64_t)c_all);
+        }
+    }
     auto fetch = [&](int rr0, int cnt) {
         const int oyb = oy_base + rr0;
         const int64_t pixbase = (n * ho + oyb) * (int64_t)wo + ox_base;
         const float* __restrict__ src = dy + pixbase * c_all + c;
+        const float* __restrict__ src2 = APL ? ap.sc + pixbase * c_all + c : nullptr;
         const float* __restrict__ psrc = inv != nullptr ? inv + pixbase : nullptr;
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
@@ -643,13 +657,23 @@ __global__ __launch_bounds__(256, DWG ? DX2_DWG_WAVES : 3) void dw_strip_dx2_ker
             const int row = p / PW, px = p - row * PW;
             const int oy = oyb + row, ox = ox_base + px;
             pf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (APL) pf2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             pm[i] = 0.f;
             if (row < cnt && cok && oy < ho && ox < wo) {
                 const int off = row * wo + px;
                 pf[i] = *reinterpret_cast<const float4*>(src + off * c_all);
+                if constexpr (APL) pf2[i] = *reinterpret_cast<const float4*>(src2 + off * c_all);
                 pm[i] = psrc != nullptr ? psrc[off] : 1.f;
             }
         }
+    };
+    // K6e: one element of the folded BatchNorm's backward, the stand-alone pass's arithmetic in its order (bn_bwd_apply_kernel)
+    auto bn2 = [&](float da, float y2, float mu, float is, float ga, float be, float k1, float k2) {
+        const float xh = (y2 - mu) * is;
+        const float z = xh * ga + be;
+        float dz = da * ((z > 0.f && z < ap.hi) ? 1.f : (z > 0.f ? 0.f : ap.neg));
+        dz = dz - k1 - xh * k2;
+        return dz * ga * is;
     };
     auto commit = [&](int rr0, int cnt) {
 #pragma unroll
@@ -659,7 +683,12 @@ __global__ __launch_bounds__(256, DWG ? DX2_DWG_WAVES : 3) void dw_strip_dx2_ker
             if (row >= cnt) continue;
             float4 v = pf[i];
             const float m = pm[i];
-            v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+            if constexpr (APL) {
+                const float4 y2 = pf2[APL ? i : 0];
+                v.x = bn2(v.x, y2.x, amu.x, ais.x, aga.x, abe.x, ak1.x, ak2.x); v.y = bn2(v.y, y2.y, amu.y, ais.y, aga.y, abe.y, ak1.y, ak2.y);
+                v.z = bn2(v.z, y2.z, amu.z, ais.z, aga.z, abe.z, ak1.z, ak2.z); v.w = bn2(v.w, y2.w, amu.w, ais.w, aga.w, abe.w, ak1.w, ak2.w);
+            }
+            v.x *= m; v.y *= m; v.z *= m; v.w *= m;          // m == 0 outside the tensor: the slab stays 0 there (the transform of zeros is not)
             *reinterpret_cast<float4*>(ring + (((rr0 + row) % NR) * PW + px) * ST_CB + cg * 4) = v;
         }
     };
@@ -1462,12 +1491,16 @@ static int dw_bwd_dx_impl(const float* dy, const float* inv, const float* w, con
         rc = try_launch_dw_strip(dy, inv, ws, nullptr, nullptr, nullptr, rmask, tg, dx, st, fold_ib, nullptr, bb, dwpart, fold_ib.sc != nullptr);
         if (rc <= 0) return rc;
     }
-    TSII_REQUIRE(fold_ib.sc == nullptr, "dw_bwd_dxdw_bn2: this geometry has no form with the BatchNorm backward on load (tsii_dw_bwd_dxdw_fold_ok() == 0)");
+    TSII_REQUIRE(fold_ib.sc == nullptr || (sh == 2 && sw == 2), "dw_bwd_dxdw_bn2: this geometry has no form with the BatchNorm backward on load (tsii_dw_bwd_dxdw_fold_ok() == 0)");
     if (vec && kh == 3 && kw == 3 && sh == 2 && sw == 2 && dh == 1 && dw == 1 && ph == 1 && pw == 1) {   // marching strips
         const StripPlan sp = plan_strip(n, h, wd, c, 1, 1);     // strips of the input grid
         if (sp.ok) {
             const int64_t nblk2 = (int64_t)sp.strips_x * sp.chunks_y * sp.cblocks * n;
-            if (bb.y != nullptr && dwpart != nullptr)
+            if (bb.y != nullptr && dwpart != nullptr && fold_ib.sc != nullptr) {
+                TSII_REQUIRE(aligned16(fold_ib.sc) && aligned16(fold_ib.sh), "dw_bwd_dxdw_bn2: the folded BatchNorm's operands must be 16-byte aligned");
+                hipLaunchKernelGGL((dw_strip_dx2_kernel<true, true, true>), dim3((unsigned)nblk2), dim3(256), 0, st, dy, inv, ws, rmask, n, h, wd, c, ho, wo,
+                                   sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, bb, dx, dwpart, fold_ib);
+            } else if (bb.y != nullptr && dwpart != nullptr)
                 hipLaunchKernelGGL((dw_strip_dx2_kernel<true, true>), dim3((unsigned)nblk2), dim3(256), 0, st, dy, inv, ws, rmask, n, h, wd, c, ho, wo,
                                    sp.chunk_rows, sp.strips_x, sp.chunks_y, sp.cblocks, bb, dx, dwpart);
             else if (bb.y != nullptr)
@@ -1565,7 +1598,11 @@ extern "C" int tsii_dw_bwd_dxdw_bn(const float* dy, const float* inv, const floa
 // layer (da2; bn2_y = the layer's raw output y2, bn2_coef = the [6][c] table tsii_bn_bwd_reduce leaves): that BatchNorm's backward
 // is applied while the slab is staged (dw_lean.h MODE 4) -- 1 when the geometry has the form (3x3 / stride 1 / dilation 1).
 extern "C" int tsii_dw_bwd_dxdw_fold_ok(int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw) {
-    return (sh == 1 && sw == 1 && dh == 1 && dw == 1 && tsii_dw_bwd_dxdw_ws_bytes(n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw) > 0) ? 1 : 0;
+    // stride 1 / dilation 1 (the lean strip kernel) and stride 2 / padding 1 (the parity strips)
+#ifndef DX2_FOLD
+#define DX2_FOLD 1               // A/B (tools/variants): 0 = no K6e form on the stride-2 strips
+#endif
+    return (sh == sw && (sh == 1 || (DX2_FOLD && sh == 2)) && dh == 1 && dw == 1 && tsii_dw_bwd_dxdw_ws_bytes(n, h, wd, c, kh, kw, sh, sw, ph, pw, dh, dw) > 0) ? 1 : 0;
 }
 
 extern "C" int tsii_dw_bwd_dxdw_bn2(const float* da2, const float* bn2_y, const float* bn2_coef, int bn2_act, float bn2_slope,
