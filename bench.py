@@ -32,7 +32,7 @@ ALG_GB_PER_IMG = 3 * 2.934
 WHOLE_FWD = {("ImageFill", 512): (58.8, 2.934), ("ImageFillOrigin", 512): (75.9, 0.3676), ("ImageFillOriginV2", 512): (78.8, 0.5664),
              ("TextSegament", 256): (22.7, 0.950), ("TextSegament", 512): (90.6, 3.801), ("TextSegament", 1024): (362.5, 15.205),
              ("XceptionTextSegment", 256): (37.2, 0.957), ("XceptionTextSegment", 512): (148.7, 3.828), ("XceptionTextSegment", 1024): (594.8, 15.314)}
-PMC_SUMMARY = "r06z_pmc_hbm_traffic_bs32.json"   # tools/collect_profiles.sh -> tools/pmc_summary.py
+PMC_SUMMARY = "r06ab_pmc_hbm_traffic_bs32.json"   # tools/collect_profiles.sh -> tools/pmc_summary.py
 
 
 PMC_SUMMARY_CFG5 = "r05h_pmc_hbm_traffic_cfg5_bf16storage.json"   # the same two passes around the cfg 5 line in bf16 storage
